@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native BLAS-on-flash hot path.
+
+Metric (BASELINE.json): GFLOP/s of the out-of-core GEMM hot path, with the
+roofline fraction of the dominant kernel and the CPU path timed beside it.
+
+Workload at N=1 (BASELINE.json configs[1]): flash _gemm fp32 32768 x 32768 x
+32768, 4096-tile (512 tile tasks in 64 accumulate chains of 8), A/B/C already
+resident in HBM when the timed region starts (12 GiB).  One "step" = one pass of
+the whole tile DAG (bof_gemm_resident): 70.37 TFLOP.
+At N>1 (configs[3] at N=8): the (8192*N) x 65536 x 65536 GEMM row-block sharded,
+rank g owns C rows [8192g, 8192(g+1)): per-GPU work is fixed at 70.37 TFLOP (weak
+scaling), no data-path collective.
+
+One process per GPU; launched for N>1 as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "blas-on-flash_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline_gemm(tile):
+    """Oracle ("port") timed on the host cores on a bounded sample: ONE tile task
+    of the workload (tile^3, = BASELINE configs[0] when tile=4096)."""
+    import numpy as np
+    import orc
+    L = orc.lib()
+    threads = L.orc_max_threads()
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, (tile, tile)).astype(np.float32)
+    b = rng.uniform(-1, 1, (tile, tile)).astype(np.float32)
+    c = np.empty((tile, tile), np.float32)
+    small = 512
+    L.orc_sgemm_mt(small, small, small, a.ctypes.data, b.ctypes.data, c.ctypes.data, threads)  # warm
+    t0 = time.perf_counter()
+    L.orc_sgemm_mt(tile, tile, tile, a.ctypes.data, b.ctypes.data, c.ctypes.data, threads)
+    dt = time.perf_counter() - t0
+    out = {"value": round(2.0 * tile ** 3 / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads,
+           "kind": "port",
+           "sample": f"one {tile}^3 fp32 tile task (1/512 of a step), oracle orc_sgemm_mt, "
+                     f"{dt:.2f} s"}
+    try:  # informational: the MKL the reference would call, through torch's CPU sgemm
+        import torch
+        ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+        torch.mm(ta[:512, :512], tb[:512, :512])
+        t0 = time.perf_counter()
+        torch.mm(ta, tb)
+        t1 = time.perf_counter() - t0
+        out["mkl_via_torch_gflops"] = round(2.0 * tile ** 3 / t1 / 1e9, 2)
+        out["mkl_via_torch_threads"] = torch.get_num_threads()
+    except Exception as e:  # pragma: no cover
+        out["mkl_via_torch_gflops"] = None
+        out["mkl_note"] = str(e)[:80]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=0, help="override problem edge (debug)")
+    ap.add_argument("--blk", type=int, default=4096)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="compute streams for the tile DAG (1 = serialized launches, the "
+                         "configuration the roofline/rocprof numbers are quoted on)")
+    ap.add_argument("--data", default="u", choices=["u", "s"],
+                    help="u: uniform[-1,1) (timing default); s: dense_create mode s")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--csrmm", action="store_true", help="also time the cfg3 CSRMM (extra field)")
+    args = ap.parse_args()
+
+    import torch
+    import bofhip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    bofhip.require_device()          # fails loudly: there is no CPU fallback
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n_gpus = max(world, 1)
+    if n_gpus == 1:
+        m = n = k = args.size or 32768
+        m_local, row0 = m, 0
+        workload = (f"flash _gemm fp32 {m}x{k}x{n}, {args.blk}-tile, A/B/C resident in HBM, "
+                    f"1xMI355X (BASELINE configs[1])")
+    else:
+        k = n = args.size or 65536
+        m_local = (args.size or 65536) // 8
+        m, row0 = m_local * n_gpus, m_local * rank
+        workload = (f"flash _gemm fp32 {m}x{k}x{n} row-block sharded over {n_gpus} GPUs "
+                    f"({m_local} C rows each), {args.blk}-tile, resident in HBM "
+                    f"(BASELINE configs[3] at 8 GPUs)")
+
+    # ---- inputs generated straight into HBM (no PCIe traffic) --------------------
+    a = torch.empty(m_local * k, dtype=torch.float32, device=dev)
+    b = torch.empty(k * n, dtype=torch.float32, device=dev)
+    c = torch.zeros(m_local * n, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    bofhip.gen_dense(a.data_ptr(), row0 * k, a.numel(), args.data, 1, st)
+    bofhip.gen_dense(b.data_ptr(), 0, b.numel(), args.data, 2, st)
+    torch.cuda.synchronize()
+
+    opts = bofhip.default_options(gemm_blk=args.blk, n_streams=args.streams)
+    tasks, nblk = bofhip.gemm_plan("R", "N", "N", m_local, n, k, 0.0, 0, 0, 0, args.blk)
+    launches_per_step = len(tasks)
+    flops_per_step_rank = 2.0 * m_local * n * k
+
+    def step():
+        bofhip.gemm_resident("R", "N", "N", m_local, n, k, 1.0, 0.0, a.data_ptr(), b.data_ptr(),
+                             c.data_ptr(), 0, 0, 0, opts, st)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()          # torch's current stream == the stream the DAG is forked from/joined to
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- parity spot check on the timed output (size-independent property) -------
+    # linearity/closed form is covered in tests; here: C row 0 against float64 on 64 columns
+    import numpy as np
+    cols = 64
+    a0 = a[:k].double()
+    bsub = b.view(k, n)[:, :cols].double()
+    ref = (a0 @ bsub).cpu().numpy()
+    got = c.view(m_local, n)[0, :cols].double().cpu().numpy()
+    rel = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+    if rank == 0:
+        total_flops = flops_per_step_rank * n_gpus * args.steps
+        value = total_flops / dt / 1e9
+        avg_launch_ms = ev_ms / (args.steps * launches_per_step)
+        flops_per_launch = flops_per_step_rank / launches_per_step
+        achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+        out = {
+            "metric": "GFLOP/s, out-of-core GEMM hot path (tile DAG over HBM-resident tiles)",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic " + ("uniform[-1,1) fp32 (counter hash)" if args.data == "u"
+                                    else "dense_create mode s (i%10)") + ", generated in HBM",
+            "config": {"workload": workload, "tile": args.blk, "tile_tasks_per_step": launches_per_step,
+                       "compute_streams": args.streams, "parallelism": f"row-block x{n_gpus}"},
+            "roofline": {"bound": "mfma", "kernel": "sgemm_tile_kernel<XMAJOR,KMAJOR>",
+                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "avg_launch_ms": round(avg_launch_ms, 4),
+                         "flops_per_launch": flops_per_launch, "traffic": None},
+            "parity_spot_rel_err": rel,
+        }
+        if not args.no_cpu and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline_gemm(min(args.blk, 4096))
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,227 @@
+"""ctypes binding of libbof_hip.so (the C ABI declared in include/bof_hip.h).
+
+Used by tests/, bench.py and __graft_entry__.py.  Device memory is passed as raw
+pointers (e.g. torch.Tensor.data_ptr()); streams as hipStream_t handles
+(torch.cuda.current_stream().cuda_stream).  There is no CPU fallback: every
+compute entry point raises BofError when the library or a HIP device is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libbof_hip.so")
+
+i64, u64, f32, chr_, P = C.c_int64, C.c_uint64, C.c_float, C.c_char, C.c_void_p
+
+
+class BofError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    """bof_options (reference compile-time tunables, CMakeLists.txt:38-63)."""
+    _fields_ = [("gemm_blk", i64), ("max_nnzs", i64), ("csrmm_rblk", i64), ("csrmm_cblk", i64),
+                ("hbm_budget", i64), ("n_io_threads", C.c_int32), ("n_streams", C.c_int32),
+                ("use_odirect", C.c_int32), ("pinned_slots", C.c_int32)]
+
+
+class GemmTask(C.Structure):
+    _fields_ = [("l", i64), ("i", i64), ("j", i64), ("M", i64), ("K", i64), ("N", i64),
+                ("off", i64 * 3), ("nrows", i64 * 3), ("ncols", i64 * 3),
+                ("ld_file", i64 * 3), ("beta", f32), ("parent", i64)]
+
+
+class FPtr(C.Structure):
+    """bof_fptr == flash_ptr<T> {file, byte offset} (include/pointers/pointer.h:15-18)."""
+    _fields_ = [("fd", C.c_int), ("foffset", u64)]
+
+
+class FlashStats(C.Structure):
+    _fields_ = [("bytes_read", u64), ("bytes_written", u64), ("bytes_h2d", u64),
+                ("bytes_d2h", u64), ("tasks", u64), ("tile_hits", u64), ("tile_misses", u64),
+                ("seconds", C.c_double)]
+
+
+# every symbol include/bof_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bof_abi_version", C.c_int, []),
+    ("bof_last_error", C.c_char_p, []),
+    ("bof_device_count", C.c_int, []),
+    ("bof_set_device", C.c_int, [C.c_int]),
+    ("bof_default_options", None, [C.POINTER(Options)]),
+    ("bof_malloc", C.c_int, [C.POINTER(P), C.c_size_t]),
+    ("bof_free", C.c_int, [P]),
+    ("bof_host_alloc", C.c_int, [C.POINTER(P), C.c_size_t]),
+    ("bof_host_free", C.c_int, [P]),
+    ("bof_memcpy_h2d", C.c_int, [P, P, C.c_size_t, P]),
+    ("bof_memcpy_d2h", C.c_int, [P, P, C.c_size_t, P]),
+    ("bof_memset", C.c_int, [P, C.c_int, C.c_size_t, P]),
+    ("bof_stream_create", C.c_int, [C.POINTER(P)]),
+    ("bof_stream_destroy", C.c_int, [P]),
+    ("bof_stream_sync", C.c_int, [P]),
+    ("bof_mem_info", C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("bof_sgemm", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64, P]),
+    ("bof_scsrmm", C.c_int, [chr_, i64, i64, i64, f32, P, P, P, P, i64, f32, P, i64, P]),
+    ("bof_scsrgemv", C.c_int, [chr_, i64, i64, P, P, P, P, P, P]),
+    ("bof_gemm_plan", i64, [chr_, chr_, chr_, i64, i64, i64, f32, i64, i64, i64, i64,
+                            C.POINTER(GemmTask), i64, C.POINTER(i64)]),
+    ("bof_csr_blocks", i64, [P, i64, i64, i64, i64, P, P, i64]),
+    ("bof_gemm_resident", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P, i64, i64,
+                                    i64, C.POINTER(Options), P]),
+    ("bof_csrmm_resident", C.c_int, [chr_, i64, i64, i64, f32, f32, P, P, P, P, chr_, P, P,
+                                     C.POINTER(Options), P]),
+    ("bof_csrgemv_resident", C.c_int, [chr_, i64, i64, P, P, P, P, P, P, C.POINTER(Options), P]),
+    ("bof_flash_gemm", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr,
+                                 u64, u64, u64, C.POINTER(Options)]),
+    ("bof_flash_csrmm", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, FPtr,
+                                  FPtr, C.POINTER(Options)]),
+    ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
+    ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
+    ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
+    ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
+    ("bof_gen_dense", C.c_int, [P, i64, i64, chr_, u64, P]),
+    ("bof_gen_sparse_rows", C.c_int, [i64, i64, i64, i64, P, P, P, P]),
+]
+
+
+def build(verbose=False):
+    """Compile libbof_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", HERE, "-j8"] + ([] if verbose else ["-s"]), check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BofError(f"{LIB_PATH} is missing: run `make -C {HERE}` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise BofError(f"{what} failed rc={rc}: {lib().bof_last_error().decode(errors='replace')}")
+
+
+def _c(ch):
+    return ch.encode() if isinstance(ch, str) else ch
+
+
+def default_options(**kw):
+    o = Options()
+    lib().bof_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def require_device():
+    n = lib().bof_device_count()
+    if n <= 0:
+        raise BofError("no HIP device visible: the bof_hip compute path needs an MI355X "
+                       "(there is no CPU fallback)")
+    return n
+
+
+# ---- level 1 ---------------------------------------------------------------------
+def sgemm(ord_, ta, tb, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc, stream=0):
+    check(lib().bof_sgemm(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta,
+                          c_ptr, ldc, stream), "bof_sgemm")
+
+
+def scsrmm(ord_b, m, n, k, alpha, val, col, ptr, b, ldb, beta, c, ldc, stream=0):
+    check(lib().bof_scsrmm(_c(ord_b), m, n, k, alpha, val, col, ptr, b, ldb, beta, c, ldc, stream),
+          "bof_scsrmm")
+
+
+def scsrgemv(trans, m, n, val, ptr, col, x, y, stream=0):
+    check(lib().bof_scsrgemv(_c(trans), m, n, val, ptr, col, x, y, stream), "bof_scsrgemv")
+
+
+# ---- planning ----------------------------------------------------------------------
+def gemm_plan(ord_, ta, tb, m, n, k, beta, lda, ldb, ldc, blk):
+    nblk = (i64 * 3)()
+    nt = lib().bof_gemm_plan(_c(ord_), _c(ta), _c(tb), m, n, k, beta, lda, ldb, ldc, blk, None, 0,
+                             nblk)
+    if nt < 0:
+        raise BofError("bof_gemm_plan: bad argument")
+    arr = (GemmTask * max(nt, 1))()
+    lib().bof_gemm_plan(_c(ord_), _c(ta), _c(tb), m, n, k, beta, lda, ldb, ldc, blk, arr, nt, nblk)
+    return list(arr)[:nt], list(nblk)
+
+
+def csr_blocks(ia, m, min_rows=128, max_rows=131072, max_nnz=10_000_000):
+    import numpy as np
+    ia = np.ascontiguousarray(ia, np.int64)
+    nb = lib().bof_csr_blocks(ia.ctypes.data, m, min_rows, max_rows, max_nnz, None, None, 0)
+    if nb < 0:
+        raise BofError("bof_csr_blocks: bad argument")
+    st = np.empty(nb, np.int64)
+    sz = np.empty(nb, np.int64)
+    lib().bof_csr_blocks(ia.ctypes.data, m, min_rows, max_rows, max_nnz, st.ctypes.data,
+                         sz.ctypes.data, nb)
+    return st, sz
+
+
+# ---- level 2 -----------------------------------------------------------------------
+def gemm_resident(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda=0, ldb=0, ldc=0, opts=None,
+                  stream=0):
+    check(lib().bof_gemm_resident(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, a, b, c, lda, ldb,
+                                  ldc, C.byref(opts) if opts is not None else None, stream),
+          "bof_gemm_resident")
+
+
+def csrmm_resident(trans_a, m, n, k, alpha, beta, val, ia_host, ia_dev, ja, ord_b, b, c, opts=None,
+                   stream=0):
+    check(lib().bof_csrmm_resident(_c(trans_a), m, n, k, alpha, beta, val, ia_host, ia_dev, ja,
+                                   _c(ord_b), b, c, C.byref(opts) if opts is not None else None,
+                                   stream), "bof_csrmm_resident")
+
+
+def csrgemv_resident(trans_a, m, n, val, ia_host, ia_dev, ja, x, y, opts=None, stream=0):
+    check(lib().bof_csrgemv_resident(_c(trans_a), m, n, val, ia_host, ia_dev, ja, x, y,
+                                     C.byref(opts) if opts is not None else None, stream),
+          "bof_csrgemv_resident")
+
+
+# ---- level 3 -----------------------------------------------------------------------
+def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda=0, ldb=0, ldc=0, opts=None):
+    check(lib().bof_flash_gemm(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, fa, fb, fc, lda, ldb,
+                               ldc, C.byref(opts) if opts is not None else None), "bof_flash_gemm")
+
+
+def flash_csrmm(trans_a, m, n, k, alpha, beta, fa, fia, fja, ord_b, fb, fc, opts=None):
+    check(lib().bof_flash_csrmm(_c(trans_a), m, n, k, alpha, beta, fa, fia, fja, _c(ord_b), fb, fc,
+                                C.byref(opts) if opts is not None else None), "bof_flash_csrmm")
+
+
+def flash_csrgemv(trans_a, m, n, fa, fia, fja, b_host, c_host, opts=None):
+    check(lib().bof_flash_csrgemv(_c(trans_a), m, n, fa, fia, fja, b_host, c_host,
+                                  C.byref(opts) if opts is not None else None),
+          "bof_flash_csrgemv")
+
+
+def flash_last_stats():
+    s = FlashStats()
+    check(lib().bof_flash_last_stats(C.byref(s)), "bof_flash_last_stats")
+    return {f: getattr(s, f) for f, _ in s._fields_}
+
+
+# ---- generators --------------------------------------------------------------------
+def gen_dense(ptr, first, count, mode="s", seed=0, stream=0):
+    check(lib().bof_gen_dense(ptr, first, count, _c(mode), seed, stream), "bof_gen_dense")
+
+
+def gen_sparse_rows(row0, nrows, ncols, nnz_per_row, csr, col, off, stream=0):
+    check(lib().bof_gen_sparse_rows(row0, nrows, ncols, nnz_per_row, csr, col, off, stream),
+          "bof_gen_sparse_rows")

@@ -1,0 +1,61 @@
+// bof_internal.h -- declarations shared by the translation units of libbof_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "bof_hip.h"
+
+namespace bof {
+
+// ---- error plumbing -----------------------------------------------------------
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);  // records message, returns BOF_EHIP/BOF_ENODEV
+#define BOF_HIP_TRY(expr)                                             \
+  do {                                                                \
+    hipError_t _e = (expr);                                           \
+    if (_e != hipSuccess) return ::bof::hip_fail(_e, #expr);          \
+  } while (0)
+
+// ---- kernels (gemm_f32_mfma.hip, csr_kernels.hip, gen_kernels.hip) -------------
+hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                 const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+                 int64_t ldc, hipStream_t st);
+hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
+                  const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
+                  float *c, int64_t ldc, hipStream_t st);
+hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
+                    const int64_t *col, const float *x, float *y, hipStream_t st);
+hipError_t gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed,
+                     hipStream_t st);
+hipError_t gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols, int64_t nnz_per_row,
+                           float *csr, int64_t *col, int64_t *off, hipStream_t st);
+
+// ---- tilers (plan.cpp) ----------------------------------------------------------
+struct GemmGeometry {
+  int64_t size[3];  // m, k, n
+  int64_t blk[3];   // block edge per dim
+  int64_t nblk[3];  // block count per dim (tail-merge rule applied)
+  int rdim[3], cdim[3];  // stored (row, col) dim of A, B, C
+  int64_t ld[3];    // leading dims in elements
+};
+GemmGeometry gemm_geometry(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                           int64_t lda, int64_t ldb, int64_t ldc, int64_t blk);
+void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float beta,
+                  bof_gemm_task *t);
+
+// ---- fork/join of compute streams (c_api.hip) -----------------------------------
+struct StreamSet {
+  int n = 0;
+  hipStream_t s[16];
+  hipEvent_t fork_ev = nullptr, join_ev[16];
+  int init(int n_streams);
+  int fork(hipStream_t parent);  // every stream waits for work already queued on parent
+  int join(hipStream_t parent);  // parent waits for every stream
+};
+StreamSet *stream_set(int n_streams);  // per-device singleton
+
+bof_options resolved(const bof_options *o);
+
+}  // namespace bof

@@ -1,0 +1,292 @@
+// c_api.hip -- extern "C" entry points of libbof_hip.so: library/device helpers,
+// level 1 (per-tile compute) and level 2 (tile DAG over HBM-resident matrices).
+// Level 3 (file-resident matrices) lives in flash_runtime.cpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bof_hip.h"
+#include "bof_internal.h"
+
+namespace bof {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  (void) hipGetLastError();
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? BOF_ENODEV : BOF_EHIP;
+}
+
+bof_options resolved(const bof_options *o) {
+  bof_options r;
+  bof_default_options(&r);
+  if (!o) return r;
+  if (o->gemm_blk > 0) r.gemm_blk = o->gemm_blk;
+  if (o->max_nnzs > 0) r.max_nnzs = o->max_nnzs;
+  if (o->csrmm_rblk > 0) r.csrmm_rblk = o->csrmm_rblk;
+  if (o->csrmm_cblk > 0) r.csrmm_cblk = o->csrmm_cblk;
+  if (o->hbm_budget > 0) r.hbm_budget = o->hbm_budget;
+  if (o->n_io_threads > 0) r.n_io_threads = o->n_io_threads;
+  if (o->n_streams > 0) r.n_streams = o->n_streams > 16 ? 16 : o->n_streams;
+  r.use_odirect = o->use_odirect;
+  if (o->pinned_slots > 0) r.pinned_slots = o->pinned_slots;
+  return r;
+}
+
+int StreamSet::init(int n_streams) {
+  n = n_streams;
+  BOF_HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+  for (int i = 0; i < n; i++) {
+    BOF_HIP_TRY(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    BOF_HIP_TRY(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
+  }
+  return BOF_OK;
+}
+int StreamSet::fork(hipStream_t parent) {
+  BOF_HIP_TRY(hipEventRecord(fork_ev, parent));
+  for (int i = 0; i < n; i++) BOF_HIP_TRY(hipStreamWaitEvent(s[i], fork_ev, 0));
+  return BOF_OK;
+}
+int StreamSet::join(hipStream_t parent) {
+  for (int i = 0; i < n; i++) {
+    BOF_HIP_TRY(hipEventRecord(join_ev[i], s[i]));
+    BOF_HIP_TRY(hipStreamWaitEvent(parent, join_ev[i], 0));
+  }
+  return BOF_OK;
+}
+
+static std::mutex g_ss_mu;
+static StreamSet *g_ss[64][17];
+StreamSet *stream_set(int n_streams) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ss_mu);
+  StreamSet *&p = g_ss[dev][n_streams];
+  if (!p) {
+    p = new StreamSet();
+    if (p->init(n_streams) != BOF_OK) { delete p; p = nullptr; }
+  }
+  return p;
+}
+
+static bool flag_ok(char c, char a, char b) { return c == a || c == b; }
+
+}  // namespace bof
+
+using namespace bof;
+
+extern "C" {
+
+int bof_abi_version(void) { return BOF_ABI_VERSION; }
+const char *bof_last_error(void) { return g_err.c_str(); }
+
+void bof_default_options(bof_options *o) {
+  if (!o) return;
+  o->gemm_blk = 4096;
+  o->max_nnzs = 10000000;
+  o->csrmm_rblk = 131072;
+  o->csrmm_cblk = 1024;
+  o->hbm_budget = 0;
+  o->n_io_threads = 4;
+  o->n_streams = 4;
+  o->use_odirect = 1;
+  o->pinned_slots = 6;
+}
+
+int bof_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+  return n;
+}
+int bof_set_device(int dev) { BOF_HIP_TRY(hipSetDevice(dev)); return BOF_OK; }
+
+int bof_malloc(void **dptr, size_t bytes) { BOF_HIP_TRY(hipMalloc(dptr, bytes)); return BOF_OK; }
+int bof_free(void *dptr) { BOF_HIP_TRY(hipFree(dptr)); return BOF_OK; }
+int bof_host_alloc(void **hptr, size_t bytes) {
+  BOF_HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+  return BOF_OK;
+}
+int bof_host_free(void *hptr) { BOF_HIP_TRY(hipHostFree(hptr)); return BOF_OK; }
+int bof_memcpy_h2d(void *d, const void *h, size_t bytes, void *stream) {
+  BOF_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t) stream));
+  return BOF_OK;
+}
+int bof_memcpy_d2h(void *h, const void *d, size_t bytes, void *stream) {
+  BOF_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream));
+  return BOF_OK;
+}
+int bof_memset(void *d, int value, size_t bytes, void *stream) {
+  BOF_HIP_TRY(hipMemsetAsync(d, value, bytes, (hipStream_t) stream));
+  return BOF_OK;
+}
+int bof_stream_create(void **stream) {
+  BOF_HIP_TRY(hipStreamCreateWithFlags((hipStream_t *) stream, hipStreamNonBlocking));
+  return BOF_OK;
+}
+int bof_stream_destroy(void *stream) { BOF_HIP_TRY(hipStreamDestroy((hipStream_t) stream)); return BOF_OK; }
+int bof_stream_sync(void *stream) { BOF_HIP_TRY(hipStreamSynchronize((hipStream_t) stream)); return BOF_OK; }
+int bof_mem_info(size_t *free_bytes, size_t *total_bytes) {
+  BOF_HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+  return BOF_OK;
+}
+
+// ---- level 1 ------------------------------------------------------------------
+int bof_sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+              const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+              int64_t ldc, void *stream) {
+  if (!flag_ok(ord, 'R', 'C') || !flag_ok(ta, 'N', 'T') || !flag_ok(tb, 'N', 'T') || m < 0 ||
+      n < 0 || k < 0 || m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) {
+    set_error("bof_sgemm: bad argument");
+    return BOF_EINVAL;
+  }
+  BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, (hipStream_t) stream));
+  return BOF_OK;
+}
+
+int bof_scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
+               const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
+               float *c, int64_t ldc, void *stream) {
+  if (!flag_ok(ord_b, 'R', 'C') || m < 0 || n < 0 || k < 0 || n > INT32_MAX || k > INT32_MAX) {
+    set_error("bof_scsrmm: bad argument");
+    return BOF_EINVAL;
+  }
+  BOF_HIP_TRY(scsrmm(ord_b, m, n, k, alpha, val, col, ptr, b, ldb, beta, c, ldc, (hipStream_t) stream));
+  return BOF_OK;
+}
+
+int bof_scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
+                 const int64_t *col, const float *x, float *y, void *stream) {
+  if (!flag_ok(trans, 'N', 'T') || m < 0 || n < 0) {
+    set_error("bof_scsrgemv: bad argument");
+    return BOF_EINVAL;
+  }
+  BOF_HIP_TRY(scsrgemv(trans, m, n, val, ptr, col, x, y, (hipStream_t) stream));
+  return BOF_OK;
+}
+
+// ---- level 2 ------------------------------------------------------------------
+int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                      float beta, const float *a, const float *b, float *c, int64_t lda,
+                      int64_t ldb, int64_t ldc, const bof_options *opts, void *stream) {
+  if (!flag_ok(ord, 'R', 'C') || !flag_ok(ta, 'N', 'T') || !flag_ok(tb, 'N', 'T') || m < 0 ||
+      n < 0 || k < 0) {
+    set_error("bof_gemm_resident: bad argument");
+    return BOF_EINVAL;
+  }
+  const bof_options o = resolved(opts);
+  const GemmGeometry g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
+  if (g.nblk[0] * g.nblk[2] == 0) return BOF_OK;
+  StreamSet *ss = stream_set(o.n_streams);
+  if (!ss) { set_error("bof_gemm_resident: no HIP device / stream creation failed"); return BOF_ENODEV; }
+  hipStream_t parent = (hipStream_t) stream;
+  int rc = ss->fork(parent);
+  if (rc) return rc;
+  if (g.nblk[1] == 0) {  // k == 0: C = beta*C through a single degenerate pass
+    BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, 0, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], ss->s[0]));
+    return ss->join(parent);
+  }
+  bof_gemm_task t;
+  for (int64_t l = 0; l < g.nblk[1]; l++)
+    for (int64_t i = 0; i < g.nblk[0]; i++)
+      for (int64_t j = 0; j < g.nblk[2]; j++) {
+        gemm_task_at(g, l, i, j, beta, &t);
+        // chain (i,j) is pinned to one stream: FIFO order gives (l-1,i,j) -> (l,i,j)
+        hipStream_t st = ss->s[(i * g.nblk[2] + j) % ss->n];
+        BOF_HIP_TRY(sgemm(ord, ta, tb, t.M, t.N, t.K, alpha, a + t.off[0], t.ld_file[0],
+                          b + t.off[1], t.ld_file[1], t.beta, c + t.off[2], t.ld_file[2], st));
+      }
+  return ss->join(parent);
+}
+
+int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alpha, float beta,
+                       const float *val, const int64_t *ia_host, const int64_t *ia_dev,
+                       const int64_t *ja, char ord_b, const float *b, float *c,
+                       const bof_options *opts, void *stream) {
+  if (trans_a != 'N') {  // reference: 'T' goes through csrcsc and is broken
+    set_error("bof_csrmm_resident: only trans_a='N' is supported");
+    return BOF_EINVAL;
+  }
+  if (!flag_ok(ord_b, 'R', 'C') || m < 0 || n < 0 || k < 0 || n > INT32_MAX) {
+    set_error("bof_csrmm_resident: bad argument");
+    return BOF_EINVAL;
+  }
+  if (m == 0 || k == 0) return BOF_OK;
+  const bof_options o = resolved(opts);
+  const int64_t nb = bof_csr_blocks(ia_host, m, 128, o.csrmm_rblk, o.max_nnzs, nullptr, nullptr, 0);
+  std::vector<int64_t> st(nb), sz(nb);
+  bof_csr_blocks(ia_host, m, 128, o.csrmm_rblk, o.max_nnzs, st.data(), sz.data(), nb);
+  StreamSet *ss = stream_set(o.n_streams);
+  if (!ss) { set_error("bof_csrmm_resident: no HIP device"); return BOF_ENODEV; }
+  hipStream_t parent = (hipStream_t) stream;
+  int rc = ss->fork(parent);
+  if (rc) return rc;
+  for (int64_t bi = 0; bi < nb; bi++) {
+    const int64_t s = st[bi], r = sz[bi], z = ia_host[s] - ia_host[0];
+    hipStream_t q = ss->s[bi % ss->n];
+    for (int64_t j0 = 0; j0 < k; j0 += o.csrmm_cblk) {
+      const int64_t w = std::min(k - j0, o.csrmm_cblk);
+      if (ord_b == 'R')
+        BOF_HIP_TRY(scsrmm('R', r, w, n, alpha, val + z, ja + z, ia_dev + s, b + j0, k, beta,
+                           c + s * k + j0, k, q));
+      else
+        BOF_HIP_TRY(scsrmm('C', r, w, n, alpha, val + z, ja + z, ia_dev + s, b + j0 * n, n, beta,
+                           c + j0 * m + s, m, q));
+    }
+  }
+  return ss->join(parent);
+}
+
+int bof_csrgemv_resident(char trans_a, int64_t m, int64_t n, const float *val,
+                         const int64_t *ia_host, const int64_t *ia_dev, const int64_t *ja,
+                         const float *x, float *y, const bof_options *opts, void *stream) {
+  if (!flag_ok(trans_a, 'N', 'T') || m < 0 || n < 0) {
+    set_error("bof_csrgemv_resident: bad argument");
+    return BOF_EINVAL;
+  }
+  const bof_options o = resolved(opts);
+  hipStream_t parent = (hipStream_t) stream;
+  if (trans_a == 'T' && n > 0) BOF_HIP_TRY(hipMemsetAsync(y, 0, sizeof(float) * n, parent));
+  if (m == 0) return BOF_OK;
+  const int64_t nb = bof_csr_blocks(ia_host, m, 128, o.csrmm_rblk, o.max_nnzs, nullptr, nullptr, 0);
+  std::vector<int64_t> st(nb), sz(nb);
+  bof_csr_blocks(ia_host, m, 128, o.csrmm_rblk, o.max_nnzs, st.data(), sz.data(), nb);
+  StreamSet *ss = stream_set(o.n_streams);
+  if (!ss) { set_error("bof_csrgemv_resident: no HIP device"); return BOF_ENODEV; }
+  int rc = ss->fork(parent);
+  if (rc) return rc;
+  for (int64_t bi = 0; bi < nb; bi++) {
+    const int64_t s = st[bi], r = sz[bi], z = ia_host[s] - ia_host[0];
+    hipStream_t q = ss->s[bi % ss->n];
+    if (trans_a == 'N')
+      BOF_HIP_TRY(scsrgemv('N', r, n, val + z, ia_dev + s, ja + z, x, y + s, q));
+    else
+      BOF_HIP_TRY(scsrgemv('T', r, n, val + z, ia_dev + s, ja + z, x + s, y, q));
+  }
+  return ss->join(parent);
+}
+
+// ---- generators -----------------------------------------------------------------
+int bof_gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed, void *stream) {
+  if (count < 0 || !(mode == 's' || mode == 'z' || mode == 'u')) {
+    set_error("bof_gen_dense: bad argument");
+    return BOF_EINVAL;
+  }
+  BOF_HIP_TRY(gen_dense(d, first, count, mode, seed, (hipStream_t) stream));
+  return BOF_OK;
+}
+int bof_gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols, int64_t nnz_per_row,
+                        float *csr, int64_t *col, int64_t *off, void *stream) {
+  if (nrows < 0 || ncols <= 0 || nnz_per_row <= 0 || nnz_per_row + 40 > 2048) {
+    set_error("bof_gen_sparse_rows: bad argument (nnz_per_row + 40 must be <= 2048)");
+    return BOF_EINVAL;
+  }
+  BOF_HIP_TRY(gen_sparse_rows(row0, nrows, ncols, nnz_per_row, csr, col, off, (hipStream_t) stream));
+  return BOF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// csr_kernels.hip -- CSR x dense (SpMM) and CSR x vector (SpMV) tiles for gfx950.
+//
+// Replaces mkl_scsrmm in SimpleCsrmmRmTask/SimpleCsrmmCmTask::execute
+// (reference include/tasks/csrmm_task.h:201-229, 278-313) and
+// mkl_cspblas_scsrgemv in CsrGemv{NoTrans,Trans}InMem::execute
+// (include/tasks/csrgemv_task.h:60-83, 152-179).
+//
+// These are HBM/gather-bound byte-moving kernels: no MFMA.  What matters is
+// coalescing (one wave-instruction fetches one whole B row segment), many
+// independent row gathers in flight per wave, and streaming the CSR arrays
+// exactly once.  Column indices stay int64 as stored on disk; they are only
+// read, never rewritten.
+//
+// Numerics: each output element is the fmaf chain over the row's non-zeros in
+// storage order, then c = beta==0 ? alpha*acc : fmaf(alpha, acc, beta*c):
+// identical to oracle/bof_oracle.c::orc_scsrmm / orc_scsrgemv ('N').
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bof {
+
+constexpr int CSR_WAVES = 4;  // waves per block, one CSR row per wave at a time
+
+template <int VEC> struct vecf;
+template <> struct vecf<1> { typedef float type; };
+template <> struct vecf<2> { typedef float2 type; };
+template <> struct vecf<4> { typedef float4 type; };
+
+template <int VEC>
+__device__ __forceinline__ void vfma(float v, const typename vecf<VEC>::type &b, float (&acc)[VEC]);
+template <> __device__ __forceinline__ void vfma<1>(float v, const float &b, float (&acc)[1]) {
+  acc[0] = __builtin_fmaf(v, b, acc[0]);
+}
+template <> __device__ __forceinline__ void vfma<2>(float v, const float2 &b, float (&acc)[2]) {
+  acc[0] = __builtin_fmaf(v, b.x, acc[0]);
+  acc[1] = __builtin_fmaf(v, b.y, acc[1]);
+}
+template <> __device__ __forceinline__ void vfma<4>(float v, const float4 &b, float (&acc)[4]) {
+  acc[0] = __builtin_fmaf(v, b.x, acc[0]);
+  acc[1] = __builtin_fmaf(v, b.y, acc[1]);
+  acc[2] = __builtin_fmaf(v, b.z, acc[2]);
+  acc[3] = __builtin_fmaf(v, b.w, acc[3]);
+}
+
+// Row-major B/C, contiguous columns.  One wave per CSR row; lane owns VEC
+// consecutive output columns of a 64*VEC-wide column pass.  The row's (col,val)
+// pairs are loaded 64 at a time with coalesced loads and broadcast by
+// v_readlane; the B-row gathers are issued UNROLL at a time before the fmas.
+template <int VEC, int UNROLL>
+__global__ void __launch_bounds__(64 * CSR_WAVES)
+csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ val,
+                      const int64_t *__restrict__ col, const int64_t *__restrict__ ptr,
+                      const float *__restrict__ B, int64_t ldb, float beta,
+                      float *__restrict__ C, int64_t ldc) {
+  typedef typename vecf<VEC>::type V;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t) blockIdx.x * CSR_WAVES + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const int64_t base = ptr[0];
+  const int64_t p0 = ptr[row] - base, p1 = ptr[row + 1] - base;
+
+  for (int j0 = 0; j0 < n; j0 += 64 * VEC) {
+    const int j = j0 + lane * VEC;
+    const bool active = j < n;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e++) acc[e] = 0.f;
+
+    for (int64_t p = p0; p < p1; p += 64) {
+      const int cnt = (int) min((int64_t) 64, p1 - p);
+      int mycol = 0;
+      float myval = 0.f;
+      if (lane < cnt) {
+        mycol = (int) col[p + lane];
+        myval = val[p + lane];
+      }
+      int tI = 0;
+      for (; tI + UNROLL <= cnt; tI += UNROLL) {
+        V bv[UNROLL];
+        float vv[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+          const int c = __builtin_amdgcn_readlane(mycol, tI + u);
+          vv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), tI + u));
+          if (active) bv[u] = *reinterpret_cast<const V *>(B + (int64_t) c * ldb + j);
+        }
+        if (active) {
+#pragma unroll
+          for (int u = 0; u < UNROLL; u++) vfma<VEC>(vv[u], bv[u], acc);
+        }
+      }
+      for (; tI < cnt; tI++) {
+        const int c = __builtin_amdgcn_readlane(mycol, tI);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), tI));
+        if (active) {
+          const V b = *reinterpret_cast<const V *>(B + (int64_t) c * ldb + j);
+          vfma<VEC>(v, b, acc);
+        }
+      }
+    }
+    if (active) {
+      float *cp = C + row * ldc + j;
+      if (beta == 0.f) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[e] = alpha * acc[e];
+      } else {
+        float old[VEC];
+        *reinterpret_cast<V *>(old) = *reinterpret_cast<const V *>(cp);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) acc[e] = __builtin_fmaf(alpha, acc[e], beta * old[e]);
+      }
+      *reinterpret_cast<V *>(cp) = *reinterpret_cast<V *>(acc);
+    }
+  }
+}
+
+// Generic element-strided B/C (column-major 'C' layout, or unaligned row-major):
+// B(c, j) = B[c*rsb + j*csb], C(i, j) = C[i*rsc + j*csc].  Lanes over rows for
+// column-major so C stores coalesce; one thread owns one (row, column) pair.
+__global__ void __launch_bounds__(256)
+csrmm_strided_kernel(int64_t m, int n, float alpha, const float *__restrict__ val,
+                     const int64_t *__restrict__ col, const int64_t *__restrict__ ptr,
+                     const float *__restrict__ B, int64_t rsb, int64_t csb, float beta,
+                     float *__restrict__ C, int64_t rsc, int64_t csc, int lanes_over_rows) {
+  int64_t row;
+  int j;
+  if (lanes_over_rows) {
+    row = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    j = blockIdx.y;
+  } else {
+    row = blockIdx.x;
+    j = blockIdx.y * 256 + threadIdx.x;
+  }
+  if (row >= m || j >= n) return;
+  const int64_t base = ptr[0];
+  float acc = 0.f;
+  for (int64_t p = ptr[row] - base; p < ptr[row + 1] - base; p++)
+    acc = __builtin_fmaf(val[p], B[col[p] * rsb + (int64_t) j * csb], acc);
+  float *cp = C + row * rsc + (int64_t) j * csc;
+  *cp = (beta == 0.f) ? alpha * acc : __builtin_fmaf(alpha, acc, beta * (*cp));
+}
+
+hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
+                  const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
+                  float *c, int64_t ldc, hipStream_t st) {
+  (void) k;
+  if (m == 0 || n == 0) return hipSuccess;
+  if (ord_b == 'R') {
+    const bool al16 = (n % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(b) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
+    const bool al8 = (n % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(b) & 7) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(c) & 7) == 0);
+    dim3 grid((unsigned) ((m + CSR_WAVES - 1) / CSR_WAVES)), block(64 * CSR_WAVES);
+    if (al16 && n > 128)
+      hipLaunchKernelGGL((csrmm_rowmajor_kernel<4, 8>), grid, block, 0, st, m, (int) n, alpha, val,
+                         col, ptr, b, ldb, beta, c, ldc);
+    else if (al8 && n > 64)
+      hipLaunchKernelGGL((csrmm_rowmajor_kernel<2, 8>), grid, block, 0, st, m, (int) n, alpha, val,
+                         col, ptr, b, ldb, beta, c, ldc);
+    else
+      hipLaunchKernelGGL((csrmm_rowmajor_kernel<1, 8>), grid, block, 0, st, m, (int) n, alpha, val,
+                         col, ptr, b, ldb, beta, c, ldc);
+  } else {
+    dim3 grid((unsigned) ((m + 255) / 256), (unsigned) n), block(256);
+    hipLaunchKernelGGL(csrmm_strided_kernel, grid, block, 0, st, m, (int) n, alpha, val, col, ptr,
+                       b, (int64_t) 1, ldb, beta, c, (int64_t) 1, ldc, 1);
+  }
+  return hipGetLastError();
+}
+
+// ---- SpMV --------------------------------------------------------------------
+// 'N': one thread per row, fmaf chain in storage order (bit-exact vs oracle).
+__global__ void __launch_bounds__(256)
+csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__restrict__ ptr,
+                 const int64_t *__restrict__ col, const float *__restrict__ x,
+                 float *__restrict__ y) {
+  const int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  const int64_t base = ptr[0];
+  float acc = 0.f;
+  for (int64_t p = ptr[row] - base; p < ptr[row + 1] - base; p++)
+    acc = __builtin_fmaf(val[p], x[col[p]], acc);
+  y[row] = acc;
+}
+
+// 'T': y[col[p]] += val[p] * x[row]; one thread per row, fp32 atomics (the
+// reference's mutex-guarded vector add, csrgemv_task.h:169-176, becomes
+// memory-side atomic adds; result is order-independent for integer data).
+__global__ void __launch_bounds__(256)
+csrgemv_t_kernel(int64_t m, const float *__restrict__ val, const int64_t *__restrict__ ptr,
+                 const int64_t *__restrict__ col, const float *__restrict__ x,
+                 float *__restrict__ y) {
+  const int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  const int64_t base = ptr[0];
+  const float xv = x[row];
+  for (int64_t p = ptr[row] - base; p < ptr[row + 1] - base; p++)
+    atomicAdd(y + col[p], val[p] * xv);
+}
+
+hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
+                    const int64_t *col, const float *x, float *y, hipStream_t st) {
+  (void) n;
+  if (m == 0) return hipSuccess;
+  dim3 grid((unsigned) ((m + 255) / 256)), block(256);
+  if (trans == 'N')
+    hipLaunchKernelGGL(csrgemv_n_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+  else
+    hipLaunchKernelGGL(csrgemv_t_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+  return hipGetLastError();
+}
+
+}  // namespace bof

@@ -1,0 +1,100 @@
+// plan.cpp -- host-side tilers of the hot path (pure C++, no GPU calls).
+//   GEMM   : 3-D tiling + tail-merge rule + k accumulate chains
+//            (reference src/blas/gemm.cpp:39-129)
+//   CSR    : nnz-budget row blocks (reference include/blas_utils.h:72-97; App. D-2)
+#include <algorithm>
+#include <cstdint>
+
+#include "bof_hip.h"
+#include "bof_internal.h"
+
+namespace bof {
+
+static constexpr int64_t kSectorFloats = 512 / sizeof(float);  // SECTOR_LEN / sizeof(FPTYPE)
+
+GemmGeometry gemm_geometry(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                           int64_t lda, int64_t ldb, int64_t ldc, int64_t blk) {
+  GemmGeometry g;
+  const bool colMajor = (ord == 'C');
+  const int64_t S[3] = {m, k, n};
+  int64_t ld[3] = {lda, ldb, ldc};
+  // logical (row-dim, col-dim) of A, B, C over the dim order {m,k,n}; a matrix
+  // whose stored orientation is the transpose of its logical one swaps them
+  const int logical_row[3] = {0, 1, 0}, logical_col[3] = {1, 2, 2};
+  const bool swapped[3] = {(ta == 'T') != colMajor, (tb == 'T') != colMajor, colMajor};
+  for (int x = 0; x < 3; x++) {
+    g.size[x] = S[x];
+    g.blk[x] = std::min(blk, S[x]);
+    const int64_t q = g.blk[x] ? S[x] / g.blk[x] : 0;
+    // a remainder shorter than one sector of floats is folded into the last block
+    g.nblk[x] = (g.blk[x] && S[x] - q * g.blk[x] < kSectorFloats) ? q : q + 1;
+    if (S[x] == 0) g.nblk[x] = 0;
+  }
+  for (int mat = 0; mat < 3; mat++) {
+    g.rdim[mat] = swapped[mat] ? logical_col[mat] : logical_row[mat];
+    g.cdim[mat] = swapped[mat] ? logical_row[mat] : logical_col[mat];
+    g.ld[mat] = ld[mat] ? ld[mat] : S[g.cdim[mat]];
+  }
+  return g;
+}
+
+void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float beta,
+                  bof_gemm_task *t) {
+  const int64_t idx[3] = {i, l, j};
+  int64_t ext[3];
+  for (int x = 0; x < 3; x++)
+    ext[x] = (idx[x] == g.nblk[x] - 1) ? g.size[x] - idx[x] * g.blk[x] : g.blk[x];
+  for (int mat = 0; mat < 3; mat++) {
+    const int r = g.rdim[mat], c = g.cdim[mat];
+    t->nrows[mat] = ext[r];
+    t->ncols[mat] = ext[c];
+    t->ld_file[mat] = g.ld[mat];
+    t->off[mat] = idx[r] * g.blk[r] * g.ld[mat] + idx[c] * g.blk[c];
+  }
+  t->l = l; t->i = i; t->j = j;
+  t->M = ext[0]; t->K = ext[1]; t->N = ext[2];
+  t->beta = l > 0 ? 1.0f : beta;
+  t->parent = l > 0 ? ((l - 1) * g.nblk[0] + i) * g.nblk[2] + j : -1;
+}
+
+}  // namespace bof
+
+extern "C" int64_t bof_gemm_plan(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                                 float beta, int64_t lda, int64_t ldb, int64_t ldc, int64_t blk,
+                                 bof_gemm_task *out, int64_t cap, int64_t nblk[3]) {
+  if (blk <= 0 || m < 0 || n < 0 || k < 0) return BOF_EINVAL;
+  const bof::GemmGeometry g = bof::gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, blk);
+  if (nblk) { nblk[0] = g.nblk[0]; nblk[1] = g.nblk[1]; nblk[2] = g.nblk[2]; }
+  const int64_t total = g.nblk[0] * g.nblk[1] * g.nblk[2];
+  if (!out) return total;
+  int64_t t = 0;
+  for (int64_t l = 0; l < g.nblk[1]; l++)      // reference injects l-major
+    for (int64_t i = 0; i < g.nblk[0]; i++)
+      for (int64_t j = 0; j < g.nblk[2]; j++, t++) {
+        if (t >= cap) return total;
+        bof::gemm_task_at(g, l, i, j, beta, &out[t]);
+      }
+  return total;
+}
+
+extern "C" int64_t bof_csr_blocks(const int64_t *ia, int64_t m, int64_t min_rows,
+                                  int64_t max_rows, int64_t max_nnz, int64_t *starts,
+                                  int64_t *sizes, int64_t cap) {
+  if (!ia || m < 0 || min_rows <= 0 || max_rows <= 0) return BOF_EINVAL;
+  int64_t cur = 0, nb = 0;
+  while (cur < m) {
+    const int64_t left = m - cur;
+    // grow from min_rows while the block is within the nnz budget: the block
+    // ends one row past the budget, as the reference's does
+    int64_t b = min_rows;
+    while (b < left && ia[cur + b] - ia[cur] <= max_nnz) b++;
+    b = std::min(std::min(b, max_rows), left);  // clamp: reference over-runs ia here
+    if (nb < cap) {
+      if (starts) starts[nb] = cur;
+      if (sizes) sizes[nb] = b;
+    }
+    nb++;
+    cur += b;
+  }
+  return nb;
+}

@@ -1,0 +1,212 @@
+/*
+ * bof_hip.h -- C ABI of the MI355X-native BLAS-on-flash hot path
+ * (libbof_hip.so).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The library replaces, for the reference's _gemm / _csrmm / _csrgemv path:
+ *
+ *   level 1  the per-tile MKL calls inside the task objects
+ *              cblas_sgemm            include/tasks/gemm_task.h:87-90
+ *              mkl_scsrmm             include/tasks/csrmm_task.h:226-228, 310-312
+ *              mkl_cspblas_scsrgemv   include/tasks/csrgemv_task.h:74, 165
+ *            -> bof_sgemm / bof_scsrmm / bof_scsrgemv on DEVICE pointers.
+ *   level 2  the tile DAG of flash::gemm / csrmm / csrgemv run over matrices
+ *            that are already resident in HBM (the reference's "program cache"
+ *            is host DRAM; ours is HBM)
+ *              src/blas/gemm.cpp:27-202, src/blas/csrmm.cpp:64-126,203-266,
+ *              src/blas/csrgemv.cpp:14-97
+ *            -> bof_gemm_resident / bof_csrmm_resident / bof_csrgemv_resident.
+ *   level 3  the same calls on file-resident matrices (O_DIRECT AIO reader ->
+ *            pinned ring -> hipMemcpyAsync -> HBM tile cache -> kernels ->
+ *            write-back): what the C++ flash::gemm/csrmm/csrgemv in
+ *            blas-on-flash_amd/include/flash_blas.h bind to
+ *              include/flash_blas.h:14-18, 37-40, 55-57
+ *            -> bof_flash_gemm / bof_flash_csrmm / bof_flash_csrgemv.
+ *
+ * Conventions: all integers 64-bit (reference builds with -DMKL_ILP64,
+ * include/bof_types.h:11-28); CSR index and offset arrays are int64 exactly as
+ * stored on disk; chars are 'N'/'T', 'R'/'C' as in the reference API.
+ * Every function returns BOF_OK (0) or a negative error code;
+ * bof_last_error() gives the message.  Nothing here falls back to a CPU
+ * implementation: without a usable HIP device the compute entry points fail
+ * with BOF_ENODEV.
+ */
+#ifndef BOF_HIP_H
+#define BOF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BOF_OK 0
+#define BOF_EINVAL (-1) /* bad argument (the reference returns -1 too, csrmm.cpp:433-448) */
+#define BOF_EHIP (-2)   /* a HIP runtime call failed */
+#define BOF_EIO (-3)    /* file I/O failed */
+#define BOF_ENODEV (-4) /* no HIP device */
+#define BOF_ENOMEM (-5)
+
+#define BOF_ABI_VERSION 1
+
+/* ---- library ---------------------------------------------------------------- */
+int bof_abi_version(void);
+const char *bof_last_error(void);
+int bof_device_count(void); /* hipGetDeviceCount; 0 when there is no GPU */
+int bof_set_device(int dev);
+
+/* Reference compile-time tunables (CMakeLists.txt:38-63) as run-time options. */
+typedef struct {
+  int64_t gemm_blk;      /* GEMM_BLK_SIZE            default 4096 (BASELINE cfg2) */
+  int64_t max_nnzs;      /* MAX_NNZS                 default 10,000,000           */
+  int64_t csrmm_rblk;    /* CSRMM_RM_RBLK_SIZE       default 131072               */
+  int64_t csrmm_cblk;    /* CSRMM_RM_CBLK_SIZE       default 1024                 */
+  int64_t hbm_budget;    /* PROGRAM_BUDGET analogue: bytes of HBM for the tile
+                            cache; 0 = 80% of free HBM                          */
+  int32_t n_io_threads;  /* N_IO_THR                 default 4                    */
+  int32_t n_streams;     /* compute streams (N_COMPUTE_THR analogue) default 4    */
+  int32_t use_odirect;   /* 1 = O_DIRECT + kernel AIO (default), 0 = buffered     */
+  int32_t pinned_slots;  /* pinned staging ring slots  default 6                  */
+} bof_options;
+void bof_default_options(bof_options *o);
+
+/* ---- device memory / streams (thin wrappers for non-torch hosts) ------------ */
+int bof_malloc(void **dptr, size_t bytes);
+int bof_free(void *dptr);
+int bof_host_alloc(void **hptr, size_t bytes); /* pinned */
+int bof_host_free(void *hptr);
+int bof_memcpy_h2d(void *d, const void *h, size_t bytes, void *stream);
+int bof_memcpy_d2h(void *h, const void *d, size_t bytes, void *stream);
+int bof_memset(void *d, int value, size_t bytes, void *stream);
+int bof_stream_create(void **stream);
+int bof_stream_destroy(void *stream);
+int bof_stream_sync(void *stream); /* NULL = default stream */
+int bof_mem_info(size_t *free_bytes, size_t *total_bytes);
+
+/* ---- level 1: per-tile compute on device pointers --------------------------- */
+/* C = alpha*op(A)*op(B) + beta*C, fp32, cblas_sgemm argument meaning
+ * (include/tasks/gemm_task.h:87-90).  Exact-f32 MFMA: every output element is a
+ * k-ordered fmaf chain started at 0, then
+ *   c = (beta == 0) ? alpha*acc : fmaf(alpha, acc, beta*c).
+ * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous. */
+int bof_sgemm(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
+              int64_t k, float alpha, const float *a, int64_t lda, const float *b,
+              int64_t ldb, float beta, float *c, int64_t ldc, void *stream);
+
+/* C[m x n] = alpha * A[m x k] * B[k x n] + beta * C with A in 0-based CSR:
+ * mkl_scsrmm('N', m, n, k, alpha, "GXXC"|"GXXF", val, col, ptr, ptr+1, b, ldb,
+ * beta, c, ldc) (include/tasks/csrmm_task.h:226-228, 310-312).  `ptr` has m+1
+ * entries and may carry a base: row i spans [ptr[i]-ptr[0], ptr[i+1]-ptr[0]) of
+ * val/col.  col stays int64 as on disk and is NEVER modified (the reference's
+ * in-place 1-based conversion, SURVEY App. B-15, is not reproduced).
+ * ord_b 'R': B,C row-major; 'C': column-major. */
+int bof_scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha,
+               const float *val, const int64_t *col, const int64_t *ptr,
+               const float *b, int64_t ldb, float beta, float *c, int64_t ldc,
+               void *stream);
+
+/* mkl_cspblas_scsrgemv (include/tasks/csrgemv_task.h:74, 165) on a row block:
+ * 'N': y[0..m) = A x (overwrites).  'T': y[0..n) += A^T x[0..m) (accumulates
+ * with fp32 atomics; the caller zeroes y once, src/blas/csrgemv.cpp:64). */
+int bof_scsrgemv(char trans, int64_t m, int64_t n, const float *val,
+                 const int64_t *ptr, const int64_t *col, const float *x, float *y,
+                 void *stream);
+
+/* ---- planning (pure host code; usable without a GPU) ------------------------ */
+/* One tile task as src/blas/gemm.cpp:83-129 builds it (offsets/LDs in elements). */
+typedef struct {
+  int64_t l, i, j;
+  int64_t M, K, N;
+  int64_t off[3];     /* A, B, C tile origin in the file / resident matrix */
+  int64_t nrows[3];   /* StrideInfo.n_strides                              */
+  int64_t ncols[3];   /* StrideInfo.len_per_stride / sizeof(float)         */
+  int64_t ld_file[3]; /* StrideInfo.stride / sizeof(float)                 */
+  float beta;         /* caller's beta for l == 0, 1 for l > 0            */
+  int64_t parent;     /* index of (l-1,i,j) in the plan or -1             */
+} bof_gemm_task;
+/* Returns the task count (tasks listed in the reference's l-major injection
+ * order); fills out[0..min(count,cap)).  nblk = {N_m, N_k, N_n}. */
+int64_t bof_gemm_plan(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
+                      int64_t k, float beta, int64_t lda, int64_t ldb, int64_t ldc,
+                      int64_t blk, bof_gemm_task *out, int64_t cap, int64_t nblk[3]);
+/* CSR row blocks (include/blas_utils.h:72-97) with the rows-remaining clamp. */
+int64_t bof_csr_blocks(const int64_t *ia, int64_t m, int64_t min_rows,
+                       int64_t max_rows, int64_t max_nnz, int64_t *starts,
+                       int64_t *sizes, int64_t cap);
+
+/* ---- level 2: the tile DAG over HBM-resident matrices ----------------------- */
+/* flash::gemm semantics (src/blas/gemm.cpp:27-202) with a,b,c device pointers to
+ * the whole matrices (file layout, leading dims as the caller passes them; 0 =
+ * default).  Tasks run in the reference's order; every (i,j) accumulate chain
+ * is serialised on one of opts->n_streams compute streams forked from / joined
+ * into `stream`.  Asynchronous with respect to the host. */
+int bof_gemm_resident(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
+                      int64_t k, float alpha, float beta, const float *a,
+                      const float *b, float *c, int64_t lda, int64_t ldb,
+                      int64_t ldc, const bof_options *opts, void *stream);
+/* flash::csrmm 'N' (src/blas/csrmm.cpp:64-126, 203-266): row blocks by nnz
+ * budget x column panels; ia_host is the host copy of the offsets (the
+ * reference also reads `ia` to the host first, csrmm.cpp:69-71), ia_dev the
+ * same array in HBM. */
+int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alpha,
+                       float beta, const float *val, const int64_t *ia_host,
+                       const int64_t *ia_dev, const int64_t *ja, char ord_b,
+                       const float *b, float *c, const bof_options *opts,
+                       void *stream);
+/* flash::csrgemv (src/blas/csrgemv.cpp:82-97) with x, y in HBM. */
+int bof_csrgemv_resident(char trans_a, int64_t m, int64_t n, const float *val,
+                         const int64_t *ia_host, const int64_t *ia_dev,
+                         const int64_t *ja, const float *x, float *y,
+                         const bof_options *opts, void *stream);
+
+/* ---- level 3: file-resident matrices (the flash_ptr boundary) --------------- */
+/* A flash_ptr<T> is {file, byte offset}: include/pointers/pointer.h:15-18. */
+typedef struct {
+  int fd;           /* open file descriptor (O_DIRECT or buffered)            */
+  uint64_t foffset; /* byte offset of element 0                              */
+} bof_fptr;
+/* Blocking; returns after C has been written back to its file. */
+int bof_flash_gemm(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
+                   uint64_t k, float alpha, float beta, bof_fptr a, bof_fptr b,
+                   bof_fptr c, uint64_t lda, uint64_t ldb, uint64_t ldc,
+                   const bof_options *opts);
+int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha,
+                    float beta, bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b,
+                    bof_fptr b, bof_fptr c, const bof_options *opts);
+/* b (input vector) and c (output vector) are HOST pointers as in the reference
+ * (include/flash_blas.h:55-57). */
+int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a,
+                      bof_fptr ia, bof_fptr ja, const float *b, float *c,
+                      const bof_options *opts);
+/* Counters of the last level-3 call (bytes moved per stage, seconds). */
+typedef struct {
+  uint64_t bytes_read, bytes_written; /* file I/O                      */
+  uint64_t bytes_h2d, bytes_d2h;      /* PCIe                          */
+  uint64_t tasks;                     /* tile tasks executed           */
+  uint64_t tile_hits, tile_misses;    /* HBM tile cache                */
+  double seconds;                     /* wall time of the call         */
+} bof_flash_stats;
+int bof_flash_last_stats(bof_flash_stats *out);
+
+/* File handle primitives (FlashFileHandle::read/write/sread/swrite,
+ * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided
+ * region {stride, n_strides, len_per_stride} in bytes <-> packed host buffer. */
+int bof_file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
+                   uint64_t len_per_stride, void *buf, int use_aio);
+int bof_file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
+                    uint64_t len_per_stride, const void *buf, int use_aio);
+
+/* ---- synthetic inputs generated in HBM (bench / tests) ---------------------- */
+/* misc/dense_create.cpp:28-37: mode 's' -> x[i] = (first+i) % 10, 'z' -> 0;
+ * mode 'u' (ours) -> uniform [-1,1) from a counter-based hash of (seed, index). */
+int bof_gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed,
+                  void *stream);
+/* misc/sparse_create.cpp:50-81 for rows [row0, row0+nrows): csr/col get
+ * nrows*nnz_per_row entries, off gets nrows+1 (global offsets). */
+int bof_gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols,
+                        int64_t nnz_per_row, float *csr, int64_t *col, int64_t *off,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOF_HIP_H */

@@ -1,0 +1,138 @@
+"""-m gpu parity of the CSR kernels (SpMM / SpMV) against the oracle, the MKL
+golden vectors and the generator known answers."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import bofhip
+import orc
+from gpu_util import ptr, rel_err, stream, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def meta_rows(golden, prefix):
+    for line in golden["meta"]:
+        t = line.split()
+        if t[0].startswith(prefix):
+            yield t
+
+
+def exact_hash(golden, name):
+    for t in meta_rows(golden, "exact"):
+        if t[1] == name:
+            return t[2]
+    raise KeyError(name)
+
+
+def run_scsrmm(ord_b, m, n, k, alpha, beta, val, ia, ja, b, ldb, c0, ldc):
+    dv, di, dj, db, dc = to_dev(val), to_dev(ia), to_dev(ja), to_dev(b), to_dev(c0)
+    bofhip.scsrmm(ord_b, m, n, k, alpha, ptr(dv), ptr(dj), ptr(di), ptr(db), ldb, beta, ptr(dc),
+                  ldc, stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dj.cpu().numpy(), ja)  # indices never modified (App. B-15)
+    return dc.cpu().numpy()
+
+
+def test_golden_mkl_csrmm(dev, golden):
+    for t in meta_rows(golden, "csrmm"):
+        key, mat = t[0], t[7]
+        m, n, k = map(int, t[1:4])      # A m x n, B n x k
+        ord_b, alpha, beta = t[4], float(t[5]), float(t[6])
+        val, ia, ja = golden[mat + "_val"], golden[mat + "_ia"], golden[mat + "_ja"]
+        ldb, ldc = (k, k) if ord_b == "R" else (n, m)
+        got = run_scsrmm(ord_b, m, k, n, alpha, beta, val, ia, ja, golden[key + "_b"], ldb,
+                         golden[key + "_c0"], ldc)
+        assert rel_err(got, golden[key + "_c1"]) < TOL, key
+        ref = orc.scsrmm(ord_b, m, k, n, alpha, val, ja, ia, golden[key + "_b"], ldb, beta,
+                         golden[key + "_c0"].copy(), ldc)
+        assert np.array_equal(got, ref), key   # same fmaf chain as the oracle
+
+
+@pytest.mark.parametrize("ncol", [128, 40, 1030, 7, 256, 64])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (0.5, 2.0)])
+def test_scsrmm_rowmajor_widths(dev, ncol, alpha, beta):
+    """Every vector width / column-pass path, ragged rows incl. empty rows and a
+    row longer than one 64-entry segment."""
+    rng = np.random.default_rng(ncol)
+    m, n = 333, 900
+    counts = rng.integers(0, 30, m)
+    counts[5] = 0
+    counts[17] = 200
+    counts[m - 1] = 65
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, ncol)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, ncol)).astype(np.float32)
+    ref = orc.scsrmm("R", m, ncol, n, alpha, val, ja, ia, b, ncol, beta, c0.copy(), ncol)
+    got = run_scsrmm("R", m, ncol, n, alpha, beta, val, ia, ja, b, ncol, c0, ncol)
+    assert np.array_equal(got, ref)
+
+
+def test_csrmm_resident_blocks_and_panels(dev, golden):
+    """flash::csrmm structure: nnz-budget row blocks x column panels (k=1030 > CBLK
+    forces two panels), R and C layouts, on the reference generator's matrix; the
+    k=128 'R' result is pinned by the MKL golden hash."""
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    dv, dj, di = to_dev(val), to_dev(ja), to_dev(ia)
+    opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000, csrmm_cblk=1024)
+    for k, ord_b, alpha, beta in [(128, "R", 1.0, 0.0), (1030, "R", 0.5, 2.0), (1030, "C", 0.5, 2.0),
+                                  (128, "C", 1.0, 0.0)]:
+        b = orc.dense_fill(n, k, "s")
+        rng = np.random.default_rng(k)
+        c0 = rng.integers(0, 5, (m, k)).astype(np.float32) if beta else np.zeros((m, k), np.float32)
+        if ord_b == "C":
+            b = np.ascontiguousarray(b.T)      # col-major n x k
+            c0 = np.ascontiguousarray(c0.T)
+        ref = orc.flash_csrmm(ord_b, m, n, k, alpha, beta, val, ia, ja, b, c0.copy(),
+                              max_rows=1000, max_nnz=5000, cblk=1024)
+        db, dc = to_dev(b), to_dev(c0)
+        bofhip.csrmm_resident("N", m, n, k, alpha, beta, ptr(dv), ia.ctypes.data, ptr(di), ptr(dj),
+                              ord_b, ptr(db), ptr(dc), opts, stream())
+        torch.cuda.synchronize()
+        got = dc.cpu().numpy()
+        assert np.array_equal(got, ref), (k, ord_b)
+        if (k, ord_b, beta) == (128, "R", 0.0):
+            assert hashlib.sha256(got.tobytes()).hexdigest() == exact_hash(golden, "gen_csrmm_c")
+    with pytest.raises(bofhip.BofError):   # reference returns -1 for bad flags too
+        bofhip.csrmm_resident("N", m, n, 128, 1.0, 0.0, ptr(dv), ia.ctypes.data, ptr(di), ptr(dj),
+                              "X", ptr(db), ptr(dc), opts, stream())
+
+
+def test_golden_mkl_csrgemv(dev, golden):
+    for t in meta_rows(golden, "csrgemv"):
+        key, mat = t[0], t[4]
+        m, n, trans = int(t[1]), int(t[2]), t[3]
+        val, ia, ja = golden[mat + "_val"], golden[mat + "_ia"], golden[mat + "_ja"]
+        x = golden[key + "_x"]
+        dv, di, dj, dx = to_dev(val), to_dev(ia), to_dev(ja), to_dev(x)
+        dy = torch.zeros(m if trans == "N" else n, dtype=torch.float32, device=dev)
+        bofhip.scsrgemv(trans, m, n, ptr(dv), ptr(di), ptr(dj), ptr(dx), ptr(dy), stream())
+        torch.cuda.synchronize()
+        got = dy.cpu().numpy()
+        assert rel_err(got, golden[key + "_y"]) < TOL, key
+        if trans == "N":
+            ref = orc.scsrgemv("N", m, n, val, ia, ja, x, np.zeros(m, np.float32))
+            assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("trans", ["N", "T"])
+def test_csrgemv_resident_generator_known_answer(dev, golden, trans):
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    x = (np.arange(n if trans == "N" else m) % 10).astype(np.float32)
+    dv, dj, di, dx = to_dev(val), to_dev(ja), to_dev(ia), to_dev(x)
+    dy = torch.full((m if trans == "N" else n,), 7.0, dtype=torch.float32, device=dev)
+    opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000)
+    bofhip.csrgemv_resident(trans, m, n, ptr(dv), ia.ctypes.data, ptr(di), ptr(dj), ptr(dx),
+                            ptr(dy), opts, stream())
+    torch.cuda.synchronize()
+    got = dy.cpu().numpy()
+    ref = orc.flash_csrgemv(trans, m, n, val, ia, ja, x, np.zeros_like(got), 1000, 5000)
+    assert np.array_equal(got, ref)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == exact_hash(golden, "gen_csrgemv_" + trans)

@@ -1,0 +1,146 @@
+"""-m gpu parity of the fp32 MFMA tile GEMM and the resident tile DAG against the
+oracle (bit-exact: both are k-ordered fmaf chains) and the MKL golden vectors
+(1e-4 relative, BASELINE.json north_star)."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+import bofhip
+import orc
+from gpu_util import ptr, rel_err, stream, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # north_star: fp32 within 1e-4 relative
+
+
+def stored_shapes(ord_, ta, tb, m, n, k):
+    a = (m, k) if (ta == "T") == (ord_ == "C") else (k, m)
+    b = (k, n) if (tb == "T") == (ord_ == "C") else (n, k)
+    c = (m, n) if ord_ == "R" else (n, m)
+    return a, b, c
+
+
+def run_sgemm(ord_, ta, tb, m, n, k, alpha, beta, a, lda, b, ldb, c, ldc):
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c)
+    bofhip.sgemm(ord_, ta, tb, m, n, k, alpha, ptr(da), lda, ptr(db), ldb, beta, ptr(dc), ldc,
+                 stream())
+    torch.cuda.synchronize()
+    return dc.cpu().numpy()
+
+
+def test_golden_mkl_gemm(dev, golden):
+    """The reference's cblas_sgemm outputs (tests/golden) for all 8 layouts."""
+    for line in golden["meta"]:
+        t = line.split()
+        if not t[0].startswith("gemm"):
+            continue
+        key = t[0]
+        m, n, k = map(int, t[1:4])
+        ord_, ta, tb = t[4:7]
+        alpha, beta = float(t[7]), float(t[8])
+        lda, ldb, ldc = map(int, t[9:12])
+        got = run_sgemm(ord_, ta, tb, m, n, k, alpha, beta, golden[key + "_a"], lda,
+                        golden[key + "_b"], ldb, golden[key + "_c0"], ldc)
+        ref = golden[key + "_c1"]
+        assert rel_err(got, ref) < TOL, (key, ord_, ta, tb)
+        # padding columns of C (beyond the logical width) must be untouched
+        cc = n if ord_ == "R" else m
+        assert np.array_equal(got[:, cc:], golden[key + "_c0"][:, cc:]), key
+
+
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+@pytest.mark.parametrize("m,n,k,alpha,beta", [
+    (256, 384, 320, 1.0, 0.0),      # aligned fast path (multiples of the 128x128x32 tile)
+    (300, 200, 500, 0.5, 2.0),      # ragged: guarded path, m/n/k tails
+    (128, 128, 32, 1.0, 1.0),       # single block, single K slab
+    (1, 1, 1, 2.0, 0.0),            # degenerate
+    (129, 127, 33, -1.5, 0.25),     # one past / one short of the tile edges
+])
+def test_sgemm_bit_exact_vs_oracle(dev, ord_, ta, tb, m, n, k, alpha, beta):
+    rng = np.random.default_rng(hash((ord_, ta, tb, m, n, k)) & 0xFFFF)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    pad = 0 if (m % 128 == 0) else 3
+    lda, ldb, ldc = sa[1] + pad, sb[1] + pad, sc[1] + pad
+    a = rng.uniform(-1, 1, (sa[0], lda)).astype(np.float32)
+    b = rng.uniform(-1, 1, (sb[0], ldb)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (sc[0], ldc)).astype(np.float32)
+    ref = orc.sgemm(ord_, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0.copy(), ldc)
+    got = run_sgemm(ord_, ta, tb, m, n, k, alpha, beta, a, lda, b, ldb, c0, ldc)
+    assert np.array_equal(got, ref), (rel_err(got, ref))
+    # and against float64 within the north-star tolerance
+    A = a[:, :sa[1]].astype(np.float64)
+    B = b[:, :sb[1]].astype(np.float64)
+    if ord_ == "C":
+        opA = A.T if ta == "N" else A
+        opB = B.T if tb == "N" else B
+    else:
+        opA = A if ta == "N" else A.T
+        opB = B if tb == "N" else B.T
+    full = alpha * (opA @ opB)
+    c64 = c0[:, :sc[1]].astype(np.float64)
+    full = full + beta * (c64 if ord_ == "R" else c64.T)
+    gotl = got[:, :sc[1]] if ord_ == "R" else got[:, :sc[1]].T
+    assert rel_err(gotl, full) < TOL
+
+
+def test_sgemm_k_zero_and_empty(dev):
+    c0 = np.arange(12, dtype=np.float32).reshape(3, 4)
+    a = np.zeros((3, 1), np.float32)
+    b = np.zeros((1, 4), np.float32)
+    got = run_sgemm("R", "N", "N", 3, 4, 0, 1.0, 2.0, a, 1, b, 4, c0, 4)
+    assert np.array_equal(got, 2.0 * c0)
+    got = run_sgemm("R", "N", "N", 0, 4, 5, 1.0, 2.0, a, 5, b, 4, c0, 4)
+    assert np.array_equal(got, c0)
+
+
+def test_sgemm_bad_args(dev):
+    with pytest.raises(bofhip.BofError):
+        bofhip.sgemm("X", "N", "N", 1, 1, 1, 1.0, 0, 1, 0, 1, 0.0, 0, 1)
+
+
+@pytest.mark.parametrize("ord_,ta,tb", [("R", "N", "N"), ("R", "T", "N"), ("C", "N", "T"),
+                                        ("C", "T", "T")])
+def test_gemm_resident_matches_flash_oracle(dev, ord_, ta, tb):
+    """Tile DAG with tail-merge (640x600x500, tile 256: m 256+256+128, k 256+344,
+    n 256+244 -- SURVEY App. D-1 example) against the restated flash::gemm."""
+    m, k, n, blk = 640, 600, 500, 256
+    alpha, beta = 0.5, 2.0
+    rng = np.random.default_rng(7)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c0.copy(), 0, 0, 0, blk)
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c0)
+    opts = bofhip.default_options(gemm_blk=blk, n_streams=3)
+    bofhip.gemm_resident(ord_, ta, tb, m, n, k, alpha, beta, ptr(da), ptr(db), ptr(dc), 0, 0, 0,
+                         opts, stream())
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy()
+    assert np.array_equal(got, ref), rel_err(got, ref)
+    whole = orc.sgemm(ord_, ta, tb, m, n, k, alpha, a, sa[1], b, sb[1], beta, c0.copy(), sc[1])
+    assert rel_err(got, whole) < TOL   # in_mem_gemm oracle (gemm_run.sh comparison)
+
+
+def test_gemm_4096_generator_known_answer(dev):
+    """cfg1 known answer: dense_create 's' inputs, 4096^3,
+    C[0,0:4] = [81850, 100270, 73670, 92090]; full check against the closed form
+    (C[i,j] depends on (i mod 5, j mod 10) because 4096 = 6 mod 10)."""
+    n = 4096
+    a = torch.empty(n * n, dtype=torch.float32, device=dev)
+    c = torch.empty(n * n, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(ptr(a), 0, n * n, "s", 0, stream())
+    bofhip.gemm_resident("R", "N", "N", n, n, n, 1.0, 0.0, ptr(a), ptr(a), ptr(c), 0, 0, 0,
+                         bofhip.default_options(gemm_blk=1024), stream())
+    torch.cuda.synchronize()
+    C = c.view(n, n)
+    assert C[0, :4].tolist() == [81850.0, 100270.0, 73670.0, 92090.0]
+    # closed form: rows i and i+5 equal, columns j and j+10 equal
+    idx = torch.arange(n, device=dev)
+    pat = C[:5, :10]
+    assert torch.equal(C, pat[idx % 5][:, idx % 10])
+    A64 = (np.arange(5 * n, dtype=np.int64) % 10).reshape(5, n).astype(np.float64)
+    B64 = ((np.arange(n)[:, None] * n + np.arange(10)[None, :]) % 10).astype(np.float64)
+    assert np.array_equal(pat.cpu().numpy().astype(np.float64), A64 @ B64)
