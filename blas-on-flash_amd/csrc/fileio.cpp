@@ -1,0 +1,197 @@
+// fileio.cpp -- strided file <-> packed host buffer transfers for the tile reader.
+//
+// Host-side equivalent of the reference's FlashFileHandle::read/write/sread/swrite
+// (src/file_handles/flash_file_handle.cpp:247-716): a region is
+// {offset, stride, n_strides, len_per_stride} in bytes (StrideInfo,
+// include/file_handles/file_handle.h:19-34) and the memory side is packed.
+//
+//  * sector-aligned requests on an O_DIRECT descriptor go through Linux kernel
+//    AIO (raw io_setup/io_submit/io_getevents syscalls -- libaio is only a thin
+//    wrapper and is not required), one iocb per stride, contiguous requests cut
+//    into 32 MiB pieces, one AIO context per calling thread;
+//  * anything unaligned (CSR index/value segments, leading dimensions that are
+//    not multiples of 128 floats) goes through a buffered descriptor of the same
+//    file, where the kernel's page cache does the read-modify-write that the
+//    reference does by hand with bounce buffers and write-overlap ordering
+//    (flash_file_handle.cpp:462-716, io_executor.cpp:28-156).  Linux keeps
+//    O_DIRECT and buffered I/O on one file coherent at syscall granularity.
+#include <errno.h>
+#include <fcntl.h>
+#include <linux/aio_abi.h>
+#include <string.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "bof_internal.h"
+#include "fileio.h"
+
+namespace bof {
+
+static constexpr uint64_t kSector = 512;
+static constexpr uint64_t kMaxChunk = 32ull << 20;  // reference MAX_CHUNK_SIZE
+static constexpr unsigned kAioEvents = 1024;
+static constexpr int kIoRetries = 5;                // reference submit_and_reap retries
+
+static inline bool al(uint64_t v) { return (v % kSector) == 0; }
+
+// ---- per-thread AIO context -------------------------------------------------------
+struct AioCtx {
+  aio_context_t ctx = 0;
+  bool ok = false;
+  AioCtx() { ok = (syscall(SYS_io_setup, kAioEvents, &ctx) == 0); }
+  ~AioCtx() { if (ok) syscall(SYS_io_destroy, ctx); }
+};
+static AioCtx &tls_ctx() {
+  static thread_local AioCtx c;
+  return c;
+}
+
+static int aio_run(std::vector<struct iocb> &cbs) {
+  AioCtx &c = tls_ctx();
+  if (!c.ok) return -ENOSYS;
+  std::vector<struct iocb *> ptrs(cbs.size());
+  for (size_t i = 0; i < cbs.size(); i++) ptrs[i] = &cbs[i];
+  std::vector<struct io_event> evs(kAioEvents);
+  size_t submitted = 0, done = 0;
+  int retries = 0;
+  while (done < cbs.size()) {
+    const size_t inflight = submitted - done;
+    if (submitted < cbs.size() && inflight < kAioEvents) {
+      const long want = (long) std::min<size_t>(cbs.size() - submitted, kAioEvents - inflight);
+      long r = syscall(SYS_io_submit, c.ctx, want, ptrs.data() + submitted);
+      if (r < 0) {
+        if ((errno == EAGAIN || errno == EINTR) && ++retries <= kIoRetries) continue;
+        if (inflight == 0) return -errno;
+      } else {
+        submitted += (size_t) r;
+      }
+    }
+    if (submitted > done) {
+      long r = syscall(SYS_io_getevents, c.ctx, 1L, (long) std::min<size_t>(submitted - done, kAioEvents),
+                       evs.data(), nullptr);
+      if (r < 0) {
+        if (errno == EINTR) continue;
+        return -errno;
+      }
+      for (long i = 0; i < r; i++) {
+        const struct iocb *cb = reinterpret_cast<const struct iocb *>(evs[i].obj);
+        if ((int64_t) evs[i].res < 0) return (int) evs[i].res;
+        if ((uint64_t) evs[i].res != cb->aio_nbytes) return -EIO;  // short transfer
+      }
+      done += (size_t) r;
+    }
+  }
+  return 0;
+}
+
+// ---- buffered twin of an O_DIRECT descriptor ---------------------------------------
+static std::mutex g_twin_mu;
+static std::unordered_map<int, int> g_twin;
+static int buffered_twin(int fd) {
+  std::lock_guard<std::mutex> lk(g_twin_mu);
+  auto it = g_twin.find(fd);
+  if (it != g_twin.end()) return it->second;
+  const std::string path = "/proc/self/fd/" + std::to_string(fd);
+  int t = ::open(path.c_str(), O_RDWR);
+  if (t < 0) t = ::open(path.c_str(), O_RDONLY);
+  g_twin[fd] = t;
+  return t;
+}
+void file_forget(int fd) {
+  std::lock_guard<std::mutex> lk(g_twin_mu);
+  auto it = g_twin.find(fd);
+  if (it != g_twin.end()) {
+    if (it->second >= 0) ::close(it->second);
+    g_twin.erase(it);
+  }
+}
+bool file_is_direct(int fd) {
+  const int fl = fcntl(fd, F_GETFL);
+  return fl >= 0 && (fl & O_DIRECT);
+}
+
+static int rw_full(int fd, bool wr, char *buf, uint64_t len, uint64_t off) {
+  uint64_t done = 0;
+  int retries = 0;
+  while (done < len) {
+    ssize_t r = wr ? ::pwrite(fd, buf + done, len - done, (off_t) (off + done))
+                   : ::pread(fd, buf + done, len - done, (off_t) (off + done));
+    if (r < 0) {
+      if ((errno == EINTR || errno == EAGAIN) && ++retries <= kIoRetries) continue;
+      return -errno;
+    }
+    if (r == 0) return -EIO;  // EOF inside the region
+    done += (uint64_t) r;
+  }
+  return 0;
+}
+
+static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_t n_strides,
+                      uint64_t len, void *buf, bool use_aio) {
+  if (n_strides == 0 || len == 0) return 0;
+  if (n_strides > 1 && stride == len) {  // dense region: one contiguous transfer
+    len *= n_strides;
+    n_strides = 1;
+  }
+  const bool direct = file_is_direct(fd);
+  const bool aligned = al(offset) && al(len) && (n_strides == 1 || al(stride)) &&
+                       al(reinterpret_cast<uintptr_t>(buf));
+  if (direct && !aligned) {
+    fd = buffered_twin(fd);
+    if (fd < 0) return -EBADF;
+  }
+  char *p = static_cast<char *>(buf);
+  if (direct && aligned && use_aio && tls_ctx().ok) {
+    std::vector<struct iocb> cbs;
+    cbs.reserve(n_strides == 1 ? (size_t) (len / kMaxChunk + 1) : (size_t) n_strides);
+    for (uint64_t s = 0; s < n_strides; s++) {
+      for (uint64_t o = 0; o < len; o += kMaxChunk) {
+        struct iocb cb;
+        memset(&cb, 0, sizeof(cb));
+        cb.aio_fildes = (uint32_t) fd;
+        cb.aio_lio_opcode = wr ? IOCB_CMD_PWRITE : IOCB_CMD_PREAD;
+        cb.aio_buf = reinterpret_cast<uint64_t>(p + s * len + o);
+        cb.aio_nbytes = std::min(kMaxChunk, len - o);
+        cb.aio_offset = (int64_t) (offset + s * stride + o);
+        cbs.push_back(cb);
+      }
+    }
+    const int rc = aio_run(cbs);
+    if (rc != -ENOSYS) return rc;
+  }
+  for (uint64_t s = 0; s < n_strides; s++) {
+    const int rc = rw_full(fd, wr, p + s * len, len, offset + s * stride);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
+               void *buf, bool use_aio) {
+  return strided_io(fd, false, offset, stride, n_strides, len, buf, use_aio);
+}
+int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
+                const void *buf, bool use_aio) {
+  return strided_io(fd, true, offset, stride, n_strides, len, const_cast<void *>(buf), use_aio);
+}
+
+}  // namespace bof
+
+extern "C" int bof_file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
+                              uint64_t len_per_stride, void *buf, int use_aio) {
+  const int rc = bof::file_sread(fd, offset, stride, n_strides, len_per_stride, buf, use_aio != 0);
+  if (rc) { bof::set_error(std::string("bof_file_sread: ") + strerror(-rc)); return BOF_EIO; }
+  return BOF_OK;
+}
+extern "C" int bof_file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
+                               uint64_t len_per_stride, const void *buf, int use_aio) {
+  const int rc = bof::file_swrite(fd, offset, stride, n_strides, len_per_stride, buf, use_aio != 0);
+  if (rc) { bof::set_error(std::string("bof_file_swrite: ") + strerror(-rc)); return BOF_EIO; }
+  return BOF_OK;
+}

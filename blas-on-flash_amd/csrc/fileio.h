@@ -1,0 +1,12 @@
+// fileio.h -- strided file <-> packed host buffer transfers (fileio.cpp)
+#pragma once
+#include <stdint.h>
+namespace bof {
+// return 0 or -errno
+int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
+               void *buf, bool use_aio);
+int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
+                const void *buf, bool use_aio);
+bool file_is_direct(int fd);
+void file_forget(int fd);  // drop the cached buffered twin of fd (call before close)
+}  // namespace bof
