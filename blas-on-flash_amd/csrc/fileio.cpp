@@ -19,6 +19,7 @@
 #include <fcntl.h>
 #include <linux/aio_abi.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -96,7 +97,15 @@ static std::unordered_map<int, int> g_twin;
 static int buffered_twin(int fd) {
   std::lock_guard<std::mutex> lk(g_twin_mu);
   auto it = g_twin.find(fd);
-  if (it != g_twin.end()) return it->second;
+  if (it != g_twin.end()) {
+    // descriptor numbers get recycled: the cached twin must still name the same file
+    struct stat a, b;
+    if (it->second >= 0 && fstat(fd, &a) == 0 && fstat(it->second, &b) == 0 &&
+        a.st_dev == b.st_dev && a.st_ino == b.st_ino)
+      return it->second;
+    if (it->second >= 0) ::close(it->second);
+    g_twin.erase(it);
+  }
   const std::string path = "/proc/self/fd/" + std::to_string(fd);
   int t = ::open(path.c_str(), O_RDWR);
   if (t < 0) t = ::open(path.c_str(), O_RDONLY);

@@ -1,0 +1,37 @@
+// flash_blas.h -- the flash BLAS kernel API, hot-path subset, with the reference's
+// names, argument order and defaults (include/flash_blas.h:14-18, 37-46, 55-57).
+// Implemented in src/flash_api.cpp on top of the C ABI of libbof_hip.so
+// (include/bof_hip.h): tiles stream file -> pinned ring -> HBM and are computed
+// by hand-written gfx950 kernels.  Out-of-scope kernels of the reference (kmeans,
+// csrcsc, sort, map, reduce, the never-defined gemv) are not declared.
+#pragma once
+#include <functional>
+
+#include "bof_logger.h"
+#include "bof_types.h"
+#include "pointers/allocator.h"
+#include "pointers/pointer.h"
+
+namespace flash {
+  // C = alpha*op(A)*op(B) + beta*C ; mat_ord 'R'|'C', trans_* 'N'|'T'; leading dims in
+  // elements (0 = tight).  Returns 0.
+  FBLAS_INT gemm(CHAR mat_ord, CHAR trans_a, CHAR trans_b, FBLAS_UINT m, FBLAS_UINT n,
+                 FBLAS_UINT k, FPTYPE alpha, FPTYPE beta, flash_ptr<FPTYPE> a,
+                 flash_ptr<FPTYPE> b, flash_ptr<FPTYPE> c, FBLAS_UINT lda_a = 0,
+                 FBLAS_UINT lda_b = 0, FBLAS_UINT lda_c = 0);
+
+  // C = alpha*A*B + beta*C with A (m x n) in CSR {a, ia, ja}, B (n x k) and C (m x k)
+  // dense row- ('R') or column-major ('C').  Returns 0, or -1 for unrecognised flags.
+  FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha,
+                  FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
+                  CHAR ord_b, flash_ptr<FPTYPE> b, flash_ptr<FPTYPE> c);
+
+  // variant with B and C in host memory
+  FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha,
+                  FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
+                  CHAR ord_b, FPTYPE* b, FPTYPE* c);
+
+  // c = A*b ('N') or A^T*b ('T'); b and c are host vectors
+  FBLAS_INT csrgemv(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, flash_ptr<FPTYPE> a,
+                    flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja, FPTYPE* b, FPTYPE* c);
+}  // namespace flash

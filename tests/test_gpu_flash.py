@@ -1,0 +1,266 @@
+"""-m gpu parity of the FILE-resident path (level 3: reader -> pinned ring -> HBM
+tile cache -> kernels -> write-back) through the C ABI and through the C++
+drivers, against the oracle's restated flash::gemm/csrmm/csrgemv (bit-exact)."""
+import itertools
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bofhip
+import orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "blas-on-flash_amd", "bin")
+
+
+def stored_shapes(ord_, ta, tb, m, n, k):
+    a = (m, k) if (ta == "T") == (ord_ == "C") else (k, m)
+    b = (k, n) if (tb == "T") == (ord_ == "C") else (n, k)
+    c = (m, n) if ord_ == "R" else (n, m)
+    return a, b, c
+
+
+def open_rw(path, direct=True):
+    if direct:
+        try:
+            return os.open(path, os.O_RDWR | os.O_DIRECT)
+        except OSError:
+            pass
+    return os.open(path, os.O_RDWR)
+
+
+class Files:
+    def __init__(self, tmp_path, direct=True, **arrays):
+        self.paths, self.fds = {}, {}
+        for name, arr in arrays.items():
+            p = str(tmp_path / f"{name}.bin")
+            np.ascontiguousarray(arr).tofile(p)
+            self.paths[name] = p
+            self.fds[name] = open_rw(p, direct)
+
+    def fptr(self, name, byte_off=0):
+        return bofhip.FPtr(self.fds[name], byte_off)
+
+    def read(self, name, dtype, shape):
+        return np.fromfile(self.paths[name], dtype).reshape(shape)
+
+    def close(self):
+        for fd in self.fds.values():
+            os.close(fd)
+
+
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_flash_gemm_layouts_unaligned(dev, tmp_path, ord_, ta, tb):
+    """SURVEY 8c trust-matrix shape: 640x600x500 with unaligned leading dims, tile
+    256 (separate tail, merged tail), alpha=0.5, beta=2, random C, all 8 layouts."""
+    m, k, n, blk = 640, 600, 500, 256
+    rng = np.random.default_rng(11)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=3, pinned_slots=4)
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"),
+                          0, 0, 0, opts)
+        got = F.read("c", np.float32, sc)
+        assert np.array_equal(got, ref)
+        st = bofhip.flash_last_stats()
+        assert st["tasks"] == 12
+        assert st["bytes_read"] == 4 * (a.size + b.size + c0.size)   # every tile read once
+        assert st["bytes_written"] == 4 * c0.size                    # C written once
+    finally:
+        F.close()
+
+
+def test_flash_gemm_aligned_multitile_small_budget(dev, tmp_path):
+    """1024^3 with 256-tiles (4x4x4 = 64 tasks), HBM budget of 12 tile slots: forces the
+    C super-block ordering and farthest-next-use eviction; C written once, never re-read."""
+    n, blk = 1024, 256
+    a = orc.dense_fill(n, n, "s")
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    c0 = np.zeros((n, n), np.float32)
+    ref = orc.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, hbm_budget=12 * blk * blk * 4, n_streams=2)
+        bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"),
+                          0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, (n, n)), ref)
+        st = bofhip.flash_last_stats()
+        assert st["tasks"] == 64 and st["bytes_written"] == 4 * n * n
+        # beta == 0: C never read; A and B re-read at most (#super-block passes) times
+        assert 2 * 4 * n * n <= st["bytes_read"] <= 6 * 4 * n * n
+    finally:
+        F.close()
+    # with the whole working set resident every tile is read exactly once
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"),
+                          0, 0, 0, bofhip.default_options(gemm_blk=blk))
+        assert np.array_equal(F.read("c", np.float32, (n, n)), ref)
+        assert bofhip.flash_last_stats()["bytes_read"] == 2 * 4 * n * n
+    finally:
+        F.close()
+
+
+def test_flash_gemm_foffset_and_row_shard(dev, tmp_path):
+    """flash_ptr + offset: two 'ranks' each compute a row slab of C in place (the
+    multi-GPU sharding of SURVEY 8e run sequentially on one GPU), with a 4 KiB header
+    in front of every matrix (foffset != 0)."""
+    import bof_dist
+    m, k, n, blk, hdr = 512, 384, 256, 128, 4096
+    rng = np.random.default_rng(2)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    ref = orc.flash_gemm("R", "N", "N", m, n, k, 1.0, 1.0, a, b, c0.copy(), 0, 0, 0, blk)
+    pad = np.zeros(hdr // 4, np.float32)
+    F = Files(tmp_path, a=np.concatenate([pad, a.ravel()]), b=np.concatenate([pad, b.ravel()]),
+              c=np.concatenate([pad, c0.ravel()]))
+    try:
+        opts = bofhip.default_options(gemm_blk=blk)
+        for rank in range(2):
+            ml, offa, offc = bof_dist.gemm_shard_args(m, n, k, 0, 0, 2, rank, blk)
+            bofhip.flash_gemm("R", "N", "N", ml, n, k, 1.0, 1.0, F.fptr("a", hdr + 4 * offa),
+                              F.fptr("b", hdr), F.fptr("c", hdr + 4 * offc), 0, 0, 0, opts)
+        got = F.read("c", np.float32, (-1,))[hdr // 4:].reshape(m, n)
+        assert np.array_equal(got, ref)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_b,k,alpha,beta", [("R", 128, 1.0, 0.0), ("R", 1030, 0.5, 2.0),
+                                               ("C", 128, 1.0, 0.0), ("C", 1030, 0.5, 2.0)])
+def test_flash_csrmm(dev, tmp_path, golden, ord_b, k, alpha, beta):
+    """SURVEY 8c csrmm cases incl. ('C', k=1030) which the reference gets wrong
+    (App. B-15: in-place 1-based conversion of a shared cached buffer)."""
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    b = orc.dense_fill(n, k, "s")
+    rng = np.random.default_rng(k)
+    c0 = rng.integers(0, 5, (m, k)).astype(np.float32) if beta else np.zeros((m, k), np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    ref = orc.flash_csrmm(ord_b, m, n, k, alpha, beta, val, ia, ja, b, c0.copy(), 1000, 5000, 1024)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000, n_io_threads=2)
+        bofhip.flash_csrmm("N", m, n, k, alpha, beta, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
+                           ord_b, F.fptr("b"), F.fptr("c"), opts)
+        got = F.read("c", np.float32, c0.shape)
+        assert np.array_equal(got, ref)
+        assert np.array_equal(F.read("ja", np.int64, (-1,)), ja)     # CSR files untouched
+        assert np.array_equal(F.read("ia", np.int64, (-1,)), ia)
+        # reference error behaviour: -1 for unrecognised flags (csrmm.cpp:433-448)
+        with pytest.raises(bofhip.BofError):
+            bofhip.flash_csrmm("N", m, n, k, alpha, beta, F.fptr("val"), F.fptr("ia"),
+                               F.fptr("ja"), "X", F.fptr("b"), F.fptr("c"), opts)
+        with pytest.raises(bofhip.BofError):
+            bofhip.flash_csrmm("Q", m, n, k, alpha, beta, F.fptr("val"), F.fptr("ia"),
+                               F.fptr("ja"), ord_b, F.fptr("b"), F.fptr("c"), opts)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("trans", ["N", "T"])
+def test_flash_csrgemv(dev, tmp_path, golden, trans):
+    import hashlib
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    x = (np.arange(n if trans == "N" else m) % 10).astype(np.float32)
+    y = np.full(m if trans == "N" else n, 3.0, np.float32)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000)
+        bofhip.flash_csrgemv(trans, m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), x.ctypes.data,
+                             y.ctypes.data, opts)
+        want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
+        assert hashlib.sha256(y.tobytes()).hexdigest() == want["gen_csrgemv_" + trans]
+    finally:
+        F.close()
+
+
+def test_flash_csr_ragged_random(dev, tmp_path):
+    """Random values, ragged rows incl. empty rows and empty blocks; buffered descriptors."""
+    rng = np.random.default_rng(9)
+    m, n, k = 3000, 777, 96
+    counts = rng.integers(0, 12, m)
+    counts[100:400] = 0
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    ref = orc.flash_csrmm("R", m, n, k, 0.5, 2.0, val, ia, ja, b, c0.copy(), 200, 300, 64)
+    F = Files(tmp_path, direct=False, val=val, ja=ja, ia=ia, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(max_nnzs=300, csrmm_rblk=200, csrmm_cblk=64, use_odirect=0)
+        bofhip.flash_csrmm("N", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), "R",
+                           F.fptr("b"), F.fptr("c"), opts)
+        assert np.array_equal(F.read("c", np.float32, (m, k)), ref)
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        y = np.zeros(m, np.float32)
+        bofhip.flash_csrgemv("N", m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), x.ctypes.data,
+                             y.ctypes.data, opts)
+        assert np.array_equal(y, orc.flash_csrgemv("N", m, n, val, ia, ja, x, np.zeros(m, np.float32), 200, 300))
+        xt = rng.uniform(-1, 1, m).astype(np.float32)
+        yt = np.zeros(n, np.float32)
+        bofhip.flash_csrgemv("T", m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), xt.ctypes.data,
+                             yt.ctypes.data, opts)
+        rt = orc.flash_csrgemv("T", m, n, val, ia, ja, xt, np.zeros(n, np.float32), 200, 300)
+        assert np.abs(yt - rt).max() / np.abs(rt).max() < 1e-4   # atomics: order-dependent rounding
+    finally:
+        F.close()
+
+
+# ---- the C++ API through the drivers (same argv as the reference's drivers) ----------------
+def run_driver(name, args, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([os.path.join(BIN, name)] + [str(a) for a in args], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_gemm_driver(dev, tmp_path):
+    m, k, n = 384, 256, 512
+    rng = np.random.default_rng(4)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)       # 'T': stored n x k
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    ref = orc.flash_gemm("R", "N", "T", m, n, k, 1.5, 0.5, a, b, c0.copy(), 0, 0, 0, 128)
+    pa, pb, pc = (str(tmp_path / f) for f in ("A", "B", "C"))
+    a.tofile(pa); b.tofile(pb); c0.tofile(pc)
+    out = run_driver("gemm_driver", [pa, pb, pc, m, k, n, 1.5, 0.5, "N", "T", "R", k, k, n],
+                     {"BOF_GEMM_BLK_SIZE": "128"})
+    assert "gemm() took" in out and "returned with 0" in out
+    assert np.array_equal(np.fromfile(pc, np.float32).reshape(m, n), ref)
+
+
+def test_csrmm_and_csrgemv_drivers(dev, tmp_path, golden):
+    import hashlib
+    m, n, k = 4096, 2048, 128
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    b = orc.dense_fill(n, k, "s")
+    p = {x: str(tmp_path / x) for x in ("csr", "col", "off", "B", "C", "x", "y")}
+    val.tofile(p["csr"]); ja.tofile(p["col"]); ia.tofile(p["off"]); b.tofile(p["B"])
+    np.zeros((m, k), np.float32).tofile(p["C"])
+    env = {"BOF_MAX_NNZS": "5000", "BOF_CSRMM_RBLK_SIZE": "1000"}
+    out = run_driver("csrmm_driver", [p["csr"], p["col"], p["off"], p["B"], p["C"], m, n, k, 1.0, 0.0,
+                                      "N", "R"], env)
+    assert "csrmm() took" in out
+    want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
+    assert hashlib.sha256(np.fromfile(p["C"], np.float32).tobytes()).hexdigest() == want["gen_csrmm_c"]
+    for trans in "NT":
+        (np.arange(n if trans == "N" else m) % 10).astype(np.float32).tofile(p["x"])
+        np.zeros(m if trans == "N" else n, np.float32).tofile(p["y"])
+        run_driver("csrgemv_driver", [p["csr"], p["col"], p["off"], p["x"], p["y"], m, n, trans], env)
+        assert hashlib.sha256(np.fromfile(p["y"], np.float32).tobytes()).hexdigest() == \
+            want["gen_csrgemv_" + trans]

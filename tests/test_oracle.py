@@ -1,0 +1,211 @@
+"""CPU tests of the oracle (oracle/bof_oracle.c): pinned to the reference tools'
+known answers, to oracle/_ref/dense_create (the reference's
+own source compiled unmodified) and to the MKL golden vectors."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def h16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_rand_r_matches_glibc():
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.rand_r.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+    for seed in (0, 1, 12345, 2**31, 2**32 - 1):
+        a, b = ctypes.c_uint(seed), ctypes.c_uint(seed)
+        for _ in range(50):
+            assert orc.lib().orc_rand_r(ctypes.byref(a)) == libc.rand_r(ctypes.byref(b))
+            assert a.value == b.value
+
+
+# sha256[:16] of the files written by the compiled reference tools
+@pytest.mark.parametrize("nrows,ncols,sp,npr,csr,col,off,first", [
+    (64, 1000, 0.01, 10, "d8503dd0b005b159", "5c25d609762b16cd", "6cfa6d1ddb47f16a",
+     [5, 19, 55, 99, 117, 118]),
+    (1000, 100000, 0.0001, 10, "4ab90aabd38c5029", "df0b4409a7318e45", "f0510c987daf1cfe",
+     [2668, 3601, 5099, 5836, 8828, 9165]),
+    (4096, 2048, 0.01, 21, "0f7f6e93eeac0fdb", "19d3d33d2e9e0cfc", "2b8ca0ee3390fec1",
+     [21, 85, 87, 97, 129, 134]),
+])
+def test_sparse_create_kat(nrows, ncols, sp, npr, csr, col, off, first):
+    assert orc.lib().orc_sparse_nnz_per_row(ncols, sp) == npr
+    v, c, o = orc.sparse_create(nrows, ncols, sp)
+    assert (h16(v), h16(c), h16(o)) == (csr, col, off)
+    assert c[:6].tolist() == first
+    assert o[-1] == nrows * npr and np.all(np.diff(o) == npr)
+    rows = c.reshape(nrows, npr)
+    assert np.all(np.diff(rows, axis=1) > 0)          # sorted, unique within a row
+
+
+def test_sparse_create_cfg3_row0():
+    """First row of the full-size cfg3 matrix (App. A-3) -- rows are independent."""
+    v, c, o = orc.sparse_create(4, 1000000, 0.0001)
+    assert c[:8].tolist() == [2180, 20218, 49198, 51205, 60867, 67543, 68547, 69224]
+    assert v[:12].tolist() == [1, 2, 3, 4, 5, 6, 7, 8, 9, 1, 2, 3]
+
+
+def test_dense_fill_kat_and_ref_binary(tmp_path):
+    d = orc.dense_fill(37, 53, "s")
+    assert h16(d) == "d08eb5a3728513a6"                 # dense_create d.bin 37 53 s
+    assert np.array_equal(orc.dense_fill(5, 7, "z"), np.zeros((5, 7), np.float32))
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "dense_create")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/dense_create not built (reference tree absent)")
+    for (r, c, mode) in [(37, 53, "s"), (128, 100, "s"), (10, 10, "z")]:
+        f = tmp_path / f"d_{r}_{c}_{mode}.bin"
+        subprocess.run([ref_bin, str(f), str(r), str(c), mode], check=True)
+        got = np.fromfile(f, np.float32).reshape(r, c)
+        assert np.array_equal(got, orc.dense_fill(r, c, mode))
+
+
+def test_gemm_plan_survey_example():
+    """SURVEY App. D-1 (verified against the compiled reference): m,k,n = 640,600,500,
+    BLK 256 -> N=[3,2,2]; extents m:[256,256,128], k:[256,344] (tail merged), n:[256,244]."""
+    tasks, nblk = orc.gemm_plan("R", "N", "N", 640, 500, 600, 2.0, 0, 0, 0, 256)
+    assert nblk == [3, 2, 2] and len(tasks) == 12
+    assert sorted({t.M for t in tasks}) == [128, 256]
+    assert sorted({t.K for t in tasks}) == [256, 344]
+    assert sorted({t.N for t in tasks}) == [244, 256]
+    # l-major injection; chain dependency (l,i,j) <- (l-1,i,j); beta only on l == 0
+    assert [(t.l, t.i, t.j) for t in tasks[:5]] == [(0, 0, 0), (0, 0, 1), (0, 1, 0), (0, 1, 1), (0, 2, 0)]
+    for idx, t in enumerate(tasks):
+        assert t.parent == (idx - 6 if t.l > 0 else -1)
+        assert t.beta == (2.0 if t.l == 0 else 1.0)
+    t = tasks[6 + 2 * 2 + 1]                            # (l=1, i=2, j=1)
+    assert (t.l, t.i, t.j) == (1, 2, 1)
+    assert list(t.off) == [512 * 600 + 256, 256 * 500 + 256, 512 * 500 + 256]
+    assert list(t.nrows) == [128, 344, 128] and list(t.ncols) == [344, 244, 244]
+    assert list(t.ld_file) == [600, 500, 500]
+
+
+def test_gemm_plan_layout_swaps_and_cfg2():
+    # 'C','T','N': A stored swapped iff transA xor colMajor -> not swapped: (m,k) row-major view
+    tasks, nblk = orc.gemm_plan("C", "T", "N", 640, 500, 600, 0.0, 0, 0, 0, 256)
+    t = tasks[0]
+    assert list(t.ld_file) == [600, 600, 640]           # A:(m,k) ld=k ; B:(n,k) ld=k ; C:(n,m) ld=m
+    assert list(t.nrows) == [256, 256, 256] and list(t.ncols) == [256, 256, 256]
+    # cfg2: 32768^3 / 4096 -> 8x8x8 = 512 tasks, 64 MiB tiles, stride 131072 B
+    tasks, nblk = orc.gemm_plan("R", "N", "N", 32768, 32768, 32768, 0.0, 0, 0, 0, 4096)
+    assert nblk == [8, 8, 8] and len(tasks) == 512
+    assert all(t.M == t.N == t.K == 4096 for t in tasks)
+    assert tasks[-1].ld_file[0] * 4 == 131072 and tasks[-1].off[2] == (7 * 4096) * 32768 + 7 * 4096
+    # remainder >= 128 keeps its own block; < 128 merges
+    assert orc.gemm_plan("R", "N", "N", 256 + 128, 10, 10, 0.0, 0, 0, 0, 256)[1][0] == 2
+    assert orc.gemm_plan("R", "N", "N", 256 + 127, 10, 10, 0.0, 0, 0, 0, 256)[1][0] == 1
+
+
+def test_csr_blocks_cfg3_shape():
+    """cfg3: 10M rows x 100 nnz/row, MAX_NNZS 1e7, RBLK 131072 -> 99 blocks of 100001
+    rows + one of 99901 (the loop overshoots the budget by one row)."""
+    m = 10_000_000
+    ia = np.arange(m + 1, dtype=np.int64) * 100
+    st, sz = orc.csr_blocks(ia, m)
+    assert len(sz) == 100 and np.all(sz[:99] == 100001) and sz[99] == 99901
+    assert st[0] == 0 and np.all(np.diff(st) == sz[:-1]) and st[-1] + sz[-1] == m
+
+
+def test_csr_blocks_edges():
+    # fewer than 128 rows left: clamp to the rows remaining (reference over-runs, App. B-9)
+    ia = np.arange(201, dtype=np.int64) * 3
+    st, sz = orc.csr_blocks(ia, 200, 128, 131072, 10_000_000)
+    assert st.tolist() == [0] and sz.tolist() == [200]
+    st, sz = orc.csr_blocks(ia, 200, 128, 150, 10)
+    assert sz.tolist() == [128, 72]
+    # row cap
+    st, sz = orc.csr_blocks(ia, 200, 16, 50, 10_000_000)
+    assert sz.tolist() == [50, 50, 50, 50]
+    # empty rows and a heavy row
+    ia = np.array([0, 0, 0, 1000, 1000, 1001], np.int64)
+    st, sz = orc.csr_blocks(ia, 5, 1, 10, 100)
+    assert st.tolist() == [0, 3] and sz.tolist() == [3, 2]
+    assert orc.csr_blocks(np.zeros(1, np.int64), 0)[1].size == 0
+
+
+def test_oracle_vs_mkl_golden(golden):
+    worst = 0.0
+    for line in golden["meta"]:
+        t = line.split()
+        key = t[0]
+        if key.startswith("gemm"):
+            m, n, k = map(int, t[1:4])
+            ord_, ta, tb = t[4:7]
+            alpha, beta = float(t[7]), float(t[8])
+            lda, ldb, ldc = map(int, t[9:12])
+            c = orc.sgemm(ord_, ta, tb, m, n, k, alpha, golden[key + "_a"], lda, golden[key + "_b"],
+                          ldb, beta, golden[key + "_c0"].copy(), ldc)
+            ref = golden[key + "_c1"]
+        elif key.startswith("csrmm"):
+            m, n, k = map(int, t[1:4])
+            ord_b, alpha, beta, mat = t[4], float(t[5]), float(t[6]), t[7]
+            ldb, ldc = (k, k) if ord_b == "R" else (n, m)
+            c = orc.scsrmm(ord_b, m, k, n, alpha, golden[mat + "_val"], golden[mat + "_ja"],
+                           golden[mat + "_ia"], golden[key + "_b"], ldb, beta,
+                           golden[key + "_c0"].copy(), ldc)
+            ref = golden[key + "_c1"]
+        elif key.startswith("csrgemv"):
+            m, n, tr, mat = int(t[1]), int(t[2]), t[3], t[4]
+            c = orc.scsrgemv(tr, m, n, golden[mat + "_val"], golden[mat + "_ia"],
+                             golden[mat + "_ja"], golden[key + "_x"],
+                             np.zeros(m if tr == "N" else n, np.float32))
+            ref = golden[key + "_y"]
+        else:
+            continue
+        err = np.abs(c - ref).max() / np.abs(ref).max()
+        worst = max(worst, err)
+        assert err < 1e-5, (key, err)     # far inside the 1e-4 north-star tolerance
+    assert worst > 0                       # (different summation order than MKL: not bit-equal)
+
+
+def test_oracle_flash_paths_vs_mkl_exact_hashes(golden):
+    """Integer-valued generator data: every correct fp32 implementation is exact."""
+    want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
+    val, ja, ia = orc.sparse_create(4096, 2048, 0.01)
+    b = orc.dense_fill(2048, 128, "s")
+    c = orc.flash_csrmm("R", 4096, 2048, 128, 1.0, 0.0, val, ia, ja, b,
+                        np.zeros((4096, 128), np.float32), 1000, 5000, 64)
+    assert hashlib.sha256(c.tobytes()).hexdigest() == want["gen_csrmm_c"]
+    x = (np.arange(2048) % 10).astype(np.float32)
+    y = orc.flash_csrgemv("N", 4096, 2048, val, ia, ja, x, np.zeros(4096, np.float32), 1000, 5000)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == want["gen_csrgemv_N"]
+    x = (np.arange(4096) % 10).astype(np.float32)
+    y = orc.flash_csrgemv("T", 4096, 2048, val, ia, ja, x, np.zeros(2048, np.float32), 1000, 5000)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == want["gen_csrgemv_T"]
+    a = orc.dense_fill(512, 512, "s")
+    c = orc.flash_gemm("R", "N", "N", 512, 512, 512, 1.0, 0.0, a, a,
+                       np.zeros((512, 512), np.float32), 0, 0, 0, 128)
+    assert hashlib.sha256(c.tobytes()).hexdigest() == want["gen_gemm512_c"]
+
+
+def test_flash_gemm_oracle_all_layouts_vs_whole_matrix():
+    """Tiled chain vs whole-matrix sgemm (the reference's gemm_run.sh comparison)."""
+    rng = np.random.default_rng(3)
+    m, k, n = 300, 280, 260
+    for ord_ in "RC":
+        for ta in "NT":
+            for tb in "NT":
+                sa = (m, k) if (ta == "T") == (ord_ == "C") else (k, m)
+                sb = (k, n) if (tb == "T") == (ord_ == "C") else (n, k)
+                sc = (m, n) if ord_ == "R" else (n, m)
+                a = rng.uniform(-1, 1, sa).astype(np.float32)
+                b = rng.uniform(-1, 1, sb).astype(np.float32)
+                c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+                tiled = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, 128)
+                whole = orc.sgemm(ord_, ta, tb, m, n, k, 0.5, a, sa[1], b, sb[1], 2.0, c0.copy(), sc[1])
+                assert np.abs(tiled - whole).max() / np.abs(whole).max() < 1e-5
+
+
+def test_helpers():
+    assert orc.lib().orc_buf_size(1, 1000) == 1024 + 512      # src/utils.cpp:48-53
+    assert orc.lib().orc_buf_size(4096, 16384) == 4096 * 16384
+    assert orc.lib().orc_fnv64a(b"", 0) == 14695981039346656037
+    assert orc.lib().orc_fnv64a(b"a", 1) == 0xaf63dc4c8601ec8c  # FNV-1a test vector
