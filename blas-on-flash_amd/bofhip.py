@@ -96,6 +96,15 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7.
+        # Loading torch FIRST makes the dynamic linker satisfy our DT_NEEDED
+        # libamdhip64.so.7 with that already-loaded copy (same SONAME), so torch
+        # tensors/streams and our kernels share one runtime.  Loaded the other way
+        # round the process ends up with two runtimes and torch sees no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise BofError(f"{LIB_PATH} is missing: run `make -C {HERE}` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
