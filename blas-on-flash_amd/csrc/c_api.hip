@@ -226,7 +226,7 @@ int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alph
   int rc = ss->fork(parent);
   if (rc) return rc;
   for (int64_t bi = 0; bi < nb; bi++) {
-    const int64_t s = st[bi], r = sz[bi], z = ia_host[s] - ia_host[0];
+    const int64_t s = st[bi], r = sz[bi], z = ia_host[s];  // absolute, as the reference (csrmm.cpp:97-98)
     hipStream_t q = ss->s[bi % ss->n];
     for (int64_t j0 = 0; j0 < k; j0 += o.csrmm_cblk) {
       const int64_t w = std::min(k - j0, o.csrmm_cblk);
@@ -260,7 +260,7 @@ int bof_csrgemv_resident(char trans_a, int64_t m, int64_t n, const float *val,
   int rc = ss->fork(parent);
   if (rc) return rc;
   for (int64_t bi = 0; bi < nb; bi++) {
-    const int64_t s = st[bi], r = sz[bi], z = ia_host[s] - ia_host[0];
+    const int64_t s = st[bi], r = sz[bi], z = ia_host[s];  // absolute, as the reference (csrmm.cpp:97-98)
     hipStream_t q = ss->s[bi % ss->n];
     if (trans_a == 'N')
       BOF_HIP_TRY(scsrgemv('N', r, n, val + z, ia_dev + s, ja + z, x, y + s, q));

@@ -18,6 +18,7 @@
 //     scheduler ticks (reference scheduler.cpp:92-93,206-212).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
@@ -476,8 +477,10 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   for (auto &th : writers) th.join();
   (void) hipDeviceSynchronize();
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, "bof_flash_gemm dispatch");
-  if (R.io_error.load() && !fail) {
-    set_error("bof_flash_gemm: file I/O failed: " + std::string(strerror(-R.io_error.load())));
+  if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
+    const int e = R.io_error.load();
+    set_error("bof_flash_gemm: I/O pipeline failed: " +
+              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
     fail = BOF_EIO;
   }
   R.rring.destroy();
@@ -526,12 +529,17 @@ struct CsrRun {
   int dev = 0;
   bool use_aio = true;
 
-  // sector-widened segment of a block (reference csrmm_task.h:156-172)
+  uint64_t fsize_ja = 0, fsize_a = 0;
+  // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
+  // end of the file (the last sector of a file is usually partial)
   void seg(int64_t b, int esz, const bof_fptr &f, uint64_t &start, uint64_t &len, uint64_t &delta) const {
     const uint64_t z = (uint64_t) ia[st[b]], nnz = (uint64_t) (ia[st[b] + sz[b]] - ia[st[b]]);
     const uint64_t b0 = f.foffset + z * esz, b1 = b0 + nnz * esz;
+    const uint64_t fsize = esz == 8 ? fsize_ja : fsize_a;
     start = b0 / 512 * 512;
-    len = round_up(b1, 512) - start;
+    uint64_t end = round_up(b1, 512);
+    if (fsize && end > fsize) end = std::max(b1, std::min(end, fsize));
+    len = nnz ? end - start : 0;
     delta = b0 - start;
   }
   size_t c_bytes(int64_t b) const { return (size_t) sz[b] * k * sizeof(float); }
@@ -666,6 +674,11 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   R.st.resize((size_t) nb); R.sz.resize((size_t) nb);
   bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
 
+  {
+    struct stat sb;
+    if (fstat(fja.fd, &sb) == 0) R.fsize_ja = (uint64_t) sb.st_size;
+    if (fstat(fa.fd, &sb) == 0) R.fsize_a = (uint64_t) sb.st_size;
+  }
   size_t max_idx = 0, max_val = 0, max_c = 0;
   for (int64_t b = 0; b < nb; b++) {
     uint64_t s, l, d;
@@ -784,8 +797,10 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     R.cnt.d2h += (uint64_t) ylen * 4;
   }
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, "flash csr dispatch");
-  if (R.io_error.load() && !fail) {
-    set_error("flash csr: file I/O failed: " + std::string(strerror(-R.io_error.load())));
+  if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
+    const int e = R.io_error.load();
+    set_error("flash csr: I/O pipeline failed: " +
+              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
     fail = BOF_EIO;
   }
   for (auto &c : R.ctx) {

@@ -303,7 +303,7 @@ void orc_flash_csrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha,
   int64_t *sz = (int64_t *) malloc(sizeof(int64_t) * (size_t) nb);
   orc_csr_blocks(ia, m, ORC_SECTOR / sizeof(float), max_rows, max_nnz, st, sz, nb);
   for (int64_t bi = 0; bi < nb; bi++) {
-    const int64_t s = st[bi], r = sz[bi], z = ia[s] - ia[0];
+    const int64_t s = st[bi], r = sz[bi], z = ia[s]; /* absolute: ja + ia[start], src/blas/csrmm.cpp:97-98 */
     for (int64_t j0 = 0; j0 < k; j0 += cblk) {
       const int64_t w = (k - j0 < cblk) ? k - j0 : cblk;
       if (ord_b == 'R')
@@ -355,7 +355,7 @@ void orc_flash_csrgemv(char trans, int64_t m, int64_t n, const float *val,
     for (int64_t j = 0; j < n; j++) y[j] = 0.0f;
   }
   for (int64_t bi = 0; bi < nb; bi++) {
-    const int64_t s = st[bi], r = sz[bi], z = ia[s] - ia[0];
+    const int64_t s = st[bi], r = sz[bi], z = ia[s]; /* absolute: ja + ia[start], src/blas/csrmm.cpp:97-98 */
     if (trans == 'N') {
       orc_scsrgemv('N', r, n, val + z, ia + s, ja + z, x, y + s);
     } else {

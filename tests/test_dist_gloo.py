@@ -56,16 +56,16 @@ def _worker(rank, world, port, out_dir):
     val, ja, ia = orc.sparse_create(m, n, 0.01)
     x = (np.arange(m) % 10).astype(np.float32)
     r0, r1 = bof_dist.csr_row_shard(ia, world, rank, align=128)
-    z0, z1 = ia[r0], ia[r1]
     # this rank's partial y_g = A_g^T x_g (on the GPU box: bof_flash_csrgemv 'T' on the slab)
     part = np.zeros(n, np.float32)
-    orc.flash_csrgemv("T", r1 - r0, n, val[z0:z1], ia[r0:r1 + 1], ja[z0:z1], x[r0:r1], part, 1000, 5000)
+    # shard = offset `ia` pointer; val/ja stay whole-file (absolute offsets, as flash_ptr + r0)
+    orc.flash_csrgemv("T", r1 - r0, n, val, ia[r0:r1 + 1], ja, x[r0:r1], part, 1000, 5000)
     y = torch.from_numpy(part)
     bof_dist.allreduce_partial(y)
     # 'N' needs no collective: disjoint slices
     xn = (np.arange(n) % 10).astype(np.float32)
     yn = np.zeros(r1 - r0, np.float32)
-    orc.flash_csrgemv("N", r1 - r0, n, val[z0:z1], ia[r0:r1 + 1], ja[z0:z1], xn, yn, 1000, 5000)
+    orc.flash_csrgemv("N", r1 - r0, n, val, ia[r0:r1 + 1], ja, xn, yn, 1000, 5000)
     np.save(os.path.join(out_dir, f"T_{rank}.npy"), y.numpy())
     np.save(os.path.join(out_dir, f"N_{rank}.npy"), np.concatenate([[r0, r1], yn]))
     dist.barrier()
