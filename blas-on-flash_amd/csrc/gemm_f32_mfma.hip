@@ -9,12 +9,6 @@
 //   XMAJOR  element (x,k) at g[x*ld + k]   (k contiguous: A 'N', B 'T')
 //   KMAJOR  element (x,k) at g[k*ld + x]   (x contiguous: A 'T', B 'N')
 //
-// Kernel shape: 256 threads = 4 waves (2x2), block tile 128x128x32, wave tile
-// 64x64 = 2x2 MFMA 32x32 accumulators (64 VGPR).  Global->register->LDS staging
-// with the next K-slab's global loads issued before the current slab's MFMAs
-// (async-STAGE split); single LDS buffer (36 KB) so 3-4 blocks stay resident
-// per CU and hide each other's barriers.
-//
 // Numerics: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain.  The LDS images
 // are arranged so MFMA step s consumes k = 2s (lanes 0-31) and 2s+1 (lanes
 // 32-63): every output element is therefore EXACTLY
@@ -29,23 +23,21 @@ namespace bof {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32, NTHR = 256;
+constexpr int BK = 32;
 constexpr int XLD = BK + 4;  // XMAJOR LDS row stride (floats): conflict-free b128 reads
 enum { XMAJOR = 0, KMAJOR = 1 };
-constexpr int LDS_FLOATS_OP = BM * XLD;  // >= BK*BM, one operand slab
 
 // ---- global -> registers ---------------------------------------------------
-// One K-slab of one operand = 1024 float4; thread t owns float4 #(t + 256*p),
-// p = 0..3.  Kept as four named vector registers (an array passed by reference
-// ends up in scratch and forces an early vmcnt wait).
-struct Stage { f32x4 v0, v1, v2, v3; };
+// One K-slab of one operand of extent BX is BX*8 float4; thread t owns float4
+// #(t + NTHR*p), p = 0..NP-1, kept in registers across the MFMA phase.
+template <int NP> struct Stage { f32x4 v[NP]; };
 
-template <int MODE, bool GUARD>
+template <int MODE, int BX, bool GUARD>
 __device__ __forceinline__ f32x4 g2r1(const float *__restrict__ g, int64_t ld, int x0, int k0,
                                       int X, int K, int f) {
   int x, k;
   if (MODE == XMAJOR) { x = x0 + (f >> 3); k = k0 + 4 * (f & 7); }
-  else                { k = k0 + (f >> 5); x = x0 + 4 * (f & 31); }
+  else                { k = k0 + f / (BX / 4); x = x0 + 4 * (f % (BX / 4)); }
   const float *src = (MODE == XMAJOR) ? g + (int64_t) x * ld + k : g + (int64_t) k * ld + x;
   if (!GUARD) return *reinterpret_cast<const f32x4 *>(src);
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -66,14 +58,13 @@ __device__ __forceinline__ f32x4 g2r1(const float *__restrict__ g, int64_t ld, i
   }
   return v;
 }
-template <int MODE, bool GUARD>
-__device__ __forceinline__ Stage g2r(const float *__restrict__ g, int64_t ld, int x0, int k0,
-                                     int X, int K, int t) {
-  Stage s;
-  s.v0 = g2r1<MODE, GUARD>(g, ld, x0, k0, X, K, t);
-  s.v1 = g2r1<MODE, GUARD>(g, ld, x0, k0, X, K, t + NTHR);
-  s.v2 = g2r1<MODE, GUARD>(g, ld, x0, k0, X, K, t + 2 * NTHR);
-  s.v3 = g2r1<MODE, GUARD>(g, ld, x0, k0, X, K, t + 3 * NTHR);
+template <int MODE, int BX, int NTHR, bool GUARD>
+__device__ __forceinline__ Stage<BX * 8 / NTHR> g2r(const float *__restrict__ g, int64_t ld,
+                                                    int x0, int k0, int X, int K, int t) {
+  Stage<BX * 8 / NTHR> s;
+#pragma unroll
+  for (int p = 0; p < BX * 8 / NTHR; p++)
+    s.v[p] = g2r1<MODE, BX, GUARD>(g, ld, x0, k0, X, K, t + p * NTHR);
   return s;
 }
 
@@ -81,7 +72,7 @@ __device__ __forceinline__ Stage g2r(const float *__restrict__ g, int64_t ld, in
 // XMAJOR image: row x holds, per group of 8 k's, [k0 k2 k4 k6 | k1 k3 k5 k7] so a
 // lane of half h reads its four operands k = 8q+2c+h (c=0..3) with one
 // ds_read_b128.  KMAJOR image: plain [k][x].
-template <int MODE>
+template <int MODE, int BX>
 __device__ __forceinline__ void r2s1(float *__restrict__ s, const f32x4 v, int f) {
   if (MODE == XMAJOR) {
     const int row = f >> 3, kq = f & 7;
@@ -89,42 +80,55 @@ __device__ __forceinline__ void r2s1(float *__restrict__ s, const f32x4 v, int f
     *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[2]);
     *reinterpret_cast<float2 *>(dst + 4) = make_float2(v[1], v[3]);
   } else {
-    const int krow = f >> 5, xq = f & 31;
-    *reinterpret_cast<f32x4 *>(s + krow * BM + 4 * xq) = v;
+    const int krow = f / (BX / 4), xq = f % (BX / 4);
+    *reinterpret_cast<f32x4 *>(s + krow * BX + 4 * xq) = v;
   }
 }
-template <int MODE>
-__device__ __forceinline__ void r2s(float *__restrict__ s, const Stage &r, int t) {
-  r2s1<MODE>(s, r.v0, t);
-  r2s1<MODE>(s, r.v1, t + NTHR);
-  r2s1<MODE>(s, r.v2, t + 2 * NTHR);
-  r2s1<MODE>(s, r.v3, t + 3 * NTHR);
+template <int MODE, int BX, int NTHR>
+__device__ __forceinline__ void r2s(float *__restrict__ s, const Stage<BX * 8 / NTHR> &r, int t) {
+#pragma unroll
+  for (int p = 0; p < BX * 8 / NTHR; p++) r2s1<MODE, BX>(s, r.v[p], t + p * NTHR);
 }
 
 // ---- LDS -> MFMA operands ----------------------------------------------------
 // returns the 4 operands (c = 0..3) of k-group q for sub-tile row/col `x`
-template <int MODE>
+template <int MODE, int BX>
 __device__ __forceinline__ f32x4 s2op(const float *__restrict__ s, int x, int q, int h) {
   if (MODE == XMAJOR) {
     return *reinterpret_cast<const f32x4 *>(s + x * XLD + 8 * q + 4 * h);
   } else {
-    const float *p = s + (8 * q + h) * BM + x;
+    const float *p = s + (8 * q + h) * BX + x;
     f32x4 v;
-    v[0] = p[0]; v[1] = p[2 * BM]; v[2] = p[4 * BM]; v[3] = p[6 * BM];
+    v[0] = p[0]; v[1] = p[2 * BX]; v[2] = p[4 * BX]; v[3] = p[6 * BX];
     return v;
   }
 }
 
-template <int AMODE, int BMODE, bool GUARD>
-__global__ void __launch_bounds__(NTHR)
+// Block tile BM x BN x 32 computed by WM x WN waves; wave tile (BM/WM) x (BN/WN) =
+// MT x NT accumulators of 32x32.  Two shapes are instantiated:
+//   <128,128, 2x2 waves, single LDS buffer>: 64 accumulator VGPRs, 3 blocks/CU, two
+//        barriers per slab -- ragged / small problems (GUARD variant) and tiles that
+//        are not multiples of 256;
+//   <256,256, 2x4 waves, double LDS buffer>: wave tile 128x64 (128 accumulator VGPRs),
+//        144 KB LDS = one block per CU; a 4096^2 C tile is exactly 256 blocks, so the
+//        whole launch is co-resident (no tail round); one barrier per slab: while slab
+//        kt is multiplied out of buffer kt&1, slab kt+1 (fetched one slab earlier) is
+//        written to the other buffer and slab kt+2's global loads are in flight.
+template <int BM, int BN, int WM, int WN, bool DBUF, int AMODE, int BMODE, bool GUARD>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 3)
 sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                   int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
                   float alpha, float beta, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_FLOATS_OP];
-  float *sA = lds, *sB = lds + LDS_FLOATS_OP;
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int LDS_A = (AMODE == XMAJOR) ? BM * XLD : BK * BM;
+  constexpr int LDS_B = (BMODE == XMAJOR) ? BN * XLD : BK * BN;
+  constexpr int LDS_BUF = LDS_A + LDS_B;
+  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * LDS_BUF];
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch),
-  // so give each XCD a contiguous run of tiles, walked in groups of 8 tile-rows
+  // so give each XCD a contiguous run of tiles, walked in groups of tile-rows
   // so concurrently resident blocks share A row-panels / B column-panels in L2.
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -132,7 +136,7 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  constexpr int GROUP_M = 8;
+  constexpr int GROUP_M = (BM == 256) ? 4 : 8;
   const int per_group = GROUP_M * tiles_n;
   const int gid = bid / per_group;
   const int first_m = gid * GROUP_M;
@@ -144,46 +148,63 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+  for (int a = 0; a < MT; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < NT; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   const int nkt = (K + BK - 1) / BK;
-  Stage ra = g2r<AMODE, GUARD>(A, lda, m0, 0, M, K, t);
-  Stage rb = g2r<BMODE, GUARD>(B, ldb, n0, 0, N, K, t);
-  r2s<AMODE>(sA, ra, t);
-  r2s<BMODE>(sB, rb, t);
+  auto ra = g2r<AMODE, BM, NTHR, GUARD>(A, lda, m0, 0, M, K, t);
+  auto rb = g2r<BMODE, BN, NTHR, GUARD>(B, ldb, n0, 0, N, K, t);
+  r2s<AMODE, BM, NTHR>(lds, ra, t);
+  r2s<BMODE, BN, NTHR>(lds + LDS_A, rb, t);
+  if (DBUF && nkt > 1) {
+    ra = g2r<AMODE, BM, NTHR, GUARD>(A, lda, m0, BK, M, K, t);
+    rb = g2r<BMODE, BN, NTHR, GUARD>(B, ldb, n0, BK, N, K, t);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nkt; kt++) {
-    if (kt + 1 < nkt) {  // issue the next slab's global loads under this slab's MFMAs
-      ra = g2r<AMODE, GUARD>(A, lda, m0, (kt + 1) * BK, M, K, t);
-      rb = g2r<BMODE, GUARD>(B, ldb, n0, (kt + 1) * BK, N, K, t);
+    const float *sA = lds + ((DBUF && (kt & 1)) ? LDS_BUF : 0);
+    const float *sB = sA + LDS_A;
+    if (DBUF) {
+      if (kt + 1 < nkt) {  // slab kt+1 (loaded during slab kt-1) -> the other buffer
+        float *nA = lds + ((kt & 1) ? 0 : LDS_BUF);
+        r2s<AMODE, BM, NTHR>(nA, ra, t);
+        r2s<BMODE, BN, NTHR>(nA + LDS_A, rb, t);
+      }
+      if (kt + 2 < nkt) {  // slab kt+2's global loads fly under this slab's MFMAs
+        ra = g2r<AMODE, BM, NTHR, GUARD>(A, lda, m0, (kt + 2) * BK, M, K, t);
+        rb = g2r<BMODE, BN, NTHR, GUARD>(B, ldb, n0, (kt + 2) * BK, N, K, t);
+      }
+    } else if (kt + 1 < nkt) {  // issue the next slab's global loads under this slab's MFMAs
+      ra = g2r<AMODE, BM, NTHR, GUARD>(A, lda, m0, (kt + 1) * BK, M, K, t);
+      rb = g2r<BMODE, BN, NTHR, GUARD>(B, ldb, n0, (kt + 1) * BK, N, K, t);
     }
 #pragma unroll
     for (int q = 0; q < BK / 8; q++) {
-      const f32x4 a0 = s2op<AMODE>(sA, wm * 64 + i, q, h);
-      const f32x4 a1 = s2op<AMODE>(sA, wm * 64 + 32 + i, q, h);
-      const f32x4 b0 = s2op<BMODE>(sB, wn * 64 + i, q, h);
-      const f32x4 b1 = s2op<BMODE>(sB, wn * 64 + 32 + i, q, h);
+      f32x4 a[MT], b[NT];
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; mt++) a[mt] = s2op<AMODE, BM>(sA, wm * WTM + mt * 32 + i, q, h);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) b[nt] = s2op<BMODE, BN>(sB, wn * WTN + nt * 32 + i, q, h);
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][c], b[nt][c], acc[mt][nt], 0, 0, 0);
     }
     __syncthreads();
-    if (kt + 1 < nkt) {
-      r2s<AMODE>(sA, ra, t);
-      r2s<BMODE>(sB, rb, t);
+    if (!DBUF && kt + 1 < nkt) {
+      r2s<AMODE, BM, NTHR>(lds, ra, t);
+      r2s<BMODE, BN, NTHR>(lds + LDS_A, rb, t);
       __syncthreads();
     }
   }
@@ -193,12 +214,12 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
   // they stay in SGPRs; for beta != 0 a sub-tile's 16 C values are fetched before its
   // stores so the loads pipeline.
   float *ctile = C + (int64_t) m0 * ldc + n0;
-  const int lrow = wm * 64 + 4 * h, lcol = wn * 64 + i;
+  const int lrow = wm * WTM + 4 * h, lcol = wn * WTN + i;
   const int lane_off = lrow * (int) ldc + lcol;
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++)
+  for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
+    for (int nt = 0; nt < NT; nt++) {
       f32x16 old;
       if (beta != 0.f) {
 #pragma unroll
@@ -223,17 +244,24 @@ template <int AMODE, int BMODE>
 static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int64_t ldb,
                                float *C, int64_t ldc, int M, int N, int K, float alpha,
                                float beta, hipStream_t st) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && (K > 0) && (lda % 4 == 0) &&
-                    (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  dim3 grid(tiles_m * tiles_n), block(NTHR);
-  if (fast)
-    hipLaunchKernelGGL((sgemm_tile_kernel<AMODE, BMODE, false>), grid, block, 0, st, A, lda, B,
-                       ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+  const bool vec_ok = (K % BK == 0) && (K > 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  if (vec_ok && M % 256 == 0 && N % 256 == 0 && (int64_t) (M / 256) * (N / 256) >= 128) {
+    const int tiles_m = M / 256, tiles_n = N / 256;
+    hipLaunchKernelGGL((sgemm_tile_kernel<256, 256, 2, 4, true, AMODE, BMODE, false>),
+                       dim3(tiles_m * tiles_n), dim3(512), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                       alpha, beta, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
+  const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+  dim3 grid(tiles_m * tiles_n), block(256);
+  if (vec_ok && M % 128 == 0 && N % 128 == 0)
+    hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, false>), grid, block,
+                       0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
   else
-    hipLaunchKernelGGL((sgemm_tile_kernel<AMODE, BMODE, true>), grid, block, 0, st, A, lda, B,
-                       ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+    hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, true>), grid, block,
+                       0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
   return hipGetLastError();
 }
 

@@ -85,6 +85,22 @@ def test_sgemm_bit_exact_vs_oracle(dev, ord_, ta, tb, m, n, k, alpha, beta):
     assert rel_err(gotl, full) < TOL
 
 
+@pytest.mark.parametrize("ta,tb", list(itertools.product("NT", "NT")))
+def test_sgemm_big_tile_kernel_bit_exact(dev, ta, tb):
+    """4096 x 2048 x 96 is 16 x 8 = 128 blocks of 256 x 256: the double-buffered 8-wave
+    kernel the BASELINE tile size runs on (3 K-slabs: prologue, steady state, drain)."""
+    m, n, k = 4096, 2048, 96
+    rng = np.random.default_rng(42)
+    sa, sb, sc = stored_shapes("R", ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    for alpha, beta in [(1.0, 0.0), (0.5, 2.0)]:
+        ref = orc.sgemm("R", ta, tb, m, n, k, alpha, a, sa[1], b, sb[1], beta, c0.copy(), sc[1])
+        got = run_sgemm("R", ta, tb, m, n, k, alpha, beta, a, sa[1], b, sb[1], c0, sc[1])
+        assert np.array_equal(got, ref), rel_err(got, ref)
+
+
 def test_sgemm_k_zero_and_empty(dev):
     c0 = np.arange(12, dtype=np.float32).reshape(3, 4)
     a = np.zeros((3, 1), np.float32)
