@@ -1,0 +1,120 @@
+"""-m gpu parity at BASELINE.json's FULL sizes against the known answers the compiled
+reference produced.  The generator data is integer valued with every
+partial sum < 2^24, so any correct fp32 implementation must reproduce these bit-exactly,
+whatever its summation order."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import bofhip
+import orc
+from gpu_util import ptr, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(t):
+    """sha256 of a device tensor's bytes (chunked D2H so host memory stays small)."""
+    h = hashlib.sha256()
+    flat = t.view(-1)
+    step = 1 << 28
+    for i in range(0, flat.numel(), step):
+        h.update(flat[i:i + step].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def test_cfg2_gemm_32768_closed_form(dev):
+    """cfg2: 32768^3, 4096-tile (512 tile tasks), dense_create mode-s inputs.
+    A[i,k] = (i*K+k)%10, B[k,j] = (k*N+j)%10 with N = K = 32768 = 8 (mod 10), so C[i,j]
+    depends only on (i mod 5, j mod 10): 50 distinct values, C[0,0:4] known (App. A-3)."""
+    n = 32768
+    a = torch.empty(n * n, dtype=torch.float32, device=dev)
+    b = torch.empty(n * n, dtype=torch.float32, device=dev)
+    c = torch.empty(n * n, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(ptr(a), 0, n * n, "s", 0, stream())
+    bofhip.gen_dense(ptr(b), 0, n * n, "s", 0, stream())
+    c.fill_(-1.0)
+    bofhip.gemm_resident("R", "N", "N", n, n, n, 1.0, 0.0, ptr(a), ptr(b), ptr(c), 0, 0, 0,
+                         bofhip.default_options(gemm_blk=4096), stream())
+    torch.cuda.synchronize()
+    C = c.view(n, n)
+    assert C[0, :4].tolist() == [589810.0, 737258.0, 655316.0, 802764.0]
+    A64 = ((np.arange(5)[:, None] * n + np.arange(n)[None, :]) % 10).astype(np.float64)
+    B64 = ((np.arange(n)[:, None] * n + np.arange(10)[None, :]) % 10).astype(np.float64)
+    pat = torch.from_numpy((A64 @ B64).astype(np.float32)).to(dev)       # 5 x 10, exact
+    assert float(pat.max()) == 802864.0                                  # App. A-3: max 802864
+    idx = torch.arange(n, device=dev)
+    for r0 in range(0, n, 4096):                                         # compare slab-wise
+        want = pat[idx[r0:r0 + 4096] % 5][:, idx % 10]
+        assert torch.equal(C[r0:r0 + 4096], want), r0
+    del a, b, c
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_csrmm_10M_sha256(dev):
+    """cfg3: sparse_create(10M, 1M, 1e-4) x dense_create(1M,128,'s'), alpha=1 beta=0 'N','R'.
+    Known answers (App. A-3): input file hashes, C sha256, total and per-1M-row sums."""
+    m, n, k, npr = 10_000_000, 1_000_000, 128, 100
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    chunk = 1_000_000
+    for r0 in range(0, m, chunk):
+        bofhip.gen_sparse_rows(r0, chunk, n, npr, ptr(val) + 4 * r0 * npr, ptr(col) + 8 * r0 * npr,
+                               ptr(off) + 8 * r0, stream())
+    torch.cuda.synchronize()
+    assert sha(off)[:16] == "553385bd432e9f76"
+    assert sha(val)[:16] == "102affabbce7531e"
+    assert sha(col)[:16] == "aad815cb3075a8ef"
+    assert int(col.max()) == 874867
+    b = torch.empty(n * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(ptr(b), 0, n * k, "s", 0, stream())
+    c = torch.full((m * k,), -1.0, dtype=torch.float32, device=dev)
+    ia_host = off.cpu().numpy()
+    bofhip.csrmm_resident("N", m, n, k, 1.0, 0.0, ptr(val), ia_host.ctypes.data, ptr(off), ptr(col),
+                          "R", ptr(b), ptr(c), bofhip.default_options(), stream())
+    torch.cuda.synchronize()
+    C = c.view(m, k)
+    assert C[0, :6].tolist() == [1950.0, 2446.0, 1692.0, 2188.0, 1944.0, 2440.0]
+    assert C[m - 1, 122:].tolist() == [1868.0, 2364.0, 1750.0, 2246.0, 1872.0, 2368.0]
+    sums = [int(C[i * 1_000_000:(i + 1) * 1_000_000].double().sum().item()) for i in range(10)]
+    assert sums == [287999856260, 287999894392, 287999723152, 287999924916, 288000225420,
+                    288000255068, 288000071792, 287999600252, 287999768548, 288000141276]
+    assert sum(sums) == 2879999461076
+    assert sha(c) == "d08df7c04907bec66f4638df05ffe2bbfb447c2a01e2bc03e5e6fd1d8daf2382"
+    assert sha(col)[:16] == "aad815cb3075a8ef"          # indices untouched by the kernel
+    del val, col, off, b, c
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_csrgemv_50M_sha256(dev):
+    """cfg5 size: sparse_create(50M, 50M, 2e-7) (10 nnz/row), x[i] = i % 10; 'N' and 'T'."""
+    m = n = 50_000_000
+    npr = orc.lib().orc_sparse_nnz_per_row(n, 0.0000002)
+    assert npr == 10
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    chunk = 5_000_000
+    for r0 in range(0, m, chunk):
+        bofhip.gen_sparse_rows(r0, chunk, n, npr, ptr(val) + 4 * r0 * npr, ptr(col) + 8 * r0 * npr,
+                               ptr(off) + 8 * r0, stream())
+    x = (torch.arange(n, device=dev) % 10).float()
+    y = torch.full((m,), -1.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ia_host = off.cpu().numpy()
+    opts = bofhip.default_options()
+    bofhip.csrgemv_resident("N", m, n, ptr(val), ia_host.ctypes.data, ptr(off), ptr(col), ptr(x),
+                            ptr(y), opts, stream())
+    torch.cuda.synchronize()
+    assert y[:6].tolist() == [230.0, 274.0, 243.0, 172.0, 222.0, 348.0]
+    assert int(y.double().sum().item()) == 11249621586 and float(y.max()) == 475.0
+    assert sha(y) == "1c0a44dbb962be0a2d7027f5f298ff94ab5b2ee66c8fe467c0408b286b1881e4"
+    bofhip.csrgemv_resident("T", m, n, ptr(val), ia_host.ctypes.data, ptr(off), ptr(col), ptr(x),
+                            ptr(y), opts, stream())
+    torch.cuda.synchronize()
+    assert y[:6].tolist() == [2072.0, 1313.0, 443.0, 1164.0, 1769.0, 1290.0]
+    assert int(y.double().sum().item()) == 11249999940 and float(y.max()) == 5700.0
+    assert sha(y) == "486766062199bef476611a2675893df3266338c91bfc30db4640ef5dbc2cbf40"
