@@ -84,10 +84,15 @@ extern "C" int64_t bof_csr_blocks(const int64_t *ia, int64_t m, int64_t min_rows
   int64_t cur = 0, nb = 0;
   while (cur < m) {
     const int64_t left = m - cur;
-    // grow from min_rows while the block is within the nnz budget: the block
-    // ends one row past the budget, as the reference's does
+    // The reference grows the block one row at a time from min_rows while its nnz stays
+    // within the budget (so it ends one row PAST the budget).  `ia` is non-decreasing, so
+    // the same end is the first row offset b >= min_rows with ia[cur+b] > ia[cur]+max_nnz,
+    // found by binary search (the linear scan costs 0.1 s of host time at 50M rows).
     int64_t b = min_rows;
-    while (b < left && ia[cur + b] - ia[cur] <= max_nnz) b++;
+    if (b < left) {
+      const int64_t *lo = ia + cur + min_rows, *hi = ia + cur + left;
+      b = std::upper_bound(lo, hi, ia[cur] + max_nnz) - (ia + cur);
+    }
     b = std::min(std::min(b, max_rows), left);  // clamp: reference over-runs ia here
     if (nb < cap) {
       if (starts) starts[nb] = cur;

@@ -44,6 +44,57 @@ def gemm(args):
                       f"{2.0 * m * n * k / best / 1e9:.1f} TFLOP/s", flush=True)
 
 
+def csr(args):
+    """cfg3 CSRMM (10M x 1M, 1e9 nnz, k=128) and cfg5 CSRGEMV (50M, 5e8 nnz), resident."""
+    import numpy as np
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    scale = args.scale
+    m, n, k, npr = 10_000_000 // scale, 1_000_000, 128, 100
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 1_000_000):
+        r = min(1_000_000, m - r0)
+        bofhip.gen_sparse_rows(r0, r, n, npr, val.data_ptr() + 4 * r0 * npr, col.data_ptr() + 8 * r0 * npr,
+                               off.data_ptr() + 8 * r0, st)
+    b = torch.empty(n * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(b.data_ptr(), 0, n * k, args.data, 3, st)
+    c = torch.zeros(m * k, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ia = off.cpu().numpy()
+    opts = bofhip.default_options(n_streams=args.streams)
+    f = lambda: bofhip.csrmm_resident("N", m, n, k, 1.0, 0.0, val.data_ptr(), ia.ctypes.data, off.data_ptr(),
+                                      col.data_ptr(), "R", b.data_ptr(), c.data_ptr(), opts, st)
+    best = min(time_ms(f, 3) for _ in range(args.rounds))
+    nnz = m * npr
+    alg = nnz * 12 + (m + 1) * 8 + 4 * n * k + 4 * m * k
+    print(f"csrmm {m}x{n} nnz={nnz} k={k}: {best:.3f} ms  {2.0 * nnz * k / best / 1e6:.1f} GFLOP/s  "
+          f"algorithmic {alg / best / 1e6:.1f} GB/s  gather {nnz * k * 4 / best / 1e6:.1f} GB/s", flush=True)
+    del val, col, off, b, c
+    m = n = 50_000_000 // scale
+    npr = 10
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 5_000_000):
+        r = min(5_000_000, m - r0)
+        bofhip.gen_sparse_rows(r0, r, n, npr, val.data_ptr() + 4 * r0 * npr, col.data_ptr() + 8 * r0 * npr,
+                               off.data_ptr() + 8 * r0, st)
+    x = (torch.arange(n, device=dev) % 10).float()
+    y = torch.zeros(m, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ia = off.cpu().numpy()
+    for tr in "NT":
+        f = lambda: bofhip.csrgemv_resident(tr, m, n, val.data_ptr(), ia.ctypes.data, off.data_ptr(),
+                                            col.data_ptr(), x.data_ptr(), y.data_ptr(), opts, st)
+        best = min(time_ms(f, 3) for _ in range(args.rounds))
+        nnz = m * npr
+        alg = nnz * 12 + (m + 1) * 8 + 8 * n
+        print(f"csrgemv {tr} {m}x{n} nnz={nnz}: {best:.3f} ms  {2.0 * nnz / best / 1e6:.1f} GFLOP/s  "
+              f"algorithmic {alg / best / 1e6:.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
@@ -52,8 +103,14 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="4096x4096x4096")
     ap.add_argument("--layouts", default="NN,NT,TN,TT")
     ap.add_argument("--betas", default="0,1")
+    ap.add_argument("--what", default="gemm")
+    ap.add_argument("--scale", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1)
     a = ap.parse_args()
     a.shapes = [tuple(int(x) for x in s.split("x")) for s in a.shapes.split(",")]
     a.layouts = [(s[0], s[1]) for s in a.layouts.split(",")]
     a.betas = [float(x) for x in a.betas.split(",")]
-    gemm(a)
+    if a.what == "gemm":
+        gemm(a)
+    else:
+        csr(a)
