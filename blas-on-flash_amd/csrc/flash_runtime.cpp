@@ -17,6 +17,8 @@
 //   * everything is event driven (hipEvents + condition variables): no 50-100 ms
 //     scheduler ticks (reference scheduler.cpp:92-93,206-212).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 
@@ -291,6 +293,17 @@ struct GemmRun {
 
 }  // namespace
 
+static bool trace_on() {
+  static const bool on = getenv("BOF_TRACE") != nullptr;
+  return on;
+}
+#define BOF_TRACE_T(label)                                                                       \
+  do {                                                                                           \
+    if (trace_on())                                                                              \
+      fprintf(stderr, "[bof trace] %-28s %8.3f ms\n", label,                                     \
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); \
+  } while (0)
+
 static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                            float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
                            int64_t ldb, int64_t ldc, const bof_options *opts) {
@@ -364,7 +377,9 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   const int T = (int) R.tasks.size();
 
   // ---- resources ----------------------------------------------------------------------
+  BOF_TRACE_T("plan done");
   BOF_HIP_TRY(hipMalloc((void **) &R.slab, (size_t) n_slots * R.slot_bytes));
+  BOF_TRACE_T("device slab allocated");
   R.slots.resize((size_t) n_slots);
   for (int64_t s = 0; s < n_slots; s++) {
     R.slots[s].ptr = R.slab + (size_t) s * R.slot_bytes;
@@ -382,6 +397,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   R.ss = stream_set(R.o.n_streams);
   if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
 
+  BOF_TRACE_T("rings/streams ready");
   std::vector<std::thread> readers, writers;
   for (int i = 0; i < std::max(1, R.o.n_io_threads); i++) readers.emplace_back([&R] { R.reader_main(); });
   writers.emplace_back([&R] { R.writer_main(); });
@@ -471,11 +487,13 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   }
 
   // ---- drain ---------------------------------------------------------------------------
+  BOF_TRACE_T("all tasks dispatched");
   R.fetch_q.close();
   for (auto &th : readers) th.join();
   R.write_q.close();
   for (auto &th : writers) th.join();
   (void) hipDeviceSynchronize();
+  BOF_TRACE_T("drained (writes done)");
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, "bof_flash_gemm dispatch");
   if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
     const int e = R.io_error.load();
@@ -492,6 +510,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   (void) hipStreamDestroy(R.h2d);
   (void) hipStreamDestroy(R.d2h);
   (void) hipFree(R.slab);
+  BOF_TRACE_T("resources released");
   publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   return fail;
 }
