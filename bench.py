@@ -66,6 +66,91 @@ def cpu_baseline_gemm(tile):
     return out
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+    this same command (profiles/rNN/bench_gemm_pmc.json; FETCH_SIZE/WRITE_SIZE are collected
+    in separate passes and corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot run
+    under the counters itself, so it reports the latest committed measurement."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_gemm_pmc.json")))
+    if not cands:
+        return None, None
+    try:
+        d = json.load(open(cands[-1]))
+        return float(d["hbm_traffic_bytes_per_launch"]), os.path.relpath(cands[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def csr_secondary(bofhip, torch, dev, st):
+    """Secondary lines of the metric: flash _csrmm at BASELINE configs[2] (10M x 1M CSR, 1e9 nnz,
+    x 1M x 128 dense) and _csrgemv at the configs[4] size (50M x 50M, 5e8 nnz), HBM-resident,
+    inputs generated in HBM by the reference generators' device restatement."""
+    def timed(fn, iters=3):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    out = {}
+    opts = bofhip.default_options(n_streams=1)
+    m, n, k, npr = 10_000_000, 1_000_000, 128, 100
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 1_000_000):
+        bofhip.gen_sparse_rows(r0, 1_000_000, n, npr, val.data_ptr() + 4 * r0 * npr,
+                               col.data_ptr() + 8 * r0 * npr, off.data_ptr() + 8 * r0, st)
+    b = torch.empty(n * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(b.data_ptr(), 0, n * k, "u", 3, st)
+    c = torch.zeros(m * k, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ia = off.cpu().numpy()
+    ms = timed(lambda: bofhip.csrmm_resident("N", m, n, k, 1.0, 0.0, val.data_ptr(), ia.ctypes.data,
+                                             off.data_ptr(), col.data_ptr(), "R", b.data_ptr(),
+                                             c.data_ptr(), opts, st))
+    nnz = m * npr
+    alg = nnz * 12 + (m + 1) * 8 + 4 * n * k + 4 * m * k          # BASELINE.md work definition
+    out["csrmm"] = {"workload": "flash _csrmm 10M x 1M CSR (1e9 nnz) x 1M x 128, resident in HBM "
+                                "(BASELINE configs[2])",
+                    "ms": round(ms, 3), "gflops": round(2.0 * nnz * k / ms / 1e6, 1), "row_block_tasks": 100,
+                    "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                 "algorithmic_bytes": alg,
+                                 "gather_GBps": round(nnz * k * 4 / ms / 1e6, 1)}}
+    del val, col, off, b, c
+    torch.cuda.empty_cache()
+    m = n = 50_000_000
+    npr = 10
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 5_000_000):
+        bofhip.gen_sparse_rows(r0, 5_000_000, n, npr, val.data_ptr() + 4 * r0 * npr,
+                               col.data_ptr() + 8 * r0 * npr, off.data_ptr() + 8 * r0, st)
+    x = (torch.arange(n, device=dev) % 10).float()
+    y = torch.zeros(m, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ia = off.cpu().numpy()
+    nnz = m * npr
+    alg = nnz * 12 + (m + 1) * 8 + 8 * n
+    for tr in "NT":
+        ms = timed(lambda: bofhip.csrgemv_resident(tr, m, n, val.data_ptr(), ia.ctypes.data, off.data_ptr(),
+                                                   col.data_ptr(), x.data_ptr(), y.data_ptr(), opts, st))
+        out["csrgemv_" + tr] = {"workload": "flash _csrgemv 50M x 50M CSR (5e8 nnz), resident in HBM",
+                                "ms": round(ms, 3), "gflops": round(2.0 * nnz / ms / 1e6, 1),
+                                "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1),
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +164,8 @@ def main():
     ap.add_argument("--data", default="u", choices=["u", "s"],
                     help="u: uniform[-1,1) (timing default); s: dense_create mode s")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--csrmm", action="store_true", help="also time the cfg3 CSRMM (extra field)")
+    ap.add_argument("--no-csr", action="store_true",
+                    help="skip the CSRMM (cfg3) / CSRGEMV (cfg5-size) secondary measurements")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +256,7 @@ def main():
         avg_launch_ms = ev_ms / (args.steps * launches_per_step)
         flops_per_launch = flops_per_step_rank / launches_per_step
         achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": "GFLOP/s, out-of-core GEMM hot path (tile DAG over HBM-resident tiles)",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -183,11 +270,20 @@ def main():
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "avg_launch_ms": round(avg_launch_ms, 4),
-                         "flops_per_launch": flops_per_launch, "traffic": None},
+                         "flops_per_launch": flops_per_launch, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, PMC)",
+                         "traffic_source": traffic_src},
             "parity_spot_rel_err": rel,
         }
         if not args.no_cpu and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline_gemm(min(args.blk, 4096))
+        if not args.no_csr and n_gpus == 1 and not args.size:
+            del a, b, c
+            torch.cuda.empty_cache()
+            try:
+                out["secondary"] = csr_secondary(bofhip, torch, dev, st)
+            except Exception as e:  # the headline line must still be printed
+                out["secondary"] = {"error": str(e)[:200]}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
