@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--data", default="u", choices=["u", "s"],
                     help="u: uniform[-1,1) (timing default); s: dense_create mode s")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--as-shard-of", type=int, default=0,
+                    help="debug: run rank 0's slab of the N-GPU workload on one GPU")
     ap.add_argument("--no-csr", action="store_true",
                     help="skip the CSRMM (cfg3) / CSRGEMV (cfg5-size) secondary measurements")
     args = ap.parse_args()
@@ -184,6 +186,9 @@ def main():
     dev = torch.device("cuda", local)
 
     n_gpus = max(world, 1)
+    shard_of = args.as_shard_of if world == 1 else 0
+    if shard_of > 1:
+        n_gpus = shard_of
     if n_gpus == 1:
         m = n = k = args.size or 32768
         m_local, row0 = m, 0
@@ -251,6 +256,8 @@ def main():
     rel = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
 
     if rank == 0:
+        if shard_of > 1:
+            n_gpus = 1          # only this rank's slab actually ran
         total_flops = flops_per_step_rank * n_gpus * args.steps
         value = total_flops / dt / 1e9
         avg_launch_ms = ev_ms / (args.steps * launches_per_step)

@@ -76,6 +76,8 @@ SYMBOLS = [
                                  u64, u64, u64, C.POINTER(Options)]),
     ("bof_flash_csrmm", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, FPtr,
                                   FPtr, C.POINTER(Options)]),
+    ("bof_flash_csrmm_inmem", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, P, P,
+                                        C.POINTER(Options)]),
     ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
@@ -212,6 +214,12 @@ def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda=0, ldb=0, ldc
 def flash_csrmm(trans_a, m, n, k, alpha, beta, fa, fia, fja, ord_b, fb, fc, opts=None):
     check(lib().bof_flash_csrmm(_c(trans_a), m, n, k, alpha, beta, fa, fia, fja, _c(ord_b), fb, fc,
                                 C.byref(opts) if opts is not None else None), "bof_flash_csrmm")
+
+
+def flash_csrmm_inmem(trans_a, m, n, k, alpha, beta, fa, fia, fja, ord_b, b_host, c_host, opts=None):
+    check(lib().bof_flash_csrmm_inmem(_c(trans_a), m, n, k, alpha, beta, fa, fia, fja, _c(ord_b), b_host,
+                                      c_host, C.byref(opts) if opts is not None else None),
+          "bof_flash_csrmm_inmem")
 
 
 def flash_csrgemv(trans_a, m, n, fa, fia, fja, b_host, c_host, opts=None):

@@ -535,6 +535,8 @@ struct CsrRun {
   int64_t m = 0, n = 0, k = 0;
   float alpha = 1.f, beta = 0.f;
   bof_fptr fa, fja, fb, fc;
+  const float *host_b = nullptr;  // csrmm overload with B and C in host memory
+  float *host_c = nullptr;
   std::vector<int64_t> ia, st, sz;
   std::vector<CsrCtx> ctx;
   int depth = 3;
@@ -593,7 +595,12 @@ struct CsrRun {
       }
       if (!rc && e == hipSuccess && is_mm && beta != 0.f) {
         // C block: 'R' contiguous rows, 'C' strided columns of the block (packed [k][r])
-        if (ord_b == 'R')
+        if (host_c) {
+          if (ord_b == 'R') memcpy(c.h_c, host_c + (size_t) st[b] * k, c_bytes(b));
+          else
+            for (int64_t j = 0; j < k; j++)
+              memcpy(c.h_c + (size_t) j * sz[b] * 4, host_c + (size_t) j * m + st[b], (size_t) sz[b] * 4);
+        } else if (ord_b == 'R')
           rc = file_sread(fc.fd, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, use_aio);
         else
           rc = file_sread(fc.fd, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
@@ -620,7 +627,12 @@ struct CsrRun {
       CsrCtx &c = ctx[b % depth];
       hipError_t e = hipEventSynchronize(c.done);
       if (e != hipSuccess) io_error.store(-1000 - (int) e);
-      if (is_mm && !io_error.load()) {
+      if (is_mm && !io_error.load() && host_c) {
+        if (ord_b == 'R') memcpy(host_c + (size_t) st[b] * k, c.h_c, c_bytes(b));
+        else
+          for (int64_t j = 0; j < k; j++)
+            memcpy(host_c + (size_t) j * m + st[b], c.h_c + (size_t) j * sz[b] * 4, (size_t) sz[b] * 4);
+      } else if (is_mm && !io_error.load()) {
         int rc;
         if (ord_b == 'R')
           rc = file_swrite(fc.fd, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, use_aio);
@@ -680,6 +692,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   R.is_mm = is_mm; R.trans = trans; R.ord_b = ord_b;
   R.m = m; R.n = n; R.k = k; R.alpha = alpha; R.beta = beta;
   R.fa = fa; R.fja = fja; R.fb = fb; R.fc = fc;
+  if (is_mm && fb.fd < 0) { R.host_b = hb; R.host_c = hc; }
   R.use_aio = R.o.use_odirect != 0;
   BOF_HIP_TRY(hipGetDevice(&R.dev));
   if (m == 0) return BOF_OK;
@@ -720,8 +733,13 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     // B stays resident for the whole call (one shared read, like the reference's
     // single "use_full" cache key, csrmm_task.h:175-183)
     BOF_HIP_TRY(hipMalloc((void **) &d_b, (size_t) n * k * 4));
-    rc = load_dense_to_device(fb, (uint64_t) n * k * 4, d_b, R.h2d, R.use_aio, R.cnt);
-    if (rc) return rc;
+    if (R.host_b) {
+      BOF_HIP_TRY(hipMemcpyAsync(d_b, R.host_b, (size_t) n * k * 4, hipMemcpyHostToDevice, R.h2d));
+      R.cnt.h2d += (uint64_t) n * k * 4;
+    } else {
+      rc = load_dense_to_device(fb, (uint64_t) n * k * 4, d_b, R.h2d, R.use_aio, R.cnt);
+      if (rc) return rc;
+    }
   } else {
     BOF_HIP_TRY(hipMalloc((void **) &d_x, (size_t) xlen * 4));
     BOF_HIP_TRY(hipMalloc((void **) &d_y, (size_t) ylen * 4));
@@ -875,6 +893,20 @@ int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alph
   if (k == 0) return BOF_OK;
   return flash_csr_impl(true, 'N', (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, ia, ja,
                         ord_b, b, c, nullptr, nullptr, opts);
+}
+
+int bof_flash_csrmm_inmem(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha, float beta,
+                          bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b, const float *b, float *c,
+                          const bof_options *opts) {
+  if (trans_a != 'N' || (ord_b != 'R' && ord_b != 'C') || !b || !c || a.fd < 0 || ia.fd < 0 ||
+      ja.fd < 0 || n > (uint64_t) INT32_MAX) {
+    set_error("bof_flash_csrmm_inmem: bad argument (only trans_a='N', ord_b 'R'|'C')");
+    return BOF_EINVAL;
+  }
+  if (k == 0) return BOF_OK;
+  bof_fptr none{-1, 0};
+  return flash_csr_impl(true, 'N', (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, ia, ja,
+                        ord_b, none, none, b, c, opts);
 }
 
 int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a, bof_fptr ia, bof_fptr ja,

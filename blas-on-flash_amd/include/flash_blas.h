@@ -26,7 +26,7 @@ namespace flash {
                   FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
                   CHAR ord_b, flash_ptr<FPTYPE> b, flash_ptr<FPTYPE> c);
 
-  // variant with B and C in host memory
+  // variant with B and C in host memory (row- or column-major; returns 0 on success)
   FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha,
                   FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
                   CHAR ord_b, FPTYPE* b, FPTYPE* c);

@@ -204,12 +204,19 @@ namespace flash {
                   "flash::csrmm");
   }
 
-  FBLAS_INT csrmm(CHAR, FBLAS_UINT, FBLAS_UINT, FBLAS_UINT, FPTYPE, FPTYPE, flash_ptr<FPTYPE>,
-                  flash_ptr<MKL_INT>, flash_ptr<MKL_INT>, CHAR, FPTYPE*, FPTYPE*) {
-    // SURVEY 8(f) "next" row 1: in the reference this overload returns -1 for
-    // row-major even after doing the work (src/blas/csrmm.cpp:463-466)
-    GLOG_ERROR("csrmm with in-memory B/C is not implemented in this build");
-    return -1;
+  // B and C in host memory.  The reference's version returns -1 for row-major even after
+  // doing the work (src/blas/csrmm.cpp:463-466) and rejects 'T'; here both layouts return 0.
+  FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha, FPTYPE beta,
+                  flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja, CHAR ord_b,
+                  FPTYPE* b, FPTYPE* c) {
+    if (trans_a == 'T') {
+      GLOG_ERROR("csrmm in mem transpose not implemented");
+      return -1;
+    }
+    const bof_options o = current_options();
+    return finish(bof_flash_csrmm_inmem(trans_a, m, n, k, alpha, beta, as_fptr(a), as_fptr(ia),
+                                        as_fptr(ja), ord_b, b, c, &o),
+                  "flash::csrmm(in-memory B/C)");
   }
 
   FBLAS_INT csrgemv(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, flash_ptr<FPTYPE> a,

@@ -172,6 +172,11 @@ int bof_flash_gemm(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
 int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha,
                     float beta, bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b,
                     bof_fptr b, bof_fptr c, const bof_options *opts);
+/* csrmm with B (n x k) and C (m x k) in HOST memory: the reference's second overload
+ * (include/flash_blas.h:43-46, src/blas/csrmm.cpp:453-472). */
+int bof_flash_csrmm_inmem(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha,
+                          float beta, bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b,
+                          const float *b, float *c, const bof_options *opts);
 /* b (input vector) and c (output vector) are HOST pointers as in the reference
  * (include/flash_blas.h:55-57). */
 int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a,

@@ -169,6 +169,32 @@ def test_flash_csrmm(dev, tmp_path, golden, ord_b, k, alpha, beta):
         F.close()
 
 
+@pytest.mark.parametrize("ord_b", ["R", "C"])
+def test_flash_csrmm_inmem_bc(dev, tmp_path, ord_b):
+    """csrmm overload with B and C in host memory (include/flash_blas.h:43-46).
+    The reference returns -1 for 'R' even after doing the work; both layouts succeed here."""
+    m, n, k = 4096, 2048, 136
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    rng = np.random.default_rng(1)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    ref = orc.flash_csrmm(ord_b, m, n, k, 0.5, 2.0, val, ia, ja, b, c0.copy(), 1000, 5000, 1024)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia)
+    try:
+        c = c0.copy()
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000)
+        bofhip.flash_csrmm_inmem("N", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
+                                 ord_b, b.ctypes.data, c.ctypes.data, opts)
+        assert np.array_equal(c, ref)
+        with pytest.raises(bofhip.BofError):
+            bofhip.flash_csrmm_inmem("T", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"),
+                                     F.fptr("ja"), ord_b, b.ctypes.data, c.ctypes.data, opts)
+    finally:
+        F.close()
+
+
 @pytest.mark.parametrize("trans", ["N", "T"])
 def test_flash_csrgemv(dev, tmp_path, golden, trans):
     import hashlib
