@@ -17,6 +17,7 @@
 // which is what oracle/bof_oracle.c::orc_sgemm computes -> bit-exact parity.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace bof {
 
@@ -115,7 +116,7 @@ __device__ __forceinline__ f32x4 s2op(const float *__restrict__ s, int x, int q,
 //        kt is multiplied out of buffer kt&1, slab kt+1 (fetched one slab earlier) is
 //        written to the other buffer and slab kt+2's global loads are in flight.
 template <int BM, int BN, int WM, int WN, bool DBUF, int AMODE, int BMODE, bool GUARD>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 3)
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : (BM * BN == 65536 ? 1 : 3))
 sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                   int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
                   float alpha, float beta, int tiles_m, int tiles_n) {
@@ -240,6 +241,161 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 256 x 256 x 32 block tile, ONE wave per SIMD (4 waves, wave tile 128 x 128 = 16
+// accumulators = 256 AGPRs), double-buffered LDS, one barrier per slab.
+//
+// Why not two waves per SIMD: measured with s_memtime stamps (tools/gemm_exp.hip) on the
+// 8-wave shape, the matrix pipe is arbitrated by age, so the older wave of each SIMD runs
+// its 128 MFMAs nearly back-to-back, then idles ~8k cycles at the barrier while the younger
+// wave runs alone with every LDS/staging stall exposed (13 % of the pipe idle).  With one
+// wave per SIMD nothing is arbitrated; instead the wave hides its own latencies: the side
+// work of a slab (operand reads for the NEXT k-group, LDS staging writes of slab kt+1,
+// global loads of slab kt+2) is cut into 16 slots, one after each batch of 16 MFMAs, so the
+// in-order issue stream never leaves the matrix pipe waiting on it.
+template <int AMODE, int BMODE, bool W, bool L, int ABL = 0>
+__device__ __forceinline__ void slab_1w(const float *__restrict__ sA, const float *__restrict__ sB,
+                                        float *__restrict__ nA, float *__restrict__ nB,
+                                        const float *__restrict__ A, int64_t lda,
+                                        const float *__restrict__ B, int64_t ldb, int m0, int n0,
+                                        int k2, int M, int N, int K, Stage<8> &ra, Stage<8> &rb,
+                                        f32x16 (&acc)[4][4], int t, int arow, int bcol, int h) {
+  f32x4 a[2][4], b[2][4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    a[0][x] = s2op<AMODE, 256>(sA, arow + x * 32, 0, h);
+    b[0][x] = s2op<BMODE, 256>(sB, bcol + x * 32, 0, h);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
+                                                             acc[mt][nt], 0, 0, 0);
+      // ---- side slot s = 4q + c ------------------------------------------------------
+      if (q < 3 && c < 3) {  // the next k-group's operand fragments: quarters {0,1}, 2, 3 in slots
+                             // 0, 1, 2, so the last one is issued a full MFMA batch before its use
+#pragma unroll
+        for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
+          if (ABL & 4) {  // dev ablation: no LDS operand reads
+            a[(q + 1) & 1][x] = a[q & 1][x] + 1.0f;
+            b[(q + 1) & 1][x] = b[q & 1][x] + 1.0f;
+          } else {
+            a[(q + 1) & 1][x] = s2op<AMODE, 256>(sA, arow + x * 32, q + 1, h);
+            b[(q + 1) & 1][x] = s2op<BMODE, 256>(sB, bcol + x * 32, q + 1, h);
+          }
+        }
+      }
+      const int s = 4 * q + c;
+      // slot s stages float4 #s of slab kt+1 into LDS and refills its registers from slab kt+2
+      // (refilling two slots later instead was measured slower)
+      if (s < 8) {
+        if (W && !(ABL & 1)) r2s1<AMODE, 256>(nA, ra.v[s], t + s * 256);
+        if ((ABL & 1) && W) asm volatile("" ::"v"(ra.v[s]));  // dev ablation: keep the load alive
+        if (L && !(ABL & 2)) ra.v[s] = g2r1<AMODE, 256, false>(A, lda, m0, k2, M, K, t + s * 256);
+      } else {
+        if (W && !(ABL & 1)) r2s1<BMODE, 256>(nB, rb.v[s - 8], t + (s - 8) * 256);
+        if ((ABL & 1) && W) asm volatile("" ::"v"(rb.v[s - 8]));
+        if (L && !(ABL & 2)) rb.v[s - 8] = g2r1<BMODE, 256, false>(B, ldb, n0, k2, N, K, t + (s - 8) * 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int AMODE, int BMODE, int ABL = 0>
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_1w_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                        int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                        float alpha, float beta, int tiles_m, int tiles_n) {
+  constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_BUF = LDS_A + LDS_B;
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_BUF];
+
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int arow = wm * 128 + i, bcol = wn * 128 + i;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = K / BK;  // caller guarantees K % 32 == 0, nkt >= 2
+  Stage<8> ra = g2r<AMODE, 256, 256, false>(A, lda, m0, 0, M, K, t);
+  Stage<8> rb = g2r<BMODE, 256, 256, false>(B, ldb, n0, 0, N, K, t);
+  r2s<AMODE, 256, 256>(lds, ra, t);
+  r2s<BMODE, 256, 256>(lds + LDS_A, rb, t);
+  ra = g2r<AMODE, 256, 256, false>(A, lda, m0, BK, M, K, t);
+  rb = g2r<BMODE, 256, 256, false>(B, ldb, n0, BK, N, K, t);
+  __syncthreads();
+
+  int kt = 0;
+  for (; kt + 2 < nkt; kt++) {  // steady state: write slab kt+1, fetch slab kt+2
+    float *cur = lds + ((kt & 1) ? LDS_BUF : 0), *nxt = lds + ((kt & 1) ? 0 : LDS_BUF);
+    slab_1w<AMODE, BMODE, true, true, ABL>(cur, cur + LDS_A, nxt, nxt + LDS_A, A, lda, B, ldb, m0, n0,
+                                           (kt + 2) * BK, M, N, K, ra, rb, acc, t, arow, bcol, h);
+    if (!(ABL & 8)) __syncthreads();
+  }
+  {  // slab nkt-2: write the last slab, nothing left to fetch
+    float *cur = lds + ((kt & 1) ? LDS_BUF : 0), *nxt = lds + ((kt & 1) ? 0 : LDS_BUF);
+    slab_1w<AMODE, BMODE, true, false>(cur, cur + LDS_A, nxt, nxt + LDS_A, A, lda, B, ldb, m0, n0, 0,
+                                       M, N, K, ra, rb, acc, t, arow, bcol, h);
+    __syncthreads();
+    kt++;
+  }
+  {  // last slab
+    float *cur = lds + ((kt & 1) ? LDS_BUF : 0), *nxt = lds + ((kt & 1) ? 0 : LDS_BUF);
+    slab_1w<AMODE, BMODE, false, false>(cur, cur + LDS_A, nxt, nxt + LDS_A, A, lda, B, ldb, m0, n0,
+                                        0, M, N, K, ra, rb, acc, t, arow, bcol, h);
+  }
+
+  float *ctile = C + (int64_t) m0 * ldc + n0;
+  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      f32x16 old;
+      if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
+        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+      }
+    }
+}
+
 template <int AMODE, int BMODE>
 static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int64_t ldb,
                                float *C, int64_t ldc, int M, int N, int K, float alpha,
@@ -247,6 +403,16 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   const bool vec_ok = (K % BK == 0) && (K > 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // 0 (default): 8 waves, 2 per SIMD; 1: 4 waves, 1 per SIMD with slotted side work.  Both
+  // measure 137-139 TFLOP/s at 4096^3; the switch is kept for tuning work.
+  static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 0;
+  if (big_tile_variant == 1 && vec_ok && M % 256 == 0 && N % 256 == 0 && K >= 2 * BK &&
+      (int64_t) (M / 256) * (N / 256) >= 128) {
+    const int tiles_m = M / 256, tiles_n = N / 256;
+    hipLaunchKernelGGL((sgemm_tile256_1w_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0,
+                       st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   if (vec_ok && M % 256 == 0 && N % 256 == 0 && (int64_t) (M / 256) * (N / 256) >= 128) {
     const int tiles_m = M / 256, tiles_n = N / 256;
     hipLaunchKernelGGL((sgemm_tile_kernel<256, 256, 2, 4, true, AMODE, BMODE, false>),
