@@ -80,6 +80,7 @@ SYMBOLS = [
                                         C.POINTER(Options)]),
     ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
+    ("bof_flash_release", C.c_int, []),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_gen_dense", C.c_int, [P, i64, i64, chr_, u64, P]),

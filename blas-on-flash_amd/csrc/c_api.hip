@@ -92,10 +92,10 @@ void bof_default_options(bof_options *o) {
   o->csrmm_rblk = 131072;
   o->csrmm_cblk = 1024;
   o->hbm_budget = 0;
-  o->n_io_threads = 4;
+  o->n_io_threads = 8;
   o->n_streams = 4;
   o->use_odirect = 1;
-  o->pinned_slots = 6;
+  o->pinned_slots = 8;
 }
 
 int bof_device_count(void) {
@@ -259,9 +259,15 @@ int bof_csrgemv_resident(char trans_a, int64_t m, int64_t n, const float *val,
   if (!ss) { set_error("bof_csrgemv_resident: no HIP device"); return BOF_ENODEV; }
   int rc = ss->fork(parent);
   if (rc) return rc;
-  for (int64_t bi = 0; bi < nb; bi++) {
-    const int64_t s = st[bi], r = sz[bi], z = ia_host[s];  // absolute, as the reference (csrmm.cpp:97-98)
-    hipStream_t q = ss->s[bi % ss->n];
+  // With everything resident the row blocks are independent and contiguous, so runs of
+  // up to 32 of them (~4M rows) go out as one launch: the per-block launches of the file
+  // path (131072 rows = 2 workgroups per CU) are latency-bound on the x gather.
+  const int64_t kRun = 32;
+  for (int64_t b0 = 0; b0 < nb; b0 += kRun) {
+    const int64_t b1 = std::min(nb, b0 + kRun);
+    const int64_t s = st[b0], r = st[b1 - 1] + sz[b1 - 1] - s;
+    const int64_t z = ia_host[s];  // absolute, as the reference (csrmm.cpp:97-98)
+    hipStream_t q = ss->s[(b0 / kRun) % ss->n];
     if (trans_a == 'N')
       BOF_HIP_TRY(scsrgemv('N', r, n, val + z, ia_dev + s, ja + z, x, y + s, q));
     else

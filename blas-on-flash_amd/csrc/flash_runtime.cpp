@@ -83,7 +83,14 @@ class PinnedRing {
 
  public:
   size_t bytes = 0;
+  int count() const { return (int) slots.size(); }
   int init(int n, size_t nbytes) {
+    if ((int) slots.size() == n && bytes == nbytes) {  // reuse a cached ring as is
+      free_.clear();
+      for (int i = 0; i < n; i++) free_.push_back(i);
+      return BOF_OK;
+    }
+    destroy();
     bytes = nbytes;
     for (int i = 0; i < n; i++) {
       void *p = nullptr;
@@ -172,6 +179,17 @@ struct DevSlot {
   bool used[kMaxStreams + 1] = {};
 };
 
+// Pinned rings and the device slab are expensive to create (pinning 0.5 GB takes ~60 ms,
+// about as long as the whole 16384^3 product), so they are kept per device between calls,
+// like the reference keeps its program cache for the life of the process.
+struct GemmResources {
+  PinnedRing rring, wring;
+  char *slab = nullptr;
+  size_t slab_bytes = 0;
+};
+static std::mutex g_res_mu;
+static GemmResources *g_res[64];
+
 struct FetchReq { int tile; int slot; std::vector<hipEvent_t> waits; };
 struct WriteReq { int wslot; int tile; };
 
@@ -188,7 +206,7 @@ struct GemmRun {
   std::vector<int> free_slots;
   size_t slot_bytes = 0;
   char *slab = nullptr;
-  PinnedRing rring, wring;
+  GemmResources *res = nullptr;
   hipStream_t h2d = nullptr, d2h = nullptr;
   StreamSet *ss = nullptr;
   WorkQueue<FetchReq> fetch_q;
@@ -207,11 +225,11 @@ struct GemmRun {
     FetchReq rq;
     while (fetch_q.pop(rq)) {
       Tile &t = tiles[rq.tile];
-      const int ps = rring.acquire();
+      const int ps = res->rring.acquire();
       int rc = 0;
       if (!io_error.load())
         rc = file_sread(f[t.mat].fd, f[t.mat].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
-                        (uint64_t) t.nrows, (uint64_t) t.ncols * 4, rring.ptr(ps), use_aio);
+                        (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->rring.ptr(ps), use_aio);
       if (rc) io_error.store(rc);
       cnt.rd += tile_bytes(t);
       DevSlot &s = slots[rq.slot];
@@ -219,12 +237,12 @@ struct GemmRun {
       for (hipEvent_t w : rq.waits)  // WAR: previous occupant's kernels / write-back
         if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
       if (e == hipSuccess)
-        e = hipMemcpyAsync(s.ptr, rring.ptr(ps), tile_bytes(t), hipMemcpyHostToDevice, h2d);
+        e = hipMemcpyAsync(s.ptr, res->rring.ptr(ps), tile_bytes(t), hipMemcpyHostToDevice, h2d);
       if (e == hipSuccess) e = hipEventRecord(s.ready, h2d);
-      if (e == hipSuccess) rring.mark_busy(ps, h2d);
+      if (e == hipSuccess) res->rring.mark_busy(ps, h2d);
       if (e != hipSuccess) io_error.store(-1000 - (int) e);
       cnt.h2d += tile_bytes(t);
-      rring.release(ps);
+      res->rring.release(ps);
       { std::lock_guard<std::mutex> lk(mu); t.state = 2; }
       cv.notify_all();
     }
@@ -235,15 +253,15 @@ struct GemmRun {
     WriteReq rq;
     while (write_q.pop(rq)) {
       Tile &t = tiles[rq.tile];
-      hipError_t e = hipEventSynchronize(wring.event(rq.wslot));
+      hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
       if (e != hipSuccess) io_error.store(-1000 - (int) e);
       int rc = 0;
       if (!io_error.load())
         rc = file_swrite(f[2].fd, f[2].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
-                         (uint64_t) t.nrows, (uint64_t) t.ncols * 4, wring.ptr(rq.wslot), use_aio);
+                         (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->wring.ptr(rq.wslot), use_aio);
       if (rc) io_error.store(rc);
       cnt.wr += tile_bytes(t);
-      wring.release(rq.wslot);
+      res->wring.release(rq.wslot);
     }
   }
 
@@ -378,7 +396,20 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
 
   // ---- resources ----------------------------------------------------------------------
   BOF_TRACE_T("plan done");
-  BOF_HIP_TRY(hipMalloc((void **) &R.slab, (size_t) n_slots * R.slot_bytes));
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    if (!g_res[R.dev & 63]) g_res[R.dev & 63] = new GemmResources();
+    R.res = g_res[R.dev & 63];
+  }
+  const size_t slab_need = (size_t) n_slots * R.slot_bytes;
+  if (R.res->slab_bytes < slab_need) {  // grow-only device slab, kept between calls
+    if (R.res->slab) (void) hipFree(R.res->slab);
+    R.res->slab = nullptr;
+    R.res->slab_bytes = 0;
+    BOF_HIP_TRY(hipMalloc((void **) &R.res->slab, slab_need));
+    R.res->slab_bytes = slab_need;
+  }
+  R.slab = R.res->slab;
   BOF_TRACE_T("device slab allocated");
   R.slots.resize((size_t) n_slots);
   for (int64_t s = 0; s < n_slots; s++) {
@@ -388,9 +419,9 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
       BOF_HIP_TRY(hipEventCreateWithFlags(&R.slots[s].use[q], hipEventDisableTiming));
     R.free_slots.push_back((int) (n_slots - 1 - s));
   }
-  rc = R.rring.init(std::max(2, R.o.pinned_slots), R.slot_bytes);
+  rc = R.res->rring.init(std::max(2, R.o.pinned_slots), R.slot_bytes);
   if (rc) return rc;
-  rc = R.wring.init(2, R.slot_bytes);
+  rc = R.res->wring.init(2, R.slot_bytes);
   if (rc) return rc;
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
@@ -471,11 +502,11 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
     }
     if (tk.l == Nk - 1) {  // chain finished: write the C tile back, then it becomes evictable
       Tile &C = R.tiles[ids[2]];
-      const int ws = R.wring.acquire();
+      const int ws = R.res->wring.acquire();
       herr = hipStreamWaitEvent(R.d2h, sc.use[sidx], 0);
       if (herr == hipSuccess)
-        herr = hipMemcpyAsync(R.wring.ptr(ws), sc.ptr, R.tile_bytes(C), hipMemcpyDeviceToHost, R.d2h);
-      if (herr == hipSuccess) herr = hipEventRecord(R.wring.event(ws), R.d2h);
+        herr = hipMemcpyAsync(R.res->wring.ptr(ws), sc.ptr, R.tile_bytes(C), hipMemcpyDeviceToHost, R.d2h);
+      if (herr == hipSuccess) herr = hipEventRecord(R.res->wring.event(ws), R.d2h);
       if (herr == hipSuccess) herr = hipEventRecord(sc.use[kMaxStreams], R.d2h);
       if (herr != hipSuccess) break;
       sc.used[kMaxStreams] = true;
@@ -501,15 +532,13 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
               (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
     fail = BOF_EIO;
   }
-  R.rring.destroy();
-  R.wring.destroy();
+  // the pinned rings and the device slab stay cached for the next call (bof_flash_release)
   for (auto &s : R.slots) {
     (void) hipEventDestroy(s.ready);
     for (int q = 0; q <= kMaxStreams; q++) (void) hipEventDestroy(s.use[q]);
   }
   (void) hipStreamDestroy(R.h2d);
   (void) hipStreamDestroy(R.d2h);
-  (void) hipFree(R.slab);
   BOF_TRACE_T("resources released");
   publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   return fail;
@@ -919,6 +948,20 @@ int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a, bof_fptr
   bof_fptr none{-1, 0};
   return flash_csr_impl(false, trans_a, (int64_t) m, (int64_t) n, 1, 1.f, 0.f, a, ia, ja, 'R', none,
                         none, b, c, opts);
+}
+
+int bof_flash_release(void) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  for (int d = 0; d < 64; d++) {
+    GemmResources *r = g_res[d];
+    if (!r) continue;
+    r->rring.destroy();
+    r->wring.destroy();
+    if (r->slab) (void) hipFree(r->slab);
+    delete r;
+    g_res[d] = nullptr;
+  }
+  return BOF_OK;
 }
 
 int bof_flash_last_stats(bof_flash_stats *out) {

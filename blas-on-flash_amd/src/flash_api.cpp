@@ -60,7 +60,7 @@ namespace flash {
       GLOG_FATAL("no HIP device visible: this build has no CPU compute path");
     if (bof_set_device((int) dev) != BOF_OK) GLOG_FATAL("bof_set_device failed: ", bof_last_error());
   }
-  void flash_destroy() {}
+  void flash_destroy() { bof_flash_release(); }
 
   // ---- utilities (src/utils.cpp in the reference) --------------------------------
   void alloc_aligned(void** ptr, size_t size, size_t align) {

@@ -62,10 +62,10 @@ typedef struct {
   int64_t csrmm_cblk;    /* CSRMM_RM_CBLK_SIZE       default 1024                 */
   int64_t hbm_budget;    /* PROGRAM_BUDGET analogue: bytes of HBM for the tile
                             cache; 0 = 80% of free HBM                          */
-  int32_t n_io_threads;  /* N_IO_THR                 default 4                    */
+  int32_t n_io_threads;  /* N_IO_THR (reference 4)   default 8                    */
   int32_t n_streams;     /* compute streams (N_COMPUTE_THR analogue) default 4    */
   int32_t use_odirect;   /* 1 = O_DIRECT + kernel AIO (default), 0 = buffered     */
-  int32_t pinned_slots;  /* pinned staging ring slots  default 6                  */
+  int32_t pinned_slots;  /* pinned staging ring slots  default 8                  */
 } bof_options;
 void bof_default_options(bof_options *o);
 
@@ -191,6 +191,10 @@ typedef struct {
   double seconds;                     /* wall time of the call         */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
+/* Level-3 calls keep their pinned staging rings and HBM tile slab between calls (the
+ * reference keeps its program cache for the life of the process, src/lib_funcs.cpp:9);
+ * this frees them. */
+int bof_flash_release(void);
 
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
  * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided

@@ -44,7 +44,7 @@ def test_header_cites_reference_for_each_level():
 def test_default_options_match_reference_tunables():
     o = bofhip.default_options()
     assert (o.gemm_blk, o.max_nnzs, o.csrmm_rblk, o.csrmm_cblk) == (4096, 10_000_000, 131072, 1024)
-    assert o.n_io_threads == 4 and o.n_streams == 4 and o.use_odirect == 1
+    assert o.n_io_threads == 8 and o.n_streams == 4 and o.use_odirect == 1
 
 
 @pytest.mark.parametrize("args", [

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--io-threads", type=int, default=8)
     ap.add_argument("--pinned", type=int, default=8)
     ap.add_argument("--drop-cache", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=2)
     args = ap.parse_args()
     os.makedirs(args.dir, exist_ok=True)
     dev = torch.device("cuda:0")
@@ -61,10 +62,12 @@ def main():
             os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
     opts = bofhip.default_options(gemm_blk=args.blk, n_io_threads=args.io_threads,
                                   pinned_slots=args.pinned, use_odirect=args.direct, n_streams=4)
-    t0 = time.time()
-    bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
-                      bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
-    dt = time.time() - t0
+    for rep in range(args.reps):
+        t0 = time.time()
+        bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                          bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
+        dt = time.time() - t0
+        print(f"call {rep}: {dt:.3f} s  {2.0 * n ** 3 / dt / 1e9:.0f} GFLOP/s", flush=True)
     st = bofhip.flash_last_stats()
     for fd in fds:
         os.close(fd)
