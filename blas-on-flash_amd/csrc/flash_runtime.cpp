@@ -421,7 +421,8 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   }
   rc = R.res->rring.init(std::max(2, R.o.pinned_slots), R.slot_bytes);
   if (rc) return rc;
-  rc = R.res->wring.init(2, R.slot_bytes);
+  const int n_writers = 2;
+  rc = R.res->wring.init(n_writers + 1, R.slot_bytes);
   if (rc) return rc;
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
@@ -431,7 +432,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   BOF_TRACE_T("rings/streams ready");
   std::vector<std::thread> readers, writers;
   for (int i = 0; i < std::max(1, R.o.n_io_threads); i++) readers.emplace_back([&R] { R.reader_main(); });
-  writers.emplace_back([&R] { R.writer_main(); });
+  for (int i = 0; i < n_writers; i++) writers.emplace_back([&R] { R.writer_main(); });
 
   // ---- dispatch loop ------------------------------------------------------------------
   const int lookahead = std::max(2, R.o.pinned_slots) * 2;

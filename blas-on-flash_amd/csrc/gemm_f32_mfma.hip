@@ -302,6 +302,8 @@ __device__ __forceinline__ void slab_1w(const float *__restrict__ sA, const floa
         if ((ABL & 1) && W) asm volatile("" ::"v"(rb.v[s - 8]));
         if (L && !(ABL & 2)) rb.v[s - 8] = g2r1<BMODE, 256, false>(B, ldb, n0, k2, N, K, t + (s - 8) * 256);
       }
+      // (Forcing exactly one memory instruction per MFMA gap with sched_group_barrier was
+      // measured: 136.4 vs 138.2 TFLOP/s without it -- hipcc's own interleave is kept.)
       __builtin_amdgcn_sched_barrier(0);
     }
   }

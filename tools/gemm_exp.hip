@@ -236,6 +236,6 @@ int main() {
   std::vector<float> h((size_t) n * n);
   for (size_t i = 0; i < h.size(); i++) h[i] = (float) ((i * 2654435761u) >> 8 & 0xffff) / 32768.0f - 1.0f;
   hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  R1(0) R1(16) R1(1) R1(2)
+  R1(0) R1(32)
   return 0;
 }
