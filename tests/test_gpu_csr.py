@@ -136,3 +136,31 @@ def test_csrgemv_resident_generator_known_answer(dev, golden, trans):
     ref = orc.flash_csrgemv(trans, m, n, val, ia, ja, x, np.zeros_like(got), 1000, 5000)
     assert np.array_equal(got, ref)
     assert hashlib.sha256(got.tobytes()).hexdigest() == exact_hash(golden, "gen_csrgemv_" + trans)
+
+
+def test_scsrgemv_n_ragged_heavy_rows(dev):
+    """Groups of 64 rows above and below the 1024-entry LDS image, empty rows, m not a
+    multiple of 64 or 256."""
+    rng = np.random.default_rng(5)
+    m, n = 1000, 5000
+    counts = rng.integers(0, 12, m)
+    counts[64:128] = 40            # 2560 entries in one 64-row group -> direct path
+    counts[300] = 1500             # one very heavy row
+    counts[500:564] = 0            # an empty group
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    ref = orc.scsrgemv("N", m, n, val, ia, ja, x, np.zeros(m, np.float32))
+    dv, di, dj, dx = to_dev(val), to_dev(ia), to_dev(ja), to_dev(x)
+    dy = torch.full((m,), 9.0, dtype=torch.float32, device=dev)
+    bofhip.scsrgemv("N", m, n, ptr(dv), ptr(di), ptr(dj), ptr(dx), ptr(dy), stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), ref)
+    # a sub-block with a base offset in ptr (row block of a larger matrix)
+    s0, r = 200, 333
+    z = ia[s0]
+    dy2 = torch.zeros(r, dtype=torch.float32, device=dev)
+    bofhip.scsrgemv("N", r, n, ptr(dv) + 4 * int(z), ptr(di) + 8 * s0, ptr(dj) + 8 * int(z), ptr(dx), ptr(dy2), stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dy2.cpu().numpy(), ref[s0:s0 + r])
