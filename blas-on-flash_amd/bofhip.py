@@ -81,6 +81,8 @@ SYMBOLS = [
     ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
     ("bof_flash_release", C.c_int, []),
+    ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
+                                          C.c_int32, C.POINTER(FlashStats)]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_gen_dense", C.c_int, [P, i64, i64, chr_, u64, P]),
@@ -227,6 +229,13 @@ def flash_csrgemv(trans_a, m, n, fa, fia, fja, b_host, c_host, opts=None):
     check(lib().bof_flash_csrgemv(_c(trans_a), m, n, fa, fia, fja, b_host, c_host,
                                   C.byref(opts) if opts is not None else None),
           "bof_flash_csrgemv")
+
+
+def flash_gemm_simulate(ord_, ta, tb, m, n, k, beta, blk, n_slots, lookahead=16, lda=0, ldb=0, ldc=0):
+    s = FlashStats()
+    check(lib().bof_flash_gemm_simulate(_c(ord_), _c(ta), _c(tb), m, n, k, beta, lda, ldb, ldc, blk,
+                                        n_slots, lookahead, C.byref(s)), "bof_flash_gemm_simulate")
+    return {f: getattr(s, f) for f, _ in s._fields_}
 
 
 def flash_last_stats():

@@ -193,6 +193,90 @@ static GemmResources *g_res[64];
 struct FetchReq { int tile; int slot; std::vector<hipEvent_t> waits; };
 struct WriteReq { int wslot; int tile; };
 
+// ---- schedule construction and slot replacement: pure host logic, shared by the real
+// ---- pipeline and by bof_flash_gemm_simulate (so the policy is testable without a GPU)
+static size_t tile_bytes_of(const Tile &t) { return (size_t) t.nrows * t.ncols * sizeof(float); }
+
+static void build_tiles(const GemmGeometry &g, float beta, std::vector<Tile> &tiles, size_t &max_tile) {
+  const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
+  tiles.assign((size_t) (Nm * Nk + Nk * Nn + Nm * Nn), Tile());
+  max_tile = 0;
+  bof_gemm_task t;
+  for (int64_t l = 0; l < Nk; l++)
+    for (int64_t i = 0; i < Nm; i++)
+      for (int64_t j = 0; j < Nn; j++) {
+        gemm_task_at(g, l, i, j, beta, &t);
+        const int ids[3] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
+                            (int) (Nm * Nk + Nk * Nn + i * Nn + j)};
+        for (int x = 0; x < 3; x++) {
+          Tile &T = tiles[ids[x]];
+          T.mat = x; T.off = t.off[x]; T.nrows = t.nrows[x]; T.ncols = t.ncols[x];
+          T.ld = t.ld_file[x];
+          max_tile = std::max(max_tile, tile_bytes_of(T));
+        }
+      }
+}
+
+// C super-blocks of gi x gj accumulate chains sized so that the block's C tiles plus two
+// generations of its A/B panels fit the slot budget; inside a block tasks go l-major so all
+// its chains advance together.  With everything resident this is the reference's order.
+static void build_order(const GemmGeometry &g, float beta, int64_t n_slots, std::vector<Tile> &tiles,
+                        std::vector<bof_gemm_task> &tasks, std::vector<int> &task_tiles,
+                        int64_t &gi, int64_t &gj) {
+  const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
+  gi = Nm; gj = Nn;
+  while (gi * gj + 2 * (gi + gj) > n_slots && (gi > 1 || gj > 1)) {
+    if (gi >= gj && gi > 1) gi--; else gj--;
+  }
+  for (int64_t I0 = 0; I0 < Nm; I0 += gi)
+    for (int64_t J0 = 0; J0 < Nn; J0 += gj)
+      for (int64_t l = 0; l < Nk; l++)
+        for (int64_t i = I0; i < std::min(I0 + gi, Nm); i++)
+          for (int64_t j = J0; j < std::min(J0 + gj, Nn); j++) {
+            bof_gemm_task t;
+            gemm_task_at(g, l, i, j, beta, &t);
+            const int pos = (int) tasks.size();
+            tasks.push_back(t);
+            const int ids[3] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
+                                (int) (Nm * Nk + Nk * Nn + i * Nn + j)};
+            for (int x = 0; x < 3; x++) {
+              task_tiles.push_back(ids[x]);
+              tiles[ids[x]].uses.push_back(pos);
+            }
+          }
+}
+
+// A slot for a tile that is not resident: a free one, else the resident, idle tile whose
+// next use lies farthest in the future (Belady) and beyond `horizon` (tiles needed by tasks
+// already committed to are not evictable; C accumulators in mid-chain never are).
+// Returns -1 when nothing can be evicted right now.
+static int claim_slot(std::vector<Tile> &tiles, std::vector<int> &slot_tile, std::vector<int> &free_slots,
+                      int horizon) {
+  if (!free_slots.empty()) {
+    const int sl = free_slots.back();
+    free_slots.pop_back();
+    return sl;
+  }
+  int sl = -1;
+  int64_t best = -1;
+  for (size_t s = 0; s < slot_tile.size(); s++) {
+    const int ot = slot_tile[s];
+    if (ot < 0) continue;
+    const Tile &o = tiles[ot];
+    if (o.pinned_c || o.state != 2) continue;
+    const int64_t nu = o.next_use < o.uses.size() ? o.uses[o.next_use] : INT64_MAX;
+    if (nu <= horizon) continue;
+    if (nu > best) { best = nu; sl = (int) s; }
+  }
+  if (sl >= 0) {
+    Tile &o = tiles[slot_tile[sl]];
+    o.slot = -1;
+    o.state = 0;
+  }
+  return sl;
+}
+
+
 struct GemmRun {
   bof_options o;
   GemmGeometry g;
@@ -203,6 +287,7 @@ struct GemmRun {
   std::vector<bof_gemm_task> tasks;          // execution order
   std::vector<int> task_tiles;               // 3 per task: A, B, C tile ids
   std::vector<DevSlot> slots;
+  std::vector<int> slot_tile;                // tile id per device slot (-1 = empty)
   std::vector<int> free_slots;
   size_t slot_bytes = 0;
   char *slab = nullptr;
@@ -270,26 +355,8 @@ struct GemmRun {
   bool make_resident(int tid, int launch_pos, int horizon, bool fetch) {
     Tile &t = tiles[tid];
     if (t.slot >= 0) { cnt.hits++; return true; }
-    int sl = -1;
-    if (!free_slots.empty()) {
-      sl = free_slots.back();
-      free_slots.pop_back();
-    } else {
-      int64_t best = -1;
-      for (size_t s = 0; s < slots.size(); s++) {
-        const int ot = slots[s].tile;
-        if (ot < 0) continue;
-        Tile &o = tiles[ot];
-        if (o.pinned_c || o.state != 2) continue;
-        const int64_t nu = o.next_use < o.uses.size() ? o.uses[o.next_use] : INT64_MAX;
-        if (nu <= horizon) continue;  // still needed by a task we already committed to
-        if (nu > best) { best = nu; sl = (int) s; }
-      }
-      if (sl < 0) return false;
-      Tile &o = tiles[slots[sl].tile];
-      o.slot = -1;
-      o.state = 0;
-    }
+    const int sl = claim_slot(tiles, slot_tile, free_slots, horizon);
+    if (sl < 0) return false;
     (void) launch_pos;
     cnt.misses++;
     DevSlot &s = slots[sl];
@@ -297,6 +364,7 @@ struct GemmRun {
     for (int q = 0; q <= kMaxStreams; q++)
       if (s.used[q]) { waits.push_back(s.use[q]); s.used[q] = false; }
     s.tile = tid;
+    slot_tile[sl] = tid;
     t.slot = sl;
     if (fetch) {
       t.state = 1;
@@ -341,26 +409,8 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   if (Nk == 0) { set_error("bof_flash_gemm: k == 0 is not supported on the file path"); return BOF_EINVAL; }
 
   // ---- tiles ------------------------------------------------------------------------
-  auto a_id = [&](int64_t i, int64_t l) { return (int) (i * Nk + l); };
-  auto b_id = [&](int64_t l, int64_t j) { return (int) (Nm * Nk + l * Nn + j); };
-  auto c_id = [&](int64_t i, int64_t j) { return (int) (Nm * Nk + Nk * Nn + i * Nn + j); };
-  R.tiles.resize((size_t) (Nm * Nk + Nk * Nn + Nm * Nn));
   size_t max_tile = 0;
-  {
-    bof_gemm_task t;
-    for (int64_t l = 0; l < Nk; l++)
-      for (int64_t i = 0; i < Nm; i++)
-        for (int64_t j = 0; j < Nn; j++) {
-          gemm_task_at(g, l, i, j, beta, &t);
-          const int ids[3] = {a_id(i, l), b_id(l, j), c_id(i, j)};
-          for (int x = 0; x < 3; x++) {
-            Tile &T = R.tiles[ids[x]];
-            T.mat = x; T.off = t.off[x]; T.nrows = t.nrows[x]; T.ncols = t.ncols[x];
-            T.ld = t.ld_file[x];
-            max_tile = std::max(max_tile, R.tile_bytes(T));
-          }
-        }
-  }
+  build_tiles(g, beta, R.tiles, max_tile);
   R.slot_bytes = round_up(max_tile, 4096);
 
   // ---- HBM budget -> slot count -> C super-block (gi x gj chains per pass) --------------
@@ -371,27 +421,8 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   int64_t n_slots = (int64_t) (budget / R.slot_bytes);
   n_slots = std::min<int64_t>(n_slots, (int64_t) R.tiles.size());
   if (n_slots < 6) { set_error("bof_flash_gemm: HBM budget below 6 tile slots"); return BOF_ENOMEM; }
-  int64_t gi = Nm, gj = Nn;
-  while (gi * gj + 2 * (gi + gj) > n_slots && (gi > 1 || gj > 1)) {
-    if (gi >= gj && gi > 1) gi--; else gj--;
-  }
-
-  // ---- execution order: per C super-block, l-major (chains of the block advance together)
-  for (int64_t I0 = 0; I0 < Nm; I0 += gi)
-    for (int64_t J0 = 0; J0 < Nn; J0 += gj)
-      for (int64_t l = 0; l < Nk; l++)
-        for (int64_t i = I0; i < std::min(I0 + gi, Nm); i++)
-          for (int64_t j = J0; j < std::min(J0 + gj, Nn); j++) {
-            bof_gemm_task t;
-            gemm_task_at(g, l, i, j, beta, &t);
-            const int pos = (int) R.tasks.size();
-            R.tasks.push_back(t);
-            const int ids[3] = {a_id(i, l), b_id(l, j), c_id(i, j)};
-            for (int x = 0; x < 3; x++) {
-              R.task_tiles.push_back(ids[x]);
-              R.tiles[ids[x]].uses.push_back(pos);
-            }
-          }
+  int64_t gi, gj;
+  build_order(g, beta, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
   const int T = (int) R.tasks.size();
 
   // ---- resources ----------------------------------------------------------------------
@@ -412,6 +443,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   R.slab = R.res->slab;
   BOF_TRACE_T("device slab allocated");
   R.slots.resize((size_t) n_slots);
+  R.slot_tile.assign((size_t) n_slots, -1);
   for (int64_t s = 0; s < n_slots; s++) {
     R.slots[s].ptr = R.slab + (size_t) s * R.slot_bytes;
     BOF_HIP_TRY(hipEventCreateWithFlags(&R.slots[s].ready, hipEventDisableTiming));
@@ -949,6 +981,67 @@ int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a, bof_fptr
   bof_fptr none{-1, 0};
   return flash_csr_impl(false, trans_a, (int64_t) m, (int64_t) n, 1, 1.f, 0.f, a, ia, ja, 'R', none,
                         none, b, c, opts);
+}
+
+int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_t k, float beta,
+                            uint64_t lda, uint64_t ldb, uint64_t ldc, int64_t blk, int64_t n_slots,
+                            int32_t lookahead, bof_flash_stats *out) {
+  if (!(ord == 'R' || ord == 'C') || !(ta == 'N' || ta == 'T') || !(tb == 'N' || tb == 'T') ||
+      blk <= 0 || n_slots < 6 || !out) {
+    set_error("bof_flash_gemm_simulate: bad argument (n_slots >= 6)");
+    return BOF_EINVAL;
+  }
+  const GemmGeometry g = gemm_geometry(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k,
+                                       (int64_t) lda, (int64_t) ldb, (int64_t) ldc, blk);
+  memset(out, 0, sizeof(*out));
+  if (g.nblk[0] * g.nblk[1] * g.nblk[2] == 0) return BOF_OK;
+  std::vector<Tile> tiles;
+  std::vector<bof_gemm_task> tasks;
+  std::vector<int> task_tiles;
+  size_t max_tile = 0;
+  build_tiles(g, beta, tiles, max_tile);
+  n_slots = std::min<int64_t>(n_slots, (int64_t) tiles.size());
+  int64_t gi, gj;
+  build_order(g, beta, n_slots, tiles, tasks, task_tiles, gi, gj);
+  std::vector<int> slot_tile((size_t) n_slots, -1), free_slots;
+  for (int64_t s = 0; s < n_slots; s++) free_slots.push_back((int) (n_slots - 1 - s));
+  const int T = (int) tasks.size();
+  int fetch_pos = 0;
+  auto resident = [&](int tid, int horizon, bool fetch) {
+    Tile &t = tiles[tid];
+    if (t.slot >= 0) { out->tile_hits++; return true; }
+    const int sl = claim_slot(tiles, slot_tile, free_slots, horizon);
+    if (sl < 0) return false;
+    out->tile_misses++;
+    slot_tile[sl] = tid;
+    t.slot = sl;
+    t.state = 2;  // I/O completes instantly in the simulation
+    if (fetch) out->bytes_read += tile_bytes_of(t);
+    return true;
+  };
+  for (int t = 0; t < T; t++) {
+    while (fetch_pos < T && fetch_pos <= t + std::max(lookahead, 0)) {
+      const int *ids = &task_tiles[(size_t) fetch_pos * 3];
+      bool ok = resident(ids[0], fetch_pos, true) && resident(ids[1], fetch_pos, true);
+      if (ok && tiles[ids[2]].slot < 0) {
+        ok = resident(ids[2], fetch_pos, tasks[fetch_pos].beta != 0.0f);
+        if (ok) tiles[ids[2]].pinned_c = true;
+      }
+      if (!ok) break;
+      fetch_pos++;
+    }
+    if (fetch_pos <= t) { set_error("simulate: tile budget too small"); return BOF_ENOMEM; }
+    const int *ids = &task_tiles[(size_t) t * 3];
+    for (int x = 0; x < 3; x++) tiles[ids[x]].next_use++;
+    out->tasks++;
+    if (tasks[t].l == g.nblk[1] - 1) {
+      out->bytes_written += tile_bytes_of(tiles[ids[2]]);
+      tiles[ids[2]].pinned_c = false;
+    }
+  }
+  out->bytes_h2d = out->bytes_read;
+  out->bytes_d2h = out->bytes_written;
+  return BOF_OK;
 }
 
 int bof_flash_release(void) {

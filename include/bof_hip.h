@@ -191,6 +191,13 @@ typedef struct {
   double seconds;                     /* wall time of the call         */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
+/* Dry run of bof_flash_gemm's schedule (task order, HBM tile-slot replacement, write-back)
+ * for a budget of n_slots tile slots and a prefetch lookahead in tasks: fills the byte and
+ * hit/miss counters the real call would report, without touching files or the GPU. */
+int bof_flash_gemm_simulate(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
+                            uint64_t k, float beta, uint64_t lda, uint64_t ldb, uint64_t ldc,
+                            int64_t blk, int64_t n_slots, int32_t lookahead,
+                            bof_flash_stats *out);
 /* Level-3 calls keep their pinned staging rings and HBM tile slab between calls (the
  * reference keeps its program cache for the life of the process, src/lib_funcs.cpp:9);
  * this frees them. */

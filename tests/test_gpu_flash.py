@@ -97,6 +97,10 @@ def test_flash_gemm_aligned_multitile_small_budget(dev, tmp_path):
         assert st["tasks"] == 64 and st["bytes_written"] == 4 * n * n
         # beta == 0: C never read; A and B re-read at most (#super-block passes) times
         assert 2 * 4 * n * n <= st["bytes_read"] <= 6 * 4 * n * n
+        # the real pipeline moves exactly the bytes its dry-run scheduler predicts
+        sim = bofhip.flash_gemm_simulate("R", "N", "N", n, n, n, 0.0, blk, 12, lookahead=2 * opts.pinned_slots)
+        assert (st["bytes_read"], st["bytes_written"], st["tasks"]) == \
+            (sim["bytes_read"], sim["bytes_written"], sim["tasks"])
     finally:
         F.close()
     # with the whole working set resident every tile is read exactly once
