@@ -398,6 +398,309 @@ sgemm_tile256_1w_kernel(const float *__restrict__ A, int64_t lda, const float *_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 2 of the one-wave-per-SIMD kernel: identical data flow, but every address in the
+// slab loop is "per-thread base register + compile-time constant" (LDS: `offset:` immediates;
+// global: uniform SGPR base + 32-bit per-thread byte offset), so a side slot contains memory
+// instructions only, no address VALU.  A VMEM/LDS instruction costs ~40-60 issue cycles; with
+// its 3-6 address VALUs it overflows the 64-cycle shadow of an fp32 MFMA and the overflow is
+// matrix-pipe idle time.
+struct Bases1w {
+  const float *a_rd, *b_rd;  // operand-read bases in the slab being multiplied
+  float *a_wr, *b_wr;        // staging-write bases in the other buffer
+};
+
+template <int MODE>
+__device__ __forceinline__ f32x4 rd_op(const float *__restrict__ base, int sub, int q) {
+  if (MODE == XMAJOR) {
+    return *reinterpret_cast<const f32x4 *>(base + sub * 32 * XLD + 8 * q);
+  } else {
+    const float *p = base + (8 * q) * 256 + sub * 32;
+    f32x4 v;
+    v[0] = p[0]; v[1] = p[2 * 256]; v[2] = p[4 * 256]; v[3] = p[6 * 256];
+    return v;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void wr_stage(float *__restrict__ base, const f32x4 v, int p) {
+  if (MODE == XMAJOR) {
+    float *d = base + p * 32 * XLD;
+    *reinterpret_cast<float2 *>(d) = make_float2(v[0], v[2]);
+    *reinterpret_cast<float2 *>(d + 4) = make_float2(v[1], v[3]);
+  } else {
+    *reinterpret_cast<f32x4 *>(base + p * 4 * 256) = v;
+  }
+}
+// uniform tile/slab origin (SGPRs) + this thread's constant byte offset
+template <int MODE>
+__device__ __forceinline__ f32x4 ld_stage(const float *__restrict__ origin, int64_t ld, int k0, int p,
+                                          unsigned goff) {
+  const float *u = (MODE == XMAJOR) ? origin + (int64_t) (p * 32) * ld + k0
+                                    : origin + (int64_t) (k0 + 4 * p) * ld;
+  return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(u) + goff);
+}
+
+// LDS-DMA staging of one float4-per-lane piece of a KMAJOR slab (1 KiB per wave-instruction =
+// one k-row of 256 floats): no VGPR round trip, no ds_write.  `dst` is the wave-uniform LDS
+// address of the piece (the hardware adds lane*16).
+__device__ __forceinline__ void dma_piece(const float *__restrict__ origin, int64_t ld, int k0, int p,
+                                          unsigned goff, float *dst) {
+  const float *u = origin + (int64_t) (k0 + 4 * p) * ld;
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(u) + goff,
+                                   (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+}
+
+template <int AMODE, int BMODE, bool W, bool L, bool DMA = false>
+__device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restrict__ Ao, int64_t lda,
+                                         const float *__restrict__ Bo, int64_t ldb, int k2,
+                                         unsigned a_goff, unsigned b_goff, Stage<8> &ra, Stage<8> &rb,
+                                         f32x16 (&acc)[4][4], float *a_dma = nullptr,
+                                         float *b_dma = nullptr) {
+  f32x4 a[2][4], b[2][4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    a[0][x] = rd_op<AMODE>(bs.a_rd, x, 0);
+    b[0][x] = rd_op<BMODE>(bs.b_rd, x, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
+                                                             acc[mt][nt], 0, 0, 0);
+      if (q < 3 && c < 3) {
+#pragma unroll
+        for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
+          a[(q + 1) & 1][x] = rd_op<AMODE>(bs.a_rd, x, q + 1);
+          b[(q + 1) & 1][x] = rd_op<BMODE>(bs.b_rd, x, q + 1);
+        }
+      }
+      const int s = 4 * q + c;
+      if (DMA) {  // k2 is the NEXT slab here: the piece lands directly in the other LDS buffer
+        if (W && s < 8) {  // all 16 pieces go out in the first half of the slab so that the
+                           // vmcnt(0) before the barrier finds them landed
+          dma_piece(Ao, lda, k2, s, a_goff, a_dma + s * 4 * 256);
+          dma_piece(Bo, ldb, k2, s, b_goff, b_dma + s * 4 * 256);
+        }
+      } else if (s < 8) {
+        if (W) wr_stage<AMODE>(bs.a_wr, ra.v[s], s);
+        if (L) ra.v[s] = ld_stage<AMODE>(Ao, lda, k2, s, a_goff);
+      } else {
+        if (W) wr_stage<BMODE>(bs.b_wr, rb.v[s - 8], s - 8);
+        if (L) rb.v[s - 8] = ld_stage<BMODE>(Bo, ldb, k2, s - 8, b_goff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                         int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                         float alpha, float beta, int tiles_m, int tiles_n) {
+  constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_BUF = LDS_A + LDS_B;
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_BUF];
+
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // per-thread constants: LDS element offsets inside one buffer, global byte offsets
+  const int a_rd = (AMODE == XMAJOR) ? (wm * 128 + i) * XLD + 4 * h : h * 256 + wm * 128 + i;
+  const int b_rd = LDS_A + ((BMODE == XMAJOR) ? (wn * 128 + i) * XLD + 4 * h : h * 256 + wn * 128 + i);
+  const int a_wr = (AMODE == XMAJOR) ? (t >> 3) * XLD + 8 * ((t & 7) >> 1) + 2 * (t & 1)
+                                     : (t >> 6) * 256 + 4 * (t & 63);
+  const int b_wr = LDS_A + ((BMODE == XMAJOR) ? (t >> 3) * XLD + 8 * ((t & 7) >> 1) + 2 * (t & 1)
+                                              : (t >> 6) * 256 + 4 * (t & 63));
+  const unsigned a_goff = 4u * (unsigned) ((AMODE == XMAJOR) ? (t >> 3) * (int) lda + 4 * (t & 7)
+                                                              : (t >> 6) * (int) lda + 4 * (t & 63));
+  const unsigned b_goff = 4u * (unsigned) ((BMODE == XMAJOR) ? (t >> 3) * (int) ldb + 4 * (t & 7)
+                                                              : (t >> 6) * (int) ldb + 4 * (t & 63));
+  // uniform tile origins
+  const float *Ao = (AMODE == XMAJOR) ? A + (int64_t) m0 * lda : A + m0;
+  const float *Bo = (BMODE == XMAJOR) ? B + (int64_t) n0 * ldb : B + n0;
+  Bases1w b0, b1;  // multiplying out of buffer 0 / buffer 1
+  b0.a_rd = lds + a_rd;            b0.b_rd = lds + b_rd;
+  b0.a_wr = lds + LDS_BUF + a_wr;  b0.b_wr = lds + LDS_BUF + b_wr;
+  b1.a_rd = lds + LDS_BUF + a_rd;  b1.b_rd = lds + LDS_BUF + b_rd;
+  b1.a_wr = lds + a_wr;            b1.b_wr = lds + b_wr;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = K / BK;  // caller guarantees K % 32 == 0, nkt >= 2
+  Stage<8> ra, rb;
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    ra.v[p] = ld_stage<AMODE>(Ao, lda, 0, p, a_goff);
+    rb.v[p] = ld_stage<BMODE>(Bo, ldb, 0, p, b_goff);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    wr_stage<AMODE>(b1.a_wr, ra.v[p], p);  // b1's write side is buffer 0
+    wr_stage<BMODE>(b1.b_wr, rb.v[p], p);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    ra.v[p] = ld_stage<AMODE>(Ao, lda, BK, p, a_goff);
+    rb.v[p] = ld_stage<BMODE>(Bo, ldb, BK, p, b_goff);
+  }
+  __syncthreads();
+
+  int kt = 0;
+  for (; kt + 2 < nkt; kt++) {
+    const Bases1w bs = (kt & 1) ? b1 : b0;
+    slab_1w2<AMODE, BMODE, true, true>(bs, Ao, lda, Bo, ldb, (kt + 2) * BK, a_goff, b_goff, ra, rb, acc);
+    __syncthreads();
+  }
+  {
+    const Bases1w bs = (kt & 1) ? b1 : b0;
+    slab_1w2<AMODE, BMODE, true, false>(bs, Ao, lda, Bo, ldb, 0, a_goff, b_goff, ra, rb, acc);
+    __syncthreads();
+    kt++;
+  }
+  {
+    const Bases1w bs = (kt & 1) ? b1 : b0;
+    slab_1w2<AMODE, BMODE, false, false>(bs, Ao, lda, Bo, ldb, 0, a_goff, b_goff, ra, rb, acc);
+  }
+
+  float *ctile = C + (int64_t) m0 * ldc + n0;
+  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      f32x16 old;
+      if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
+        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+      }
+    }
+}
+
+// Variant 3: both operands KMAJOR ('T','N' in row-major terms), staged exclusively by LDS-DMA.
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_dma_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                         int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                         float alpha, float beta, int tiles_m, int tiles_n) {
+  constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_BUF];
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int a_rd = h * 256 + wm * 128 + i;
+  const int b_rd = LDS_A + h * 256 + wn * 128 + i;
+  const unsigned a_goff = 4u * (unsigned) ((t >> 6) * (int) lda + 4 * (t & 63));
+  const unsigned b_goff = 4u * (unsigned) ((t >> 6) * (int) ldb + 4 * (t & 63));
+  const float *Ao = A + m0, *Bo = B + n0;
+  // wave-uniform DMA destinations (k-row `wave` of each 4-row piece), per buffer
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  float *a_dma0 = lds + wv * 256, *b_dma0 = lds + LDS_A + wv * 256;
+  float *a_dma1 = a_dma0 + LDS_BUF, *b_dma1 = b_dma0 + LDS_BUF;
+  Bases1w b0, b1;
+  b0.a_rd = lds + a_rd;           b0.b_rd = lds + b_rd;           b0.a_wr = b0.b_wr = nullptr;
+  b1.a_rd = lds + LDS_BUF + a_rd; b1.b_rd = lds + LDS_BUF + b_rd; b1.a_wr = b1.b_wr = nullptr;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = K / BK;
+  Stage<8> ra, rb;  // unused by the DMA path
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    dma_piece(Ao, lda, 0, p, a_goff, a_dma0 + p * 4 * 256);
+    dma_piece(Bo, ldb, 0, p, b_goff, b_dma0 + p * 4 * 256);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nkt; kt++) {
+    const bool odd = kt & 1;
+    slab_1w2<KMAJOR, KMAJOR, true, false, true>(odd ? b1 : b0, Ao, lda, Bo, ldb, (kt + 1) * BK, a_goff,
+                                                b_goff, ra, rb, acc, odd ? a_dma0 : a_dma1,
+                                                odd ? b_dma0 : b_dma1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+    __syncthreads();
+  }
+  slab_1w2<KMAJOR, KMAJOR, false, false, true>((kt & 1) ? b1 : b0, Ao, lda, Bo, ldb, 0, a_goff, b_goff, ra,
+                                               rb, acc);
+
+  float *ctile = C + (int64_t) m0 * ldc + n0;
+  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      f32x16 old;
+      if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
+        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+      }
+    }
+}
+
 template <int AMODE, int BMODE>
 static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int64_t ldb,
                                float *C, int64_t ldc, int M, int N, int K, float alpha,
@@ -405,9 +708,27 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   const bool vec_ok = (K % BK == 0) && (K > 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  // 0 (default): 8 waves, 2 per SIMD; 1: 4 waves, 1 per SIMD with slotted side work.  Both
-  // measure 137-139 TFLOP/s at 4096^3; the switch is kept for tuning work.
-  static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 0;
+  // Tile-aligned problems (M, N multiples of 256):
+  //   3 (default): one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (142.5 TFLOP/s at
+  //      4096^3), every other layout through variant 2 (140.6-141.3)
+  //   2: one wave per SIMD, register staging, constant-offset addressing
+  //   1: as 2 with per-access address arithmetic (138.5)      0: 8 waves, 2 per SIMD (137-138)
+  static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 3;
+  if (big_tile_variant == 3 && AMODE == KMAJOR && BMODE == KMAJOR && vec_ok && M % 256 == 0 &&
+      N % 256 == 0 && K >= 2 * BK && (int64_t) (M / 256) * (N / 256) >= 128 && lda < (1 << 22) &&
+      ldb < (1 << 22)) {
+    const int tiles_m = M / 256, tiles_n = N / 256;
+    hipLaunchKernelGGL(sgemm_tile256_dma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb,
+                       C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
+  if ((big_tile_variant == 2 || big_tile_variant == 3) && vec_ok && M % 256 == 0 && N % 256 == 0 && K >= 2 * BK &&
+      (int64_t) (M / 256) * (N / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
+    const int tiles_m = M / 256, tiles_n = N / 256;
+    hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0,
+                       st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   if (big_tile_variant == 1 && vec_ok && M % 256 == 0 && N % 256 == 0 && K >= 2 * BK &&
       (int64_t) (M / 256) * (N / 256) >= 128) {
     const int tiles_m = M / 256, tiles_n = N / 256;

@@ -85,11 +85,12 @@ def test_sgemm_bit_exact_vs_oracle(dev, ord_, ta, tb, m, n, k, alpha, beta):
     assert rel_err(gotl, full) < TOL
 
 
-def test_sgemm_big_tile_variant1_subprocess(dev):
-    """The 1-wave-per-SIMD variant of the 256x256 kernel (BOF_GEMM_VARIANT=1) is selected at
-    library load, so it is checked in a child process."""
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
+def test_sgemm_big_tile_other_variants_subprocess(dev, variant):
+    """The non-default shapes of the 256x256 kernel (BOF_GEMM_VARIANT, read once at library
+    load) stay bit-exact too; each is checked in a child process."""
     import subprocess, sys, os
-    env = dict(os.environ, BOF_GEMM_VARIANT="1")
+    env = dict(os.environ, BOF_GEMM_VARIANT=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
                         "big_tile_kernel_bit_exact"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:]
