@@ -273,7 +273,7 @@ def main():
                                     else "dense_create mode s (i%10)") + ", generated in HBM",
             "config": {"workload": workload, "tile": args.blk, "tile_tasks_per_step": launches_per_step,
                        "compute_streams": args.streams, "parallelism": f"row-block x{n_gpus}"},
-            "roofline": {"bound": "mfma", "kernel": "sgemm_tile_kernel<XMAJOR,KMAJOR>",
+            "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_1w2_kernel<XMAJOR,KMAJOR> (256x256x32 tile, 1 wave/SIMD)",
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "avg_launch_ms": round(avg_launch_ms, 4),
