@@ -118,3 +118,48 @@ def test_cfg5_csrgemv_50M_sha256(dev):
     assert y[:6].tolist() == [2072.0, 1313.0, 443.0, 1164.0, 1769.0, 1290.0]
     assert int(y.double().sum().item()) == 11249999940 and float(y.max()) == 5700.0
     assert sha(y) == "486766062199bef476611a2675893df3266338c91bfc30db4640ef5dbc2cbf40"
+
+
+def test_cfg3_csrmm_driver_files_end_to_end(dev, tmp_path):
+    """cfg3 as the reference runs it: three CSR files + B + C on disk, the C++ `csrmm_driver`
+    (same argv as the reference's), C updated in place; sha256 of the C FILE must equal the hash
+    the reference's in_mem_csrmm_driver and csrmm_driver both produced."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.disk_usage(str(tmp_path)).free < 25 * 2**30:
+        pytest.skip("needs 18 GB of scratch disk")
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "flash_e2e_cfg3.py"), str(tmp_path), "1"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    runs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(runs) == 2                      # buffered and O_DIRECT descriptors
+    for run in runs:
+        assert run["rc"] == 0 and run["matches_reference_hash"] is True, run
+
+
+def test_cfg2_flash_gemm_files_end_to_end(dev, tmp_path):
+    """cfg2 as the reference runs it: A, B, C as 4 GiB files, 4096-tile flash::gemm through the
+    C ABI (reader -> pinned ring -> HBM tile cache -> kernels -> write-back); every tile is read
+    once, C written once, and the C file matches the closed form."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.disk_usage(str(tmp_path)).free < 16 * 2**30:
+        pytest.skip("needs 12 GiB of scratch disk")
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "flash_e2e.py"), "--dir", str(tmp_path),
+                        "--n", "32768", "--direct", "1", "--reps", "1"], capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert out["first_16_rows_exact"] is True
+    st = out["stats"]
+    assert st["tasks"] == 512 and st["bytes_read"] == 2 * 4 * 32768 ** 2 and st["bytes_written"] == 4 * 32768 ** 2
