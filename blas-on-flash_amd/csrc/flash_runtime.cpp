@@ -27,6 +27,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -134,6 +135,15 @@ class PinnedRing {
 };
 
 static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// Runs the registered releases in reverse order when the call returns, on every path.
+struct Cleanup {
+  std::vector<std::function<void()>> fns;
+  void add(std::function<void()> f) { fns.push_back(std::move(f)); }
+  ~Cleanup() {
+    for (auto it = fns.rbegin(); it != fns.rend(); ++it) (*it)();
+  }
+};
 
 static int device_ready() {
   int n = 0;
@@ -444,6 +454,16 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   BOF_TRACE_T("device slab allocated");
   R.slots.resize((size_t) n_slots);
   R.slot_tile.assign((size_t) n_slots, -1);
+  Cleanup guard;
+  guard.add([&R] {
+    for (auto &sl : R.slots) {
+      if (sl.ready) (void) hipEventDestroy(sl.ready);
+      for (int q = 0; q <= kMaxStreams; q++)
+        if (sl.use[q]) (void) hipEventDestroy(sl.use[q]);
+    }
+    if (R.h2d) (void) hipStreamDestroy(R.h2d);
+    if (R.d2h) (void) hipStreamDestroy(R.d2h);
+  });
   for (int64_t s = 0; s < n_slots; s++) {
     R.slots[s].ptr = R.slab + (size_t) s * R.slot_bytes;
     BOF_HIP_TRY(hipEventCreateWithFlags(&R.slots[s].ready, hipEventDisableTiming));
@@ -566,12 +586,6 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
     fail = BOF_EIO;
   }
   // the pinned rings and the device slab stay cached for the next call (bof_flash_release)
-  for (auto &s : R.slots) {
-    (void) hipEventDestroy(s.ready);
-    for (int q = 0; q <= kMaxStreams; q++) (void) hipEventDestroy(s.use[q]);
-  }
-  (void) hipStreamDestroy(R.h2d);
-  (void) hipStreamDestroy(R.d2h);
   BOF_TRACE_T("resources released");
   publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   return fail;
@@ -785,6 +799,22 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
 
   int64_t *d_ia = nullptr;
   char *d_b = nullptr, *d_x = nullptr, *d_y = nullptr;
+  hipEvent_t resident_ev = nullptr;
+  Cleanup guard;
+  guard.add([&] {
+    for (auto &c : R.ctx) {
+      (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c);
+      if (c.h_idx) (void) hipHostFree(c.h_idx);
+      if (c.h_val) (void) hipHostFree(c.h_val);
+      if (c.h_c) (void) hipHostFree(c.h_c);
+      if (c.ready) (void) hipEventDestroy(c.ready);
+      if (c.done) (void) hipEventDestroy(c.done);
+    }
+    if (resident_ev) (void) hipEventDestroy(resident_ev);
+    (void) hipFree(d_ia); (void) hipFree(d_b); (void) hipFree(d_x); (void) hipFree(d_y);
+    if (R.h2d) (void) hipStreamDestroy(R.h2d);
+    if (R.d2h) (void) hipStreamDestroy(R.d2h);
+  });
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
   BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
@@ -809,7 +839,6 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     if (trans == 'T') BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
     R.cnt.h2d += (uint64_t) xlen * 4;
   }
-  hipEvent_t resident_ev;
   BOF_HIP_TRY(hipEventCreateWithFlags(&resident_ev, hipEventDisableTiming));
   BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
 
@@ -902,15 +931,6 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
               (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
     fail = BOF_EIO;
   }
-  for (auto &c : R.ctx) {
-    (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c);
-    (void) hipHostFree(c.h_idx); (void) hipHostFree(c.h_val); (void) hipHostFree(c.h_c);
-    (void) hipEventDestroy(c.ready); (void) hipEventDestroy(c.done);
-  }
-  (void) hipEventDestroy(resident_ev);
-  (void) hipFree(d_ia); (void) hipFree(d_b); (void) hipFree(d_x); (void) hipFree(d_y);
-  (void) hipStreamDestroy(R.h2d);
-  (void) hipStreamDestroy(R.d2h);
   publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   return fail;
 }
