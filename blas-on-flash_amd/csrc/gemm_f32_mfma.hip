@@ -450,12 +450,33 @@ __device__ __forceinline__ void dma_piece(const float *__restrict__ origin, int6
                                    (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
 }
 
-template <int AMODE, int BMODE, bool W, bool L, bool DMA = false>
+// K-tail version (only the last, partial slab is fetched with it): elements at k >= K read as 0,
+// which leaves every fmaf chain unchanged.
+template <int MODE>
+__device__ __forceinline__ f32x4 ld_stage_tail(const float *__restrict__ origin, int64_t ld, int k0, int p,
+                                               unsigned goff, int K, int t) {
+  const float *u = (MODE == XMAJOR) ? origin + (int64_t) (p * 32) * ld + k0
+                                    : origin + (int64_t) (k0 + 4 * p) * ld;
+  const float *src = reinterpret_cast<const float *>(reinterpret_cast<const char *>(u) + goff);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == XMAJOR) {
+    const int k = k0 + 4 * (t & 7);
+    if (k + 0 < K) v[0] = src[0];
+    if (k + 1 < K) v[1] = src[1];
+    if (k + 2 < K) v[2] = src[2];
+    if (k + 3 < K) v[3] = src[3];
+  } else {
+    if (k0 + 4 * p + (t >> 6) < K) v = *reinterpret_cast<const f32x4 *>(src);
+  }
+  return v;
+}
+
+template <int AMODE, int BMODE, bool W, bool L, bool DMA = false, bool TAIL = false>
 __device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restrict__ Ao, int64_t lda,
                                          const float *__restrict__ Bo, int64_t ldb, int k2,
                                          unsigned a_goff, unsigned b_goff, Stage<8> &ra, Stage<8> &rb,
                                          f32x16 (&acc)[4][4], float *a_dma = nullptr,
-                                         float *b_dma = nullptr) {
+                                         float *b_dma = nullptr, int K = 0, int t = 0) {
   f32x4 a[2][4], b[2][4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
@@ -488,17 +509,19 @@ __device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restri
         }
       } else if (s < 8) {
         if (W) wr_stage<AMODE>(bs.a_wr, ra.v[s], s);
-        if (L) ra.v[s] = ld_stage<AMODE>(Ao, lda, k2, s, a_goff);
+        if (L) ra.v[s] = TAIL ? ld_stage_tail<AMODE>(Ao, lda, k2, s, a_goff, K, t)
+                              : ld_stage<AMODE>(Ao, lda, k2, s, a_goff);
       } else {
         if (W) wr_stage<BMODE>(bs.b_wr, rb.v[s - 8], s - 8);
-        if (L) rb.v[s - 8] = ld_stage<BMODE>(Bo, ldb, k2, s - 8, b_goff);
+        if (L) rb.v[s - 8] = TAIL ? ld_stage_tail<BMODE>(Bo, ldb, k2, s - 8, b_goff, K, t)
+                                  : ld_stage<BMODE>(Bo, ldb, k2, s - 8, b_goff);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, bool KTAIL = false>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                          int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
@@ -556,7 +579,9 @@ sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-  const int nkt = K / BK;  // caller guarantees K % 32 == 0, nkt >= 2
+  // caller guarantees at least two full slabs before a partial one (K >= 64; K >= 96 if K % 32);
+  // KTAIL instantiation <=> K % 32 != 0: its last slab is fetched with guarded loads
+  const int nkt = (K + BK - 1) / BK;
   Stage<8> ra, rb;
 #pragma unroll
   for (int p = 0; p < 8; p++) {
@@ -576,10 +601,17 @@ sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *
   __syncthreads();
 
   int kt = 0;
-  for (; kt + 2 < nkt; kt++) {
+  for (; kt + (KTAIL ? 3 : 2) < nkt; kt++) {
     const Bases1w bs = (kt & 1) ? b1 : b0;
     slab_1w2<AMODE, BMODE, true, true>(bs, Ao, lda, Bo, ldb, (kt + 2) * BK, a_goff, b_goff, ra, rb, acc);
     __syncthreads();
+  }
+  if (KTAIL) {  // slab nkt-3: the slab fetched now is the partial one
+    const Bases1w bs = (kt & 1) ? b1 : b0;
+    slab_1w2<AMODE, BMODE, true, true, false, true>(bs, Ao, lda, Bo, ldb, (kt + 2) * BK, a_goff, b_goff, ra,
+                                                    rb, acc, nullptr, nullptr, K, t);
+    __syncthreads();
+    kt++;
   }
   {
     const Bases1w bs = (kt & 1) ? b1 : b0;
@@ -702,32 +734,63 @@ sgemm_tile256_dma_kernel(const float *__restrict__ A, int64_t lda, const float *
 }
 
 template <int AMODE, int BMODE>
+static hipError_t launch_guarded(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                                 int64_t ldc, int M, int N, int K, float alpha, float beta,
+                                 hipStream_t st) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+  hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, true>),
+                     dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha,
+                     beta, tiles_m, tiles_n);
+  return hipGetLastError();
+}
+
+template <int AMODE, int BMODE>
 static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int64_t ldb,
                                float *C, int64_t ldc, int M, int N, int K, float alpha,
                                float beta, hipStream_t st) {
-  const bool vec_ok = (K % BK == 0) && (K > 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+  const bool vec_ld = (lda % 4 == 0) && (ldb % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  // Tile-aligned problems (M, N multiples of 256):
+  const bool vec_ok = vec_ld && (K % BK == 0) && (K > 0);
+  // 256x256 kernels for the tile-aligned part of the problem:
   //   3 (default): one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (142.5 TFLOP/s at
   //      4096^3), every other layout through variant 2 (140.6-141.3)
   //   2: one wave per SIMD, register staging, constant-offset addressing
   //   1: as 2 with per-access address arithmetic (138.5)      0: 8 waves, 2 per SIMD (137-138)
   static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 3;
-  if (big_tile_variant == 3 && AMODE == KMAJOR && BMODE == KMAJOR && vec_ok && M % 256 == 0 &&
-      N % 256 == 0 && K >= 2 * BK && (int64_t) (M / 256) * (N / 256) >= 128 && lda < (1 << 22) &&
-      ldb < (1 << 22)) {
-    const int tiles_m = M / 256, tiles_n = N / 256;
-    hipLaunchKernelGGL(sgemm_tile256_dma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb,
-                       C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
-    return hipGetLastError();
-  }
-  if ((big_tile_variant == 2 || big_tile_variant == 3) && vec_ok && M % 256 == 0 && N % 256 == 0 && K >= 2 * BK &&
-      (int64_t) (M / 256) * (N / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
-    const int tiles_m = M / 256, tiles_n = N / 256;
-    hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0,
-                       st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
-    return hipGetLastError();
+
+  // Ragged sizes (tail-merged tiles of 4096+r, unaligned problem edges): the largest
+  // 256-aligned interior runs on the big-tile kernel (its last K slab guarded when K % 32 != 0),
+  // the right and bottom strips on the guarded 128x128 kernel.  Every output element is still
+  // produced by one kernel as one k-ordered chain, so the split does not change a single bit.
+  const int Mi = M - M % 256, Ni = N - N % 256;
+  const bool k_ok = (K % BK == 0) ? (K >= 2 * BK) : (K >= 3 * BK);
+  if (big_tile_variant >= 2 && vec_ld && k_ok && (int64_t) (Mi / 256) * (Ni / 256) >= 128 &&
+      lda < (1 << 22) && ldb < (1 << 22)) {
+    const int tiles_m = Mi / 256, tiles_n = Ni / 256;
+    if (big_tile_variant == 3 && AMODE == KMAJOR && BMODE == KMAJOR && K % BK == 0)
+      hipLaunchKernelGGL(sgemm_tile256_dma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
+                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+    else if (K % BK == 0)
+      hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, false>), dim3(tiles_m * tiles_n), dim3(256),
+                         0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, true>), dim3(tiles_m * tiles_n), dim3(256),
+                         0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (N > Ni) {  // right strip: rows [0, Mi), columns [Ni, N)
+      const float *Bs = (BMODE == XMAJOR) ? B + (int64_t) Ni * ldb : B + Ni;
+      e = launch_guarded<AMODE, BMODE>(A, lda, Bs, ldb, C + Ni, ldc, Mi, N - Ni, K, alpha, beta, st);
+      if (e != hipSuccess) return e;
+    }
+    if (M > Mi) {  // bottom strip: rows [Mi, M), all columns
+      const float *As = (AMODE == XMAJOR) ? A + (int64_t) Mi * lda : A + Mi;
+      e = launch_guarded<AMODE, BMODE>(As, lda, B, ldb, C + (int64_t) Mi * ldc, ldc, M - Mi, N, K, alpha,
+                                       beta, st);
+    }
+    return e;
   }
   if (big_tile_variant == 1 && vec_ok && M % 256 == 0 && N % 256 == 0 && K >= 2 * BK &&
       (int64_t) (M / 256) * (N / 256) >= 128) {

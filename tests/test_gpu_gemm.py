@@ -112,6 +112,23 @@ def test_sgemm_big_tile_kernel_bit_exact(dev, ta, tb):
         assert np.array_equal(got, ref), rel_err(got, ref)
 
 
+@pytest.mark.parametrize("ta,tb", list(itertools.product("NT", "NT")))
+@pytest.mark.parametrize("m,n,k", [(4096 + 100, 2048 + 37, 116), (4096, 2048 + 255, 96 + 31), (4096 + 1, 2048, 128)])
+def test_sgemm_ragged_interior_plus_strips_bit_exact(dev, ta, tb, m, n, k):
+    """Tail-merged tile shapes: 256-aligned interior on the big-tile kernel (guarded last K slab),
+    right/bottom strips on the guarded kernel -- still one k-ordered chain per element."""
+    rng = np.random.default_rng(m * 7 + n)
+    sa, sb, sc = stored_shapes("R", ta, tb, m, n, k)
+    pad = lambda c: (c + 3) // 4 * 4 + 4          # leading dims: multiples of 4, not tight
+    lda, ldb, ldc = pad(sa[1]), pad(sb[1]), sc[1] + 5
+    a = rng.uniform(-1, 1, (sa[0], lda)).astype(np.float32)
+    b = rng.uniform(-1, 1, (sb[0], ldb)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (sc[0], ldc)).astype(np.float32)
+    ref = orc.sgemm("R", ta, tb, m, n, k, 0.5, a, lda, b, ldb, 2.0, c0.copy(), ldc)
+    got = run_sgemm("R", ta, tb, m, n, k, 0.5, 2.0, a, lda, b, ldb, c0, ldc)
+    assert np.array_equal(got, ref), rel_err(got, ref)
+
+
 def test_sgemm_k_zero_and_empty(dev):
     c0 = np.arange(12, dtype=np.float32).reshape(3, 4)
     a = np.zeros((3, 1), np.float32)
