@@ -25,6 +25,11 @@ hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, fl
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
                   float *c, int64_t ldc, hipStream_t st);
+hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out,
+                         int64_t ld_out, hipStream_t st);
+// grow-only per-device scratch (index 0..17), freed by bof_flash_release
+int scratch_get(int which, size_t bytes, void **ptr);
+void scratch_release_all();
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
                     const int64_t *col, const float *x, float *y, hipStream_t st);
 hipError_t gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed,

@@ -140,6 +140,30 @@ csrmm_strided_kernel(int64_t m, int n, float alpha, const float *__restrict__ va
   *cp = (beta == 0.f) ? alpha * acc : __builtin_fmaf(alpha, acc, beta * (*cp));
 }
 
+// out[c * ld_out + r] = in[r * ld_in + c] for r < rows, c < cols: 64 x 64 tiles through a padded
+// LDS image, 256-byte coalesced segments on both sides.  Used to run column-major ('C') CSRMM
+// on the row-major kernel: B is transposed once per call, every C block on its way in/out.
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float *__restrict__ in, int64_t ld_in, int64_t rows, int64_t cols,
+                 float *__restrict__ out, int64_t ld_out) {
+  __shared__ float tile[64][65];
+  const int64_t r0 = (int64_t) blockIdx.y * 64, c0 = (int64_t) blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(r0 + i) * ld_in + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * ld_out + r0 + tx] = tile[tx][i];
+}
+
+hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out,
+                         int64_t ld_out, hipStream_t st) {
+  if (rows == 0 || cols == 0) return hipSuccess;
+  dim3 grid((unsigned) ((cols + 63) / 64), (unsigned) ((rows + 63) / 64)), block(256);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, in, ld_in, rows, cols, out, ld_out);
+  return hipGetLastError();
+}
+
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
                   float *c, int64_t ldc, hipStream_t st) {

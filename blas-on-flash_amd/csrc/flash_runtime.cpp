@@ -597,7 +597,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
 namespace {
 
 struct CsrCtx {
-  char *d_idx = nullptr, *d_val = nullptr, *d_c = nullptr;
+  char *d_idx = nullptr, *d_val = nullptr, *d_c = nullptr, *d_c_rm = nullptr;
   char *h_idx = nullptr, *h_val = nullptr, *h_c = nullptr;
   hipEvent_t ready = nullptr, done = nullptr;
   int64_t owner = -1;   // block id this context is reserved for (guarded by mu)
@@ -803,7 +803,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   Cleanup guard;
   guard.add([&] {
     for (auto &c : R.ctx) {
-      (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c);
+      (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c); (void) hipFree(c.d_c_rm);
       if (c.h_idx) (void) hipHostFree(c.h_idx);
       if (c.h_val) (void) hipHostFree(c.h_val);
       if (c.h_c) (void) hipHostFree(c.h_c);
@@ -832,6 +832,13 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       rc = load_dense_to_device(fb, (uint64_t) n * k * 4, d_b, R.h2d, R.use_aio, R.cnt);
       if (rc) return rc;
     }
+    if (ord_b == 'C') {  // column-major B (n x k, ld = n) -> row-major copy used by the kernel
+      void *tmp = nullptr;
+      rc = scratch_get(0, (size_t) n * k * 4, &tmp);
+      if (rc) return rc;
+      BOF_HIP_TRY(hipMemcpyAsync(tmp, d_b, (size_t) n * k * 4, hipMemcpyDeviceToDevice, R.h2d));
+      BOF_HIP_TRY(transpose_f32((const float *) tmp, n, k, n, (float *) d_b, k, R.h2d));
+    }
   } else {
     BOF_HIP_TRY(hipMalloc((void **) &d_x, (size_t) xlen * 4));
     BOF_HIP_TRY(hipMalloc((void **) &d_y, (size_t) ylen * 4));
@@ -852,6 +859,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     BOF_HIP_TRY(hipHostMalloc((void **) &c.h_val, max_val, hipHostMallocDefault));
     if (is_mm) {
       BOF_HIP_TRY(hipMalloc((void **) &c.d_c, max_c));
+      if (ord_b == 'C') BOF_HIP_TRY(hipMalloc((void **) &c.d_c_rm, max_c));
       BOF_HIP_TRY(hipHostMalloc((void **) &c.h_c, max_c, hipHostMallocDefault));
     }
     BOF_HIP_TRY(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
@@ -886,15 +894,19 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     const float *val = (const float *) (c.d_val + d1);
     const int64_t s = R.st[b], r = R.sz[b];
     if (is_mm) {
+      if (ord_b == 'C' && beta != 0.f)  // C block arrived packed column-major [k][r]
+        herr = transpose_f32((const float *) c.d_c, r, k, r, (float *) c.d_c_rm, k, st);
       for (int64_t j0 = 0; j0 < k && herr == hipSuccess; j0 += R.o.csrmm_cblk) {
         const int64_t w = std::min(k - j0, R.o.csrmm_cblk);
         if (ord_b == 'R')
           herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
                         (float *) c.d_c + j0, k, st);
-        else
-          herr = scsrmm('C', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0 * n, n,
-                        beta, (float *) c.d_c + j0 * r, r, st);
+        else  // 'C': same row-major kernel on the transposed block (d_b is row-major here)
+          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
+                        (float *) c.d_c_rm + j0, k, st);
       }
+      if (ord_b == 'C' && herr == hipSuccess)  // [r][k] -> packed column-major block [k][r]
+        herr = transpose_f32((const float *) c.d_c_rm, k, r, k, (float *) c.d_c, r, st);
       if (herr != hipSuccess) break;
       // C block -> pinned buffer on the D2H stream, after the kernels
       herr = hipEventRecord(c.done, st);
@@ -1065,6 +1077,7 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
 }
 
 int bof_flash_release(void) {
+  scratch_release_all();
   std::lock_guard<std::mutex> lk(g_res_mu);
   for (int d = 0; d < 64; d++) {
     GemmResources *r = g_res[d];
