@@ -502,10 +502,12 @@ __device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restri
       }
       const int s = 4 * q + c;
       if (DMA) {  // k2 is the NEXT slab here: the piece lands directly in the other LDS buffer
-        if (W && s < 8) {  // all 16 pieces go out in the first half of the slab so that the
+        if (W && s < 4) {  // all 16 pieces go out in the first quarter of the slab so that the
                            // vmcnt(0) before the barrier finds them landed
-          dma_piece(Ao, lda, k2, s, a_goff, a_dma + s * 4 * 256);
-          dma_piece(Bo, ldb, k2, s, b_goff, b_dma + s * 4 * 256);
+          dma_piece(Ao, lda, k2, 2 * s, a_goff, a_dma + (2 * s) * 4 * 256);
+          dma_piece(Bo, ldb, k2, 2 * s, b_goff, b_dma + (2 * s) * 4 * 256);
+          dma_piece(Ao, lda, k2, 2 * s + 1, a_goff, a_dma + (2 * s + 1) * 4 * 256);
+          dma_piece(Bo, ldb, k2, 2 * s + 1, b_goff, b_dma + (2 * s + 1) * 4 * 256);
         }
       } else if (s < 8) {
         if (W) wr_stage<AMODE>(bs.a_wr, ra.v[s], s);
