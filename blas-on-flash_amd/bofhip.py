@@ -64,6 +64,8 @@ SYMBOLS = [
     ("bof_sgemm", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64, P]),
     ("bof_scsrmm", C.c_int, [chr_, i64, i64, i64, f32, P, P, P, P, i64, f32, P, i64, P]),
     ("bof_scsrgemv", C.c_int, [chr_, i64, i64, P, P, P, P, P, P]),
+    ("bof_scsrcsc", C.c_int, [i64, i64, i64, P, P, P, P, P, P, P]),
+    ("bof_csrcsc_workspace_bytes", u64, [i64, i64]),
     ("bof_gemm_plan", i64, [chr_, chr_, chr_, i64, i64, i64, f32, i64, i64, i64, i64,
                             C.POINTER(GemmTask), i64, C.POINTER(i64)]),
     ("bof_csr_blocks", i64, [P, i64, i64, i64, i64, P, P, i64]),
@@ -160,6 +162,10 @@ def scsrmm(ord_b, m, n, k, alpha, val, col, ptr, b, ldb, beta, c, ldc, stream=0)
 
 def scsrgemv(trans, m, n, val, ptr, col, x, y, stream=0):
     check(lib().bof_scsrgemv(_c(trans), m, n, val, ptr, col, x, y, stream), "bof_scsrgemv")
+
+
+def scsrcsc(m, n, nnz, val, ptr, col, val_tr, ptr_tr, col_tr, stream=0):
+    check(lib().bof_scsrcsc(m, n, nnz, val, ptr, col, val_tr, ptr_tr, col_tr, stream), "bof_scsrcsc")
 
 
 # ---- planning ----------------------------------------------------------------------

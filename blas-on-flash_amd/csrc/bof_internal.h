@@ -27,7 +27,15 @@ hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, cons
                   float *c, int64_t ldc, hipStream_t st);
 hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out,
                          int64_t ld_out, hipStream_t st);
-// grow-only per-device scratch (index 0..17), freed by bof_flash_release
+size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz);
+hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
+                   const int64_t *col, float *val_tr, int64_t *ptr_tr, int64_t *col_tr,
+                   void *workspace, hipStream_t st);
+// grow-only per-device scratch, freed by bof_flash_release.  Slots: 0 row-major copy of a
+// column-major B; 1..16 per-stream row-major C blocks; 17 csrcsc workspace; 18..20 transposed
+// CSR (values, indices, offsets) of csrmm 'T'
+enum { SCR_B_RM = 0, SCR_C_RM0 = 1, SCR_CSRCSC = 17, SCR_TR_VAL = 18, SCR_TR_COL = 19, SCR_TR_PTR = 20,
+       SCR_COUNT = 21 };
 int scratch_get(int which, size_t bytes, void **ptr);
 void scratch_release_all();
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,

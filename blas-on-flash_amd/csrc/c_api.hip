@@ -79,7 +79,7 @@ static bool flag_ok(char c, char a, char b) { return c == a || c == b; }
 // ---- grow-only device scratch, per device -----------------------------------------
 struct Scratch { void *p = nullptr; size_t bytes = 0; };
 static std::mutex g_scr_mu;
-static Scratch g_scr[64][18];
+static Scratch g_scr[64][SCR_COUNT];
 int scratch_get(int which, size_t bytes, void **ptr) {
   int dev = 0;
   BOF_HIP_TRY(hipGetDevice(&dev));
@@ -196,6 +196,26 @@ int bof_scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64
   return BOF_OK;
 }
 
+uint64_t bof_csrcsc_workspace_bytes(int64_t n, int64_t nnz) {
+  return n < 0 || nnz < 0 ? 0 : (uint64_t) csrcsc_workspace_bytes(n, nnz);
+}
+
+int bof_scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
+                const int64_t *col, float *val_tr, int64_t *ptr_tr, int64_t *col_tr,
+                void *stream) {
+  if (m < 0 || n < 0 || nnz < 0 || m > INT32_MAX || n > INT32_MAX || !ptr_tr) {
+    set_error("bof_scsrcsc: bad argument (m, n must fit 31 bits)");
+    return BOF_EINVAL;
+  }
+  void *ws = nullptr;
+  if (m > 0 && nnz > 0) {
+    const int rc = scratch_get(SCR_CSRCSC, csrcsc_workspace_bytes(n, nnz), &ws);
+    if (rc) return rc;
+  }
+  BOF_HIP_TRY(scsrcsc(m, n, nnz, val, ptr, col, val_tr, ptr_tr, col_tr, ws, (hipStream_t) stream));
+  return BOF_OK;
+}
+
 // ---- level 2 ------------------------------------------------------------------
 int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                       float beta, const float *a, const float *b, float *c, int64_t lda,
@@ -234,13 +254,33 @@ int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alph
                        const float *val, const int64_t *ia_host, const int64_t *ia_dev,
                        const int64_t *ja, char ord_b, const float *b, float *c,
                        const bof_options *opts, void *stream) {
-  if (trans_a != 'N') {  // reference: 'T' goes through csrcsc and is broken
-    set_error("bof_csrmm_resident: only trans_a='N' is supported");
-    return BOF_EINVAL;
-  }
-  if (!flag_ok(ord_b, 'R', 'C') || m < 0 || n < 0 || k < 0 || n > INT32_MAX) {
+  if (!flag_ok(trans_a, 'N', 'T') || !flag_ok(ord_b, 'R', 'C') || m < 0 || n < 0 || k < 0 ||
+      n > INT32_MAX || (trans_a == 'T' && m > INT32_MAX)) {
     set_error("bof_csrmm_resident: bad argument");
     return BOF_EINVAL;
+  }
+  if (trans_a == 'T') {
+    // C[n x k] = alpha * A^T * B[m x k] + beta * C.  The reference transposes A with csrcsc
+    // into temporary files and runs the 'N' path on them (src/blas/csrmm.cpp:355-422, with
+    // wrong temp sizes -- SURVEY App. B-3); here A^T is built in HBM scratch and the 'N'
+    // path below runs on it, so every output element is the source-row-ordered fmaf chain.
+    if (n == 0 || k == 0) return BOF_OK;
+    const int64_t nnz = m > 0 ? ia_host[m] - ia_host[0] : 0;
+    void *vt = nullptr, *ct = nullptr, *pt = nullptr;
+    int rc = scratch_get(SCR_TR_VAL, (size_t) std::max<int64_t>(nnz, 1) * 4, &vt);
+    if (!rc) rc = scratch_get(SCR_TR_COL, (size_t) std::max<int64_t>(nnz, 1) * 8, &ct);
+    if (!rc) rc = scratch_get(SCR_TR_PTR, (size_t) (n + 1) * 8, &pt);
+    if (rc) return rc;
+    const int64_t z = m > 0 ? ia_host[0] : 0;
+    rc = bof_scsrcsc(m, n, nnz, val + z, ia_dev, ja + z, (float *) vt, (int64_t *) pt, (int64_t *) ct,
+                     stream);
+    if (rc) return rc;
+    std::vector<int64_t> ia_tr((size_t) n + 1);  // block planning needs the offsets on the host
+    BOF_HIP_TRY(hipMemcpyAsync(ia_tr.data(), pt, (size_t) (n + 1) * 8, hipMemcpyDeviceToHost,
+                               (hipStream_t) stream));
+    BOF_HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+    return bof_csrmm_resident('N', n, m, k, alpha, beta, (const float *) vt, ia_tr.data(),
+                              (const int64_t *) pt, (const int64_t *) ct, ord_b, b, c, opts, stream);
   }
   if (m == 0 || k == 0) return BOF_OK;
   const bof_options o = resolved(opts);
@@ -262,11 +302,11 @@ int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alph
     int64_t rmax = 0;
     for (int64_t bi = 0; bi < nb; bi++) rmax = std::max(rmax, sz[bi]);
     void *p = nullptr;
-    rc = scratch_get(0, (size_t) n * k * sizeof(float), &p);
+    rc = scratch_get(SCR_B_RM, (size_t) n * k * sizeof(float), &p);
     if (rc) return rc;
     b_rm = (float *) p;
     for (int i = 0; i < ss->n; i++) {
-      rc = scratch_get(1 + i, (size_t) rmax * k * sizeof(float), &p);
+      rc = scratch_get(SCR_C_RM0 + i, (size_t) rmax * k * sizeof(float), &p);
       if (rc) return rc;
       c_rm[(size_t) i] = (float *) p;
     }

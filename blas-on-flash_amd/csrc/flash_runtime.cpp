@@ -834,7 +834,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     }
     if (ord_b == 'C') {  // column-major B (n x k, ld = n) -> row-major copy used by the kernel
       void *tmp = nullptr;
-      rc = scratch_get(0, (size_t) n * k * 4, &tmp);
+      rc = scratch_get(SCR_B_RM, (size_t) n * k * 4, &tmp);
       if (rc) return rc;
       BOF_HIP_TRY(hipMemcpyAsync(tmp, d_b, (size_t) n * k * 4, hipMemcpyDeviceToDevice, R.h2d));
       BOF_HIP_TRY(transpose_f32((const float *) tmp, n, k, n, (float *) d_b, k, R.h2d));

@@ -111,6 +111,18 @@ int bof_scsrgemv(char trans, int64_t m, int64_t n, const float *val,
                  const int64_t *ptr, const int64_t *col, const float *x, float *y,
                  void *stream);
 
+/* mkl_csrcsc(job = {0,0,0,-1,-1,1}) (include/tasks/csrcsc_task.h:66-75) without the
+ * padding to a square: A = CSR(val, ptr[m+1] (any base), col) of shape m x n ->
+ * A^T = CSR(val_tr, ptr_tr[n+1] (0-based), col_tr) of shape n x m, source rows
+ * ascending inside every output row (stable), m, n <= INT32_MAX.  nnz =
+ * ptr[m] - ptr[0] is passed by the caller (it planned the buffers with it).
+ * Temporary HBM comes from the library's per-device scratch (bof_flash_release
+ * returns it); bof_csrcsc_workspace_bytes tells how much that is. */
+int bof_scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
+                const int64_t *col, float *val_tr, int64_t *ptr_tr, int64_t *col_tr,
+                void *stream);
+uint64_t bof_csrcsc_workspace_bytes(int64_t n, int64_t nnz);
+
 /* ---- planning (pure host code; usable without a GPU) ------------------------ */
 /* One tile task as src/blas/gemm.cpp:83-129 builds it (offsets/LDs in elements). */
 typedef struct {

@@ -317,6 +317,46 @@ void orc_flash_csrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha,
   free(st); free(sz);
 }
 
+/* include/tasks/csrcsc_task.h:66-75 (mkl_csrcsc on one row block) and
+ * src/blas/csrcsc.cpp:32-159 (blocks + merge): both amount to the stable
+ * counting-sort transposition below. */
+void orc_csrcsc(int64_t m, int64_t n, const float *val, const int64_t *ia,
+                const int64_t *ja, float *val_tr, int64_t *ia_tr, int64_t *ja_tr) {
+  const int64_t base = m > 0 ? ia[0] : 0;
+  for (int64_t j = 0; j <= n; j++) ia_tr[j] = 0;
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t p = ia[i] - base; p < ia[i + 1] - base; p++) ia_tr[ja[p] + 1]++;
+  for (int64_t j = 0; j < n; j++) ia_tr[j + 1] += ia_tr[j];
+  int64_t *cur = (int64_t *) malloc(sizeof(int64_t) * (size_t) (n > 0 ? n : 1));
+  for (int64_t j = 0; j < n; j++) cur[j] = ia_tr[j];
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t p = ia[i] - base; p < ia[i + 1] - base; p++) {
+      const int64_t q = cur[ja[p]]++;
+      ja_tr[q] = i;
+      val_tr[q] = val[p];
+    }
+  free(cur);
+}
+
+void orc_scsrmm_t(int64_t m, int64_t n, int64_t k, float alpha, const float *val,
+                  const int64_t *ia, const int64_t *ja, const float *b, int64_t ldb,
+                  float beta, float *c, int64_t ldc) {
+  const int64_t base = m > 0 ? ia[0] : 0;
+  float *acc = (float *) calloc((size_t) (n > 0 ? n : 1) * (size_t) (k > 0 ? k : 1), sizeof(float));
+  for (int64_t i = 0; i < m; i++) {
+    const float *brow = b + i * ldb;
+    for (int64_t p = ia[i] - base; p < ia[i + 1] - base; p++) {
+      const float v = val[p];
+      float *arow = acc + ja[p] * k;
+      for (int64_t j = 0; j < k; j++) arow[j] = fmaf(v, brow[j], arow[j]);
+    }
+  }
+  for (int64_t r = 0; r < n; r++)
+    for (int64_t j = 0; j < k; j++)
+      c[r * ldc + j] = epilogue(alpha, acc[r * k + j], beta, c[r * ldc + j]);
+  free(acc);
+}
+
 /* mkl_cspblas_scsrgemv (0-based CSR) as used through
  * include/tasks/csrgemv_task.h:74 ('N') and :165 ('T'); the reference pads the
  * block to a square `dim` (:36-44) which contributes only zeros. */

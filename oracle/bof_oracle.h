@@ -109,6 +109,22 @@ void orc_flash_csrgemv(char trans, int64_t m, int64_t n, const float *val,
                        const int64_t *ia, const int64_t *ja, const float *x,
                        float *y, int64_t max_rows, int64_t max_nnz);
 
+/* mkl_csrcsc(job = {0,0,0,-1,-1,1}) as called by include/tasks/csrcsc_task.h:
+ * 66-75: A (m x n CSR, 0-based, ia may carry a base) -> A^T as CSR (n x m):
+ * ia_tr[n+1] 0-based, ja_tr = original row ids ascending inside each output row
+ * (the sequential count / scan / place algorithm, i.e. a stable transposition),
+ * val_tr moved with them.  src/blas/csrcsc.cpp:32-159 produces the same arrays
+ * through row-block transposes + a column-block merge. */
+void orc_csrcsc(int64_t m, int64_t n, const float *val, const int64_t *ia,
+                const int64_t *ja, float *val_tr, int64_t *ia_tr, int64_t *ja_tr);
+/* mkl_scsrmm('T', "GXXC") semantics (src/blas/csrmm.cpp:355-422 is the broken
+ * caller): C[n x k] = alpha * A^T * B[m x k] + beta * C with A an
+ * m x n CSR, B/C row-major.  Every output element is an fmaf chain over the
+ * source rows in ascending order. */
+void orc_scsrmm_t(int64_t m, int64_t n, int64_t k, float alpha, const float *val,
+                  const int64_t *ia, const int64_t *ja, const float *b, int64_t ldb,
+                  float beta, float *c, int64_t ldc);
+
 /* ---- helpers --------------------------------------------------------------- */
 /* src/utils.cpp:31-43 */
 uint64_t orc_fnv64a(const char *s, uint64_t n);

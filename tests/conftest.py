@@ -19,6 +19,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_tr():
+    """MKL mkl_csrcsc / mkl_scsrmm('T') vectors (tests/golden/make_golden_csrcsc.py)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "mkl_golden_csrcsc.npz"))
+
+
+@pytest.fixture(scope="session")
 def dev():
     """torch device for the HIP path; the product library must be loadable and see a GPU."""
     import torch

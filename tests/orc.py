@@ -53,6 +53,8 @@ def lib():
         L.orc_flash_csrmm.argtypes = [chr_, i64, i64, i64, f32, f32, P, P, P, P, P, i64, i64, i64]
         L.orc_scsrgemv.argtypes = [chr_, i64, i64, P, P, P, P, P]
         L.orc_flash_csrgemv.argtypes = [chr_, i64, i64, P, P, P, P, P, i64, i64]
+        L.orc_csrcsc.argtypes = [i64, i64, P, P, P, P, P, P]
+        L.orc_scsrmm_t.argtypes = [i64, i64, i64, f32, P, P, P, P, i64, f32, P, i64]
         L.orc_fnv64a.argtypes = [C.c_char_p, C.c_uint64]
         L.orc_fnv64a.restype = C.c_uint64
         L.orc_buf_size.argtypes = [C.c_uint64, C.c_uint64]
@@ -149,3 +151,19 @@ def flash_csrgemv(trans, m, n, val, ia, ja, x, y, max_rows=CSRMM_RBLK, max_nnz=M
     lib().orc_flash_csrgemv(_c(trans), m, n, _p(val), _p(ia), _p(ja), _p(x), _p(y),
                             max_rows, max_nnz)
     return y
+
+
+def csrcsc(m, n, val, ia, ja):
+    """-> (val_tr, ia_tr, ja_tr) of the n x m transpose."""
+    ia = np.ascontiguousarray(ia, np.int64)
+    nnz = int(ia[m] - ia[0]) if m > 0 else 0
+    val_tr = np.zeros(max(nnz, 1), np.float32)
+    ja_tr = np.zeros(max(nnz, 1), np.int64)
+    ia_tr = np.zeros(n + 1, np.int64)
+    lib().orc_csrcsc(m, n, _p(val), _p(ia), _p(ja), _p(val_tr), _p(ia_tr), _p(ja_tr))
+    return val_tr[:nnz], ia_tr, ja_tr[:nnz]
+
+
+def scsrmm_t(m, n, k, alpha, val, ia, ja, b, ldb, beta, c, ldc):
+    lib().orc_scsrmm_t(m, n, k, alpha, _p(val), _p(ia), _p(ja), _p(b), ldb, beta, _p(c), ldc)
+    return c

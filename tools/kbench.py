@@ -95,6 +95,38 @@ def csr(args):
               f"algorithmic {alg / best / 1e6:.1f} GB/s", flush=True)
 
 
+def csrcsc(args):
+    """cfg3-size transposition (10M x 1M, 1e9 nnz) and the csrmm 'T' built on it."""
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    m, n, k, npr = 10_000_000 // args.scale, 1_000_000, 128, 100
+    nnz = m * npr
+    val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 1_000_000):
+        r = min(1_000_000, m - r0)
+        bofhip.gen_sparse_rows(r0, r, n, npr, val.data_ptr() + 4 * r0 * npr, col.data_ptr() + 8 * r0 * npr,
+                               off.data_ptr() + 8 * r0, st)
+    vt = torch.empty_like(val); ct = torch.empty_like(col)
+    pt = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    f = lambda: bofhip.scsrcsc(m, n, nnz, val.data_ptr(), off.data_ptr(), col.data_ptr(), vt.data_ptr(),
+                               pt.data_ptr(), ct.data_ptr(), st)
+    best = min(time_ms(f, 2) for _ in range(args.rounds))
+    alg = nnz * 24 + (m + n + 2) * 8   # read A once, write A^T once
+    print(f"csrcsc {m}x{n} nnz={nnz}: {best:.3f} ms  algorithmic {alg / best / 1e6:.1f} GB/s  "
+          f"workspace {bofhip.lib().bof_csrcsc_workspace_bytes(n, nnz) / 2**30:.2f} GiB", flush=True)
+    b = torch.empty(m * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(b.data_ptr(), 0, m * k, args.data, 3, st)
+    c = torch.zeros(n * k, dtype=torch.float32, device=dev)
+    ia = off.cpu().numpy()
+    opts = bofhip.default_options(n_streams=args.streams)
+    f = lambda: bofhip.csrmm_resident("T", m, n, k, 1.0, 0.0, val.data_ptr(), ia.ctypes.data, off.data_ptr(),
+                                      col.data_ptr(), "R", b.data_ptr(), c.data_ptr(), opts, st)
+    best = min(time_ms(f, 2) for _ in range(args.rounds))
+    print(f"csrmm T {m}x{n} nnz={nnz} k={k}: {best:.3f} ms  {2.0 * nnz * k / best / 1e6:.1f} GFLOP/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
@@ -112,5 +144,7 @@ if __name__ == "__main__":
     a.betas = [float(x) for x in a.betas.split(",")]
     if a.what == "gemm":
         gemm(a)
+    elif a.what == "csrcsc":
+        csrcsc(a)
     else:
         csr(a)
