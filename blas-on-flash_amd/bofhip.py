@@ -78,6 +78,7 @@ SYMBOLS = [
                                  u64, u64, u64, C.POINTER(Options)]),
     ("bof_flash_csrmm", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, FPtr,
                                   FPtr, C.POINTER(Options)]),
+    ("bof_flash_csrcsc", C.c_int, [u64, u64, FPtr, FPtr, FPtr, FPtr, FPtr, FPtr, C.POINTER(Options)]),
     ("bof_flash_csrmm_inmem", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, P, P,
                                         C.POINTER(Options)]),
     ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
@@ -223,6 +224,11 @@ def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda=0, ldb=0, ldc
 def flash_csrmm(trans_a, m, n, k, alpha, beta, fa, fia, fja, ord_b, fb, fc, opts=None):
     check(lib().bof_flash_csrmm(_c(trans_a), m, n, k, alpha, beta, fa, fia, fja, _c(ord_b), fb, fc,
                                 C.byref(opts) if opts is not None else None), "bof_flash_csrmm")
+
+
+def flash_csrcsc(m, n, fia, fja, fa, fia_tr, fja_tr, fa_tr, opts=None):
+    check(lib().bof_flash_csrcsc(m, n, fia, fja, fa, fia_tr, fja_tr, fa_tr,
+                                 C.byref(opts) if opts is not None else None), "bof_flash_csrcsc")
 
 
 def flash_csrmm_inmem(trans_a, m, n, k, alpha, beta, fa, fia, fja, ord_b, b_host, c_host, opts=None):

@@ -613,6 +613,9 @@ struct CsrRun {
   bof_fptr fa, fja, fb, fc;
   const float *host_b = nullptr;  // csrmm overload with B and C in host memory
   float *host_c = nullptr;
+  // A already in HBM (the transposed matrix of csrmm 'T'): 0-based arrays, nothing to read
+  const float *res_val = nullptr;
+  const int64_t *res_col = nullptr;
   std::vector<int64_t> ia, st, sz;
   std::vector<CsrCtx> ctx;
   int depth = 3;
@@ -657,14 +660,17 @@ struct CsrRun {
         cv.notify_all();
         continue;
       }
-      uint64_t s0, l0, d0, s1, l1, d1;
-      seg(b, 8, fja, s0, l0, d0);
-      seg(b, 4, fa, s1, l1, d1);
-      int rc = file_sread(fja.fd, s0, 0, 1, l0, c.h_idx, use_aio);
-      if (!rc) rc = file_sread(fa.fd, s1, 0, 1, l1, c.h_val, use_aio);
-      cnt.rd += l0 + l1;
+      uint64_t s0 = 0, l0 = 0, d0 = 0, s1 = 0, l1 = 0, d1 = 0;
+      int rc = 0;
+      if (!res_val) {
+        seg(b, 8, fja, s0, l0, d0);
+        seg(b, 4, fa, s1, l1, d1);
+        rc = file_sread(fja.fd, s0, 0, 1, l0, c.h_idx, use_aio);
+        if (!rc) rc = file_sread(fa.fd, s1, 0, 1, l1, c.h_val, use_aio);
+        cnt.rd += l0 + l1;
+      }
       hipError_t e = hipSuccess;
-      if (!rc) {
+      if (!rc && !res_val) {
         e = hipMemcpyAsync(c.d_idx, c.h_idx, l0, hipMemcpyHostToDevice, h2d);
         if (e == hipSuccess) e = hipMemcpyAsync(c.d_val, c.h_val, l1, hipMemcpyHostToDevice, h2d);
         cnt.h2d += l0 + l1;
@@ -752,18 +758,179 @@ int load_dense_to_device(const bof_fptr &f, uint64_t bytes, char *dptr, hipStrea
   return BOF_OK;
 }
 
+// Whole array <-> file with up to n_thr workers; each owns a 2-slot pinned ring and takes
+// 32 MiB chunks off a shared counter.  to_device: file -> pinned -> HBM; else the reverse.
+int stream_file(const bof_fptr &f, uint64_t bytes, char *dptr, bool to_device, hipStream_t st,
+                bool use_aio, int n_thr, Counters &cnt) {
+  if (bytes == 0) return BOF_OK;
+  const size_t chunk = (size_t) std::min<uint64_t>(32ull << 20, round_up(bytes, 4096));
+  const int64_t nchunks = (int64_t) ((bytes + chunk - 1) / chunk);
+  n_thr = (int) std::max<int64_t>(1, std::min<int64_t>(n_thr, nchunks));
+  std::atomic<int64_t> next{0};
+  std::atomic<int> fail{0};
+  int dev = 0;
+  BOF_HIP_TRY(hipGetDevice(&dev));
+  auto worker = [&] {
+    (void) hipSetDevice(dev);
+    PinnedRing ring;
+    if (ring.init(2, chunk)) { fail.store(-1000); return; }
+    for (;;) {
+      const int64_t i = next.fetch_add(1);
+      if (i >= nchunks || fail.load()) break;
+      const uint64_t o = (uint64_t) i * chunk, len = std::min<uint64_t>(chunk, bytes - o);
+      const int sl = ring.acquire();
+      int io = 0;
+      hipError_t e = hipSuccess;
+      if (to_device) {
+        io = file_sread(f.fd, f.foffset + o, 0, 1, len, ring.ptr(sl), use_aio);
+        if (!io) e = hipMemcpyAsync(dptr + o, ring.ptr(sl), len, hipMemcpyHostToDevice, st);
+        if (!io && e == hipSuccess && ring.mark_busy(sl, st)) e = hipErrorUnknown;
+        cnt.rd += len; cnt.h2d += len;
+      } else {
+        e = hipMemcpyAsync(ring.ptr(sl), dptr + o, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && ring.mark_busy(sl, st)) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipEventSynchronize(ring.event(sl));
+        if (e == hipSuccess) io = file_swrite(f.fd, f.foffset + o, 0, 1, len, ring.ptr(sl), use_aio);
+        cnt.d2h += len; cnt.wr += len;
+      }
+      ring.release(sl);
+      if (io) fail.store(io);
+      if (e != hipSuccess) fail.store(-1000 - (int) e);
+    }
+    ring.destroy();
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < n_thr; i++) th.emplace_back(worker);
+  worker();
+  for (auto &t : th) t.join();
+  const int fl = fail.load();
+  if (fl) {
+    set_error(std::string(to_device ? "loading" : "storing") + " an array failed: " +
+              (fl > -1000 ? std::string(strerror(-fl)) : "HIP error " + std::to_string(-1000 - fl)));
+    return fl > -1000 ? BOF_EIO : BOF_EHIP;
+  }
+  return BOF_OK;
+}
+
+// A^T of a file-resident CSR matrix, built in HBM scratch (SCR_TR_*), offsets also on the host
+struct ResidentCsr {
+  const float *val = nullptr;
+  const int64_t *col = nullptr, *ia_dev = nullptr;
+  std::vector<int64_t> ia_host;
+  int64_t nnz = 0;
+};
+
 }  // namespace
+
+// Reads CSR(a, ia, ja) (m x n) whole into HBM and transposes it there (csrcsc_kernels.hip).
+// The reference does this out of core with per-row-block mkl_csrcsc + a column-block merge
+// through temporary files (src/blas/csrcsc.cpp:32-159) because its program cache is 8 GiB of
+// DRAM; with 288 GB of HBM the matrices of the BASELINE family (12 GB) fit whole, so the
+// transposition is one device-side sort.  Matrices whose working set exceeds free HBM are
+// refused with BOF_ENOMEM (no silent fallback).
+static int flash_transpose_to_hbm(int64_t m, int64_t n, bof_fptr fa, bof_fptr fia, bof_fptr fja,
+                                  const bof_options &o, Counters &cnt, ResidentCsr &out) {
+  const bool use_aio = o.use_odirect != 0;
+  std::vector<int64_t> ia((size_t) m + 1, 0);
+  if (m > 0) {
+    const int io = read_host(fia, (uint64_t) (m + 1) * 8, ia.data(), use_aio);
+    if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
+    cnt.rd += (uint64_t) (m + 1) * 8;
+  }
+  const int64_t z = ia[0], nnz = ia[(size_t) m] - z;
+  if (nnz < 0) { set_error("csrcsc: offsets are not ascending"); return BOF_EINVAL; }
+  out.nnz = nnz;
+  const size_t in_bytes = (size_t) nnz * 12 + (size_t) (m + 1) * 8;
+  const size_t out_bytes = (size_t) nnz * 12 + (size_t) (n + 1) * 8 + csrcsc_workspace_bytes(n, nnz);
+  size_t free_b = 0, total_b = 0;
+  BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (in_bytes + out_bytes > free_b) {  // scratch that is already allocated only helps
+    set_error("csrcsc: the matrix needs " + std::to_string((in_bytes + out_bytes) >> 20) +
+              " MiB of HBM, " + std::to_string(free_b >> 20) + " MiB are free (out-of-core transposition "
+              "is not implemented)");
+    return BOF_ENOMEM;
+  }
+  void *vt = nullptr, *ct = nullptr, *pt = nullptr;
+  int rc = scratch_get(SCR_TR_VAL, (size_t) std::max<int64_t>(nnz, 1) * 4, &vt);
+  if (!rc) rc = scratch_get(SCR_TR_COL, (size_t) std::max<int64_t>(nnz, 1) * 8, &ct);
+  if (!rc) rc = scratch_get(SCR_TR_PTR, (size_t) (n + 1) * 8, &pt);
+  if (rc) return rc;
+  char *d_val = nullptr, *d_col = nullptr, *d_ia = nullptr;
+  hipStream_t st = nullptr;
+  Cleanup guard;
+  guard.add([&] {
+    (void) hipFree(d_val); (void) hipFree(d_col); (void) hipFree(d_ia);
+    if (st) (void) hipStreamDestroy(st);
+  });
+  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  BOF_HIP_TRY(hipMalloc((void **) &d_val, (size_t) std::max<int64_t>(nnz, 1) * 4));
+  BOF_HIP_TRY(hipMalloc((void **) &d_col, (size_t) std::max<int64_t>(nnz, 1) * 8));
+  BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
+  BOF_HIP_TRY(hipMemcpyAsync(d_ia, ia.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice, st));
+  cnt.h2d += (uint64_t) (m + 1) * 8;
+  bof_fptr fv = fa, fc = fja;
+  fv.foffset += (uint64_t) z * 4;
+  fc.foffset += (uint64_t) z * 8;
+  rc = stream_file(fv, (uint64_t) nnz * 4, d_val, true, st, use_aio, o.n_io_threads, cnt);
+  if (!rc) rc = stream_file(fc, (uint64_t) nnz * 8, d_col, true, st, use_aio, o.n_io_threads, cnt);
+  if (rc) return rc;
+  void *ws = nullptr;
+  if (m > 0 && nnz > 0) {
+    rc = scratch_get(SCR_CSRCSC, csrcsc_workspace_bytes(n, nnz), &ws);
+    if (rc) return rc;
+  }
+  BOF_HIP_TRY(scsrcsc(m, n, nnz, (const float *) d_val, (const int64_t *) d_ia, (const int64_t *) d_col,
+                      (float *) vt, (int64_t *) pt, (int64_t *) ct, ws, st));
+  out.ia_host.resize((size_t) n + 1);
+  BOF_HIP_TRY(hipMemcpyAsync(out.ia_host.data(), pt, (size_t) (n + 1) * 8, hipMemcpyDeviceToHost, st));
+  BOF_HIP_TRY(hipStreamSynchronize(st));
+  cnt.d2h += (uint64_t) (n + 1) * 8;
+  out.val = (const float *) vt; out.col = (const int64_t *) ct; out.ia_dev = (const int64_t *) pt;
+  return BOF_OK;
+}
+
+static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, bof_fptr fa,
+                             bof_fptr fia_tr, bof_fptr fja_tr, bof_fptr fa_tr, const bof_options *opts) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = device_ready();
+  if (rc) return rc;
+  const bof_options o = resolved(opts);
+  Counters cnt;
+  ResidentCsr T;
+  rc = flash_transpose_to_hbm(m, n, fa, fia, fja, o, cnt, T);
+  if (rc) return rc;
+  hipStream_t st = nullptr;
+  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  Cleanup guard;
+  guard.add([&] { (void) hipStreamDestroy(st); });
+  const bool use_aio = o.use_odirect != 0;
+  rc = stream_file(fa_tr, (uint64_t) T.nnz * 4, (char *) T.val, false, st, use_aio, o.n_io_threads, cnt);
+  if (!rc) rc = stream_file(fja_tr, (uint64_t) T.nnz * 8, (char *) T.col, false, st, use_aio, o.n_io_threads, cnt);
+  if (!rc) {
+    const int io = file_swrite(fia_tr.fd, fia_tr.foffset, 0, 1, (uint64_t) (n + 1) * 8, T.ia_host.data(), use_aio);
+    if (io) { set_error(std::string("writing ia_tr failed: ") + strerror(-io)); rc = BOF_EIO; }
+    cnt.wr += (uint64_t) (n + 1) * 8;
+  }
+  cnt.tasks++;
+  publish_stats(cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  return rc;
+}
 
 // Shared driver of csrmm (is_mm) and csrgemv.  For csrgemv: hb = input vector (host), hc =
 // output vector (host).
 static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t k, float alpha,
                           float beta, bof_fptr fa, bof_fptr fia, bof_fptr fja, char ord_b,
                           bof_fptr fb, bof_fptr fc, const float *hb, float *hc,
-                          const bof_options *opts) {
+                          const bof_options *opts, const ResidentCsr *res = nullptr,
+                          Counters *carry = nullptr) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
   CsrRun R;
+  if (carry) {  // bytes moved by the transposition that produced `res`
+    R.cnt.rd += carry->rd.load(); R.cnt.h2d += carry->h2d.load(); R.cnt.d2h += carry->d2h.load();
+  }
+  if (res) { R.res_val = res->val; R.res_col = res->col; }
   R.o = resolved(opts);
   R.is_mm = is_mm; R.trans = trans; R.ord_b = ord_b;
   R.m = m; R.n = n; R.k = k; R.alpha = alpha; R.beta = beta;
@@ -774,15 +941,19 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   if (m == 0) return BOF_OK;
 
   // offsets are read to the host first, as the reference does (csrmm.cpp:69-71)
-  R.ia.resize((size_t) m + 1);
-  int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia.data(), R.use_aio);
-  if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
-  R.cnt.rd += (uint64_t) (m + 1) * 8;
+  if (res) {
+    R.ia = res->ia_host;
+  } else {
+    R.ia.resize((size_t) m + 1);
+    int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia.data(), R.use_aio);
+    if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
+    R.cnt.rd += (uint64_t) (m + 1) * 8;
+  }
   const int64_t nb = bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, nullptr, nullptr, 0);
   R.st.resize((size_t) nb); R.sz.resize((size_t) nb);
   bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
 
-  {
+  if (!res) {
     struct stat sb;
     if (fstat(fja.fd, &sb) == 0) R.fsize_ja = (uint64_t) sb.st_size;
     if (fstat(fa.fd, &sb) == 0) R.fsize_a = (uint64_t) sb.st_size;
@@ -790,8 +961,10 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   size_t max_idx = 0, max_val = 0, max_c = 0;
   for (int64_t b = 0; b < nb; b++) {
     uint64_t s, l, d;
-    R.seg(b, 8, fja, s, l, d); max_idx = std::max<size_t>(max_idx, l);
-    R.seg(b, 4, fa, s, l, d);  max_val = std::max<size_t>(max_val, l);
+    if (!res) {
+      R.seg(b, 8, fja, s, l, d); max_idx = std::max<size_t>(max_idx, l);
+      R.seg(b, 4, fa, s, l, d);  max_val = std::max<size_t>(max_val, l);
+    }
     if (is_mm) max_c = std::max(max_c, R.c_bytes(b));
   }
   max_idx = std::max<size_t>(max_idx, 512); max_val = std::max<size_t>(max_val, 512);
@@ -811,15 +984,20 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       if (c.done) (void) hipEventDestroy(c.done);
     }
     if (resident_ev) (void) hipEventDestroy(resident_ev);
-    (void) hipFree(d_ia); (void) hipFree(d_b); (void) hipFree(d_x); (void) hipFree(d_y);
+    if (!res) (void) hipFree(d_ia);
+    (void) hipFree(d_b); (void) hipFree(d_x); (void) hipFree(d_y);
     if (R.h2d) (void) hipStreamDestroy(R.h2d);
     if (R.d2h) (void) hipStreamDestroy(R.d2h);
   });
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
-  BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
-  BOF_HIP_TRY(hipMemcpyAsync(d_ia, R.ia.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice, R.h2d));
-  R.cnt.h2d += (uint64_t) (m + 1) * 8;
+  if (res) {
+    d_ia = const_cast<int64_t *>(res->ia_dev);
+  } else {
+    BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
+    BOF_HIP_TRY(hipMemcpyAsync(d_ia, R.ia.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice, R.h2d));
+    R.cnt.h2d += (uint64_t) (m + 1) * 8;
+  }
   const int64_t xlen = trans == 'N' ? n : m, ylen = trans == 'N' ? m : n;
   if (is_mm) {
     // B stays resident for the whole call (one shared read, like the reference's
@@ -853,10 +1031,12 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   R.ctx.resize((size_t) R.depth);
   for (int i = 0; i < R.depth; i++) {
     CsrCtx &c = R.ctx[i];
-    BOF_HIP_TRY(hipMalloc((void **) &c.d_idx, max_idx));
-    BOF_HIP_TRY(hipMalloc((void **) &c.d_val, max_val));
-    BOF_HIP_TRY(hipHostMalloc((void **) &c.h_idx, max_idx, hipHostMallocDefault));
-    BOF_HIP_TRY(hipHostMalloc((void **) &c.h_val, max_val, hipHostMallocDefault));
+    if (!res) {
+      BOF_HIP_TRY(hipMalloc((void **) &c.d_idx, max_idx));
+      BOF_HIP_TRY(hipMalloc((void **) &c.d_val, max_val));
+      BOF_HIP_TRY(hipHostMalloc((void **) &c.h_idx, max_idx, hipHostMallocDefault));
+      BOF_HIP_TRY(hipHostMalloc((void **) &c.h_val, max_val, hipHostMallocDefault));
+    }
     if (is_mm) {
       BOF_HIP_TRY(hipMalloc((void **) &c.d_c, max_c));
       if (ord_b == 'C') BOF_HIP_TRY(hipMalloc((void **) &c.d_c_rm, max_c));
@@ -887,12 +1067,19 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     hipStream_t st = ss->s[b % ss->n];
     herr = hipStreamWaitEvent(st, c.ready, 0);
     if (herr != hipSuccess) break;
-    uint64_t s0, l0, d0, s1, l1, d1;
-    R.seg(b, 8, fja, s0, l0, d0);
-    R.seg(b, 4, fa, s1, l1, d1);
-    const int64_t *col = (const int64_t *) (c.d_idx + d0);  // un-shift the sector widening
-    const float *val = (const float *) (c.d_val + d1);
     const int64_t s = R.st[b], r = R.sz[b];
+    const int64_t *col;
+    const float *val;
+    if (res) {
+      col = res->col + R.ia[(size_t) s];
+      val = res->val + R.ia[(size_t) s];
+    } else {
+      uint64_t s0, l0, d0, s1, l1, d1;
+      R.seg(b, 8, fja, s0, l0, d0);
+      R.seg(b, 4, fa, s1, l1, d1);
+      col = (const int64_t *) (c.d_idx + d0);  // un-shift the sector widening
+      val = (const float *) (c.d_val + d1);
+    }
     if (is_mm) {
       if (ord_b == 'C' && beta != 0.f)  // C block arrived packed column-major [k][r]
         herr = transpose_f32((const float *) c.d_c, r, k, r, (float *) c.d_c_rm, k, st);
@@ -947,6 +1134,25 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   return fail;
 }
 
+// csrmm with trans_a = 'T': C[n x k] = alpha * A^T * B[m x k] + beta * C.  A^T is built in HBM
+// and the row-block pipeline of the 'N' case runs over it with nothing left to read for A
+// (the reference writes A^T to temporary files first, src/blas/csrmm.cpp:355-422).
+static int flash_csrmm_trans(uint64_t m, uint64_t n, uint64_t k, float alpha, float beta, bof_fptr a,
+                             bof_fptr ia, bof_fptr ja, char ord_b, bof_fptr b, bof_fptr c,
+                             const float *hb, float *hc, const bof_options *opts) {
+  int rc = device_ready();
+  if (rc) return rc;
+  if (n == 0) return BOF_OK;
+  const bof_options o = resolved(opts);
+  Counters cnt;
+  ResidentCsr T;
+  rc = flash_transpose_to_hbm((int64_t) m, (int64_t) n, a, ia, ja, o, cnt, T);
+  if (rc) return rc;
+  bof_fptr none{-1, 0};
+  return flash_csr_impl(true, 'N', (int64_t) n, (int64_t) m, (int64_t) k, alpha, beta, none, none, none,
+                        ord_b, b, c, hb, hc, opts, &T, &cnt);
+}
+
 }  // namespace bof
 
 using namespace bof;
@@ -976,29 +1182,38 @@ int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alph
     set_error("bof_flash_csrmm: unrecognized value for param: ord_b");
     return BOF_EINVAL;
   }
-  if (trans_a == 'T') {  // reference routes this through csrcsc and is wrong
-    set_error("bof_flash_csrmm: trans_a='T' is not supported");
-    return BOF_EINVAL;
-  }
-  if (n > (uint64_t) INT32_MAX || a.fd < 0 || ia.fd < 0 || ja.fd < 0 || b.fd < 0 || c.fd < 0) {
+  if (n > (uint64_t) INT32_MAX || (trans_a == 'T' && m > (uint64_t) INT32_MAX) || a.fd < 0 ||
+      ia.fd < 0 || ja.fd < 0 || b.fd < 0 || c.fd < 0) {
     set_error("bof_flash_csrmm: bad argument");
     return BOF_EINVAL;
   }
   if (k == 0) return BOF_OK;
+  if (trans_a == 'T') return flash_csrmm_trans(m, n, k, alpha, beta, a, ia, ja, ord_b, b, c, nullptr, nullptr, opts);
   return flash_csr_impl(true, 'N', (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, ia, ja,
                         ord_b, b, c, nullptr, nullptr, opts);
+}
+
+int bof_flash_csrcsc(uint64_t m, uint64_t n, bof_fptr ia, bof_fptr ja, bof_fptr a, bof_fptr ia_tr,
+                     bof_fptr ja_tr, bof_fptr a_tr, const bof_options *opts) {
+  if (m > (uint64_t) INT32_MAX || n > (uint64_t) INT32_MAX || ia.fd < 0 || ja.fd < 0 || a.fd < 0 ||
+      ia_tr.fd < 0 || ja_tr.fd < 0 || a_tr.fd < 0) {
+    set_error("bof_flash_csrcsc: bad argument (m, n must fit 31 bits)");
+    return BOF_EINVAL;
+  }
+  return flash_csrcsc_impl((int64_t) m, (int64_t) n, ia, ja, a, ia_tr, ja_tr, a_tr, opts);
 }
 
 int bof_flash_csrmm_inmem(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha, float beta,
                           bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b, const float *b, float *c,
                           const bof_options *opts) {
-  if (trans_a != 'N' || (ord_b != 'R' && ord_b != 'C') || !b || !c || a.fd < 0 || ia.fd < 0 ||
-      ja.fd < 0 || n > (uint64_t) INT32_MAX) {
-    set_error("bof_flash_csrmm_inmem: bad argument (only trans_a='N', ord_b 'R'|'C')");
+  if ((trans_a != 'N' && trans_a != 'T') || (ord_b != 'R' && ord_b != 'C') || !b || !c || a.fd < 0 ||
+      ia.fd < 0 || ja.fd < 0 || n > (uint64_t) INT32_MAX || (trans_a == 'T' && m > (uint64_t) INT32_MAX)) {
+    set_error("bof_flash_csrmm_inmem: bad argument");
     return BOF_EINVAL;
   }
   if (k == 0) return BOF_OK;
   bof_fptr none{-1, 0};
+  if (trans_a == 'T') return flash_csrmm_trans(m, n, k, alpha, beta, a, ia, ja, ord_b, none, none, b, c, opts);
   return flash_csr_impl(true, 'N', (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, ia, ja,
                         ord_b, none, none, b, c, opts);
 }

@@ -3,7 +3,7 @@
 // Implemented in src/flash_api.cpp on top of the C ABI of libbof_hip.so
 // (include/bof_hip.h): tiles stream file -> pinned ring -> HBM and are computed
 // by hand-written gfx950 kernels.  Out-of-scope kernels of the reference (kmeans,
-// csrcsc, sort, map, reduce, the never-defined gemv) are not declared.
+// sort, map, reduce, the never-defined gemv) are not declared.
 #pragma once
 #include <functional>
 
@@ -20,8 +20,9 @@ namespace flash {
                  flash_ptr<FPTYPE> b, flash_ptr<FPTYPE> c, FBLAS_UINT lda_a = 0,
                  FBLAS_UINT lda_b = 0, FBLAS_UINT lda_c = 0);
 
-  // C = alpha*A*B + beta*C with A (m x n) in CSR {a, ia, ja}, B (n x k) and C (m x k)
-  // dense row- ('R') or column-major ('C').  Returns 0, or -1 for unrecognised flags.
+  // trans_a 'N': C = alpha*A*B + beta*C with A (m x n) in CSR {a, ia, ja}, B (n x k) and
+  // C (m x k) dense row- ('R') or column-major ('C').  trans_a 'T': C (n x k) =
+  // alpha*A^T*B + beta*C with B (m x k).  Returns 0, or -1 for unrecognised flags.
   FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha,
                   FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
                   CHAR ord_b, flash_ptr<FPTYPE> b, flash_ptr<FPTYPE> c);
@@ -30,6 +31,12 @@ namespace flash {
   FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha,
                   FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
                   CHAR ord_b, FPTYPE* b, FPTYPE* c);
+
+  // A : CSR(ia, ja, a, m, n) -> A^T : CSR(ia_tr, ja_tr, a_tr, n, m); the three output files
+  // must exist (ia_tr: n+1 offsets, ja_tr / a_tr: nnz entries).  Returns 0.
+  FBLAS_INT csrcsc(FBLAS_UINT m, FBLAS_UINT n, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
+                   flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia_tr, flash_ptr<MKL_INT> ja_tr,
+                   flash_ptr<FPTYPE> a_tr);
 
   // c = A*b ('N') or A^T*b ('T'); b and c are host vectors
   FBLAS_INT csrgemv(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, flash_ptr<FPTYPE> a,

@@ -204,15 +204,22 @@ namespace flash {
                   "flash::csrmm");
   }
 
+  // include/flash_blas.h:49-52; src/blas/csrcsc.cpp:32-159
+  FBLAS_INT csrcsc(FBLAS_UINT m, FBLAS_UINT n, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja,
+                   flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia_tr, flash_ptr<MKL_INT> ja_tr,
+                   flash_ptr<FPTYPE> a_tr) {
+    const bof_options o = current_options();
+    return finish(bof_flash_csrcsc(m, n, as_fptr(ia), as_fptr(ja), as_fptr(a), as_fptr(ia_tr),
+                                   as_fptr(ja_tr), as_fptr(a_tr), &o),
+                  "flash::csrcsc");
+  }
+
   // B and C in host memory.  The reference's version returns -1 for row-major even after
-  // doing the work (src/blas/csrmm.cpp:463-466) and rejects 'T'; here both layouts return 0.
+  // doing the work (src/blas/csrmm.cpp:463-466) and rejects 'T'; here every combination
+  // is computed and returns 0.
   FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha, FPTYPE beta,
                   flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja, CHAR ord_b,
                   FPTYPE* b, FPTYPE* c) {
-    if (trans_a == 'T') {
-      GLOG_ERROR("csrmm in mem transpose not implemented");
-      return -1;
-    }
     const bof_options o = current_options();
     return finish(bof_flash_csrmm_inmem(trans_a, m, n, k, alpha, beta, as_fptr(a), as_fptr(ia),
                                         as_fptr(ja), ord_b, b, c, &o),

@@ -181,9 +181,21 @@ int bof_flash_gemm(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
                    uint64_t k, float alpha, float beta, bof_fptr a, bof_fptr b,
                    bof_fptr c, uint64_t lda, uint64_t ldb, uint64_t ldc,
                    const bof_options *opts);
+/* include/flash_blas.h:37-40.  A is an m x n CSR.  trans_a 'N': B n x k, C m x k.
+ * trans_a 'T': C[n x k] = alpha * A^T * B[m x k] + beta * C; A^T is built in HBM by
+ * bof_scsrcsc (the reference goes through csrcsc into temporary files,
+ * src/blas/csrmm.cpp:355-422, and is wrong there -- SURVEY App. B-3). */
 int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha,
                     float beta, bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b,
                     bof_fptr b, bof_fptr c, const bof_options *opts);
+/* flash::csrcsc (include/flash_blas.h:49-52, src/blas/csrcsc.cpp:32-159):
+ * CSR(ia, ja, a) of shape m x n -> CSR(ia_tr, ja_tr, a_tr) of shape n x m in the three
+ * output files (ia_tr: n+1 int64, ja_tr: nnz int64, a_tr: nnz fp32), source rows
+ * ascending inside every output row.  The matrix is transposed whole in HBM;
+ * BOF_ENOMEM if it does not fit (there is no out-of-core merge path). */
+int bof_flash_csrcsc(uint64_t m, uint64_t n, bof_fptr ia, bof_fptr ja, bof_fptr a,
+                     bof_fptr ia_tr, bof_fptr ja_tr, bof_fptr a_tr,
+                     const bof_options *opts);
 /* csrmm with B (n x k) and C (m x k) in HOST memory: the reference's second overload
  * (include/flash_blas.h:43-46, src/blas/csrmm.cpp:453-472). */
 int bof_flash_csrmm_inmem(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha,

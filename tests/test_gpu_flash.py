@@ -193,8 +193,91 @@ def test_flash_csrmm_inmem_bc(dev, tmp_path, ord_b):
                                  ord_b, b.ctypes.data, c.ctypes.data, opts)
         assert np.array_equal(c, ref)
         with pytest.raises(bofhip.BofError):
-            bofhip.flash_csrmm_inmem("T", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"),
+            bofhip.flash_csrmm_inmem("Q", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"),
                                      F.fptr("ja"), ord_b, b.ctypes.data, c.ctypes.data, opts)
+        # trans_a = 'T' with host B (m x k) / C (n x k): rejected by the reference, computed here
+        bt = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+        ct0 = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+        ref_t = orc.scsrmm_t(m, n, k, 0.5, val, ia, ja, bt, k, 2.0, ct0.copy(), k)
+        if ord_b == "C":
+            bt, ct = np.ascontiguousarray(bt.T), np.ascontiguousarray(ct0.T)
+        else:
+            ct = ct0.copy()
+        bofhip.flash_csrmm_inmem("T", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
+                                 ord_b, bt.ctypes.data, ct.ctypes.data, opts)
+        assert np.array_equal(ct.T if ord_b == "C" else ct, ref_t)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_flash_csrcsc(dev, tmp_path, golden_tr, direct):
+    """flash::csrcsc on files (SURVEY 8f-3): generator matrix pinned by the mkl_csrcsc hashes,
+    a ragged random matrix with empty rows/columns against the oracle, inputs left untouched."""
+    import hashlib
+    want = {t.split()[1]: t.split()[2] for t in golden_tr["meta"] if t.startswith("exact")}
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    nnz = ja.size
+    F = Files(tmp_path, direct, val=val, ja=ja, ia=ia, val_tr=np.zeros(nnz, np.float32),
+              ja_tr=np.zeros(nnz, np.int64), ia_tr=np.zeros(n + 1, np.int64))
+    try:
+        bofhip.flash_csrcsc(m, n, F.fptr("ia"), F.fptr("ja"), F.fptr("val"), F.fptr("ia_tr"),
+                            F.fptr("ja_tr"), F.fptr("val_tr"), bofhip.default_options(n_io_threads=3))
+        st = bofhip.flash_last_stats()
+        assert st["bytes_read"] == nnz * 12 + (m + 1) * 8 and st["bytes_written"] == nnz * 12 + (n + 1) * 8
+        h = lambda name, dt: hashlib.sha256(F.read(name, dt, (-1,)).tobytes()).hexdigest()
+        assert h("val_tr", np.float32) == want["gen_tr_val"]
+        assert h("ja_tr", np.int64) == want["gen_tr_ja"]
+        assert h("ia_tr", np.int64) == want["gen_tr_ia"]
+        assert np.array_equal(F.read("ja", np.int64, (-1,)), ja)
+        assert np.array_equal(F.read("val", np.float32, (-1,)), val)
+    finally:
+        F.close()
+    rng = np.random.default_rng(9)
+    m, n = 3000, 70000
+    counts = rng.integers(0, 40, m); counts[0] = 0; counts[m - 1] = 0; counts[77] = 900
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+    wv, wi, wj = orc.csrcsc(m, n, val, ia, ja)
+    sub = tmp_path / "r"; sub.mkdir()
+    F = Files(sub, direct, val=val, ja=ja, ia=ia, val_tr=np.zeros(ja.size, np.float32),
+              ja_tr=np.zeros(ja.size, np.int64), ia_tr=np.zeros(n + 1, np.int64))
+    try:
+        bofhip.flash_csrcsc(m, n, F.fptr("ia"), F.fptr("ja"), F.fptr("val"), F.fptr("ia_tr"),
+                            F.fptr("ja_tr"), F.fptr("val_tr"), None)
+        assert np.array_equal(F.read("ia_tr", np.int64, (-1,)), wi)
+        assert np.array_equal(F.read("ja_tr", np.int64, (-1,)), wj)
+        assert np.array_equal(F.read("val_tr", np.float32, (-1,)), wv)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_b,k,alpha,beta", [("R", 128, 1.0, 0.0), ("R", 1030, 0.5, 2.0),
+                                               ("C", 128, 0.5, 2.0), ("C", 1030, 1.0, 0.0)])
+def test_flash_csrmm_trans(dev, tmp_path, golden_tr, ord_b, k, alpha, beta):
+    """csrmm trans_a='T' on files: C[n x k] = alpha A^T B[m x k] + beta C (the reference's path
+    is broken; the oracle is mkl_scsrmm('T')-pinned)."""
+    import hashlib
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    b = orc.dense_fill(m, k, "s")
+    rng = np.random.default_rng(k)
+    c0 = rng.integers(0, 5, (n, k)).astype(np.float32) if beta else np.zeros((n, k), np.float32)
+    ref = orc.scsrmm_t(m, n, k, alpha, val, ia, ja, b, k, beta, c0.copy(), k)
+    if k == 128 and alpha == 1.0 and beta == 0.0:
+        want = {t.split()[1]: t.split()[2] for t in golden_tr["meta"] if t.startswith("exact")}
+        assert hashlib.sha256(ref.tobytes()).hexdigest() == want["gen_csrmmT_c"]
+    bs, cs = (np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)) if ord_b == "C" else (b, c0)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia, b=bs, c=cs)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=300, n_io_threads=2)
+        bofhip.flash_csrmm("T", m, n, k, alpha, beta, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
+                           ord_b, F.fptr("b"), F.fptr("c"), opts)
+        got = F.read("c", np.float32, cs.shape)
+        assert np.array_equal(got.T if ord_b == "C" else got, ref)
+        assert np.array_equal(F.read("ja", np.int64, (-1,)), ja)
     finally:
         F.close()
 
@@ -294,3 +377,32 @@ def test_csrmm_and_csrgemv_drivers(dev, tmp_path, golden):
         run_driver("csrgemv_driver", [p["csr"], p["col"], p["off"], p["x"], p["y"], m, n, trans], env)
         assert hashlib.sha256(np.fromfile(p["y"], np.float32).tobytes()).hexdigest() == \
             want["gen_csrgemv_" + trans]
+
+
+def test_csrcsc_driver_and_csrmm_driver_trans(dev, tmp_path, golden_tr):
+    """The C++ boundary for the transposition row: csrcsc_driver (reference argv,
+    drivers/csrcsc.cpp:17-28) and csrmm_driver with trans_a = T."""
+    import hashlib
+    want = {t.split()[1]: t.split()[2] for t in golden_tr["meta"] if t.startswith("exact")}
+    m, n, k = 4096, 2048, 128
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    p = {x: str(tmp_path / x) for x in ("csr", "col", "off", "tcsr", "tcol", "toff", "B", "C")}
+    val.tofile(p["csr"]); ja.tofile(p["col"]); ia.tofile(p["off"])
+    np.zeros(ja.size, np.float32).tofile(p["tcsr"]); np.zeros(ja.size, np.int64).tofile(p["tcol"])
+    np.zeros(n + 1, np.int64).tofile(p["toff"])
+    out = run_driver("csrcsc_driver", [p["csr"], p["col"], p["off"], p["tcsr"], p["tcol"], p["toff"], m, n], {})
+    assert "csrcsc() took" in out
+    h = lambda f, dt: hashlib.sha256(np.fromfile(p[f], dt).tobytes()).hexdigest()
+    assert (h("tcsr", np.float32), h("tcol", np.int64), h("toff", np.int64)) == \
+        (want["gen_tr_val"], want["gen_tr_ja"], want["gen_tr_ia"])
+    orc.dense_fill(m, k, "s").tofile(p["B"])
+    np.zeros((n, k), np.float32).tofile(p["C"])
+    out = run_driver("csrmm_driver", [p["csr"], p["col"], p["off"], p["B"], p["C"], m, n, k, 1.0, 0.0,
+                                      "T", "R"], {"BOF_MAX_NNZS": "5000", "BOF_CSRMM_RBLK_SIZE": "300"})
+    assert "csrmm() took" in out
+    assert h("C", np.float32) == want["gen_csrmmT_c"]
+    # transposed matrix fed back through the 'N' path gives the same product
+    np.zeros((n, k), np.float32).tofile(p["C"])
+    run_driver("csrmm_driver", [p["tcsr"], p["tcol"], p["toff"], p["B"], p["C"], n, m, k, 1.0, 0.0,
+                                "N", "R"], {})
+    assert h("C", np.float32) == want["gen_csrmmT_c"]

@@ -14,12 +14,12 @@ REF = "/root/reference"
 
 def test_own_drivers_build():
     subprocess.run(["make", "-C", os.path.join(PKG, "drivers"), "-s"], check=True)
-    for d in ("gemm_driver", "csrmm_driver", "csrgemv_driver"):
+    for d in ("gemm_driver", "csrmm_driver", "csrgemv_driver", "csrcsc_driver"):
         assert os.access(os.path.join(PKG, "bin", d), os.X_OK)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
-@pytest.mark.parametrize("drv", ["gemm", "csrmm", "csrgemv"])
+@pytest.mark.parametrize("drv", ["gemm", "csrmm", "csrgemv", "csrcsc"])
 def test_reference_driver_compiles_unchanged(tmp_path, drv):
     subprocess.run(["make", "-C", os.path.join(PKG, "drivers"), "-s"], check=True)
     out = str(tmp_path / f"ref_{drv}")
