@@ -12,8 +12,9 @@
 //                                exclusive_scan     -> global base of every (digit, tile)
 //                                radix_scatter_kernel -> stable placement
 //   the first pass reads the CSR arrays directly (row ids recovered from the offsets by a
-//   binary search bounded to the tile's row range) and also counts the columns (-> ia_tr);
-//   the last pass writes ja_tr (int64 row ids) and val_tr directly.
+//   binary search bounded to the tile's row range); the last pass writes ja_tr (int64 row
+//   ids), val_tr and the sorted keys, from which ia_tr follows (no global atomics anywhere:
+//   device-scope atomics execute at the memory side on MI355X and cost 37 ms per 1e9).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -114,7 +115,12 @@ inline size_t scan_tmp_elems(int64_t n) {  // int64 elements needed by exclusive
 // ---------------------------------------------------------------------------------------
 // stable LSD radix sort of the non-zeros by column
 // ---------------------------------------------------------------------------------------
-constexpr int RS_T = 256, RS_WAVES = RS_T / 64, RS_SUB = 4096, RS_TILE = RS_WAVES * RS_SUB;
+// A tile is 4096 consecutive records handled by one 256-thread workgroup: wave w owns the
+// w-th quarter, lane l of its c-th chunk owns record 64*c + l, so "wave, chunk, lane" order is
+// the input order.  The tile is first sorted by digit inside LDS (stable), then written out
+// run by run, so every global store instruction covers consecutive addresses.
+constexpr int RS_T = 256, RS_WAVES = RS_T / 64, RS_CHUNKS = 16, RS_SUB = 64 * RS_CHUNKS,
+              RS_TILE = RS_WAVES * RS_SUB;
 
 struct SortArgs {
   // source: pass 0 reads the CSR arrays, later passes the (key,row,val) records
@@ -122,13 +128,14 @@ struct SortArgs {
   const int64_t *ptr;   // pass 0 (m + 1 offsets, any base)
   const float *val_in;  // pass 0: CSR values; later: record values
   const uint32_t *key_in, *row_in;
-  // destination: records, or (last pass) the transposed CSR arrays
+  // destination: records; the last pass writes the transposed CSR arrays + the sorted keys
   uint32_t *key_out, *row_out;
   float *val_out;
   int64_t *col_tr;
   int64_t m, nnz;
   int shift, wbits;
   int64_t nblocks;
+  const int64_t *tile_row;  // pass 0: row holding the first record of every tile (nblocks + 1)
 };
 
 // row of position p (0-based among the non-zeros): largest r in [lo, hi] with ptr[r] - ptr[0] <= p
@@ -143,9 +150,19 @@ __device__ inline int64_t row_of(const int64_t *__restrict__ ptr, int64_t z, int
   return lo;
 }
 
+// tile_row[t] = row of record min(t * RS_TILE, nnz - 1): one full-depth search per tile here
+// instead of a serial one at the head of every scatter workgroup
+__global__ __launch_bounds__(256) void tile_rows_kernel(const int64_t *__restrict__ ptr, int64_t m,
+                                                        int64_t nnz, int64_t nblocks,
+                                                        int64_t *__restrict__ tile_row) {
+  const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (t > nblocks) return;
+  const int64_t p = t * RS_TILE < nnz - 1 ? t * RS_TILE : nnz - 1;
+  tile_row[t] = row_of(ptr, ptr[0], p, 0, m - 1);
+}
+
 template <bool FIRST>
-__global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *__restrict__ hist,
-                                                          uint32_t *__restrict__ colcnt) {
+__global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *__restrict__ hist) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -153,95 +170,130 @@ __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
   const uint32_t mask = (1u << a.wbits) - 1u;
   for (int64_t p = t0 + threadIdx.x; p < t1; p += RS_T) {
-    uint32_t key;
-    if (FIRST) {
-      key = (uint32_t) a.col[p];
-      atomicAdd(&colcnt[key], 1u);  // column populations -> ia_tr
-    } else {
-      key = a.key_in[p];
-    }
+    const uint32_t key = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
     atomicAdd(&h[(key >> a.shift) & mask], 1u);
   }
   __syncthreads();
-  hist[(int64_t) threadIdx.x * a.nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
+  if (threadIdx.x <= mask) hist[(int64_t) threadIdx.x * a.nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
 }
 
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
                                                              const int64_t *__restrict__ bases) {
-  __shared__ uint32_t cnt[RS_WAVES][256];
-  __shared__ int64_t run[RS_WAVES][256];
-  __shared__ int64_t rng[2];
+  __shared__ uint32_t skey[RS_TILE], srow[RS_TILE];
+  __shared__ float sval[RS_TILE];
+  __shared__ uint32_t run[RS_WAVES][256];  // counts, then running local positions
+  __shared__ uint32_t lstart[256];         // local start of every digit's run
+  __shared__ int64_t gbase[256];           // global start of this tile's run of every digit
+  __shared__ uint32_t wsum[RS_WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t mask = (1u << a.wbits) - 1u;
   const int64_t t0 = (int64_t) blockIdx.x * RS_TILE;
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
-  const int64_t s0 = t0 + (int64_t) w * RS_SUB;                 // this wave's sub-tile
-  const int64_t s1 = s0 + RS_SUB < t1 ? s0 + RS_SUB : t1;
-  for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_T) (&cnt[0][0])[i] = 0;
-  int64_t z = 0;
-  if (FIRST) {
-    z = a.ptr[0];
-    if (threadIdx.x < 2) {
-      const int64_t p = threadIdx.x == 0 ? t0 : t1 - 1;
-      rng[threadIdx.x] = row_of(a.ptr, z, p, 0, a.m - 1);
+  const int64_t s0 = t0 + (int64_t) w * RS_SUB;  // this wave's quarter
+  for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_T) (&run[0][0])[i] = 0;
+  if (threadIdx.x <= mask) gbase[threadIdx.x] = bases[(int64_t) threadIdx.x * a.nblocks + blockIdx.x];
+  const int64_t z = FIRST ? a.ptr[0] : 0;
+  __syncthreads();
+  // phase 0/1: records into registers, digit counts per wave
+  uint32_t key[RS_CHUNKS], row[RS_CHUNKS];
+  float v[RS_CHUNKS];
+  // rows that can own a record of this tile (the upper one may start exactly at the tile end)
+  const int64_t r_lo = FIRST ? a.tile_row[blockIdx.x] : 0, r_hi = FIRST ? a.tile_row[blockIdx.x + 1] : 0;
+#pragma unroll
+  for (int c = 0; c < RS_CHUNKS; c++) {
+    const int64_t p = s0 + c * 64 + lane;
+    key[c] = 0; row[c] = 0; v[c] = 0.f;
+    if (p < t1) {
+      key[c] = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
+      v[c] = a.val_in[p];
+      if (!FIRST) row[c] = a.row_in[p];
+    }
+  }
+  // first pass: row ids.  The offsets of the tile's row range [r_lo, r_hi] are copied into LDS
+  // (tile-relative, in the still unused skey area); every wave then paints the row id over the
+  // positions of "its" rows in the srow area (64 positions per LDS store) and each record picks
+  // its id up from there.  A range that does not fit (thousands of empty rows inside one tile)
+  // is searched in global memory instead.
+  const int64_t nr = r_hi - r_lo + 1;
+  const bool paint = FIRST && nr < RS_TILE;
+  if (paint) {
+    const int cnt = (int) (t1 - t0);
+    for (int64_t i = threadIdx.x; i <= nr; i += RS_T) {
+      int64_t rel = a.ptr[r_lo + i] - z - t0;  // first row may start before, last end after the tile
+      rel = rel < 0 ? 0 : (rel > cnt ? cnt : rel);
+      skey[i] = (uint32_t) rel;
+    }
+    __syncthreads();
+    for (int ri = w; ri < (int) nr; ri += RS_WAVES) {
+      const int b = (int) skey[ri], e = (int) skey[ri + 1];
+      for (int q = b + lane; q < e; q += 64) srow[q] = (uint32_t) (r_lo + ri);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < RS_CHUNKS; c++) {
+    const int64_t p = s0 + c * 64 + lane;
+    if (p < t1) {
+      if (FIRST) row[c] = paint ? srow[w * RS_SUB + c * 64 + lane] : (uint32_t) row_of(a.ptr, z, p, r_lo, r_hi);
+      atomicAdd(&run[w][(key[c] >> a.shift) & mask], 1u);
     }
   }
   __syncthreads();
-  // phase 1: digit counts of every wave's sub-tile
-  for (int64_t p = s0 + lane; p < s1; p += 64) {
-    const uint32_t key = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
-    atomicAdd(&cnt[w][(key >> a.shift) & mask], 1u);
-  }
-  __syncthreads();
+  // local layout: digit-major, wave-minor (= input order inside a digit)
   {
-    const int d = threadIdx.x;  // one digit per thread: running base of each wave
-    int64_t base = bases[(int64_t) d * a.nblocks + blockIdx.x];
-    for (int i = 0; i < RS_WAVES; i++) {
-      run[i][d] = base;
-      base += cnt[i][d];
+    const int d = threadIdx.x;
+    uint32_t cw[RS_WAVES], tot = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) { cw[i] = run[i][d]; tot += cw[i]; }
+    uint32_t inc = tot;  // exclusive scan of tot over the 256 digits
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
     }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t start = inc - tot;
+    for (int i = 0; i < w; i++) start += wsum[i];
+    lstart[d] = start;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) { run[i][d] = start; start += cw[i]; }
   }
   __syncthreads();
-  const int64_t r_lo = FIRST ? rng[0] : 0, r_hi = FIRST ? rng[1] : 0;
+  // phase 2: stable placement into the LDS image
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  // phase 2: chunks of 64 in order; inside a chunk the lane order is the element order
-  for (int64_t c0 = s0; c0 < s1; c0 += 64) {
-    const int64_t p = c0 + lane;
-    const bool ok = p < s1;
-    uint32_t key = 0, row = 0;
-    float v = 0.f;
-    if (ok) {
-      if (FIRST) {
-        key = (uint32_t) a.col[p];
-        row = (uint32_t) row_of(a.ptr, z, p, r_lo, r_hi);
-      } else {
-        key = a.key_in[p];
-        row = a.row_in[p];
-      }
-      v = a.val_in[p];
-    }
-    const uint32_t d = (key >> a.shift) & mask;
+#pragma unroll
+  for (int c = 0; c < RS_CHUNKS; c++) {
+    const bool ok = s0 + c * 64 + lane < t1;
+    const uint32_t d = (key[c] >> a.shift) & mask;
     uint64_t peers = __ballot(ok);
     for (int b = 0; b < a.wbits; b++) {
       const uint64_t vote = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? vote : ~vote;
     }
     const int rank = __popcll(peers & lt);
-    int64_t pos = 0;
+    uint32_t pos = 0;
     if (ok) pos = run[w][d] + rank;
     __builtin_amdgcn_wave_barrier();
     if (ok && rank == 0) run[w][d] += __popcll(peers);
     __builtin_amdgcn_wave_barrier();
-    if (ok) {
-      if (LAST) {
-        a.col_tr[pos] = (int64_t) row;
-        a.val_out[pos] = v;
-      } else {
-        a.key_out[pos] = key;
-        a.row_out[pos] = row;
-        a.val_out[pos] = v;
-      }
+    if (ok) { skey[pos] = key[c]; srow[pos] = row[c]; sval[pos] = v[c]; }
+  }
+  __syncthreads();
+  // phase 3: run-by-run write-out, consecutive threads -> consecutive addresses
+  const int cnt = (int) (t1 - t0);
+  for (int i = threadIdx.x; i < cnt; i += RS_T) {
+    const uint32_t k = skey[i];
+    const uint32_t d = (k >> a.shift) & mask;
+    const int64_t g = gbase[d] + (int64_t) (i - lstart[d]);
+    if (LAST) {
+      a.col_tr[g] = (int64_t) srow[i];
+      a.val_out[g] = sval[i];
+      a.key_out[g] = k;  // sorted keys: the offsets are derived from them
+    } else {
+      a.key_out[g] = k;
+      a.row_out[g] = srow[i];
+      a.val_out[g] = sval[i];
     }
   }
 }
@@ -252,12 +304,55 @@ hipError_t scatter_launch(const SortArgs &a, const int64_t *bases, hipStream_t s
   return hipGetLastError();
 }
 
+// offsets of the transpose from the sorted keys: position i opens every row in
+// (key[i-1], key[i]]; i == nnz closes the rows above the last key.  8 positions per thread.
+constexpr int OFS_PER_T = 8;
+__global__ __launch_bounds__(256) void offsets_from_sorted_keys_kernel(const uint32_t *__restrict__ key,
+                                                                        int64_t nnz, int64_t n,
+                                                                        int64_t *__restrict__ ptr_tr) {
+  const int64_t i0 = ((int64_t) blockIdx.x * 256 + threadIdx.x) * OFS_PER_T;
+  if (i0 > nnz) return;
+  uint32_t k[OFS_PER_T];
+  if (i0 + OFS_PER_T <= nnz) {
+    const uint4 lo = *reinterpret_cast<const uint4 *>(key + i0);
+    const uint4 hi = *reinterpret_cast<const uint4 *>(key + i0 + 4);
+    k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < OFS_PER_T; j++) k[j] = i0 + j < nnz ? key[i0 + j] : 0u;
+  }
+  int64_t prev = i0 == 0 ? -1 : (int64_t) key[i0 - 1];
+#pragma unroll
+  for (int j = 0; j < OFS_PER_T; j++) {
+    const int64_t i = i0 + j;
+    if (i > nnz) break;
+    const int64_t cur = i == nnz ? n : (int64_t) k[j];
+    for (int64_t c = prev + 1; c <= cur; c++) ptr_tr[c] = i;
+    prev = cur;
+  }
+}
+
+// same offsets, one lower_bound per output row: cheaper when rows are long (n << nnz)
+__global__ __launch_bounds__(256) void offsets_by_search_kernel(const uint32_t *__restrict__ key,
+                                                                 int64_t nnz, int64_t n,
+                                                                 int64_t *__restrict__ ptr_tr) {
+  const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (c > n) return;
+  int64_t lo = 0, hi = nnz;  // first i with key[i] >= c
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t) key[mid] < c) lo = mid + 1;
+    else hi = mid;
+  }
+  ptr_tr[c] = lo;
+}
+
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct Layout {
   int passes, wbits;
   int64_t nblocks;
-  size_t off_hist, off_bases, off_colcnt, off_scan, off_rec[2], total;
+  size_t off_hist, off_bases, off_scan, off_keys, off_tilerow, off_rec[2], total;
 };
 
 Layout make_layout(int64_t n, int64_t nnz) {
@@ -267,13 +362,13 @@ Layout make_layout(int64_t n, int64_t nnz) {
   L.passes = (bits + 7) / 8;
   L.wbits = (bits + L.passes - 1) / L.passes;
   L.nblocks = (nnz + RS_TILE - 1) / RS_TILE;
-  const size_t nh = (size_t) 256 * (size_t) (L.nblocks > 0 ? L.nblocks : 1);
+  const size_t nh = ((size_t) 1 << L.wbits) * (size_t) (L.nblocks > 0 ? L.nblocks : 1);
   size_t o = 0;
   L.off_hist = o;   o += align256(nh * 4);
   L.off_bases = o;  o += align256(nh * 8);
-  L.off_colcnt = o; o += align256((size_t) (n + 1) * 4);
-  const size_t scan_n = nh > (size_t) (n + 1) ? nh : (size_t) (n + 1);
-  L.off_scan = o;   o += align256(scan_tmp_elems((int64_t) scan_n) * 8);
+  L.off_scan = o;   o += align256(scan_tmp_elems((int64_t) nh) * 8);
+  L.off_keys = o;   o += align256((size_t) nnz * 4);
+  L.off_tilerow = o; o += align256((size_t) (L.nblocks + 1) * 8);
   const int n_rec = L.passes == 1 ? 0 : (L.passes == 2 ? 1 : 2);
   for (int i = 0; i < 2; i++) {
     L.off_rec[i] = o;
@@ -296,13 +391,15 @@ hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const in
   char *ws = (char *) workspace;
   uint32_t *hist = (uint32_t *) (ws + L.off_hist);
   int64_t *bases = (int64_t *) (ws + L.off_bases);
-  uint32_t *colcnt = (uint32_t *) (ws + L.off_colcnt);
   int64_t *scan_tmp = (int64_t *) (ws + L.off_scan);
+  uint32_t *keys_sorted = (uint32_t *) (ws + L.off_keys);
   const size_t rec = align256((size_t) nnz * 4);
-  e = hipMemsetAsync(colcnt, 0, (size_t) (n + 1) * 4, st);
-  if (e != hipSuccess) return e;
 
+  int64_t *tile_row = (int64_t *) (ws + L.off_tilerow);
+  tile_rows_kernel<<<(unsigned) ((L.nblocks + 1 + 255) / 256), 256, 0, st>>>(ptr, m, nnz, L.nblocks, tile_row);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
   SortArgs a{};
+  a.tile_row = tile_row;
   a.col = col; a.ptr = ptr; a.m = m; a.nnz = nnz; a.nblocks = L.nblocks; a.wbits = L.wbits;
   a.col_tr = col_tr;
   for (int pass = 0; pass < L.passes; pass++) {
@@ -317,17 +414,17 @@ hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const in
       a.val_in = (const float *) (src + 2 * rec);
     }
     if (last) {
-      a.key_out = nullptr; a.row_out = nullptr; a.val_out = val_tr;
+      a.key_out = keys_sorted; a.row_out = nullptr; a.val_out = val_tr;
     } else {
       char *dst = ws + L.off_rec[pass & 1];
       a.key_out = (uint32_t *) dst;
       a.row_out = (uint32_t *) (dst + rec);
       a.val_out = (float *) (dst + 2 * rec);
     }
-    if (first) radix_hist_kernel<true><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist, colcnt);
-    else radix_hist_kernel<false><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist, colcnt);
+    if (first) radix_hist_kernel<true><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
+    else radix_hist_kernel<false><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    e = exclusive_scan<uint32_t>(hist, bases, 256 * L.nblocks, scan_tmp, st);
+    e = exclusive_scan<uint32_t>(hist, bases, ((int64_t) 1 << L.wbits) * L.nblocks, scan_tmp, st);
     if (e != hipSuccess) return e;
     if (first && last) e = scatter_launch<true, true>(a, bases, st);
     else if (first) e = scatter_launch<true, false>(a, bases, st);
@@ -335,8 +432,11 @@ hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const in
     else e = scatter_launch<false, false>(a, bases, st);
     if (e != hipSuccess) return e;
   }
-  // ia_tr = exclusive scan of the column populations (colcnt[n] = 0 -> ia_tr[n] = nnz)
-  return exclusive_scan<uint32_t>(colcnt, ptr_tr, n + 1, scan_tmp, st);
+  if ((n + 1) * 16 < nnz)
+    offsets_by_search_kernel<<<(unsigned) ((n + 1 + 255) / 256), 256, 0, st>>>(keys_sorted, nnz, n, ptr_tr);
+  else
+    offsets_from_sorted_keys_kernel<<<(unsigned) ((nnz / OFS_PER_T + 1 + 255) / 256), 256, 0, st>>>(keys_sorted, nnz, n, ptr_tr);
+  return hipGetLastError();
 }
 
 }  // namespace bof
