@@ -73,7 +73,62 @@ def main():
                "gflops": round(2.0 * m * npr * k / secs / 1e9, 1) if secs == secs else None,
                "sha256_C": h.hexdigest(), "matches_reference_hash": (h.hexdigest() == GOLD) if scale == 1 else None}
         print(json.dumps(out), flush=True)
-    for f in p.values():
+    # ---- transposition row: csrcsc_driver on the same files, twice -----------
+    def sha(path):
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            while True:
+                chunk = f.read(1 << 26)
+                if not chunk:
+                    break
+                h.update(chunk)
+        return h.hexdigest()
+
+    nnz = m * npr
+    q = {x: os.path.join(d, x) for x in ("T.csr", "T.col", "T.off", "U.csr", "U.col", "U.off", "Bt.bin", "Ct.bin")}
+    for name, size in (("T.csr", nnz * 4), ("T.col", nnz * 8), ("T.off", (n + 1) * 8), ("U.csr", nnz * 4),
+                       ("U.col", nnz * 8), ("U.off", (m + 1) * 8), ("Ct.bin", n * k * 4)):
+        with open(q[name], "wb") as f:
+            f.truncate(size)
+    orig = {x: sha(p[x]) for x in ("A.csr", "A.col", "A.off")}
+    drv = os.path.join(ROOT, "blas-on-flash_amd", "bin", "csrcsc_driver")
+
+    def took(out, tag):
+        ln = [x for x in out.splitlines() if tag in x]
+        return float(ln[0].split("took")[1].split("\x1b")[0]) if ln else float("nan")
+
+    for odirect in ("0", "1"):
+        env = dict(os.environ, BOF_ODIRECT=odirect)
+        r1 = subprocess.run([drv, p["A.csr"], p["A.col"], p["A.off"], q["T.csr"], q["T.col"], q["T.off"], str(m), str(n)],
+                            capture_output=True, text=True, env=env)
+        r2 = subprocess.run([drv, q["T.csr"], q["T.col"], q["T.off"], q["U.csr"], q["U.col"], q["U.off"], str(n), str(m)],
+                            capture_output=True, text=True, env=env)
+        back = {"A.csr": sha(q["U.csr"]), "A.col": sha(q["U.col"]), "A.off": sha(q["U.off"])}
+        print(json.dumps({"what": "csrcsc_driver end to end (cfg3 files), A -> A^T -> A", "odirect": int(odirect),
+                          "rc": [r1.returncode, r2.returncode], "csrcsc_took_s": [took(r1.stdout, "csrcsc() took"),
+                                                                                  took(r2.stdout, "csrcsc() took")],
+                          "transpose_of_transpose_equals_input": back == orig,
+                          "input_sha256_16": {x: orig[x][:16] for x in orig}}), flush=True)
+    # csrmm 'T' on A  ==  csrmm 'N' on the A^T files (B' = dense_create(10M, 128, 's'))
+    bt = torch.empty(m * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(bt.data_ptr(), 0, m * k, "s", 0, st)
+    torch.cuda.synchronize()
+    dump(bt, q["Bt.bin"])
+    del bt
+    drv = os.path.join(ROOT, "blas-on-flash_amd", "bin", "csrmm_driver")
+    res = {}
+    for tag, args in (("T_on_A", [p["A.csr"], p["A.col"], p["A.off"], q["Bt.bin"], q["Ct.bin"], str(m), str(n), str(k),
+                                  "1.0", "0.0", "T", "R"]),
+                      ("N_on_At", [q["T.csr"], q["T.col"], q["T.off"], q["Bt.bin"], q["Ct.bin"], str(n), str(m), str(k),
+                                   "1.0", "0.0", "N", "R"])):
+        with open(q["Ct.bin"], "wb") as f:
+            f.truncate(n * k * 4)
+        r = subprocess.run([drv] + args, capture_output=True, text=True, env=dict(os.environ, BOF_ODIRECT="0"))
+        res[tag] = {"rc": r.returncode, "csrmm_took_s": took(r.stdout, "csrmm() took"), "sha256_C": sha(q["Ct.bin"])}
+    print(json.dumps({"what": "csrmm_driver trans_a=T end to end (cfg3 files)", "runs": res,
+                      "T_equals_N_on_transposed_files": res["T_on_A"]["sha256_C"] == res["N_on_At"]["sha256_C"]}),
+          flush=True)
+    for f in list(p.values()) + list(q.values()):
         os.remove(f)
 
 
