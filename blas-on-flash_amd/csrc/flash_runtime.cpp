@@ -235,8 +235,17 @@ static void build_order(const GemmGeometry &g, float beta, int64_t n_slots, std:
                         int64_t &gi, int64_t &gj) {
   const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
   gi = Nm; gj = Nn;
-  while (gi * gj + 2 * (gi + gj) > n_slots && (gi > 1 || gj > 1)) {
-    if (gi >= gj && gi > 1) gi--; else gj--;
+  if (Nk * Nn + Nn + 2 > n_slots || Nm == 1) {
+    while (gi * gj + 2 * (gi + gj) > n_slots && (gi > 1 || gj > 1)) {
+      if (gi >= gj && gi > 1) gi--; else gj--;
+    }
+  } else {
+    // All of B fits beside one row of C tiles and an A panel: sweep C in row blocks with B
+    // resident.  A and B are still read exactly once, and the chains of a row block finish
+    // (and are written back) while the next rows compute -- with a single whole-C block every
+    // write-back lands after the last multiply (measured: 60 % of the cfg2 file run).
+    const int64_t fit = (n_slots - Nk * Nn) / (Nn + 2);
+    gi = std::max<int64_t>(1, std::min(fit, (Nm + 7) / 8));
   }
   for (int64_t I0 = 0; I0 < Nm; I0 += gi)
     for (int64_t J0 = 0; J0 < Nn; J0 += gj)
@@ -473,8 +482,12 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   }
   rc = R.res->rring.init(std::max(2, R.o.pinned_slots), R.slot_bytes);
   if (rc) return rc;
-  const int n_writers = 2;
-  rc = R.res->wring.init(n_writers + 1, R.slot_bytes);
+  // write-back ring: a whole C super-block can be in flight, so the dispatcher does not
+  // stall at the end of a block while the writers drain the previous one
+  // (buffered writes to one file serialise on the inode lock: more than a few writers only
+  // add contention -- 4 writers 0.84 s, 8 writers 1.01 s on the cfg2 file run)
+  const int n_writers = std::max(2, std::min(4, R.o.n_io_threads / 2));
+  rc = R.res->wring.init((int) std::min<int64_t>(gi * gj, 16) + 2, R.slot_bytes);
   if (rc) return rc;
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
   BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
@@ -517,6 +530,11 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
     }
     const bof_gemm_task &tk = R.tasks[t];
     const int *ids = &R.task_tiles[(size_t) t * 3];
+    if (trace_on() && (t == 0 || tk.l != R.tasks[t - 1].l)) {
+      char lbl[64];
+      snprintf(lbl, sizeof(lbl), "task %d (l=%d) next", t, (int) tk.l);
+      BOF_TRACE_T(lbl);
+    }
     {
       std::unique_lock<std::mutex> lk(R.mu);
       R.cv.wait(lk, [&] {
