@@ -124,8 +124,30 @@ def csr_secondary(bofhip, torch, dev, st):
                                  "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes": alg,
                                  "gather_GBps": round(nnz * k * 4 / ms / 1e6, 1)}}
-    del val, col, off, b, c
+    # transposition row on the same matrix: A -> A^T, and csrmm trans_a='T'
+    vt = torch.empty_like(val)
+    ct = torch.empty_like(col)
+    pt = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ms = timed(lambda: bofhip.scsrcsc(m, n, nnz, val.data_ptr(), off.data_ptr(), col.data_ptr(),
+                                      vt.data_ptr(), pt.data_ptr(), ct.data_ptr(), st), iters=2)
+    alg = nnz * 24 + (m + n + 2) * 8                                # read A once, write A^T once
+    out["csrcsc"] = {"workload": "flash csrcsc 10M x 1M CSR (1e9 nnz) -> 1M x 10M, resident in HBM",
+                     "ms": round(ms, 3),
+                     "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes": alg}}
+    del vt, ct, pt
+    bt = torch.empty(m * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(bt.data_ptr(), 0, m * k, "u", 5, st)
+    ms = timed(lambda: bofhip.csrmm_resident("T", m, n, k, 1.0, 0.0, val.data_ptr(), ia.ctypes.data,
+                                             off.data_ptr(), col.data_ptr(), "R", bt.data_ptr(),
+                                             c.data_ptr(), opts, st), iters=2)
+    out["csrmm_T"] = {"workload": "flash _csrmm trans_a=T: (10M x 1M CSR)^T x 10M x 128, resident in HBM "
+                                  "(transposition + 'N' product over A^T)",
+                      "ms": round(ms, 3), "gflops": round(2.0 * nnz * k / ms / 1e6, 1)}
+    del val, col, off, b, c, bt
     torch.cuda.empty_cache()
+    bofhip.lib().bof_flash_release()      # the 26 GiB sort workspace goes back before cfg5
     m = n = 50_000_000
     npr = 10
     val = torch.empty(m * npr, dtype=torch.float32, device=dev)
