@@ -31,6 +31,11 @@ size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz);
 hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
                    const int64_t *col, float *val_tr, int64_t *ptr_tr, int64_t *col_tr,
                    void *workspace, hipStream_t st);
+// y = A^T x by partitioning the products by column bin (no global atomics); y overwritten
+size_t csrgemv_t_workspace_bytes(int64_t n, int64_t nnz);
+hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
+                                  const int64_t *col, const float *x, float *y, void *workspace,
+                                  hipStream_t st);
 // grow-only per-device scratch, freed by bof_flash_release.  Slots: 0 row-major copy of a
 // column-major B; 1..16 per-stream row-major C blocks; 17 csrcsc workspace; 18..20 transposed
 // CSR (values, indices, offsets) of csrmm 'T'

@@ -2,6 +2,7 @@
 // level 1 (per-tile compute) and level 2 (tile DAG over HBM-resident matrices).
 // Level 3 (file-resident matrices) lives in flash_runtime.cpp.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <cstdio>
 #include <cstring>
@@ -347,6 +348,22 @@ int bof_csrgemv_resident(char trans_a, int64_t m, int64_t n, const float *val,
   }
   const bof_options o = resolved(opts);
   hipStream_t parent = (hipStream_t) stream;
+  if (trans_a == 'T' && m > 0 && m <= INT32_MAX && n <= INT32_MAX) {
+    // Whole matrix resident: partition the products by column bin and sum per bin in LDS
+    // (csrcsc_kernels.hip) instead of one memory-side atomic per non-zero.  Small problems
+    // keep the per-block atomic kernel (a dozen launches would dominate).
+    const int64_t nnz = ia_host[m] - ia_host[0];
+    const char *env = getenv("BOF_GEMV_T_PARTITION_MIN_NNZ");
+    const int64_t min_nnz = env ? atoll(env) : (int64_t) 4 << 20;
+    if (nnz >= min_nnz && nnz > 0) {
+      void *ws = nullptr;
+      const int rc = scratch_get(SCR_CSRCSC, csrgemv_t_workspace_bytes(n, nnz), &ws);
+      if (rc) return rc;
+      const int64_t z = ia_host[0];
+      BOF_HIP_TRY(scsrgemv_t_partitioned(m, n, nnz, val + z, ia_dev, ja + z, x, y, ws, parent));
+      return BOF_OK;
+    }
+  }
   if (trans_a == 'T' && n > 0) BOF_HIP_TRY(hipMemsetAsync(y, 0, sizeof(float) * n, parent));
   if (m == 0) return BOF_OK;
   const int64_t nb = bof_csr_blocks(ia_host, m, 128, o.csrmm_rblk, o.max_nnzs, nullptr, nullptr, 0);

@@ -136,6 +136,7 @@ struct SortArgs {
   int shift, wbits;
   int64_t nblocks;
   const int64_t *tile_row;  // pass 0: row holding the first record of every tile (nblocks + 1)
+  const float *x;           // GEMV mode, pass 0: the record value becomes val * x[row]
 };
 
 // row of position p (0-based among the non-zeros): largest r in [lo, hi] with ptr[r] - ptr[0] <= p
@@ -177,10 +178,12 @@ __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *
   if (threadIdx.x <= mask) hist[(int64_t) threadIdx.x * a.nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
 }
 
-template <bool FIRST, bool LAST>
+// GEMV mode (the partition passes of A^T x): records are (column, product) only -- no row
+// payload is carried or staged.
+template <bool FIRST, bool LAST, bool GEMV>
 __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
                                                              const int64_t *__restrict__ bases) {
-  __shared__ uint32_t skey[RS_TILE], srow[RS_TILE];
+  __shared__ uint32_t skey[RS_TILE], srow[(GEMV && !FIRST) ? 64 : RS_TILE];
   __shared__ float sval[RS_TILE];
   __shared__ uint32_t run[RS_WAVES][256];  // counts, then running local positions
   __shared__ uint32_t lstart[256];         // local start of every digit's run
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
     if (p < t1) {
       key[c] = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
       v[c] = a.val_in[p];
-      if (!FIRST) row[c] = a.row_in[p];
+      if (!FIRST && !GEMV) row[c] = a.row_in[p];
     }
   }
   // first pass: row ids.  The offsets of the tile's row range [r_lo, r_hi] are copied into LDS
@@ -231,14 +234,23 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
     }
     __syncthreads();
   }
+  if (FIRST) {
 #pragma unroll
-  for (int c = 0; c < RS_CHUNKS; c++) {
-    const int64_t p = s0 + c * 64 + lane;
-    if (p < t1) {
-      if (FIRST) row[c] = paint ? srow[w * RS_SUB + c * 64 + lane] : (uint32_t) row_of(a.ptr, z, p, r_lo, r_hi);
-      atomicAdd(&run[w][(key[c] >> a.shift) & mask], 1u);
+    for (int c = 0; c < RS_CHUNKS; c++) {
+      const int64_t p = s0 + c * 64 + lane;
+      if (p < t1) row[c] = paint ? srow[w * RS_SUB + c * 64 + lane] : (uint32_t) row_of(a.ptr, z, p, r_lo, r_hi);
     }
   }
+  if (FIRST && GEMV) {  // all 16 x loads in flight before the first product
+    float xv[RS_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < RS_CHUNKS; c++) xv[c] = s0 + c * 64 + lane < t1 ? a.x[row[c]] : 0.f;
+#pragma unroll
+    for (int c = 0; c < RS_CHUNKS; c++) v[c] *= xv[c];
+  }
+#pragma unroll
+  for (int c = 0; c < RS_CHUNKS; c++)
+    if (s0 + c * 64 + lane < t1) atomicAdd(&run[w][(key[c] >> a.shift) & mask], 1u);
   __syncthreads();
   // local layout: digit-major, wave-minor (= input order inside a digit)
   {
@@ -277,7 +289,11 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
     __builtin_amdgcn_wave_barrier();
     if (ok && rank == 0) run[w][d] += __popcll(peers);
     __builtin_amdgcn_wave_barrier();
-    if (ok) { skey[pos] = key[c]; srow[pos] = row[c]; sval[pos] = v[c]; }
+    if (ok) {
+      skey[pos] = key[c];
+      if (!GEMV) srow[pos] = row[c];
+      sval[pos] = v[c];
+    }
   }
   __syncthreads();
   // phase 3: run-by-run write-out, consecutive threads -> consecutive addresses
@@ -292,56 +308,31 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
       a.key_out[g] = k;  // sorted keys: the offsets are derived from them
     } else {
       a.key_out[g] = k;
-      a.row_out[g] = srow[i];
+      if (!GEMV) a.row_out[g] = srow[i];
       a.val_out[g] = sval[i];
     }
   }
 }
 
-template <bool FIRST, bool LAST>
+template <bool FIRST, bool LAST, bool GEMV = false>
 hipError_t scatter_launch(const SortArgs &a, const int64_t *bases, hipStream_t st) {
-  radix_scatter_kernel<FIRST, LAST><<<(unsigned) a.nblocks, RS_T, 0, st>>>(a, bases);
+  radix_scatter_kernel<FIRST, LAST, GEMV><<<(unsigned) a.nblocks, RS_T, 0, st>>>(a, bases);
   return hipGetLastError();
 }
 
-// offsets of the transpose from the sorted keys: position i opens every row in
-// (key[i-1], key[i]]; i == nnz closes the rows above the last key.  8 positions per thread.
-constexpr int OFS_PER_T = 8;
-__global__ __launch_bounds__(256) void offsets_from_sorted_keys_kernel(const uint32_t *__restrict__ key,
-                                                                        int64_t nnz, int64_t n,
-                                                                        int64_t *__restrict__ ptr_tr) {
-  const int64_t i0 = ((int64_t) blockIdx.x * 256 + threadIdx.x) * OFS_PER_T;
-  if (i0 > nnz) return;
-  uint32_t k[OFS_PER_T];
-  if (i0 + OFS_PER_T <= nnz) {
-    const uint4 lo = *reinterpret_cast<const uint4 *>(key + i0);
-    const uint4 hi = *reinterpret_cast<const uint4 *>(key + i0 + 4);
-    k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
-  } else {
-#pragma unroll
-    for (int j = 0; j < OFS_PER_T; j++) k[j] = i0 + j < nnz ? key[i0 + j] : 0u;
-  }
-  int64_t prev = i0 == 0 ? -1 : (int64_t) key[i0 - 1];
-#pragma unroll
-  for (int j = 0; j < OFS_PER_T; j++) {
-    const int64_t i = i0 + j;
-    if (i > nnz) break;
-    const int64_t cur = i == nnz ? n : (int64_t) k[j];
-    for (int64_t c = prev + 1; c <= cur; c++) ptr_tr[c] = i;
-    prev = cur;
-  }
-}
-
-// same offsets, one lower_bound per output row: cheaper when rows are long (n << nnz)
+// offsets of the transpose from the sorted keys: one lower_bound per output row.  (A linear
+// boundary scan over the keys was tried first: a run of empty rows -- the reference generator
+// leaves the top 29 % of the columns empty -- serialises in one thread there: 586 ms.)
 __global__ __launch_bounds__(256) void offsets_by_search_kernel(const uint32_t *__restrict__ key,
                                                                  int64_t nnz, int64_t n,
-                                                                 int64_t *__restrict__ ptr_tr) {
+                                                                 int64_t *__restrict__ ptr_tr,
+                                                                 int kshift = 0) {
   const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (c > n) return;
-  int64_t lo = 0, hi = nnz;  // first i with key[i] >= c
+  int64_t lo = 0, hi = nnz;  // first i with (key[i] >> kshift) >= c
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t) key[mid] < c) lo = mid + 1;
+    if ((int64_t) (key[mid] >> kshift) < c) lo = mid + 1;
     else hi = mid;
   }
   ptr_tr[c] = lo;
@@ -378,7 +369,112 @@ Layout make_layout(int64_t n, int64_t nnz) {
   return L;
 }
 
+// ---------------------------------------------------------------------------------------
+// y = A^T x without global atomics: partition the products by column bin, then sum per bin
+// ---------------------------------------------------------------------------------------
+// Bins of GT_W consecutive columns.  The radix passes above sort the (column, val * x[row])
+// records by BIN only (the bits above log2(GT_W)); one workgroup per bin then adds its records
+// into an LDS image of its slice of y and stores the slice.  Replaces one device-scope
+// `global_atomic_add_f32` per non-zero (memory-side, ~20 G/s on scattered columns).
+constexpr int GT_LOGW = 13, GT_W = 1 << GT_LOGW;
+
+__global__ __launch_bounds__(256) void gemv_t_accumulate_kernel(const uint32_t *__restrict__ key,
+                                                                const float *__restrict__ prod,
+                                                                const int64_t *__restrict__ bin_off,
+                                                                int64_t n, float *__restrict__ y) {
+  __shared__ float ys[GT_W];
+  for (int i = threadIdx.x; i < GT_W; i += 256) ys[i] = 0.f;
+  __syncthreads();
+  const int64_t b = blockIdx.x, e = bin_off[b + 1];
+  for (int64_t i = bin_off[b] + threadIdx.x; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+  __syncthreads();
+  const int64_t c0 = b * GT_W;
+  for (int i = threadIdx.x; i < GT_W && c0 + i < n; i += 256) y[c0 + i] = ys[i];
+}
+
+struct GemvLayout {
+  int passes, wbits;
+  int64_t nblocks, nbins;
+  size_t off_hist, off_bases, off_scan, off_tilerow, off_binoff, off_rec[2], total;
+};
+
+GemvLayout make_gemv_layout(int64_t n, int64_t nnz) {
+  GemvLayout L{};
+  L.nbins = (n + GT_W - 1) / GT_W;
+  int bits = 1;
+  while (bits < 32 && ((int64_t) 1 << bits) < L.nbins) bits++;
+  L.passes = (bits + 7) / 8;
+  L.wbits = (bits + L.passes - 1) / L.passes;
+  L.nblocks = (nnz + RS_TILE - 1) / RS_TILE;
+  const size_t nh = ((size_t) 1 << L.wbits) * (size_t) (L.nblocks > 0 ? L.nblocks : 1);
+  size_t o = 0;
+  L.off_hist = o;    o += align256(nh * 4);
+  L.off_bases = o;   o += align256(nh * 8);
+  L.off_scan = o;    o += align256(scan_tmp_elems((int64_t) nh) * 8);
+  L.off_tilerow = o; o += align256((size_t) (L.nblocks + 1) * 8);
+  L.off_binoff = o;  o += align256((size_t) (L.nbins + 1) * 8);
+  for (int i = 0; i < 2; i++) {
+    L.off_rec[i] = o;
+    if (i == 0 || L.passes > 1) o += 2 * align256((size_t) nnz * 4);
+  }
+  L.total = o;
+  return L;
+}
+
 }  // namespace
+
+size_t csrgemv_t_workspace_bytes(int64_t n, int64_t nnz) { return make_gemv_layout(n, nnz).total; }
+
+// y[0..n) = A^T x for A = CSR(val, ptr[m+1] (any base), col), m x n; y is overwritten.
+hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
+                                  const int64_t *col, const float *x, float *y, void *workspace,
+                                  hipStream_t st) {
+  hipError_t e;
+  if (n <= 0) return hipSuccess;
+  if (m <= 0 || nnz <= 0) return hipMemsetAsync(y, 0, (size_t) n * 4, st);
+  const GemvLayout L = make_gemv_layout(n, nnz);
+  char *ws = (char *) workspace;
+  uint32_t *hist = (uint32_t *) (ws + L.off_hist);
+  int64_t *bases = (int64_t *) (ws + L.off_bases);
+  int64_t *scan_tmp = (int64_t *) (ws + L.off_scan);
+  int64_t *tile_row = (int64_t *) (ws + L.off_tilerow);
+  int64_t *bin_off = (int64_t *) (ws + L.off_binoff);
+  const size_t rec = align256((size_t) nnz * 4);
+  tile_rows_kernel<<<(unsigned) ((L.nblocks + 1 + 255) / 256), 256, 0, st>>>(ptr, m, nnz, L.nblocks, tile_row);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  SortArgs a{};
+  a.tile_row = tile_row; a.x = x;
+  a.col = col; a.ptr = ptr; a.m = m; a.nnz = nnz; a.nblocks = L.nblocks; a.wbits = L.wbits;
+  const char *sorted = nullptr;
+  for (int pass = 0; pass < L.passes; pass++) {
+    const bool first = pass == 0;
+    a.shift = GT_LOGW + pass * L.wbits;
+    if (first) {
+      a.val_in = val; a.key_in = nullptr;
+    } else {
+      const char *src = ws + L.off_rec[(pass - 1) & 1];
+      a.key_in = (const uint32_t *) src;
+      a.val_in = (const float *) (src + rec);
+    }
+    char *dst = ws + L.off_rec[pass & 1];
+    a.key_out = (uint32_t *) dst;
+    a.val_out = (float *) (dst + rec);
+    sorted = dst;
+    if (first) radix_hist_kernel<true><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
+    else radix_hist_kernel<false><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e = exclusive_scan<uint32_t>(hist, bases, ((int64_t) 1 << L.wbits) * L.nblocks, scan_tmp, st);
+    if (e != hipSuccess) return e;
+    e = first ? scatter_launch<true, false, true>(a, bases, st) : scatter_launch<false, false, true>(a, bases, st);
+    if (e != hipSuccess) return e;
+  }
+  offsets_by_search_kernel<<<(unsigned) ((L.nbins + 1 + 255) / 256), 256, 0, st>>>(
+      (const uint32_t *) sorted, nnz, L.nbins, bin_off, GT_LOGW);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  gemv_t_accumulate_kernel<<<(unsigned) L.nbins, 256, 0, st>>>((const uint32_t *) sorted,
+                                                               (const float *) (sorted + rec), bin_off, n, y);
+  return hipGetLastError();
+}
 
 size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz) { return make_layout(n, nnz).total; }
 
@@ -432,10 +528,7 @@ hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const in
     else e = scatter_launch<false, false>(a, bases, st);
     if (e != hipSuccess) return e;
   }
-  if ((n + 1) * 16 < nnz)
-    offsets_by_search_kernel<<<(unsigned) ((n + 1 + 255) / 256), 256, 0, st>>>(keys_sorted, nnz, n, ptr_tr);
-  else
-    offsets_from_sorted_keys_kernel<<<(unsigned) ((nnz / OFS_PER_T + 1 + 255) / 256), 256, 0, st>>>(keys_sorted, nnz, n, ptr_tr);
+  offsets_by_search_kernel<<<(unsigned) ((n + 1 + 255) / 256), 256, 0, st>>>(keys_sorted, nnz, n, ptr_tr);
   return hipGetLastError();
 }
 

@@ -164,3 +164,57 @@ def test_scsrgemv_n_ragged_heavy_rows(dev):
     bofhip.scsrgemv("N", r, n, ptr(dv) + 4 * int(z), ptr(di) + 8 * s0, ptr(dj) + 8 * int(z), ptr(dx), ptr(dy2), stream())
     torch.cuda.synchronize()
     assert np.array_equal(dy2.cpu().numpy(), ref[s0:s0 + r])
+
+
+@pytest.mark.parametrize("m,n,per_row", [(4096, 2048, 21), (3000, 70000, 30), (2000, 5_000_000, 40),
+                                         (60000, 300, 5), (500, 3_000_000_0 // 10 + 7, 50)])
+def test_csrgemv_t_partitioned_path(dev, golden, m, n, per_row, monkeypatch):
+    """y = A^T x through the bin-partition path of bof_csrgemv_resident (forced for small inputs):
+    one bin (n <= 8192), one digit pass, two digit passes (n > 2M columns); random data within
+    the BASELINE tolerance of the oracle's chain, integer data exact, untouched columns zero."""
+    monkeypatch.setenv("BOF_GEMV_T_PARTITION_MIN_NNZ", "1")
+    rng = np.random.default_rng(m + n)
+    counts = rng.integers(0, per_row + 1, m)
+    counts[0] = 0
+    counts[m // 2] = min(n, 700)
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    for data in ("random", "integer"):
+        if data == "random":
+            val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+            x = rng.uniform(-1, 1, m).astype(np.float32)
+        else:
+            val = rng.integers(1, 10, ja.size).astype(np.float32)
+            x = (np.arange(m) % 10).astype(np.float32)
+        ref = orc.scsrgemv("T", m, n, val, ia, ja, x, np.zeros(n, np.float32))
+        dv, dj, di, dx = to_dev(val), to_dev(ja), to_dev(ia), to_dev(x)
+        dy = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
+        bofhip.csrgemv_resident("T", m, n, ptr(dv), ia.ctypes.data, ptr(di), ptr(dj), ptr(dx), ptr(dy),
+                                None, stream())
+        torch.cuda.synchronize()
+        got = dy.cpu().numpy()
+        if data == "integer":
+            assert np.array_equal(got, ref)
+        else:
+            assert rel_err(got, ref) < TOL
+            assert np.array_equal(got == 0, ref == 0)   # columns without entries are exactly zero
+
+
+def test_csrgemv_t_partitioned_generator_hash_and_row_range(dev, golden, monkeypatch):
+    monkeypatch.setenv("BOF_GEMV_T_PARTITION_MIN_NNZ", "1")
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    x = (np.arange(m) % 10).astype(np.float32)
+    dv, dj, di, dx = to_dev(val), to_dev(ja), to_dev(ia), to_dev(x)
+    dy = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
+    bofhip.csrgemv_resident("T", m, n, ptr(dv), ia.ctypes.data, ptr(di), ptr(dj), ptr(dx), ptr(dy), None, stream())
+    torch.cuda.synchronize()
+    assert hashlib.sha256(dy.cpu().numpy().tobytes()).hexdigest() == exact_hash(golden, "gen_csrgemv_T")
+    # a row range with absolute offsets (how a row shard of a bigger matrix is passed)
+    s0, r = 1000, 2500
+    ia_s = np.ascontiguousarray(ia[s0:s0 + r + 1])
+    ref = orc.scsrgemv("T", r, n, val[ia[s0]:], ia_s, ja[ia[s0]:], x[s0:s0 + r], np.zeros(n, np.float32))
+    bofhip.csrgemv_resident("T", r, n, ptr(dv), ia_s.ctypes.data, ptr(di) + 8 * s0, ptr(dj), ptr(dx) + 4 * s0,
+                            ptr(dy), None, stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), ref)

@@ -100,6 +100,8 @@ def csrcsc(args):
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     m, n, k, npr = 10_000_000 // args.scale, 1_000_000, 128, 100
+    if args.csr_shape:
+        m, n, npr = (int(v) for v in args.csr_shape.split("x"))
     nnz = m * npr
     val = torch.empty(nnz, dtype=torch.float32, device=dev)
     col = torch.empty(nnz, dtype=torch.int64, device=dev)
@@ -116,6 +118,8 @@ def csrcsc(args):
     alg = nnz * 24 + (m + n + 2) * 8   # read A once, write A^T once
     print(f"csrcsc {m}x{n} nnz={nnz}: {best:.3f} ms  algorithmic {alg / best / 1e6:.1f} GB/s  "
           f"workspace {bofhip.lib().bof_csrcsc_workspace_bytes(n, nnz) / 2**30:.2f} GiB", flush=True)
+    if args.csr_shape:
+        return
     b = torch.empty(m * k, dtype=torch.float32, device=dev)
     bofhip.gen_dense(b.data_ptr(), 0, m * k, args.data, 3, st)
     c = torch.zeros(n * k, dtype=torch.float32, device=dev)
@@ -138,6 +142,7 @@ if __name__ == "__main__":
     ap.add_argument("--what", default="gemm")
     ap.add_argument("--scale", type=int, default=1)
     ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--csr-shape", default="", help="csrcsc mode: MxNxNNZ_PER_ROW")
     a = ap.parse_args()
     a.shapes = [tuple(int(x) for x in s.split("x")) for s in a.shapes.split(",")]
     a.layouts = [(s[0], s[1]) for s in a.layouts.split(",")]
