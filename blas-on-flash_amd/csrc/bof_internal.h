@@ -39,8 +39,9 @@ hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float
 // grow-only per-device scratch, freed by bof_flash_release.  Slots: 0 row-major copy of a
 // column-major B; 1..16 per-stream row-major C blocks; 17 csrcsc workspace; 18..20 transposed
 // CSR (values, indices, offsets) of csrmm 'T'
+// 21, 22 k-major copies of GEMM operands (bof_gemm_resident)
 enum { SCR_B_RM = 0, SCR_C_RM0 = 1, SCR_CSRCSC = 17, SCR_TR_VAL = 18, SCR_TR_COL = 19, SCR_TR_PTR = 20,
-       SCR_COUNT = 21 };
+       SCR_GEMM_A = 21, SCR_GEMM_B = 22, SCR_COUNT = 23 };
 int scratch_get(int which, size_t bytes, void **ptr);
 void scratch_release_all();
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,

@@ -130,16 +130,28 @@ def test_cfg3_csrmm_driver_files_end_to_end(dev, tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if shutil.disk_usage(str(tmp_path)).free < 25 * 2**30:
-        pytest.skip("needs 18 GB of scratch disk")
+    if shutil.disk_usage(str(tmp_path)).free < 50 * 2**30:
+        pytest.skip("needs 48 GB of scratch disk")
     torch.cuda.empty_cache()
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "flash_e2e_cfg3.py"), str(tmp_path), "1"],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     runs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(runs) == 2                      # buffered and O_DIRECT descriptors
-    for run in runs:
+    mm = [x for x in runs if x["what"].startswith("csrmm_driver end to end")]
+    assert len(mm) == 2                        # buffered and O_DIRECT descriptors
+    for run in mm:
         assert run["rc"] == 0 and run["matches_reference_hash"] is True, run
+    # transposition row on the same files: A -> A^T -> A reproduces the input files (whose
+    # hashes are the reference generator's known answers), csrmm 'T' on A == 'N' on the A^T files
+    tr = [x for x in runs if x["what"].startswith("csrcsc_driver end to end")]
+    assert len(tr) == 2
+    for run in tr:
+        assert run["rc"] == [0, 0] and run["transpose_of_transpose_equals_input"] is True, run
+        assert run["input_sha256_16"] == {"A.csr": "102affabbce7531e", "A.col": "aad815cb3075a8ef",
+                                          "A.off": "553385bd432e9f76"}
+    tt = [x for x in runs if x["what"].startswith("csrmm_driver trans_a=T")]
+    assert len(tt) == 1 and tt[0]["T_equals_N_on_transposed_files"] is True, tt
+    assert all(v["rc"] == 0 for v in tt[0]["runs"].values())
 
 
 def test_cfg2_flash_gemm_files_end_to_end(dev, tmp_path):

@@ -168,6 +168,29 @@ def test_gemm_resident_matches_flash_oracle(dev, ord_, ta, tb):
     assert rel_err(got, whole) < TOL   # in_mem_gemm oracle (gemm_run.sh comparison)
 
 
+@pytest.mark.parametrize("ord_,ta,tb", list(__import__("itertools").product("RC", "NT", "NT")))
+def test_gemm_resident_pretransposed_operands(dev, ord_, ta, tb):
+    """Shapes on which bof_gemm_resident replaces x-major operands by k-major copies (>= 4 tiles
+    of reuse per operand tile, k % 32 == 0, m, n >= 2048): all 8 layouts, padded leading
+    dimensions, bit-exact against the restated flash::gemm."""
+    m, k, n, blk = 2304, 512, 2048, 512
+    alpha, beta = 0.5, 2.0
+    rng = np.random.default_rng(13)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    lda, ldb, ldc = sa[1] + 8, sb[1] + 4, sc[1] + 12
+    a = rng.uniform(-1, 1, (sa[0], lda)).astype(np.float32)
+    b = rng.uniform(-1, 1, (sb[0], ldb)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (sc[0], ldc)).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c0.copy(), lda, ldb, ldc, blk)
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c0)
+    opts = bofhip.default_options(gemm_blk=blk, n_streams=2)
+    bofhip.gemm_resident(ord_, ta, tb, m, n, k, alpha, beta, ptr(da), ptr(db), ptr(dc), lda, ldb, ldc,
+                         opts, stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(db.cpu().numpy(), b)  # inputs untouched
+
+
 def test_gemm_4096_generator_known_answer(dev):
     """cfg1 known answer: dense_create 's' inputs, 4096^3,
     C[0,0:4] = [81850, 100270, 73670, 92090]; full check against the closed form
