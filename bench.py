@@ -173,6 +173,74 @@ def csr_secondary(bofhip, torch, dev, st):
     return out
 
 
+def csr_secondary_sharded(bofhip, torch, dev, st, rank, n_gpus):
+    """N > 1: this rank's row shard of the SAME matrices (strong scaling): CSRMM rows
+    [r0, r1) of the 10M x 1M matrix with B replicated, CSRGEMV 'N' rows of the 50M x 50M one with
+    x replicated -- no collective; CSRGEMV 'T' yields a full-length partial per rank that the caller
+    all-reduces.  Returns this rank's milliseconds; the caller takes the max over ranks."""
+    def timed(fn, iters=3):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    import numpy as np
+    res = {}
+    opts = bofhip.default_options(n_streams=1)
+
+    def shard(m_total, npr, n):
+        per = (m_total // n_gpus + 127) // 128 * 128
+        r0 = min(m_total, per * rank)
+        r1 = min(m_total, r0 + per) if rank < n_gpus - 1 else m_total
+        rows = r1 - r0
+        val = torch.empty(max(rows, 1) * npr, dtype=torch.float32, device=dev)
+        col = torch.empty(max(rows, 1) * npr, dtype=torch.int64, device=dev)
+        off = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+        step = 1_000_000
+        for q in range(0, rows, step):
+            r = min(step, rows - q)
+            bofhip.gen_sparse_rows(r0 + q, r, n, npr, val.data_ptr() + 4 * q * npr, col.data_ptr() + 8 * q * npr,
+                                   off.data_ptr() + 8 * q, st)
+        torch.cuda.synchronize()
+        ia = off.cpu().numpy()      # absolute offsets (ia[0] = r0 * npr), as a row shard of the files has
+        assert rows == 0 or (ia[0] == r0 * npr and ia[-1] == r1 * npr)
+        base = r0 * npr             # element 0 of the virtual full arrays
+        return r0, rows, val, col, off, ia, base
+
+    m, n, k, npr = 10_000_000, 1_000_000, 128, 100
+    r0, rows, val, col, off, ia, base = shard(m, npr, n)
+    b = torch.empty(n * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(b.data_ptr(), 0, n * k, "u", 3, st)
+    c = torch.zeros(max(rows, 1) * k, dtype=torch.float32, device=dev)
+    res["csrmm_ms"] = timed(lambda: bofhip.csrmm_resident(
+        "N", rows, n, k, 1.0, 0.0, val.data_ptr() - 4 * base, ia.ctypes.data, off.data_ptr(),
+        col.data_ptr() - 8 * base, "R", b.data_ptr(), c.data_ptr(), opts, st))
+    del val, col, off, b, c
+    torch.cuda.empty_cache()
+    m = n = 50_000_000
+    npr = 10
+    r0, rows, val, col, off, ia, base = shard(m, npr, n)
+    x = (torch.arange(n, device=dev) % 10).float()
+    y = torch.zeros(max(rows, 1), dtype=torch.float32, device=dev)
+    res["csrgemv_N_ms"] = timed(lambda: bofhip.csrgemv_resident(
+        "N", rows, n, val.data_ptr() - 4 * base, ia.ctypes.data, off.data_ptr(), col.data_ptr() - 8 * base,
+        x.data_ptr(), y.data_ptr(), opts, st))
+    yt = torch.zeros(n, dtype=torch.float32, device=dev)
+    res["csrgemv_T_local_ms"] = timed(lambda: bofhip.csrgemv_resident(
+        "T", rows, n, val.data_ptr() - 4 * base, ia.ctypes.data, off.data_ptr(), col.data_ptr() - 8 * base,
+        x.data_ptr() + 4 * r0, yt.data_ptr(), opts, st))
+    res["csrgemv_T_partial"] = yt
+    del val, col, off, x, y
+    bofhip.lib().bof_flash_release()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,14 +266,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # debug only: BOF_BENCH_ONE_GPU=1 runs every rank on cuda:0 with the gloo backend, so the
+    # N > 1 code path can be exercised on a single-GPU box (RCCL refuses two ranks per device)
+    one_gpu = os.environ.get("BOF_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     bofhip.require_device()          # fails loudly: there is no CPU fallback
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red_dev = torch.device("cpu") if one_gpu else dev     # where cross-rank reductions live
 
     n_gpus = max(world, 1)
     shard_of = args.as_shard_of if world == 1 else 0
@@ -263,7 +340,7 @@ def main():
     ev_ms = e0.elapsed_time(e1)
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -276,6 +353,38 @@ def main():
     ref = (a0 @ bsub).cpu().numpy()
     got = c.view(m_local, n)[0, :cols].double().cpu().numpy()
     rel = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+    sharded = None
+    if world > 1 and not args.no_csr and not args.size:
+        # every rank runs its shard; failures are turned into -1 so the collectives below always match
+        import torch.distributed as dist
+        del a, b, c
+        torch.cuda.empty_cache()
+        keys = ["csrmm_ms", "csrgemv_N_ms", "csrgemv_T_local_ms"]
+        try:
+            mine = csr_secondary_sharded(bofhip, torch, dev, st, rank, world)
+            vec = [float(mine[q]) for q in keys]
+            part = mine["csrgemv_T_partial"]
+        except Exception as e:
+            vec = [-1.0] * len(keys)
+            part = torch.zeros(50_000_000, dtype=torch.float32, device=dev)
+            sys.stderr.write(f"[rank {rank}] sharded CSR secondary failed: {e}\n")
+        hi = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+        lo = hi.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        # csrgemv 'T': the one real exchange of the path -- all-reduce(sum) of the partial vectors
+        part_r = part.cpu() if one_gpu else part
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_red = time.perf_counter()
+        dist.all_reduce(part_r, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        red_ms = torch.tensor([(time.perf_counter() - t_red) * 1e3], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(red_ms, op=dist.ReduceOp.MAX)
+        ysum = float(part_r.double().sum().item())
+        sharded = {"ok": bool(lo.min().item() >= 0), "max_ms": dict(zip(keys, [float(v) for v in hi.tolist()])),
+                   "allreduce_ms": float(red_ms.item()), "y_T_sum": ysum}
 
     if rank == 0:
         if shard_of > 1:
@@ -318,6 +427,26 @@ def main():
                 out["secondary"] = csr_secondary(bofhip, torch, dev, st)
             except Exception as e:  # the headline line must still be printed
                 out["secondary"] = {"error": str(e)[:200]}
+        if sharded is not None:
+            sec = {"scaling": "strong (the BASELINE matrices row-sharded over the ranks; max over ranks)",
+                   "ok": sharded["ok"]}
+            if sharded["ok"]:
+                ms = sharded["max_ms"]
+                nnz3, nnz5 = 10_000_000 * 100, 50_000_000 * 10
+                sec["csrmm"] = {"workload": "flash _csrmm 10M x 1M CSR x 1M x 128, row-sharded, B replicated",
+                                "ms": round(ms["csrmm_ms"], 3),
+                                "gflops": round(2.0 * nnz3 * 128 / ms["csrmm_ms"] / 1e6, 1)}
+                sec["csrgemv_N"] = {"workload": "flash _csrgemv 50M x 50M (5e8 nnz), row-sharded, x replicated",
+                                    "ms": round(ms["csrgemv_N_ms"], 3),
+                                    "gflops": round(2.0 * nnz5 / ms["csrgemv_N_ms"] / 1e6, 1)}
+                t_ms = ms["csrgemv_T_local_ms"] + sharded["allreduce_ms"]
+                sec["csrgemv_T"] = {"workload": "flash _csrgemv 'T': per-rank partial + one all-reduce(sum) of 200 MB",
+                                    "local_ms": round(ms["csrgemv_T_local_ms"], 3),
+                                    "allreduce_ms": round(sharded["allreduce_ms"], 3),
+                                    "gflops": round(2.0 * nnz5 / t_ms / 1e6, 1),
+                                    # known answer of the full product: sum(y) = 11249999940
+                                    "sum_y": sharded["y_T_sum"], "sum_y_expected": 11249999940.0}
+            out["secondary"] = sec
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
