@@ -395,8 +395,9 @@ def main():
         flops_per_launch = flops_per_step_rank / launches_per_step
         achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
-        pre = os.environ.get("BOF_GEMM_PRETRANSPOSE", "1") != "0" and os.environ.get("BOF_GEMM_VARIANT", "3") == "3"
-        kernel_label = ("sgemm_tile256_dma_kernel (256x256x32 tile, 1 wave/SIMD, LDS-DMA staging of k-major "
+        pre = os.environ.get("BOF_GEMM_PRETRANSPOSE", "1") != "0" and os.environ.get("BOF_GEMM_VARIANT", "4") in ("3", "4")
+        kname = "sgemm_tile256_dma2_kernel" if os.environ.get("BOF_GEMM_VARIANT", "4") == "4" else "sgemm_tile256_dma_kernel"
+        kernel_label = (kname + " (256x256x32 tile, 1 wave/SIMD, LDS-DMA staging of k-major "
                         "operands; A is copied k-major once per call, inside the timed region and inside "
                         "avg_launch_ms)" if pre else
                         "sgemm_tile256_1w2_kernel<XMAJOR,KMAJOR> (256x256x32 tile, 1 wave/SIMD)")

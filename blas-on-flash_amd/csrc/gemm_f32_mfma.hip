@@ -735,6 +735,200 @@ sgemm_tile256_dma_kernel(const float *__restrict__ A, int64_t lda, const float *
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 4: variant 3 with the two remaining sources of VALU work in the slab loop removed.
+//  * LDS operand reads are explicit `ds_read2st64_b32` (two k-rows of the same sub-tile per
+//    instruction; the 8-bit offsets count 256-byte units, so every (k-group, k) position of a
+//    32 KB operand image is an immediate on one of four per-sub-tile base registers).  The
+//    compiler's own pairing chose (sub-tile, sub-tile+1) pairs whose bases need a v_add each:
+//    32 VALU adds per slab.
+//  * LDS-DMA pieces are issued as `global_load_lds_dwordx4 voff, s[base:base+1]`: the piece
+//    origin lives in SGPRs and advances with scalar adds; the builtin form computed a 64-bit
+//    per-lane address (3 VALU ops per piece, 48 per slab) in the shadow of the same MFMAs.
+//  * even/odd slabs are separate code, so the buffer choice is a constant, not a v_cndmask.
+// Loads issued from inline asm are invisible to the compiler's waitcnt insertion: every k-group
+// starts with an explicit `s_waitcnt lgkmcnt(0)` that also "produces" the fragment registers,
+// which pins the MFMAs behind it.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_rd2st64(uint32_t addr) {
+  f32x2 r;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+  return r;
+}
+// k-group Q (k = 8Q .. 8Q+7) of one sub-tile: rows 8Q + {0,2,4,6} + h of the [k][256] image
+template <int Q>
+__device__ __forceinline__ f32x4 rd_frag(uint32_t base) {
+  const f32x2 lo = lds_rd2st64<Q * 32, Q * 32 + 8>(base);
+  const f32x2 hi = lds_rd2st64<Q * 32 + 16, Q * 32 + 24>(base);
+  f32x4 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+  return v;
+}
+__device__ __forceinline__ void lgkm_fence(f32x4 (&a)[4], f32x4 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+               :: "memory");
+}
+// (M0 carries the LDS destination; it is declared clobbered so the compiler reloads its own uses)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16(uint32_t voff, uint64_t sbase, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// One 32-deep slab out of LDS buffer BUF.  Slots 0-3 issue the 16 DMA pieces of the next slab
+// (origins a_next / b_next, 4-k-row stride a_step4 / b_step4 bytes) into the other buffer; 4 per
+// slot is the measured optimum (all in slot 0: 141.9, 8 per slot: 144.5, 4: 146.1-146.7, 2: 145.0,
+// 1: 144.6 TFLOP/s at 4096^3).  The barrier sits in front of the LAST k-group instead of after
+// it: by then every wave has issued and consumed all its reads of this buffer (the fragments of
+// group 3 were fetched during group 2) and the DMA pieces have had 8 slots to land, so the
+// fragments of the next slab's group 0 are read under the MFMAs of group 3 and a slab starts
+// with its operands in registers.  On entry a[0] / b[0] hold group 0 of this slab.
+template <int BUF>
+__device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const uint32_t (&b_base)[2][4],
+                                          uint64_t a_next, uint64_t b_next, uint64_t a_step4, uint64_t b_step4,
+                                          unsigned a_goff, unsigned b_goff, uint32_t a_dst, uint32_t b_dst,
+                                          f32x4 (&a)[2][4], f32x4 (&b)[2][4], f32x16 (&acc)[4][4]) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    lgkm_fence(a[q & 1], b[q & 1]);
+    if (q == 3) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
+                                                             acc[mt][nt], 0, 0, 0);
+      if (c < 3) {
+#pragma unroll
+        for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
+          if (q == 0) { a[1][x] = rd_frag<1>(a_base[BUF][x]); b[1][x] = rd_frag<1>(b_base[BUF][x]); }
+          if (q == 1) { a[0][x] = rd_frag<2>(a_base[BUF][x]); b[0][x] = rd_frag<2>(b_base[BUF][x]); }
+          if (q == 2) { a[1][x] = rd_frag<3>(a_base[BUF][x]); b[1][x] = rd_frag<3>(b_base[BUF][x]); }
+          if (q == 3) { a[0][x] = rd_frag<0>(a_base[BUF ^ 1][x]); b[0][x] = rd_frag<0>(b_base[BUF ^ 1][x]); }
+        }
+      }
+      const int s = 4 * q + c;
+      if (s < 4) {  // pieces 2s, 2s+1 of A and of B; piece p = k-rows 4p..4p+3 (one per wave)
+        dma16(a_goff, a_next + (uint64_t) (2 * s) * a_step4, a_dst + (2 * s) * 4096);
+        dma16(b_goff, b_next + (uint64_t) (2 * s) * b_step4, b_dst + (2 * s) * 4096);
+        dma16(a_goff, a_next + (uint64_t) (2 * s + 1) * a_step4, a_dst + (2 * s + 1) * 4096);
+        dma16(b_goff, b_next + (uint64_t) (2 * s + 1) * b_step4, b_dst + (2 * s + 1) * 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                          int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                          float alpha, float beta, int tiles_m, int tiles_n) {
+  constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;   // floats
+  __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF];
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) lds;
+  uint32_t a_base[2][4], b_base[2][4];
+#pragma unroll
+  for (int bf = 0; bf < 2; bf++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      a_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF + h * 256 + wm * 128 + x * 32 + i);
+      b_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF + LDS_A + h * 256 + wn * 128 + x * 32 + i);
+    }
+  const unsigned a_goff = 4u * (unsigned) ((t >> 6) * (int) lda + 4 * (t & 63));
+  const unsigned b_goff = 4u * (unsigned) ((t >> 6) * (int) ldb + 4 * (t & 63));
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  // wave-uniform DMA destinations (byte addresses): k-row `wave` of piece 0, per buffer
+  const uint32_t a_dst0 = lds0 + 4u * (unsigned) (wv * 256), b_dst0 = a_dst0 + 4u * LDS_A;
+  const uint32_t a_dst1 = a_dst0 + 4u * LDS_BUF, b_dst1 = b_dst0 + 4u * LDS_BUF;
+  const uint64_t a_org = reinterpret_cast<uint64_t>(A + m0), b_org = reinterpret_cast<uint64_t>(B + n0);
+  const uint64_t a_step4 = (uint64_t) lda * 16, b_step4 = (uint64_t) ldb * 16;   // 4 k-rows, bytes
+  const uint64_t a_slab = a_step4 * 8, b_slab = b_step4 * 8;                     // 32 k-rows
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = K / BK;
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    dma16(a_goff, a_org + (uint64_t) p * a_step4, a_dst0 + p * 4096);
+    dma16(b_goff, b_org + (uint64_t) p * b_step4, b_dst0 + p * 4096);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 fa[2][4], fb[2][4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    fa[0][x] = rd_frag<0>(a_base[0][x]);
+    fb[0][x] = rd_frag<0>(b_base[0][x]);
+    fa[1][x] = fa[0][x]; fb[1][x] = fb[0][x];
+  }
+  // K is a multiple of 64 here (launch_modes), so the slabs go in (buffer 0, buffer 1) pairs and
+  // the loop body is the same code for every pair: the last pair simply prefetches the last slab
+  // again (valid memory, never used), which keeps the accumulators in one register assignment.
+  uint64_t a_next = a_org + a_slab, b_next = b_org + b_slab;
+  for (int kt = 0; kt < nkt; kt += 2) {
+    slab_dma2<0>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc);
+    const bool more = kt + 2 < nkt;
+    a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
+    slab_dma2<1>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc);
+    a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead fragment reads of the last slab
+
+  float *ctile = C + (int64_t) m0 * ldc + n0;
+  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      f32x16 old;
+      if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
+        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+      }
+    }
+}
+
 template <int AMODE, int BMODE>
 static hipError_t launch_guarded(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                                  int64_t ldc, int M, int N, int K, float alpha, float beta,
@@ -756,11 +950,14 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   const bool vec_ok = vec_ld && (K % BK == 0) && (K > 0);
   // 256x256 kernels for the tile-aligned part of the problem:
-  //   3 (default): one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (142.5 TFLOP/s at
+  //   4 (default): as 3, with explicit ds_read2st64 operand reads, scalar-addressed DMA and the
+  //      barrier in front of the last k-group (147.6 TFLOP/s at 4096^3, 149.7 at K = 16384);
+  //      needs K % 64 == 0, otherwise 3
+  //   3: one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (143.3 TFLOP/s at
   //      4096^3), every other layout through variant 2 (140.6-141.3)
   //   2: one wave per SIMD, register staging, constant-offset addressing
   //   1: as 2 with per-access address arithmetic (138.5)      0: 8 waves, 2 per SIMD (137-138)
-  static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 3;
+  static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 4;
 
   // Ragged sizes (tail-merged tiles of 4096+r, unaligned problem edges): the largest
   // 256-aligned interior runs on the big-tile kernel (its last K slab guarded when K % 32 != 0),
@@ -771,7 +968,10 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   if (big_tile_variant >= 2 && vec_ld && k_ok && (int64_t) (Mi / 256) * (Ni / 256) >= 128 &&
       lda < (1 << 22) && ldb < (1 << 22)) {
     const int tiles_m = Mi / 256, tiles_n = Ni / 256;
-    if (big_tile_variant == 3 && AMODE == KMAJOR && BMODE == KMAJOR && K % BK == 0)
+    if (big_tile_variant == 4 && AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
+      hipLaunchKernelGGL(sgemm_tile256_dma2_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
+                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+    else if (big_tile_variant >= 3 && AMODE == KMAJOR && BMODE == KMAJOR && K % BK == 0)
       hipLaunchKernelGGL(sgemm_tile256_dma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                          ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
     else if (K % BK == 0)
