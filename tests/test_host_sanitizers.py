@@ -1,0 +1,22 @@
+"""The host-side runtime pieces (tilers, strided AIO file reader/writer, level-3 schedule) under AddressSanitizer
+and UBSan.  GPU sanitizers are not available on the pool, so this is the CPU build only."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_fileio_and_schedule_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_sanitize")
+    csrc = os.path.join(ROOT, "blas-on-flash_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+           os.path.join(csrc, "plan.cpp"), os.path.join(csrc, "fileio.cpp"), os.path.join(csrc, "flash_runtime.cpp"),
+           os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "host_sanitize ok" in r.stdout

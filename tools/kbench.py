@@ -51,6 +51,8 @@ def csr(args):
     st = torch.cuda.current_stream().cuda_stream
     scale = args.scale
     m, n, k, npr = 10_000_000 // scale, 1_000_000, 128, 100
+    if args.csr_shape:
+        m, n, npr = (int(v) for v in args.csr_shape.split("x"))
     val = torch.empty(m * npr, dtype=torch.float32, device=dev)
     col = torch.empty(m * npr, dtype=torch.int64, device=dev)
     off = torch.empty(m + 1, dtype=torch.int64, device=dev)
@@ -72,6 +74,8 @@ def csr(args):
     print(f"csrmm {m}x{n} nnz={nnz} k={k}: {best:.3f} ms  {2.0 * nnz * k / best / 1e6:.1f} GFLOP/s  "
           f"algorithmic {alg / best / 1e6:.1f} GB/s  gather {nnz * k * 4 / best / 1e6:.1f} GB/s", flush=True)
     del val, col, off, b, c
+    if args.csr_shape:
+        return
     m = n = 50_000_000 // scale
     npr = 10
     val = torch.empty(m * npr, dtype=torch.float32, device=dev)
