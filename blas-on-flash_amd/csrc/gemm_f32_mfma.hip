@@ -929,6 +929,253 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant 4 for the layouts with an x-major operand (register staging: LDS-DMA cannot produce
+// the permuted x-major image): the same hand-scheduled loop as sgemm_tile256_dma2_kernel --
+// explicit LDS reads/writes with immediate offsets, global loads in the "SGPR base + VGPR
+// offset" form, even/odd slabs as separate code, barrier in front of the last k-group.
+// Data flow per slab n (buffer n & 1): slots 0-11 store the staged registers (slab n+1, fetched
+// during slab n-1) into the other buffer and refill them with slab n+2; slot s waits with
+// vmcnt(15): exactly the 15 younger loads may still be in flight.
+template <int O>
+__device__ __forceinline__ f32x4 lds_rd128(uint32_t addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(O) : "memory");
+  return r;
+}
+template <int O>
+__device__ __forceinline__ void lds_wr128(uint32_t addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(O) : "memory");
+}
+template <int O>
+__device__ __forceinline__ void lds_wr64(uint32_t addr, f32x2 v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(O) : "memory");
+}
+__device__ __forceinline__ f32x4 gld128(uint32_t voff, uint64_t sbase) {
+  f32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+__device__ __forceinline__ void vm_fence15(f32x4 &v) { asm volatile("s_waitcnt vmcnt(15)" : "+v"(v) :: "memory"); }
+
+// fragment of k-group Q, sub-tile X out of an operand image whose per-thread read base is `base`
+template <int MODE, int Q, int X>
+__device__ __forceinline__ f32x4 rd_frag_m(uint32_t base) {
+  if (MODE == XMAJOR) return lds_rd128<4 * (X * 32 * XLD + 8 * Q)>(base);
+  const f32x2 lo = lds_rd2st64<Q * 32, Q * 32 + 8>(base + 128 * X);
+  const f32x2 hi = lds_rd2st64<Q * 32 + 16, Q * 32 + 24>(base + 128 * X);
+  f32x4 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+  return v;
+}
+// staged piece P -> LDS image (x-major: permuted 8-groups [k0 k2 | k1 k3] + [k4 k6 | k5 k7] halves)
+template <int MODE, int P>
+__device__ __forceinline__ void wr_piece(uint32_t base, f32x4 v) {
+  if (MODE == XMAJOR) {
+    f32x2 lo, hi;
+    lo[0] = v[0]; lo[1] = v[2]; hi[0] = v[1]; hi[1] = v[3];
+    lds_wr64<4 * (P * 32 * XLD)>(base, lo);
+    lds_wr64<4 * (P * 32 * XLD + 4)>(base, hi);
+  } else {
+    lds_wr128<4 * (P * 4 * 256)>(base, v);
+  }
+}
+
+template <int Q, int MODE>
+__device__ __forceinline__ void rd_group_x(uint32_t base, f32x4 (&dst)[4], int x) {
+  if (x == 0) dst[0] = rd_frag_m<MODE, Q, 0>(base);
+  if (x == 1) dst[1] = rd_frag_m<MODE, Q, 1>(base);
+  if (x == 2) dst[2] = rd_frag_m<MODE, Q, 2>(base);
+  if (x == 3) dst[3] = rd_frag_m<MODE, Q, 3>(base);
+}
+
+template <int MODE, int S>
+__device__ __forceinline__ void stage_slot(uint32_t wr_base, f32x4 &reg, unsigned goff, uint64_t next, uint64_t step) {
+  vm_fence15(reg);
+  wr_piece<MODE, S>(wr_base, reg);
+  reg = gld128(goff, next + (uint64_t) S * step);
+}
+
+// slab out of buffer BUF; a_rd/b_rd: read bases per buffer, a_wr/b_wr: write bases per buffer
+template <int AMODE, int BMODE, int BUF>
+__device__ __forceinline__ void slab_1w3(const uint32_t (&a_rd)[2], const uint32_t (&b_rd)[2],
+                                         const uint32_t (&a_wr)[2], const uint32_t (&b_wr)[2],
+                                         uint64_t a_next, uint64_t b_next, uint64_t a_step, uint64_t b_step,
+                                         unsigned a_goff, unsigned b_goff, f32x4 (&ra)[8], f32x4 (&rb)[8],
+                                         f32x4 (&a)[2][4], f32x4 (&b)[2][4], f32x16 (&acc)[4][4]) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    lgkm_fence(a[q & 1], b[q & 1]);   // lgkmcnt(0): fragments of this group AND this wave's LDS stores
+    if (q == 3) __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
+                                                             acc[mt][nt], 0, 0, 0);
+      if (c < 3) {
+#pragma unroll
+        for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
+          if (q == 0) { rd_group_x<1, AMODE>(a_rd[BUF], a[1], x); rd_group_x<1, BMODE>(b_rd[BUF], b[1], x); }
+          if (q == 1) { rd_group_x<2, AMODE>(a_rd[BUF], a[0], x); rd_group_x<2, BMODE>(b_rd[BUF], b[0], x); }
+          if (q == 2) { rd_group_x<3, AMODE>(a_rd[BUF], a[1], x); rd_group_x<3, BMODE>(b_rd[BUF], b[1], x); }
+          if (q == 3) { rd_group_x<0, AMODE>(a_rd[BUF ^ 1], a[0], x); rd_group_x<0, BMODE>(b_rd[BUF ^ 1], b[0], x); }
+        }
+      }
+      const int s = 4 * q + c;   // staging: 16 pieces over slots 0-11 (A pieces 0-7, then B pieces 0-7)
+      if (s == 0)  { stage_slot<AMODE, 0>(a_wr[BUF ^ 1], ra[0], a_goff, a_next, a_step); stage_slot<AMODE, 1>(a_wr[BUF ^ 1], ra[1], a_goff, a_next, a_step); }
+      if (s == 1)  { stage_slot<AMODE, 2>(a_wr[BUF ^ 1], ra[2], a_goff, a_next, a_step); }
+      if (s == 2)  { stage_slot<AMODE, 3>(a_wr[BUF ^ 1], ra[3], a_goff, a_next, a_step); }
+      if (s == 3)  { stage_slot<AMODE, 4>(a_wr[BUF ^ 1], ra[4], a_goff, a_next, a_step); stage_slot<AMODE, 5>(a_wr[BUF ^ 1], ra[5], a_goff, a_next, a_step); }
+      if (s == 4)  { stage_slot<AMODE, 6>(a_wr[BUF ^ 1], ra[6], a_goff, a_next, a_step); }
+      if (s == 5)  { stage_slot<AMODE, 7>(a_wr[BUF ^ 1], ra[7], a_goff, a_next, a_step); }
+      if (s == 6)  { stage_slot<BMODE, 0>(b_wr[BUF ^ 1], rb[0], b_goff, b_next, b_step); stage_slot<BMODE, 1>(b_wr[BUF ^ 1], rb[1], b_goff, b_next, b_step); }
+      if (s == 7)  { stage_slot<BMODE, 2>(b_wr[BUF ^ 1], rb[2], b_goff, b_next, b_step); }
+      if (s == 8)  { stage_slot<BMODE, 3>(b_wr[BUF ^ 1], rb[3], b_goff, b_next, b_step); }
+      if (s == 9)  { stage_slot<BMODE, 4>(b_wr[BUF ^ 1], rb[4], b_goff, b_next, b_step); stage_slot<BMODE, 5>(b_wr[BUF ^ 1], rb[5], b_goff, b_next, b_step); }
+      if (s == 10) { stage_slot<BMODE, 6>(b_wr[BUF ^ 1], rb[6], b_goff, b_next, b_step); }
+      if (s == 11) { stage_slot<BMODE, 7>(b_wr[BUF ^ 1], rb[7], b_goff, b_next, b_step); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                         int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                         float alpha, float beta, int tiles_m, int tiles_n) {
+  constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_BUF = LDS_A + LDS_B;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF];
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) lds;
+  // per-thread element offsets inside one buffer (same maps as the 1w2 kernel)
+  const int a_rd_e = (AMODE == XMAJOR) ? (wm * 128 + i) * XLD + 4 * h : h * 256 + wm * 128 + i;
+  const int b_rd_e = LDS_A + ((BMODE == XMAJOR) ? (wn * 128 + i) * XLD + 4 * h : h * 256 + wn * 128 + i);
+  const int a_wr_e = (AMODE == XMAJOR) ? (t >> 3) * XLD + 8 * ((t & 7) >> 1) + 2 * (t & 1)
+                                       : (t >> 6) * 256 + 4 * (t & 63);
+  const int b_wr_e = LDS_A + ((BMODE == XMAJOR) ? (t >> 3) * XLD + 8 * ((t & 7) >> 1) + 2 * (t & 1)
+                                                : (t >> 6) * 256 + 4 * (t & 63));
+  uint32_t a_rd[2], b_rd[2], a_wr[2], b_wr[2];
+#pragma unroll
+  for (int bf = 0; bf < 2; bf++) {
+    a_rd[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + a_rd_e);
+    b_rd[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + b_rd_e);
+    a_wr[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + a_wr_e);
+    b_wr[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + b_wr_e);
+  }
+  const unsigned a_goff = 4u * (unsigned) ((AMODE == XMAJOR) ? (t >> 3) * (int) lda + 4 * (t & 7)
+                                                              : (t >> 6) * (int) lda + 4 * (t & 63));
+  const unsigned b_goff = 4u * (unsigned) ((BMODE == XMAJOR) ? (t >> 3) * (int) ldb + 4 * (t & 7)
+                                                              : (t >> 6) * (int) ldb + 4 * (t & 63));
+  // piece origins: x-major piece p = rows 32p.. (step 32 rows), slab = +32 floats along the row;
+  // k-major piece p = k-rows 4p.. (step 4 rows), slab = +32 rows
+  const uint64_t a_org = reinterpret_cast<uint64_t>((AMODE == XMAJOR) ? A + (int64_t) m0 * lda : A + m0);
+  const uint64_t b_org = reinterpret_cast<uint64_t>((BMODE == XMAJOR) ? B + (int64_t) n0 * ldb : B + n0);
+  const uint64_t a_step = (AMODE == XMAJOR) ? (uint64_t) lda * 128 : (uint64_t) lda * 16;
+  const uint64_t b_step = (BMODE == XMAJOR) ? (uint64_t) ldb * 128 : (uint64_t) ldb * 16;
+  const uint64_t a_slab = (AMODE == XMAJOR) ? 128 : (uint64_t) lda * 128;
+  const uint64_t b_slab = (BMODE == XMAJOR) ? 128 : (uint64_t) ldb * 128;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = K / BK;   // even, >= 2 (launch_modes)
+  f32x4 ra[8], rb[8];
+  // prologue: slab 0 -> buffer 0 through the registers, slab 1 -> registers
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    ra[p] = gld128(a_goff, a_org + (uint64_t) p * a_step);
+    rb[p] = gld128(b_goff, b_org + (uint64_t) p * b_step);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]),
+               "+v"(ra[6]), "+v"(ra[7]) :: "memory");
+  asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]),
+               "+v"(rb[7]) :: "memory");
+  wr_piece<AMODE, 0>(a_wr[0], ra[0]); wr_piece<AMODE, 1>(a_wr[0], ra[1]); wr_piece<AMODE, 2>(a_wr[0], ra[2]);
+  wr_piece<AMODE, 3>(a_wr[0], ra[3]); wr_piece<AMODE, 4>(a_wr[0], ra[4]); wr_piece<AMODE, 5>(a_wr[0], ra[5]);
+  wr_piece<AMODE, 6>(a_wr[0], ra[6]); wr_piece<AMODE, 7>(a_wr[0], ra[7]);
+  wr_piece<BMODE, 0>(b_wr[0], rb[0]); wr_piece<BMODE, 1>(b_wr[0], rb[1]); wr_piece<BMODE, 2>(b_wr[0], rb[2]);
+  wr_piece<BMODE, 3>(b_wr[0], rb[3]); wr_piece<BMODE, 4>(b_wr[0], rb[4]); wr_piece<BMODE, 5>(b_wr[0], rb[5]);
+  wr_piece<BMODE, 6>(b_wr[0], rb[6]); wr_piece<BMODE, 7>(b_wr[0], rb[7]);
+  // the stores above read ra/rb: make the refills below wait for them (asm order is program order)
+#pragma unroll
+  for (int p = 0; p < 8; p++) ra[p] = gld128(a_goff, a_org + a_slab + (uint64_t) p * a_step);
+#pragma unroll
+  for (int p = 0; p < 8; p++) rb[p] = gld128(b_goff, b_org + b_slab + (uint64_t) p * b_step);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 fa[2][4], fb[2][4];
+  fa[0][0] = rd_frag_m<AMODE, 0, 0>(a_rd[0]); fa[0][1] = rd_frag_m<AMODE, 0, 1>(a_rd[0]);
+  fa[0][2] = rd_frag_m<AMODE, 0, 2>(a_rd[0]); fa[0][3] = rd_frag_m<AMODE, 0, 3>(a_rd[0]);
+  fb[0][0] = rd_frag_m<BMODE, 0, 0>(b_rd[0]); fb[0][1] = rd_frag_m<BMODE, 0, 1>(b_rd[0]);
+  fb[0][2] = rd_frag_m<BMODE, 0, 2>(b_rd[0]); fb[0][3] = rd_frag_m<BMODE, 0, 3>(b_rd[0]);
+#pragma unroll
+  for (int x = 0; x < 4; x++) { fa[1][x] = fa[0][x]; fb[1][x] = fb[0][x]; }
+
+  // slab n stores slab n+1 (already in ra/rb) and fetches slab n+2; past the end the fetch
+  // address stops advancing (valid memory, data never used)
+  uint64_t a_next = a_org + 2 * a_slab, b_next = b_org + 2 * b_slab;
+  if (nkt <= 2) { a_next = a_org + a_slab; b_next = b_org + b_slab; }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    slab_1w3<AMODE, BMODE, 0>(a_rd, b_rd, a_wr, b_wr, a_next, b_next, a_step, b_step, a_goff, b_goff, ra, rb,
+                              fa, fb, acc);
+    const bool m1 = kt + 3 < nkt;
+    a_next += m1 ? a_slab : 0; b_next += m1 ? b_slab : 0;
+    slab_1w3<AMODE, BMODE, 1>(a_rd, b_rd, a_wr, b_wr, a_next, b_next, a_step, b_step, a_goff, b_goff, ra, rb,
+                              fa, fb, acc);
+    const bool m2 = kt + 4 < nkt;
+    a_next += m2 ? a_slab : 0; b_next += m2 ? b_slab : 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // look-ahead loads/reads of the last slabs
+
+  float *ctile = C + (int64_t) m0 * ldc + n0;
+  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      f32x16 old;
+      if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
+        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+      }
+    }
+}
+
 template <int AMODE, int BMODE>
 static hipError_t launch_guarded(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                                  int64_t ldc, int M, int N, int K, float alpha, float beta,
@@ -950,9 +1197,11 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   const bool vec_ok = vec_ld && (K % BK == 0) && (K > 0);
   // 256x256 kernels for the tile-aligned part of the problem:
-  //   4 (default): as 3, with explicit ds_read2st64 operand reads, scalar-addressed DMA and the
-  //      barrier in front of the last k-group (147.6 TFLOP/s at 4096^3, 149.7 at K = 16384);
-  //      needs K % 64 == 0, otherwise 3
+  //   4 (default): hand-scheduled slab loops (explicit LDS reads/writes with immediate offsets,
+  //      scalar-addressed global loads / DMA, barrier in front of the last k-group): 'T','N'
+  //      through LDS-DMA (147.6-149.5 TFLOP/s at 4096^3, 149.7 at K = 16384), the layouts with an
+  //      x-major operand through registers (NN 145.0, TT 145.4, NT 141.8); needs K % 64 == 0,
+  //      otherwise 3
   //   3: one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (143.3 TFLOP/s at
   //      4096^3), every other layout through variant 2 (140.6-141.3)
   //   2: one wave per SIMD, register staging, constant-offset addressing
@@ -974,6 +1223,9 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
     else if (big_tile_variant >= 3 && AMODE == KMAJOR && BMODE == KMAJOR && K % BK == 0)
       hipLaunchKernelGGL(sgemm_tile256_dma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                          ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+    else if (big_tile_variant == 4 && K % (2 * BK) == 0)
+      hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
+                         A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
     else if (K % BK == 0)
       hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, false>), dim3(tiles_m * tiles_n), dim3(256),
                          0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);

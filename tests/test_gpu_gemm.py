@@ -129,20 +129,22 @@ def test_sgemm_ragged_interior_plus_strips_bit_exact(dev, ta, tb, m, n, k):
     assert np.array_equal(got, ref), rel_err(got, ref)
 
 
+@pytest.mark.parametrize("ta,tb", list(itertools.product("NT", "NT")))
 @pytest.mark.parametrize("k", [64, 128, 192, 1024])
-def test_sgemm_dma_kernel_slab_pairs(dev, k):
-    """'T','N' (both operands k-major) with K % 64 == 0 runs the inline-asm DMA kernel whose slabs go
-    in (buffer 0, buffer 1) pairs: one pair, two, three, many; padded leading dimensions;
-    bit-exact against the oracle's k-ordered chain for beta = 0 and beta != 0."""
+def test_sgemm_big_tile_slab_pairs(dev, ta, tb, k):
+    """K % 64 == 0 runs the hand-scheduled kernels whose slabs go in (buffer 0, buffer 1) pairs
+    ('T','N': LDS-DMA staging; the other layouts: register staging): one pair, two, three, many;
+    padded leading dimensions; bit-exact against the oracle's k-ordered chain."""
     m, n = 4096, 2048
     rng = np.random.default_rng(k)
-    lda, ldb, ldc = m + 8, n + 4, n + 12
-    a = rng.uniform(-1, 1, (k, lda)).astype(np.float32)      # 'T': stored k x m
-    b = rng.uniform(-1, 1, (k, ldb)).astype(np.float32)      # 'N': stored k x n
+    sa, sb, sc = stored_shapes("R", ta, tb, m, n, k)
+    lda, ldb, ldc = sa[1] + 8, sb[1] + 4, n + 12
+    a = rng.uniform(-1, 1, (sa[0], lda)).astype(np.float32)
+    b = rng.uniform(-1, 1, (sb[0], ldb)).astype(np.float32)
     c0 = rng.uniform(-1, 1, (m, ldc)).astype(np.float32)
     for alpha, beta in [(1.0, 0.0), (0.5, 2.0)]:
-        ref = orc.sgemm("R", "T", "N", m, n, k, alpha, a, lda, b, ldb, beta, c0.copy(), ldc)
-        got = run_sgemm("R", "T", "N", m, n, k, alpha, beta, a, lda, b, ldb, c0, ldc)
+        ref = orc.sgemm("R", ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0.copy(), ldc)
+        got = run_sgemm("R", ta, tb, m, n, k, alpha, beta, a, lda, b, ldb, c0, ldc)
         assert np.array_equal(got, ref), rel_err(got, ref)
 
 
