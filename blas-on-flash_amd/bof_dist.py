@@ -55,3 +55,72 @@ def allreduce_partial(y, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
     return y
+
+
+def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0, ldc=0, opts=None, group=None,
+                           device=None, one_gpu_debug=False):
+    """Multi-GPU flash::gemm('R','N','N') on FILE-resident matrices (BASELINE configs[3]; SURVEY 8f-4):
+    rank g owns the C rows [r0, r1) (tile-aligned, `row_shard`).  With 288 GB of HBM per GPU the
+    rank's A slab, its C slab and the whole of B are simply made resident:
+
+      * A[r0:r1, :] and (beta != 0) C[r0:r1, :] stream from the files into HBM;
+      * B is read from storage ONCE per node, not once per GPU: rank g reads the k-row panel
+        B[k0:k1, :] and one all-gather (RCCL over xGMI) assembles the full matrix on every
+        GPU -- the reference design would have every worker pull all of B through its own cache;
+      * the tile DAG runs over the resident slabs (bof_gemm_resident, same tiles, same k-order as
+        the single-GPU file path, so the C file is bit-identical);
+      * C[r0:r1, :] streams back into the file.
+
+    Returns {bytes_read, bytes_written} of this rank.  `one_gpu_debug` runs the collective
+    through host memory (gloo) so that two ranks can share one device on a single-GPU box."""
+    import torch
+    import torch.distributed as dist
+    import bofhip
+    lda, ldb, ldc = lda or k, ldb or n, ldc or n
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    o = opts if opts is not None else bofhip.default_options()
+    tile = int(o.gemm_blk)
+    r0, r1 = row_shard(m, world, rank, tile)
+    rows = r1 - r0
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rd = wr = 0
+    # --- B: this rank's k-row panel from the file, then all-gather ---------------------------
+    per = (k + world - 1) // world
+    k0, k1 = min(k, rank * per), min(k, (rank + 1) * per)
+    panel = torch.zeros(per * ldb, dtype=torch.float32, device=dev)
+    if k1 > k0:
+        nbytes = ((k1 - k0 - 1) * ldb + n) * 4          # the last row may end before a full ldb
+        bofhip.file_to_device(bofhip.FPtr(fd_b, k0 * ldb * 4), nbytes, panel.data_ptr(), o)
+        rd += nbytes
+    if world > 1:
+        full = torch.empty(world * per * ldb, dtype=torch.float32, device=dev)
+        if one_gpu_debug:
+            hp, hf = panel.cpu(), torch.empty(world * per * ldb, dtype=torch.float32)
+            dist.all_gather_into_tensor(hf, hp, group=group)
+            full.copy_(hf)
+        else:
+            dist.all_gather_into_tensor(full, panel, group=group)
+        b_dev = full
+    else:
+        b_dev = panel
+    stats = {"bytes_read": 0, "bytes_written": 0, "rows": rows, "b_panel_rows": k1 - k0}
+    if rows > 0:
+        a_dev = torch.empty(rows * lda, dtype=torch.float32, device=dev)
+        a_bytes = ((rows - 1) * lda + k) * 4
+        bofhip.file_to_device(bofhip.FPtr(fd_a, r0 * lda * 4), a_bytes, a_dev.data_ptr(), o)
+        rd += a_bytes
+        c_dev = torch.zeros(rows * ldc, dtype=torch.float32, device=dev)
+        c_bytes = ((rows - 1) * ldc + n) * 4
+        if beta != 0.0 or ldc != n:       # padded rows: keep what lies between the row ends
+            bofhip.file_to_device(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o)
+            rd += c_bytes
+        torch.cuda.synchronize(dev)
+        bofhip.gemm_resident("R", "N", "N", rows, n, k, alpha, beta, a_dev.data_ptr(), b_dev.data_ptr(),
+                             c_dev.data_ptr(), lda, ldb, ldc, o, st)
+        torch.cuda.synchronize(dev)
+        bofhip.device_to_file(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o)
+        wr += c_bytes
+    stats["bytes_read"], stats["bytes_written"] = rd, wr
+    return stats

@@ -1309,6 +1309,29 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
   return BOF_OK;
 }
 
+static int region_transfer(bof_fptr f, uint64_t bytes, void *dptr, bool to_device, const bof_options *opts) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = device_ready();
+  if (rc) return rc;
+  if (f.fd < 0 || (!dptr && bytes)) { set_error("bof_file_to_device / bof_device_to_file: bad argument"); return BOF_EINVAL; }
+  const bof_options o = resolved(opts);
+  hipStream_t st = nullptr;
+  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  Counters cnt;
+  rc = stream_file(f, bytes, (char *) dptr, to_device, st, o.use_odirect != 0, o.n_io_threads, cnt);
+  const hipError_t e = hipStreamSynchronize(st);
+  (void) hipStreamDestroy(st);
+  if (!rc && e != hipSuccess) rc = hip_fail(e, "region transfer");
+  publish_stats(cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  return rc;
+}
+int bof_file_to_device(bof_fptr f, uint64_t bytes, void *dptr, const bof_options *opts) {
+  return region_transfer(f, bytes, dptr, true, opts);
+}
+int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_options *opts) {
+  return region_transfer(f, bytes, const_cast<void *>(dptr), false, opts);
+}
+
 int bof_flash_release(void) {
   scratch_release_all();
   std::lock_guard<std::mutex> lk(g_res_mu);

@@ -206,6 +206,12 @@ int bof_flash_csrmm_inmem(char trans_a, uint64_t m, uint64_t n, uint64_t k, floa
 int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a,
                       bof_fptr ia, bof_fptr ja, const float *b, float *c,
                       const bof_options *opts);
+/* A contiguous file region <-> HBM through the pinned rings of the level-3 reader
+ * (n_io_threads workers, 32 MiB chunks; O_DIRECT AIO where the region is sector
+ * aligned).  Building blocks of the multi-GPU file path (bof_dist.py): with 288 GB
+ * per GPU a rank's A / C row slabs and the whole of B are simply made resident. */
+int bof_file_to_device(bof_fptr f, uint64_t bytes, void *dptr, const bof_options *opts);
+int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_options *opts);
 /* Counters of the last level-3 call (bytes moved per stage, seconds). */
 typedef struct {
   uint64_t bytes_read, bytes_written; /* file I/O                      */
