@@ -124,3 +124,61 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
         wr += c_bytes
     stats["bytes_read"], stats["bytes_written"] = rd, wr
     return stats
+
+
+def _world_rank(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def flash_csrmm_row_sharded(m, n, k, alpha, beta, fd_a, fd_ia, fd_ja, ord_b, fd_b, fd_c, ia_host, opts=None,
+                            group=None):
+    """Multi-GPU flash::csrmm('N') on files: rank g owns the row range [r0, r1) balanced by
+    non-zeros (`csr_row_shard`, 128-row aligned).  The shard is the offsets pointer advanced by
+    r0 (offsets stay absolute, src/blas/csrmm.cpp:97-98); B is read by every rank (512 MB at
+    BASELINE configs[2]); C rows are disjoint -- no collective.  Row-major C only ('R'): a
+    column-major C slab is not contiguous in the file."""
+    import bofhip
+    if ord_b != "R":
+        raise ValueError("flash_csrmm_row_sharded: ord_b must be 'R'")
+    world, rank = _world_rank(group)
+    r0, r1 = csr_row_shard(ia_host, world, rank, 128)
+    if r1 > r0:
+        bofhip.flash_csrmm("N", r1 - r0, n, k, alpha, beta, bofhip.FPtr(fd_a, 0), bofhip.FPtr(fd_ia, r0 * 8),
+                           bofhip.FPtr(fd_ja, 0), "R", bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * k * 4), opts)
+    return r0, r1
+
+
+def flash_csrgemv_row_sharded(trans, m, n, fd_a, fd_ia, fd_ja, x, y, ia_host, opts=None, group=None,
+                              reduce_device=None):
+    """Multi-GPU flash::csrgemv on files with host vectors x, y (numpy fp32).  'N': rank g fills
+    y[r0:r1] (disjoint; the caller gathers if it wants y everywhere).  'T': every rank computes the
+    full-length partial of its rows and ONE all-reduce(sum) -- the only collective of the whole
+    path -- leaves y = A^T x on every rank (`reduce_device`: torch device the reduce runs on;
+    None = host/gloo)."""
+    import numpy as np
+    import torch
+    import bofhip
+    world, rank = _world_rank(group)
+    r0, r1 = csr_row_shard(ia_host, world, rank, 128)
+    rows = r1 - r0
+    if trans == "N":
+        if rows > 0:
+            part = np.zeros(rows, np.float32)
+            bofhip.flash_csrgemv("N", rows, n, bofhip.FPtr(fd_a, 0), bofhip.FPtr(fd_ia, r0 * 8),
+                                 bofhip.FPtr(fd_ja, 0), x.ctypes.data, part.ctypes.data, opts)
+            y[r0:r1] = part
+        return r0, r1
+    part = np.zeros(n, np.float32)
+    if rows > 0:
+        xs = np.ascontiguousarray(x[r0:r1])
+        bofhip.flash_csrgemv("T", rows, n, bofhip.FPtr(fd_a, 0), bofhip.FPtr(fd_ia, r0 * 8),
+                             bofhip.FPtr(fd_ja, 0), xs.ctypes.data, part.ctypes.data, opts)
+    t = torch.from_numpy(part)
+    if reduce_device is not None:
+        t = t.to(reduce_device)
+    allreduce_partial(t, group)
+    y[:] = t.cpu().numpy()
+    return r0, r1

@@ -442,3 +442,33 @@ def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc):
     assert sum(x["b_panel_rows"] for x in recs) == k          # B read from storage exactly once
     got = np.fromfile(pc, np.float32).reshape(m, ldc)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_flash_csr_row_sharded_files(dev, tmp_path, golden, nproc):
+    """csrmm / csrgemv 'N' / csrgemv 'T' on files, rows sharded over the ranks by non-zeros; only
+    csrgemv 'T' uses a collective (all-reduce of the partial vectors).  Results pinned by the MKL
+    hashes of the generator matrix (identical whatever the number of ranks)."""
+    import hashlib
+    import json
+    import sys
+    m, n, k = 4096, 2048, 128
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    val.tofile(tmp_path / "A.csr"); ja.tofile(tmp_path / "A.col"); ia.tofile(tmp_path / "A.off")
+    orc.dense_fill(n, k, "s").tofile(tmp_path / "B.bin")
+    np.zeros((m, k), np.float32).tofile(tmp_path / "C.bin")
+    (np.arange(max(m, n)) % 10).astype(np.float32).tofile(tmp_path / "x.bin")
+    tool = os.path.join(ROOT, "tools", "dist_file_csr.py")
+    cmd = [sys.executable, tool] if nproc == 1 else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+         "127.0.0.1", "--master-port", "29579", tool]
+    r = subprocess.run(cmd + [str(tmp_path), str(m), str(n), str(k)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, BOF_BENCH_ONE_GPU="1", BOF_MAX_NNZS="5000", BOF_CSRMM_RBLK_SIZE="1000"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(recs) == nproc and recs[0]["rows"][0] == 0 and recs[-1]["rows"][1] == m
+    want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
+    h = lambda f: hashlib.sha256(np.fromfile(tmp_path / f, np.float32).tobytes()).hexdigest()
+    assert h("C.bin") == want["gen_csrmm_c"]
+    assert h("yN.bin") == want["gen_csrgemv_N"]
+    assert h("yT.bin") == want["gen_csrgemv_T"]
