@@ -31,6 +31,9 @@ size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz);
 hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
                    const int64_t *col, float *val_tr, int64_t *ptr_tr, int64_t *col_tr,
                    void *workspace, hipStream_t st);
+hipError_t csc_merge(int nb, int64_t cw, const int64_t *blk_ptr, const int64_t *seg_base, const int64_t *row0,
+                     const int64_t *out_ptr, const float *val_in, const int64_t *col_in, float *val_out,
+                     int64_t *col_out, hipStream_t st);
 // y = A^T x by partitioning the products by column bin (no global atomics); y overwritten
 size_t csrgemv_t_workspace_bytes(int64_t n, int64_t nnz);
 hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,

@@ -423,6 +423,41 @@ GemvLayout make_gemv_layout(int64_t n, int64_t nnz) {
 
 }  // namespace
 
+// Column-block merge of the out-of-core transposition (reference BlockMergeTask,
+// include/tasks/csrcsc_task.h:93-163): for every output row c of the block, the runs that the
+// row blocks b = 0..nb-1 hold for it are concatenated in block order (= ascending source rows);
+// block-local row ids get the block's first row added.  One wave per output row.
+__global__ __launch_bounds__(256) void csc_merge_kernel(int nb, int64_t cw, const int64_t *__restrict__ blk_ptr,
+                                                        const int64_t *__restrict__ seg_base,
+                                                        const int64_t *__restrict__ row0,
+                                                        const int64_t *__restrict__ out_ptr,
+                                                        const float *__restrict__ val_in,
+                                                        const int64_t *__restrict__ col_in,
+                                                        float *__restrict__ val_out, int64_t *__restrict__ col_out) {
+  const int64_t c = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= cw) return;
+  const int lane = threadIdx.x & 63;
+  int64_t cursor = out_ptr[c];
+  for (int b = 0; b < nb; b++) {
+    const int64_t s = blk_ptr[(int64_t) b * (cw + 1) + c], e = blk_ptr[(int64_t) b * (cw + 1) + c + 1];
+    const int64_t src = seg_base[b], r0 = row0[b];
+    for (int64_t i = s + lane; i < e; i += 64) {
+      val_out[cursor + (i - s)] = val_in[src + i];
+      col_out[cursor + (i - s)] = col_in[src + i] + r0;
+    }
+    cursor += e - s;
+  }
+}
+
+hipError_t csc_merge(int nb, int64_t cw, const int64_t *blk_ptr, const int64_t *seg_base, const int64_t *row0,
+                     const int64_t *out_ptr, const float *val_in, const int64_t *col_in, float *val_out,
+                     int64_t *col_out, hipStream_t st) {
+  if (cw <= 0 || nb <= 0) return hipSuccess;
+  csc_merge_kernel<<<(unsigned) ((cw + 3) / 4), 256, 0, st>>>(nb, cw, blk_ptr, seg_base, row0, out_ptr, val_in, col_in,
+                                                              val_out, col_out);
+  return hipGetLastError();
+}
+
 size_t csrgemv_t_workspace_bytes(int64_t n, int64_t nnz) { return make_gemv_layout(n, nnz).total; }
 
 // y[0..n) = A^T x for A = CSR(val, ptr[m+1] (any base), col), m x n; y is overwritten.

@@ -16,11 +16,16 @@
 //     compute and HBM->host->NVMe all overlap;
 //   * everything is event driven (hipEvents + condition variables): no 50-100 ms
 //     scheduler ticks (reference scheduler.cpp:92-93,206-212).
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -844,8 +849,8 @@ struct ResidentCsr {
 // The reference does this out of core with per-row-block mkl_csrcsc + a column-block merge
 // through temporary files (src/blas/csrcsc.cpp:32-159) because its program cache is 8 GiB of
 // DRAM; with 288 GB of HBM the matrices of the BASELINE family (12 GB) fit whole, so the
-// transposition is one device-side sort.  Matrices whose working set exceeds free HBM are
-// refused with BOF_ENOMEM (no silent fallback).
+// transposition is one device-side sort.  Callers that can go out of core (flash::csrcsc) check
+// the budget first; here a working set beyond free HBM is refused with BOF_ENOMEM.
 static int flash_transpose_to_hbm(int64_t m, int64_t n, bof_fptr fa, bof_fptr fia, bof_fptr fja,
                                   const bof_options &o, Counters &cnt, ResidentCsr &out) {
   const bool use_aio = o.use_odirect != 0;
@@ -907,6 +912,169 @@ static int flash_transpose_to_hbm(int64_t m, int64_t n, bof_fptr fa, bof_fptr fi
   return BOF_OK;
 }
 
+// An unnamed temporary file next to `near_fd` (falls back to $TMPDIR, /tmp): the reference's
+// flash_malloc'ed block files (src/blas/csrcsc.cpp:61-66).
+static int temp_file_near(int near_fd) {
+  char link[64], path[4096];
+  snprintf(link, sizeof(link), "/proc/self/fd/%d", near_fd);
+  std::vector<std::string> dirs;
+  const ssize_t len = readlink(link, path, sizeof(path) - 1);
+  if (len > 0) {
+    path[len] = 0;
+    std::string d(path);
+    const size_t slash = d.rfind('/');
+    if (slash != std::string::npos) dirs.push_back(slash ? d.substr(0, slash) : "/");
+  }
+  if (getenv("TMPDIR")) dirs.push_back(getenv("TMPDIR"));
+  dirs.push_back("/tmp");
+  for (const auto &d : dirs) {
+    const int fd = open(d.c_str(), O_TMPFILE | O_RDWR, 0600);
+    if (fd >= 0) return fd;
+  }
+  return -1;
+}
+
+// Out-of-core transposition for matrices whose working set exceeds the HBM budget -- the
+// reference's scheme (src/blas/csrcsc.cpp:32-159) with the GPU doing both halves:
+//   phase A: row blocks sized to the budget are transposed in HBM (bof::scsrcsc) and their
+//            (values, block-local row ids) written to temporary files, offsets kept on the host;
+//   phase B: column blocks sized to the budget gather their runs from every row block's file
+//            segment and are merged in block order (csc_merge_kernel) into the output files.
+static int flash_csrcsc_blocked(int64_t m, int64_t n, const std::vector<int64_t> &ia, bof_fptr fja, bof_fptr fa,
+                                bof_fptr fia_tr, bof_fptr fja_tr, bof_fptr fa_tr, const bof_options &o,
+                                size_t budget, Counters &cnt) {
+  const bool use_aio = o.use_odirect != 0;
+  const int64_t z = ia[0], nnz = ia[(size_t) m] - z;
+  // per-non-zero HBM cost of a block: input 12 B + output 12 B + sort workspace
+  const size_t fixed = (size_t) (n + 1) * 8 * 2 + (1 << 20);
+  const size_t per_nnz = 24 + (csrcsc_workspace_bytes(n, 1 << 24) >> 24) + 1;
+  if (budget <= fixed + per_nnz * 4096) {
+    set_error("csrcsc: HBM budget too small for the out-of-core transposition");
+    return BOF_ENOMEM;
+  }
+  const int64_t blk_nnz = (int64_t) ((budget - fixed) / per_nnz);
+  // ---- row blocks ----------------------------------------------------------------------
+  std::vector<int64_t> rb;  // block boundaries (rows)
+  rb.push_back(0);
+  while (rb.back() < m) {
+    const int64_t r0 = rb.back();
+    int64_t r1 = std::upper_bound(ia.begin() + r0 + 1, ia.begin() + m + 1, ia[(size_t) r0] + blk_nnz) - ia.begin() - 1;
+    if (r1 <= r0) {
+      set_error("csrcsc: one row of the matrix exceeds the HBM budget");
+      return BOF_ENOMEM;
+    }
+    rb.push_back(std::min(r1, m));
+  }
+  const int nb = (int) rb.size() - 1;
+  const int tfd_val = temp_file_near(fa_tr.fd), tfd_col = temp_file_near(fja_tr.fd);
+  hipStream_t st = nullptr;
+  char *d_val = nullptr, *d_col = nullptr, *d_ia = nullptr, *d_vt = nullptr, *d_ct = nullptr, *d_pt = nullptr;
+  char *d_aux = nullptr;
+  Cleanup guard;
+  guard.add([&] {
+    if (tfd_val >= 0) close(tfd_val);
+    if (tfd_col >= 0) close(tfd_col);
+    (void) hipFree(d_val); (void) hipFree(d_col); (void) hipFree(d_ia); (void) hipFree(d_vt); (void) hipFree(d_ct);
+    (void) hipFree(d_pt); (void) hipFree(d_aux);
+    if (st) (void) hipStreamDestroy(st);
+  });
+  if (tfd_val < 0 || tfd_col < 0) { set_error("csrcsc: cannot create temporary files"); return BOF_EIO; }
+  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  int64_t max_b = 0, max_rows = 0;
+  for (int b = 0; b < nb; b++) {
+    max_b = std::max(max_b, ia[(size_t) rb[b + 1]] - ia[(size_t) rb[b]]);
+    max_rows = std::max(max_rows, rb[b + 1] - rb[b]);
+  }
+  const size_t cap = (size_t) std::max<int64_t>(max_b, 1);
+  BOF_HIP_TRY(hipMalloc((void **) &d_val, cap * 4));
+  BOF_HIP_TRY(hipMalloc((void **) &d_col, cap * 8));
+  BOF_HIP_TRY(hipMalloc((void **) &d_vt, cap * 4));
+  BOF_HIP_TRY(hipMalloc((void **) &d_ct, cap * 8));
+  BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (max_rows + 1) * 8));
+  BOF_HIP_TRY(hipMalloc((void **) &d_pt, (size_t) (n + 1) * 8));
+  void *ws = nullptr;
+  int rc = scratch_get(SCR_CSRCSC, csrcsc_workspace_bytes(n, (int64_t) cap), &ws);
+  if (rc) return rc;
+  std::vector<std::vector<int64_t>> bptr((size_t) nb, std::vector<int64_t>((size_t) n + 1));
+  std::vector<int64_t> ia_tr((size_t) n + 1, 0);
+  for (int b = 0; b < nb; b++) {
+    const int64_t r0 = rb[b], r1 = rb[b + 1], zb = ia[(size_t) r0] - z, nb_nnz = ia[(size_t) r1] - ia[(size_t) r0];
+    BOF_HIP_TRY(hipMemcpyAsync(d_ia, ia.data() + r0, (size_t) (r1 - r0 + 1) * 8, hipMemcpyHostToDevice, st));
+    bof_fptr fv = fa, fc = fja;
+    fv.foffset += (uint64_t) (z + zb) * 4;
+    fc.foffset += (uint64_t) (z + zb) * 8;
+    rc = stream_file(fv, (uint64_t) nb_nnz * 4, d_val, true, st, use_aio, o.n_io_threads, cnt);
+    if (!rc) rc = stream_file(fc, (uint64_t) nb_nnz * 8, d_col, true, st, use_aio, o.n_io_threads, cnt);
+    if (rc) return rc;
+    BOF_HIP_TRY(scsrcsc(r1 - r0, n, nb_nnz, (const float *) d_val, (const int64_t *) d_ia, (const int64_t *) d_col,
+                        (float *) d_vt, (int64_t *) d_pt, (int64_t *) d_ct, ws, st));
+    BOF_HIP_TRY(hipMemcpyAsync(bptr[(size_t) b].data(), d_pt, (size_t) (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    BOF_HIP_TRY(hipStreamSynchronize(st));
+    bof_fptr tv{tfd_val, (uint64_t) zb * 4}, tc{tfd_col, (uint64_t) zb * 8};
+    rc = stream_file(tv, (uint64_t) nb_nnz * 4, d_vt, false, st, false, o.n_io_threads, cnt);
+    if (!rc) rc = stream_file(tc, (uint64_t) nb_nnz * 8, d_ct, false, st, false, o.n_io_threads, cnt);
+    if (rc) return rc;
+    for (int64_t c = 0; c < n; c++) ia_tr[(size_t) c + 1] += bptr[(size_t) b][(size_t) c + 1] - bptr[(size_t) b][(size_t) c];
+    cnt.tasks++;
+  }
+  for (int64_t c = 0; c < n; c++) ia_tr[(size_t) c + 1] += ia_tr[(size_t) c];
+  if (ia_tr[(size_t) n] != nnz) { set_error("csrcsc: block transposes lost entries"); return BOF_EHIP; }
+  // ---- column blocks: gather the runs of every row block, merge, write ----------------------
+  (void) hipFree(d_ia); d_ia = nullptr;
+  (void) hipFree(d_pt); d_pt = nullptr;
+  int64_t c0 = 0;
+  while (c0 < n) {
+    // largest c1 with nnz(c0..c1) <= cap and auxiliary arrays within reason
+    int64_t c1 = std::upper_bound(ia_tr.begin() + c0 + 1, ia_tr.begin() + n + 1, ia_tr[(size_t) c0] + (int64_t) cap) -
+                 ia_tr.begin() - 1;
+    c1 = std::min<int64_t>(std::max(c1, c0 + 1), n);
+    c1 = std::min<int64_t>(c1, c0 + std::max<int64_t>(1, (int64_t) (64 << 20) / (nb + 1)));
+    const int64_t cw = c1 - c0, out_nnz = ia_tr[(size_t) c1] - ia_tr[(size_t) c0];
+    if (out_nnz > (int64_t) cap) { set_error("csrcsc: one column of the matrix exceeds the HBM budget"); return BOF_ENOMEM; }
+    // auxiliary arrays: nb x (cw+1) block offsets (relative to the block's segment), nb bases,
+    // nb first rows, cw+1 output offsets
+    std::vector<int64_t> aux((size_t) nb * (size_t) (cw + 1) + 2 * (size_t) nb + (size_t) (cw + 1));
+    int64_t *h_bp = aux.data(), *h_base = h_bp + (size_t) nb * (size_t) (cw + 1), *h_r0 = h_base + nb,
+            *h_out = h_r0 + nb;
+    int64_t fill = 0;
+    for (int b = 0; b < nb; b++) {
+      const std::vector<int64_t> &bp = bptr[(size_t) b];
+      const int64_t s = bp[(size_t) c0], e = bp[(size_t) c1], zb = ia[(size_t) rb[b]] - z;
+      for (int64_t c = 0; c <= cw; c++) h_bp[(size_t) b * (size_t) (cw + 1) + (size_t) c] = bp[(size_t) (c0 + c)] - s;
+      h_base[b] = fill;
+      h_r0[b] = rb[b];
+      if (e > s) {
+        bof_fptr tv{tfd_val, (uint64_t) (zb + s) * 4}, tc{tfd_col, (uint64_t) (zb + s) * 8};
+        rc = stream_file(tv, (uint64_t) (e - s) * 4, d_val + (size_t) fill * 4, true, st, false, o.n_io_threads, cnt);
+        if (!rc) rc = stream_file(tc, (uint64_t) (e - s) * 8, d_col + (size_t) fill * 8, true, st, false, o.n_io_threads, cnt);
+        if (rc) return rc;
+      }
+      fill += e - s;
+    }
+    for (int64_t c = 0; c <= cw; c++) h_out[c] = ia_tr[(size_t) (c0 + c)] - ia_tr[(size_t) c0];
+    (void) hipFree(d_aux); d_aux = nullptr;
+    BOF_HIP_TRY(hipMalloc((void **) &d_aux, aux.size() * 8));
+    BOF_HIP_TRY(hipMemcpyAsync(d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice, st));
+    const int64_t *g = (const int64_t *) d_aux;
+    BOF_HIP_TRY(csc_merge(nb, cw, g, g + (size_t) nb * (size_t) (cw + 1), g + (size_t) nb * (size_t) (cw + 1) + nb,
+                          g + (size_t) nb * (size_t) (cw + 1) + 2 * (size_t) nb, (const float *) d_val,
+                          (const int64_t *) d_col, (float *) d_vt, (int64_t *) d_ct, st));
+    BOF_HIP_TRY(hipStreamSynchronize(st));
+    bof_fptr ov = fa_tr, oc = fja_tr;
+    ov.foffset += (uint64_t) ia_tr[(size_t) c0] * 4;
+    oc.foffset += (uint64_t) ia_tr[(size_t) c0] * 8;
+    rc = stream_file(ov, (uint64_t) out_nnz * 4, d_vt, false, st, use_aio, o.n_io_threads, cnt);
+    if (!rc) rc = stream_file(oc, (uint64_t) out_nnz * 8, d_ct, false, st, use_aio, o.n_io_threads, cnt);
+    if (rc) return rc;
+    cnt.tasks++;
+    c0 = c1;
+  }
+  const int io = file_swrite(fia_tr.fd, fia_tr.foffset, 0, 1, (uint64_t) (n + 1) * 8, ia_tr.data(), use_aio);
+  if (io) { set_error(std::string("writing ia_tr failed: ") + strerror(-io)); return BOF_EIO; }
+  cnt.wr += (uint64_t) (n + 1) * 8;
+  return BOF_OK;
+}
+
 static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, bof_fptr fa,
                              bof_fptr fia_tr, bof_fptr fja_tr, bof_fptr fa_tr, const bof_options *opts) {
   const auto t_begin = std::chrono::steady_clock::now();
@@ -914,6 +1082,25 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
   if (rc) return rc;
   const bof_options o = resolved(opts);
   Counters cnt;
+  {
+    // does the whole matrix fit?  (input + output + sort workspace against the budget)
+    std::vector<int64_t> ia((size_t) m + 1, 0);
+    if (m > 0) {
+      const int io = read_host(fia, (uint64_t) (m + 1) * 8, ia.data(), o.use_odirect != 0);
+      if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
+    }
+    const int64_t nnz = ia[(size_t) m] - ia[0];
+    size_t free_b = 0, total_b = 0;
+    BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = o.hbm_budget > 0 ? std::min((size_t) o.hbm_budget, (size_t) (free_b * 0.9)) : (size_t) (free_b * 0.9);
+    const size_t need = (size_t) std::max<int64_t>(nnz, 0) * 24 + (size_t) (m + n + 2) * 8 + csrcsc_workspace_bytes(n, std::max<int64_t>(nnz, 0));
+    if (nnz > 0 && need > budget) {
+      cnt.rd += (uint64_t) (m + 1) * 8;
+      rc = flash_csrcsc_blocked(m, n, ia, fja, fa, fia_tr, fja_tr, fa_tr, o, budget, cnt);
+      publish_stats(cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+      return rc;
+    }
+  }
   ResidentCsr T;
   rc = flash_transpose_to_hbm(m, n, fa, fia, fja, o, cnt, T);
   if (rc) return rc;

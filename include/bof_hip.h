@@ -191,8 +191,9 @@ int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alph
 /* flash::csrcsc (include/flash_blas.h:49-52, src/blas/csrcsc.cpp:32-159):
  * CSR(ia, ja, a) of shape m x n -> CSR(ia_tr, ja_tr, a_tr) of shape n x m in the three
  * output files (ia_tr: n+1 int64, ja_tr: nnz int64, a_tr: nnz fp32), source rows
- * ascending inside every output row.  The matrix is transposed whole in HBM;
- * BOF_ENOMEM if it does not fit (there is no out-of-core merge path). */
+ * ascending inside every output row.  The matrix is transposed whole in HBM when
+ * it fits opts->hbm_budget (0 = most of the free HBM); otherwise in row blocks
+ * through temporary files + a column-block merge, as the reference does. */
 int bof_flash_csrcsc(uint64_t m, uint64_t n, bof_fptr ia, bof_fptr ja, bof_fptr a,
                      bof_fptr ia_tr, bof_fptr ja_tr, bof_fptr a_tr,
                      const bof_options *opts);

@@ -210,8 +210,8 @@ def test_flash_csrmm_inmem_bc(dev, tmp_path, ord_b):
         F.close()
 
 
-@pytest.mark.parametrize("direct", [True, False])
-def test_flash_csrcsc(dev, tmp_path, golden_tr, direct):
+@pytest.mark.parametrize("direct,budget", [(True, 0), (False, 0), (True, 2 << 20), (False, 3 << 20)])
+def test_flash_csrcsc(dev, tmp_path, golden_tr, direct, budget):
     """flash::csrcsc on files (SURVEY 8f-3): generator matrix pinned by the mkl_csrcsc hashes,
     a ragged random matrix with empty rows/columns against the oracle, inputs left untouched."""
     import hashlib
@@ -222,10 +222,17 @@ def test_flash_csrcsc(dev, tmp_path, golden_tr, direct):
     F = Files(tmp_path, direct, val=val, ja=ja, ia=ia, val_tr=np.zeros(nnz, np.float32),
               ja_tr=np.zeros(nnz, np.int64), ia_tr=np.zeros(n + 1, np.int64))
     try:
+        # budget > 0 forces the out-of-core scheme: row blocks transposed in HBM into temporary
+        # files, then column blocks merged (several blocks of each kind at these sizes)
         bofhip.flash_csrcsc(m, n, F.fptr("ia"), F.fptr("ja"), F.fptr("val"), F.fptr("ia_tr"),
-                            F.fptr("ja_tr"), F.fptr("val_tr"), bofhip.default_options(n_io_threads=3))
+                            F.fptr("ja_tr"), F.fptr("val_tr"),
+                            bofhip.default_options(n_io_threads=3, hbm_budget=budget))
         st = bofhip.flash_last_stats()
-        assert st["bytes_read"] == nnz * 12 + (m + 1) * 8 and st["bytes_written"] == nnz * 12 + (n + 1) * 8
+        if budget == 0:
+            assert st["bytes_read"] == nnz * 12 + (m + 1) * 8 and st["bytes_written"] == nnz * 12 + (n + 1) * 8
+        else:   # every entry goes through the temporary files once: 2x reads, 2x writes
+            assert st["bytes_read"] == 2 * nnz * 12 + (m + 1) * 8
+            assert st["bytes_written"] == 2 * nnz * 12 + (n + 1) * 8 and st["tasks"] >= 4
         h = lambda name, dt: hashlib.sha256(F.read(name, dt, (-1,)).tobytes()).hexdigest()
         assert h("val_tr", np.float32) == want["gen_tr_val"]
         assert h("ja_tr", np.int64) == want["gen_tr_ja"]
@@ -246,7 +253,10 @@ def test_flash_csrcsc(dev, tmp_path, golden_tr, direct):
               ja_tr=np.zeros(ja.size, np.int64), ia_tr=np.zeros(n + 1, np.int64))
     try:
         bofhip.flash_csrcsc(m, n, F.fptr("ia"), F.fptr("ja"), F.fptr("val"), F.fptr("ia_tr"),
-                            F.fptr("ja_tr"), F.fptr("val_tr"), None)
+                            F.fptr("ja_tr"), F.fptr("val_tr"),
+                            bofhip.default_options(hbm_budget=(3 << 20) if budget else 0))
+        if budget:
+            assert bofhip.flash_last_stats()["tasks"] >= 4
         assert np.array_equal(F.read("ia_tr", np.int64, (-1,)), wi)
         assert np.array_equal(F.read("ja_tr", np.int64, (-1,)), wj)
         assert np.array_equal(F.read("val_tr", np.float32, (-1,)), wv)

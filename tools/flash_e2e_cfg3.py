@@ -97,14 +97,17 @@ def main():
         ln = [x for x in out.splitlines() if tag in x]
         return float(ln[0].split("took")[1].split("\x1b")[0]) if ln else float("nan")
 
-    for odirect in ("0", "1"):
-        env = dict(os.environ, BOF_ODIRECT=odirect)
+    for odirect, budget in (("0", "0"), ("1", "0"), ("0", str(8 << 30))):
+        # budget 8 GiB (the reference's PROGRAM_BUDGET) forces the out-of-core scheme: row blocks
+        # transposed in HBM into temporary files, column blocks merged
+        env = dict(os.environ, BOF_ODIRECT=odirect, BOF_HBM_BUDGET=budget)
         r1 = subprocess.run([drv, p["A.csr"], p["A.col"], p["A.off"], q["T.csr"], q["T.col"], q["T.off"], str(m), str(n)],
                             capture_output=True, text=True, env=env)
         r2 = subprocess.run([drv, q["T.csr"], q["T.col"], q["T.off"], q["U.csr"], q["U.col"], q["U.off"], str(n), str(m)],
                             capture_output=True, text=True, env=env)
         back = {"A.csr": sha(q["U.csr"]), "A.col": sha(q["U.col"]), "A.off": sha(q["U.off"])}
         print(json.dumps({"what": "csrcsc_driver end to end (cfg3 files), A -> A^T -> A", "odirect": int(odirect),
+                          "hbm_budget": int(budget),
                           "rc": [r1.returncode, r2.returncode], "csrcsc_took_s": [took(r1.stdout, "csrcsc() took"),
                                                                                   took(r2.stdout, "csrcsc() took")],
                           "transpose_of_transpose_equals_input": back == orig,
