@@ -35,6 +35,8 @@ hipError_t scsrgemv(char, int64_t, int64_t, const float *, const int64_t *, cons
 hipError_t transpose_f32(const float *, int64_t, int64_t, int64_t, float *, int64_t, hipStream_t) {
   return hipErrorUnknown;
 }
+hipError_t csc_merge(int, int64_t, const int64_t *, const int64_t *, const int64_t *, const int64_t *, const float *,
+                     const int64_t *, float *, int64_t *, hipStream_t) { return hipErrorUnknown; }
 hipError_t scsrcsc(int64_t, int64_t, int64_t, const float *, const int64_t *, const int64_t *, float *,
                    int64_t *, int64_t *, void *, hipStream_t) { return hipErrorUnknown; }
 }  // namespace bof
