@@ -1350,10 +1350,43 @@ static int flash_csrmm_trans(uint64_t m, uint64_t n, uint64_t k, float alpha, fl
   if (n == 0) return BOF_OK;
   const bof_options o = resolved(opts);
   Counters cnt;
+  bof_fptr none{-1, 0};
+  {
+    // A^T + the sort workspace must fit beside B and the block contexts; if they do not, A^T goes
+    // to temporary files through the out-of-core transposition and the ordinary file pipeline
+    // of the 'N' case runs on those (what the reference intends, src/blas/csrmm.cpp:355-386)
+    std::vector<int64_t> iav((size_t) m + 1, 0);
+    if (m > 0) {
+      const int io = read_host(ia, (uint64_t) (m + 1) * 8, iav.data(), o.use_odirect != 0);
+      if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
+    }
+    const int64_t nnz = iav[(size_t) m] - iav[0];
+    size_t free_b = 0, total_b = 0;
+    BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = o.hbm_budget > 0 ? std::min((size_t) o.hbm_budget, (size_t) (free_b * 0.9)) : (size_t) (free_b * 0.9);
+    const size_t need = (size_t) std::max<int64_t>(nnz, 0) * 24 + (size_t) (m + n + 2) * 8 +
+                        csrcsc_workspace_bytes((int64_t) n, std::max<int64_t>(nnz, 0)) + (size_t) m * k * 4;
+    if (nnz > 0 && need > budget) {
+      const int anchor = c.fd >= 0 ? c.fd : a.fd;
+      const int t_ia = temp_file_near(anchor), t_ja = temp_file_near(anchor), t_a = temp_file_near(anchor);
+      Cleanup guard;
+      guard.add([&] {
+        for (int fd : {t_ia, t_ja, t_a})
+          if (fd >= 0) { file_forget(fd); close(fd); }
+      });
+      if (t_ia < 0 || t_ja < 0 || t_a < 0) { set_error("csrmm 'T': cannot create temporary files"); return BOF_EIO; }
+      bof_options plain = o;
+      plain.use_odirect = 0;   // the temporaries are buffered descriptors
+      rc = flash_csrcsc_blocked((int64_t) m, (int64_t) n, iav, ja, a, bof_fptr{t_ia, 0}, bof_fptr{t_ja, 0},
+                                bof_fptr{t_a, 0}, plain, budget, cnt);
+      if (rc) return rc;
+      return flash_csr_impl(true, 'N', (int64_t) n, (int64_t) m, (int64_t) k, alpha, beta, bof_fptr{t_a, 0},
+                            bof_fptr{t_ia, 0}, bof_fptr{t_ja, 0}, ord_b, b, c, hb, hc, opts, nullptr, &cnt);
+    }
+  }
   ResidentCsr T;
   rc = flash_transpose_to_hbm((int64_t) m, (int64_t) n, a, ia, ja, o, cnt, T);
   if (rc) return rc;
-  bof_fptr none{-1, 0};
   return flash_csr_impl(true, 'N', (int64_t) n, (int64_t) m, (int64_t) k, alpha, beta, none, none, none,
                         ord_b, b, c, hb, hc, opts, &T, &cnt);
 }

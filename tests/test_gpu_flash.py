@@ -264,9 +264,10 @@ def test_flash_csrcsc(dev, tmp_path, golden_tr, direct, budget):
         F.close()
 
 
+@pytest.mark.parametrize("budget", [0, 4 << 20])
 @pytest.mark.parametrize("ord_b,k,alpha,beta", [("R", 128, 1.0, 0.0), ("R", 1030, 0.5, 2.0),
                                                ("C", 128, 0.5, 2.0), ("C", 1030, 1.0, 0.0)])
-def test_flash_csrmm_trans(dev, tmp_path, golden_tr, ord_b, k, alpha, beta):
+def test_flash_csrmm_trans(dev, tmp_path, golden_tr, ord_b, k, alpha, beta, budget):
     """csrmm trans_a='T' on files: C[n x k] = alpha A^T B[m x k] + beta C (the reference's path
     is broken; the oracle is mkl_scsrmm('T')-pinned)."""
     import hashlib
@@ -282,7 +283,9 @@ def test_flash_csrmm_trans(dev, tmp_path, golden_tr, ord_b, k, alpha, beta):
     bs, cs = (np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)) if ord_b == "C" else (b, c0)
     F = Files(tmp_path, val=val, ja=ja, ia=ia, b=bs, c=cs)
     try:
-        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=300, n_io_threads=2)
+        # budget > 0: A^T does not "fit" -> out-of-core transposition into temporary files, then
+        # the ordinary file pipeline of the 'N' case on them
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=300, n_io_threads=2, hbm_budget=budget)
         bofhip.flash_csrmm("T", m, n, k, alpha, beta, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
                            ord_b, F.fptr("b"), F.fptr("c"), opts)
         got = F.read("c", np.float32, cs.shape)
