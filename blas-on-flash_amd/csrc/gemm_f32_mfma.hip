@@ -253,153 +253,8 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
 // work of a slab (operand reads for the NEXT k-group, LDS staging writes of slab kt+1,
 // global loads of slab kt+2) is cut into 16 slots, one after each batch of 16 MFMAs, so the
 // in-order issue stream never leaves the matrix pipe waiting on it.
-template <int AMODE, int BMODE, bool W, bool L, int ABL = 0>
-__device__ __forceinline__ void slab_1w(const float *__restrict__ sA, const float *__restrict__ sB,
-                                        float *__restrict__ nA, float *__restrict__ nB,
-                                        const float *__restrict__ A, int64_t lda,
-                                        const float *__restrict__ B, int64_t ldb, int m0, int n0,
-                                        int k2, int M, int N, int K, Stage<8> &ra, Stage<8> &rb,
-                                        f32x16 (&acc)[4][4], int t, int arow, int bcol, int h) {
-  f32x4 a[2][4], b[2][4];
-#pragma unroll
-  for (int x = 0; x < 4; x++) {
-    a[0][x] = s2op<AMODE, 256>(sA, arow + x * 32, 0, h);
-    b[0][x] = s2op<BMODE, 256>(sB, bcol + x * 32, 0, h);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-#pragma unroll
-      for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
-                                                             acc[mt][nt], 0, 0, 0);
-      // ---- side slot s = 4q + c ------------------------------------------------------
-      if (q < 3 && c < 3) {  // the next k-group's operand fragments: quarters {0,1}, 2, 3 in slots
-                             // 0, 1, 2, so the last one is issued a full MFMA batch before its use
-#pragma unroll
-        for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
-          if (ABL & 4) {  // dev ablation: no LDS operand reads
-            a[(q + 1) & 1][x] = a[q & 1][x] + 1.0f;
-            b[(q + 1) & 1][x] = b[q & 1][x] + 1.0f;
-          } else {
-            a[(q + 1) & 1][x] = s2op<AMODE, 256>(sA, arow + x * 32, q + 1, h);
-            b[(q + 1) & 1][x] = s2op<BMODE, 256>(sB, bcol + x * 32, q + 1, h);
-          }
-        }
-      }
-      const int s = 4 * q + c;
-      // slot s stages float4 #s of slab kt+1 into LDS and refills its registers from slab kt+2
-      // (refilling two slots later instead was measured slower)
-      if (s < 8) {
-        if (W && !(ABL & 1)) r2s1<AMODE, 256>(nA, ra.v[s], t + s * 256);
-        if ((ABL & 1) && W) asm volatile("" ::"v"(ra.v[s]));  // dev ablation: keep the load alive
-        if (L && !(ABL & 2)) ra.v[s] = g2r1<AMODE, 256, false>(A, lda, m0, k2, M, K, t + s * 256);
-      } else {
-        if (W && !(ABL & 1)) r2s1<BMODE, 256>(nB, rb.v[s - 8], t + (s - 8) * 256);
-        if ((ABL & 1) && W) asm volatile("" ::"v"(rb.v[s - 8]));
-        if (L && !(ABL & 2)) rb.v[s - 8] = g2r1<BMODE, 256, false>(B, ldb, n0, k2, N, K, t + (s - 8) * 256);
-      }
-      // (Forcing exactly one memory instruction per MFMA gap with sched_group_barrier was
-      // measured: 136.4 vs 138.2 TFLOP/s without it -- hipcc's own interleave is kept.)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-template <int AMODE, int BMODE, int ABL = 0>
-__global__ void __launch_bounds__(256, 1)
-sgemm_tile256_1w_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
-                        int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
-                        float alpha, float beta, int tiles_m, int tiles_n) {
-  constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
-  constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
-  constexpr int LDS_BUF = LDS_A + LDS_B;
-  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_BUF];
-
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  constexpr int GROUP_M = 4;
-  const int per_group = GROUP_M * tiles_n;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (bid % per_group) % gsz;
-  const int tn = (bid % per_group) / gsz;
-  const int m0 = tm * 256, n0 = tn * 256;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int arow = wm * 128 + i, bcol = wn * 128 + i;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-
-  const int nkt = K / BK;  // caller guarantees K % 32 == 0, nkt >= 2
-  Stage<8> ra = g2r<AMODE, 256, 256, false>(A, lda, m0, 0, M, K, t);
-  Stage<8> rb = g2r<BMODE, 256, 256, false>(B, ldb, n0, 0, N, K, t);
-  r2s<AMODE, 256, 256>(lds, ra, t);
-  r2s<BMODE, 256, 256>(lds + LDS_A, rb, t);
-  ra = g2r<AMODE, 256, 256, false>(A, lda, m0, BK, M, K, t);
-  rb = g2r<BMODE, 256, 256, false>(B, ldb, n0, BK, N, K, t);
-  __syncthreads();
-
-  int kt = 0;
-  for (; kt + 2 < nkt; kt++) {  // steady state: write slab kt+1, fetch slab kt+2
-    float *cur = lds + ((kt & 1) ? LDS_BUF : 0), *nxt = lds + ((kt & 1) ? 0 : LDS_BUF);
-    slab_1w<AMODE, BMODE, true, true, ABL>(cur, cur + LDS_A, nxt, nxt + LDS_A, A, lda, B, ldb, m0, n0,
-                                           (kt + 2) * BK, M, N, K, ra, rb, acc, t, arow, bcol, h);
-    if (!(ABL & 8)) __syncthreads();
-  }
-  {  // slab nkt-2: write the last slab, nothing left to fetch
-    float *cur = lds + ((kt & 1) ? LDS_BUF : 0), *nxt = lds + ((kt & 1) ? 0 : LDS_BUF);
-    slab_1w<AMODE, BMODE, true, false>(cur, cur + LDS_A, nxt, nxt + LDS_A, A, lda, B, ldb, m0, n0, 0,
-                                       M, N, K, ra, rb, acc, t, arow, bcol, h);
-    __syncthreads();
-    kt++;
-  }
-  {  // last slab
-    float *cur = lds + ((kt & 1) ? LDS_BUF : 0), *nxt = lds + ((kt & 1) ? 0 : LDS_BUF);
-    slab_1w<AMODE, BMODE, false, false>(cur, cur + LDS_A, nxt, nxt + LDS_A, A, lda, B, ldb, m0, n0,
-                                        0, M, N, K, ra, rb, acc, t, arow, bcol, h);
-  }
-
-  float *ctile = C + (int64_t) m0 * ldc + n0;
-  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
-#pragma unroll
-  for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
-      f32x16 old;
-      if (beta != 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
-      }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Variant 2 of the one-wave-per-SIMD kernel: identical data flow, but every address in the
+//
+// Variant 2 (the first version computed its addresses per access): every address in the
 // slab loop is "per-thread base register + compile-time constant" (LDS: `offset:` immediates;
 // global: uniform SGPR base + 32-bit per-thread byte offset), so a side slot contains memory
 // instructions only, no address VALU.  A VMEM/LDS instruction costs ~40-60 issue cycles; with
@@ -1205,7 +1060,8 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   //   3: one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (143.3 TFLOP/s at
   //      4096^3), every other layout through variant 2 (140.6-141.3)
   //   2: one wave per SIMD, register staging, constant-offset addressing
-  //   1: as 2 with per-access address arithmetic (138.5)      0: 8 waves, 2 per SIMD (137-138)
+  //   0: 8 waves, 2 per SIMD (137-138)   (a variant 1 -- variant 2 with per-access address
+  //      arithmetic, 138.5 -- existed earlier in the round)
   static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 4;
 
   // Ragged sizes (tail-merged tiles of 4096+r, unaligned problem edges): the largest
@@ -1245,13 +1101,6 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
                                        beta, st);
     }
     return e;
-  }
-  if (big_tile_variant == 1 && vec_ok && M % 256 == 0 && N % 256 == 0 && K >= 2 * BK &&
-      (int64_t) (M / 256) * (N / 256) >= 128) {
-    const int tiles_m = M / 256, tiles_n = N / 256;
-    hipLaunchKernelGGL((sgemm_tile256_1w_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0,
-                       st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
-    return hipGetLastError();
   }
   if (vec_ok && M % 256 == 0 && N % 256 == 0 && (int64_t) (M / 256) * (N / 256) >= 128) {
     const int tiles_m = M / 256, tiles_n = N / 256;

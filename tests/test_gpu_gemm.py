@@ -85,7 +85,7 @@ def test_sgemm_bit_exact_vs_oracle(dev, ord_, ta, tb, m, n, k, alpha, beta):
     assert rel_err(gotl, full) < TOL
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["0", "2", "3"])
 def test_sgemm_big_tile_other_variants_subprocess(dev, variant):
     """The non-default shapes of the 256x256 kernel (BOF_GEMM_VARIANT, read once at library
     load) stay bit-exact too; each is checked in a child process."""
