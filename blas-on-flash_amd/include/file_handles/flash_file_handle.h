@@ -1,7 +1,8 @@
-// flash_file_handle.h -- file-backed BaseFileHandle (reference
-// include/file_handles/flash_file_handle.h:21-76).  I/O goes through
-// libbof_hip.so's reader (bof_file_sread/bof_file_swrite): kernel AIO on an
-// O_DIRECT descriptor for sector-aligned requests, buffered otherwise.
+// flash_file_handle.h -- the file-backed BaseFileHandle (reference
+// include/file_handles/flash_file_handle.h:21-76: same class name, same public members
+// file_sz / file_desc / get_filename / register_thread / deregister_thread).
+// Transfers go through libbof_hip.so's reader (bof_file_sread / bof_file_swrite): kernel AIO on
+// an O_DIRECT descriptor for sector-aligned requests, the page cache for everything else.
 #pragma once
 #include <string>
 
@@ -10,34 +11,32 @@
 
 namespace flash {
   class FlashFileHandle : public BaseFileHandle {
-    std::string filename;
-
    public:
-    FBLAS_UINT file_sz;
-    int file_desc;
+    FBLAS_UINT file_sz;  // bytes, as found (or created) by open()
+    int file_desc;       // what libbof_hip.so's level-3 entry points take (bof_fptr.fd)
 
     FlashFileHandle();
-    ~FlashFileHandle();
+    ~FlashFileHandle() override;
 
-    // AIO contexts are created lazily per calling thread; kept for API compatibility
+    std::string get_filename() { return filename; }
+
+    // The reference needs every I/O thread to create an AIO context first; here contexts are
+    // made lazily per calling thread, so these two are accepted and do nothing.
     static void register_thread();
     static void deregister_thread();
 
-    std::string get_filename() { return this->filename; }
+    FBLAS_INT sread(FBLAS_UINT offset, StrideInfo sinfo, void* buf, const IoCallback& callback = dummy_std_func) override;
+    FBLAS_INT swrite(FBLAS_UINT offset, StrideInfo sinfo, void* buf, const IoCallback& callback = dummy_std_func) override;
+    FBLAS_INT scopy(FBLAS_UINT self_offset, BaseFileHandle& dest, FBLAS_UINT dest_offset, StrideInfo sinfo,
+                    const IoCallback& callback = dummy_std_func) override;
+    FBLAS_INT read(FBLAS_UINT offset, FBLAS_UINT len, void* buf, const IoCallback& callback = dummy_std_func) override;
+    FBLAS_INT write(FBLAS_UINT offset, FBLAS_UINT len, void* buf, const IoCallback& callback = dummy_std_func) override;
+    FBLAS_INT copy(FBLAS_UINT self_offset, BaseFileHandle& dest, FBLAS_UINT dest_offset, FBLAS_UINT len,
+                   const IoCallback& callback = dummy_std_func) override;
+    FBLAS_INT open(std::string& fname, Mode fmode, FBLAS_UINT size = 0) override;
+    FBLAS_INT close() override;
 
-    FBLAS_INT open(std::string& fname, Mode fmode, FBLAS_UINT size = 0);
-    FBLAS_INT close();
-    FBLAS_INT read(FBLAS_UINT offset, FBLAS_UINT len, void* buf,
-                   const std::function<void(void)>& callback = dummy_std_func);
-    FBLAS_INT write(FBLAS_UINT offset, FBLAS_UINT len, void* buf,
-                    const std::function<void(void)>& callback = dummy_std_func);
-    FBLAS_INT copy(FBLAS_UINT self_offset, BaseFileHandle& dest, FBLAS_UINT dest_offset,
-                   FBLAS_UINT len, const std::function<void(void)>& callback = dummy_std_func);
-    FBLAS_INT sread(FBLAS_UINT offset, StrideInfo sinfo, void* buf,
-                    const std::function<void(void)>& callback = dummy_std_func);
-    FBLAS_INT swrite(FBLAS_UINT offset, StrideInfo sinfo, void* buf,
-                     const std::function<void(void)>& callback = dummy_std_func);
-    FBLAS_INT scopy(FBLAS_UINT self_offset, BaseFileHandle& dest, FBLAS_UINT dest_offset,
-                    StrideInfo sinfo, const std::function<void(void)>& callback = dummy_std_func);
+   private:
+    std::string filename;
   };
 }  // namespace flash
