@@ -186,3 +186,24 @@ def test_csrcsc_involution_at_scale(dev):
     bofhip.scsrcsc(n, m, nnz, ptr(vt), ptr(pt), ptr(ct), ptr(v2), ptr(p2), ptr(c2), stream())
     torch.cuda.synchronize()
     assert torch.equal(p2, off) and torch.equal(c2, col) and torch.equal(v2, val)
+
+
+@pytest.mark.parametrize("nnz_target", [1, 63, 64, 65, 4095, 4096, 4097, 8192])
+def test_csrcsc_tile_boundaries(dev, nnz_target):
+    """Non-zero counts around the 64-record chunk and the 4096-record tile of the sort (one entry,
+    one short of / exactly / one past a boundary), including a dense single row and single column."""
+    rng = np.random.default_rng(nnz_target)
+    for (m, n) in [(max(1, nnz_target // 7 + 1), 50), (1, nnz_target), (nnz_target, 1)]:
+        cap = m * n
+        want_nnz = min(nnz_target, cap)
+        flat = np.sort(rng.choice(cap, want_nnz, replace=False))
+        rows, cols = flat // n, flat % n
+        ia = np.zeros(m + 1, np.int64)
+        np.add.at(ia, rows + 1, 1)
+        ia = np.cumsum(ia)
+        ja = cols.astype(np.int64)
+        val = rng.uniform(-1, 1, want_nnz).astype(np.float32)
+        want = orc.csrcsc(m, n, val, ia, ja)
+        got = gpu_csrcsc(m, n, val, ia, ja)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), (m, n, want_nnz)
