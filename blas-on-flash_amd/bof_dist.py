@@ -89,10 +89,15 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     # --- B: this rank's k-row panel from the file, then all-gather ---------------------------
     per = (k + world - 1) // world
     k0, k1 = min(k, rank * per), min(k, (rank + 1) * per)
-    panel = torch.zeros(per * ldb, dtype=torch.float32, device=dev)
+    # torch.empty: no fill kernel is queued on torch's stream that could land on top of the data
+    # the library's private copy stream writes; only what the file does not cover is zeroed, and
+    # the transfer itself is ordered behind `st` (bof_file_to_device's stream argument)
+    panel = torch.empty(per * ldb, dtype=torch.float32, device=dev)
+    nbytes = ((k1 - k0 - 1) * ldb + n) * 4 if k1 > k0 else 0   # the last row may end before a full ldb
+    if nbytes < panel.numel() * 4:
+        panel[nbytes // 4:].zero_()
     if k1 > k0:
-        nbytes = ((k1 - k0 - 1) * ldb + n) * 4          # the last row may end before a full ldb
-        bofhip.file_to_device(bofhip.FPtr(fd_b, k0 * ldb * 4), nbytes, panel.data_ptr(), o)
+        bofhip.file_to_device(bofhip.FPtr(fd_b, k0 * ldb * 4), nbytes, panel.data_ptr(), o, st)
         rd += nbytes
     if world > 1:
         full = torch.empty(world * per * ldb, dtype=torch.float32, device=dev)
@@ -109,18 +114,18 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     if rows > 0:
         a_dev = torch.empty(rows * lda, dtype=torch.float32, device=dev)
         a_bytes = ((rows - 1) * lda + k) * 4
-        bofhip.file_to_device(bofhip.FPtr(fd_a, r0 * lda * 4), a_bytes, a_dev.data_ptr(), o)
+        bofhip.file_to_device(bofhip.FPtr(fd_a, r0 * lda * 4), a_bytes, a_dev.data_ptr(), o, st)
         rd += a_bytes
-        c_dev = torch.zeros(rows * ldc, dtype=torch.float32, device=dev)
+        c_dev = torch.empty(rows * ldc, dtype=torch.float32, device=dev)
         c_bytes = ((rows - 1) * ldc + n) * 4
         if beta != 0.0 or ldc != n:       # padded rows: keep what lies between the row ends
-            bofhip.file_to_device(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o)
+            bofhip.file_to_device(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o, st)
             rd += c_bytes
-        torch.cuda.synchronize(dev)
+        # (the transfers above are blocking: the slabs are complete before the DAG is queued;
+        #  the write-back below is ordered behind the DAG through its stream argument)
         bofhip.gemm_resident("R", "N", "N", rows, n, k, alpha, beta, a_dev.data_ptr(), b_dev.data_ptr(),
                              c_dev.data_ptr(), lda, ldb, ldc, o, st)
-        torch.cuda.synchronize(dev)
-        bofhip.device_to_file(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o)
+        bofhip.device_to_file(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o, st)
         wr += c_bytes
     stats["bytes_read"], stats["bytes_written"] = rd, wr
     return stats

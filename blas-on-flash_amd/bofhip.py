@@ -82,14 +82,15 @@ SYMBOLS = [
     ("bof_flash_csrmm_inmem", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, P, P,
                                         C.POINTER(Options)]),
     ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
-    ("bof_file_to_device", C.c_int, [FPtr, u64, P, C.POINTER(Options)]),
-    ("bof_device_to_file", C.c_int, [FPtr, u64, P, C.POINTER(Options)]),
+    ("bof_file_to_device", C.c_int, [FPtr, u64, P, C.POINTER(Options), P]),
+    ("bof_device_to_file", C.c_int, [FPtr, u64, P, C.POINTER(Options), P]),
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
     ("bof_flash_release", C.c_int, []),
     ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
                                           C.c_int32, C.POINTER(FlashStats)]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
+    ("bof_file_forget", C.c_int, [C.c_int]),
     ("bof_gen_dense", C.c_int, [P, i64, i64, chr_, u64, P]),
     ("bof_gen_sparse_rows", C.c_int, [i64, i64, i64, i64, P, P, P, P]),
 ]
@@ -245,12 +246,15 @@ def flash_csrgemv(trans_a, m, n, fa, fia, fja, b_host, c_host, opts=None):
           "bof_flash_csrgemv")
 
 
-def file_to_device(f, nbytes, dptr, opts=None):
-    check(lib().bof_file_to_device(f, nbytes, dptr, C.byref(opts) if opts is not None else None), "bof_file_to_device")
+def file_to_device(f, nbytes, dptr, opts=None, stream=0):
+    """Blocking; ordered behind the work already queued on `stream` (raw hipStream_t)."""
+    check(lib().bof_file_to_device(f, nbytes, dptr, C.byref(opts) if opts is not None else None, stream),
+          "bof_file_to_device")
 
 
-def device_to_file(f, nbytes, dptr, opts=None):
-    check(lib().bof_device_to_file(f, nbytes, dptr, C.byref(opts) if opts is not None else None), "bof_device_to_file")
+def device_to_file(f, nbytes, dptr, opts=None, stream=0):
+    check(lib().bof_device_to_file(f, nbytes, dptr, C.byref(opts) if opts is not None else None, stream),
+          "bof_device_to_file")
 
 
 def flash_gemm_simulate(ord_, ta, tb, m, n, k, beta, blk, n_slots, lookahead=16, lda=0, ldb=0, ldc=0):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "bof_hip.h"
@@ -79,5 +80,10 @@ struct StreamSet {
 StreamSet *stream_set(int n_streams);  // per-device singleton
 
 bof_options resolved(const bof_options *o);
+
+// Level-2 and level-3 entry points share per-device state (stream set, scratch slots, pinned
+// rings, the HBM tile slab): host threads entering them on one device are serialised for the
+// whole call.  Recursive: csrmm 'T' re-enters the 'N' path.
+std::recursive_mutex &device_call_mutex();
 
 }  // namespace bof

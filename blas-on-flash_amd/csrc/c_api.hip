@@ -229,6 +229,7 @@ int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   const bof_options o = resolved(opts);
   GemmGeometry g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
   if (g.nblk[0] * g.nblk[2] == 0) return BOF_OK;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   StreamSet *ss = stream_set(o.n_streams);
   if (!ss) { set_error("bof_gemm_resident: no HIP device / stream creation failed"); return BOF_ENODEV; }
   hipStream_t parent = (hipStream_t) stream;
@@ -301,6 +302,7 @@ int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alph
     set_error("bof_csrmm_resident: bad argument");
     return BOF_EINVAL;
   }
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   if (trans_a == 'T') {
     // C[n x k] = alpha * A^T * B[m x k] + beta * C.  The reference transposes A with csrcsc
     // into temporary files and runs the 'N' path on them (src/blas/csrmm.cpp:355-422, with
@@ -387,6 +389,7 @@ int bof_csrgemv_resident(char trans_a, int64_t m, int64_t n, const float *val,
     set_error("bof_csrgemv_resident: bad argument");
     return BOF_EINVAL;
   }
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   const bof_options o = resolved(opts);
   hipStream_t parent = (hipStream_t) stream;
   if (trans_a == 'T' && m > 0 && m <= INT32_MAX && n <= INT32_MAX) {

@@ -61,14 +61,17 @@ static int aio_run(std::vector<struct iocb> &cbs) {
   std::vector<struct io_event> evs(kAioEvents);
   size_t submitted = 0, done = 0;
   int retries = 0;
-  while (done < cbs.size()) {
+  int first_err = 0;  // once set nothing new is submitted, but everything in flight is reaped:
+                      // the context is per thread and outlives this call, and the kernel may
+                      // still be writing into the caller's buffer (and into `cbs`)
+  while (done < submitted || (!first_err && submitted < cbs.size())) {
     const size_t inflight = submitted - done;
-    if (submitted < cbs.size() && inflight < kAioEvents) {
+    if (!first_err && submitted < cbs.size() && inflight < kAioEvents) {
       const long want = (long) std::min<size_t>(cbs.size() - submitted, kAioEvents - inflight);
       long r = syscall(SYS_io_submit, c.ctx, want, ptrs.data() + submitted);
       if (r < 0) {
         if ((errno == EAGAIN || errno == EINTR) && ++retries <= kIoRetries) continue;
-        if (inflight == 0) return -errno;
+        if (inflight == 0 || errno != EAGAIN) first_err = -errno;
       } else {
         submitted += (size_t) r;
       }
@@ -78,17 +81,23 @@ static int aio_run(std::vector<struct iocb> &cbs) {
                        evs.data(), nullptr);
       if (r < 0) {
         if (errno == EINTR) continue;
-        return -errno;
+        // the context itself is unusable: replace it so that stale completions can never be
+        // delivered to a later call (io_destroy cancels / waits for what is still in flight)
+        const int e = -errno;
+        syscall(SYS_io_destroy, c.ctx);
+        c.ctx = 0;
+        c.ok = (syscall(SYS_io_setup, kAioEvents, &c.ctx) == 0);
+        return first_err ? first_err : e;
       }
       for (long i = 0; i < r; i++) {
         const struct iocb *cb = reinterpret_cast<const struct iocb *>(evs[i].obj);
-        if ((int64_t) evs[i].res < 0) return (int) evs[i].res;
-        if ((uint64_t) evs[i].res != cb->aio_nbytes) return -EIO;  // short transfer
+        if ((int64_t) evs[i].res < 0) { if (!first_err) first_err = (int) evs[i].res; }
+        else if ((uint64_t) evs[i].res != cb->aio_nbytes) { if (!first_err) first_err = -EIO; }  // short transfer
       }
       done += (size_t) r;
     }
   }
-  return 0;
+  return first_err;
 }
 
 // ---- buffered twin of an O_DIRECT descriptor ---------------------------------------
@@ -192,6 +201,10 @@ int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, ui
 
 }  // namespace bof
 
+extern "C" int bof_file_forget(int fd) {
+  bof::file_forget(fd);
+  return BOF_OK;
+}
 extern "C" int bof_file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
                               uint64_t len_per_stride, void *buf, int use_aio) {
   const int rc = bof::file_sread(fd, offset, stride, n_strides, len_per_stride, buf, use_aio != 0);

@@ -44,6 +44,13 @@
 
 namespace bof {
 
+static std::recursive_mutex g_call_mu[64];
+std::recursive_mutex &device_call_mutex() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = 0; }
+  return g_call_mu[dev & 63];
+}
+
 static bof_flash_stats g_last_stats;
 static std::mutex g_stats_mu;
 
@@ -329,6 +336,17 @@ struct GemmRun {
 
   size_t tile_bytes(const Tile &t) const { return (size_t) t.nrows * t.ncols * sizeof(float); }
 
+  // first error wins; stored under the mutex the waiters hold while they test it, so the
+  // wake-up cannot fall between their test and their wait
+  void fail_io(int code) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      int none = 0;
+      io_error.compare_exchange_strong(none, code);
+    }
+    cv.notify_all();
+  }
+
   void reader_main() {
     (void) hipSetDevice(dev);
     FetchReq rq;
@@ -339,7 +357,7 @@ struct GemmRun {
       if (!io_error.load())
         rc = file_sread(f[t.mat].fd, f[t.mat].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
                         (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->rring.ptr(ps), use_aio);
-      if (rc) io_error.store(rc);
+      if (rc) fail_io(rc);
       cnt.rd += tile_bytes(t);
       DevSlot &s = slots[rq.slot];
       hipError_t e = hipSuccess;
@@ -349,7 +367,7 @@ struct GemmRun {
         e = hipMemcpyAsync(s.ptr, res->rring.ptr(ps), tile_bytes(t), hipMemcpyHostToDevice, h2d);
       if (e == hipSuccess) e = hipEventRecord(s.ready, h2d);
       if (e == hipSuccess) res->rring.mark_busy(ps, h2d);
-      if (e != hipSuccess) io_error.store(-1000 - (int) e);
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
       cnt.h2d += tile_bytes(t);
       res->rring.release(ps);
       { std::lock_guard<std::mutex> lk(mu); t.state = 2; }
@@ -363,12 +381,12 @@ struct GemmRun {
     while (write_q.pop(rq)) {
       Tile &t = tiles[rq.tile];
       hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
-      if (e != hipSuccess) io_error.store(-1000 - (int) e);
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
       int rc = 0;
       if (!io_error.load())
         rc = file_swrite(f[2].fd, f[2].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
                          (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->wring.ptr(rq.wslot), use_aio);
-      if (rc) io_error.store(rc);
+      if (rc) fail_io(rc);
       cnt.wr += tile_bytes(t);
       res->wring.release(rq.wslot);
     }
@@ -420,6 +438,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   GemmRun R;
   R.o = resolved(opts);
   R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
@@ -652,6 +671,15 @@ struct CsrRun {
   int dev = 0;
   bool use_aio = true;
 
+  void fail_io(int code) {  // see GemmRun::fail_io
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      int none = 0;
+      io_error.compare_exchange_strong(none, code);
+    }
+    cv.notify_all();
+  }
+
   uint64_t fsize_ja = 0, fsize_a = 0;
   // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
   // end of the file (the last sector of a file is usually partial)
@@ -717,8 +745,8 @@ struct CsrRun {
       if (!rc && e == hipSuccess) e = hipEventRecord(c.ready, h2d);
       // the pinned buffers are reused only after this block retires (owner hand-over),
       // which is after its kernels, which wait for these copies
-      if (rc) io_error.store(rc);
-      if (e != hipSuccess) io_error.store(-1000 - (int) e);
+      if (rc) fail_io(rc);
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
       { std::lock_guard<std::mutex> lk(mu); c.state = 1; }
       cv.notify_all();
     }
@@ -731,7 +759,7 @@ struct CsrRun {
     while (done_q.pop(b)) {
       CsrCtx &c = ctx[b % depth];
       hipError_t e = hipEventSynchronize(c.done);
-      if (e != hipSuccess) io_error.store(-1000 - (int) e);
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
       if (is_mm && !io_error.load() && host_c) {
         if (ord_b == 'R') memcpy(host_c + (size_t) st[b] * k, c.h_c, c_bytes(b));
         else
@@ -744,7 +772,7 @@ struct CsrRun {
         else
           rc = file_swrite(fc.fd, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
                            (uint64_t) sz[b] * 4, c.h_c, use_aio);
-        if (rc) io_error.store(rc);
+        if (rc) fail_io(rc);
         cnt.wr += c_bytes(b);
       }
       { std::lock_guard<std::mutex> lk(mu); c.owner = b + depth; c.state = 0; }
@@ -1080,6 +1108,7 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   const bof_options o = resolved(opts);
   Counters cnt;
   {
@@ -1131,6 +1160,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   CsrRun R;
   if (carry) {  // bytes moved by the transposition that produced `res`
     R.cnt.rd += carry->rd.load(); R.cnt.h2d += carry->h2d.load(); R.cnt.d2h += carry->d2h.load();
@@ -1318,8 +1348,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     R.cnt.tasks++;
     R.done_q.push(b);
   }
-  if (herr != hipSuccess || fail) R.io_error.store(R.io_error.load() ? R.io_error.load() : -EIO);
-  R.cv.notify_all();
+  if (herr != hipSuccess || fail) R.fail_io(-EIO);  // releases readers parked on a context hand-over
   for (auto &th : readers) th.join();
   R.done_q.close();
   retire.join();
@@ -1347,6 +1376,7 @@ static int flash_csrmm_trans(uint64_t m, uint64_t n, uint64_t k, float alpha, fl
                              const float *hb, float *hc, const bof_options *opts) {
   int rc = device_ready();
   if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   if (n == 0) return BOF_OK;
   const bof_options o = resolved(opts);
   Counters cnt;
@@ -1529,27 +1559,39 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
   return BOF_OK;
 }
 
-static int region_transfer(bof_fptr f, uint64_t bytes, void *dptr, bool to_device, const bof_options *opts) {
+static int region_transfer(bof_fptr f, uint64_t bytes, void *dptr, bool to_device, const bof_options *opts,
+                           void *after) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   if (f.fd < 0 || (!dptr && bytes)) { set_error("bof_file_to_device / bof_device_to_file: bad argument"); return BOF_EINVAL; }
   const bof_options o = resolved(opts);
   hipStream_t st = nullptr;
+  hipEvent_t ev = nullptr;
   BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  Cleanup guard;
+  guard.add([&] {
+    if (ev) (void) hipEventDestroy(ev);
+    (void) hipStreamDestroy(st);
+  });
+  // the private copy stream is non-blocking: order it behind whatever the caller has queued
+  // on `after` for this buffer (an allocator's fill kernel, the kernels that produced it)
+  BOF_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  BOF_HIP_TRY(hipEventRecord(ev, (hipStream_t) after));
+  BOF_HIP_TRY(hipStreamWaitEvent(st, ev, 0));
   Counters cnt;
   rc = stream_file(f, bytes, (char *) dptr, to_device, st, o.use_odirect != 0, o.n_io_threads, cnt);
   const hipError_t e = hipStreamSynchronize(st);
-  (void) hipStreamDestroy(st);
   if (!rc && e != hipSuccess) rc = hip_fail(e, "region transfer");
   publish_stats(cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   return rc;
 }
-int bof_file_to_device(bof_fptr f, uint64_t bytes, void *dptr, const bof_options *opts) {
-  return region_transfer(f, bytes, dptr, true, opts);
+int bof_file_to_device(bof_fptr f, uint64_t bytes, void *dptr, const bof_options *opts, void *stream) {
+  return region_transfer(f, bytes, dptr, true, opts, stream);
 }
-int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_options *opts) {
-  return region_transfer(f, bytes, const_cast<void *>(dptr), false, opts);
+int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_options *opts, void *stream) {
+  return region_transfer(f, bytes, const_cast<void *>(dptr), false, opts, stream);
 }
 
 int bof_flash_release(void) {

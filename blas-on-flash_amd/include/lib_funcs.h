@@ -73,16 +73,26 @@ namespace flash {
     if (!ok) GLOG_ERROR("flash_truncate: ftruncate failed, errno=", errno, " (", ::strerror(errno), ")");
   }
 
-  // scratch arrays backed by files in mnt_dir; names carry the pid and a serial number, so two
-  // allocations of one size never collide (they do in the reference)
+  // process-wide serial number of flash_malloc'ed files (one counter for every element type;
+  // defined in src/flash_api.cpp)
+  unsigned long next_flash_malloc_serial();
+
+  // scratch arrays backed by files in mnt_dir; names carry the pid and a process-wide serial
+  // number and the file is created exclusively, so two allocations never share a file (same-size
+  // unnamed allocations collide in the reference)
   template<typename T>
   flash_ptr<T> flash_malloc(FBLAS_UINT n_bytes, std::string opt_name = "") {
-    static unsigned long serial = 0;
     const FBLAS_UINT rounded = ROUND_UP(n_bytes == 0 ? 1 : n_bytes, 4096);
-    std::string path = mnt_dir + "tmp_";
-    if (!opt_name.empty()) path += opt_name + "_";
-    path += std::to_string(rounded) + "_" + std::to_string(::getpid()) + "_" + std::to_string(serial++);
-    const int fd = ::open(path.c_str(), O_CREAT | O_RDWR, 0666);
+    std::string stem = mnt_dir + "tmp_";
+    if (!opt_name.empty()) stem += opt_name + "_";
+    stem += std::to_string(rounded) + "_" + std::to_string(::getpid()) + "_";
+    std::string path;
+    int fd = -1;
+    for (int attempt = 0; attempt < 1000 && fd < 0; attempt++) {
+      path = stem + std::to_string(next_flash_malloc_serial());
+      fd = ::open(path.c_str(), O_CREAT | O_EXCL | O_RDWR, 0666);
+      if (fd < 0 && errno != EEXIST) break;
+    }
     const bool sized = fd >= 0 && ::ftruncate(fd, (off_t) rounded) == 0;
     if (fd >= 0) ::close(fd);
     if (!sized) GLOG_FATAL("flash_malloc(", path, ") failed, errno=", errno);

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -61,6 +62,10 @@ namespace flash {
     if (bof_set_device((int) dev) != BOF_OK) GLOG_FATAL("bof_set_device failed: ", bof_last_error());
   }
   void flash_destroy() { bof_flash_release(); }
+  unsigned long next_flash_malloc_serial() {
+    static std::atomic<unsigned long> serial{0};
+    return serial.fetch_add(1);
+  }
 
   // ---- utilities (src/utils.cpp in the reference) --------------------------------
   void alloc_aligned(void** ptr, size_t size, size_t align) {
@@ -108,6 +113,7 @@ namespace flash {
 
   FBLAS_INT FlashFileHandle::close() {
     if (this->file_desc >= 0) {
+      bof_file_forget(this->file_desc);  // the buffered twin of an O_DIRECT descriptor
       ::close(this->file_desc);
       this->file_desc = -1;
     }

@@ -25,6 +25,11 @@
  * Conventions: all integers 64-bit (reference builds with -DMKL_ILP64,
  * include/bof_types.h:11-28); CSR index and offset arrays are int64 exactly as
  * stored on disk; chars are 'N'/'T', 'R'/'C' as in the reference API.
+ * Threading: level-2 and level-3 calls share per-device state (compute streams, scratch,
+ * pinned staging rings, the HBM tile slab); the library serialises host threads that enter
+ * them on one device for the duration of the call.  Level-2 calls are asynchronous: two of
+ * them queued on DIFFERENT streams of one device may still overlap on the GPU and share
+ * scratch, so issue level-2 work for one device on one stream (or synchronise in between).
  * Every function returns BOF_OK (0) or a negative error code;
  * bof_last_error() gives the message.  Nothing here falls back to a CPU
  * implementation: without a usable HIP device the compute entry points fail
@@ -46,7 +51,7 @@ extern "C" {
 #define BOF_ENODEV (-4) /* no HIP device */
 #define BOF_ENOMEM (-5)
 
-#define BOF_ABI_VERSION 1
+#define BOF_ABI_VERSION 2
 
 /* ---- library ---------------------------------------------------------------- */
 int bof_abi_version(void);
@@ -210,9 +215,15 @@ int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a,
 /* A contiguous file region <-> HBM through the pinned rings of the level-3 reader
  * (n_io_threads workers, 32 MiB chunks; O_DIRECT AIO where the region is sector
  * aligned).  Building blocks of the multi-GPU file path (bof_dist.py): with 288 GB
- * per GPU a rank's A / C row slabs and the whole of B are simply made resident. */
-int bof_file_to_device(bof_fptr f, uint64_t bytes, void *dptr, const bof_options *opts);
-int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_options *opts);
+ * per GPU a rank's A / C row slabs and the whole of B are simply made resident.
+ * Blocking.  The copies run on a private stream that is first ordered behind the work already
+ * queued on `stream` (hipStream_t; NULL = the default stream), so a buffer that was just
+ * allocated-and-filled or produced by kernels on `stream` can be passed without a host-side
+ * synchronisation. */
+int bof_file_to_device(bof_fptr f, uint64_t bytes, void *dptr, const bof_options *opts,
+                       void *stream);
+int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_options *opts,
+                       void *stream);
 /* Counters of the last level-3 call (bytes moved per stage, seconds). */
 typedef struct {
   uint64_t bytes_read, bytes_written; /* file I/O                      */
@@ -241,6 +252,10 @@ int bof_file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
                    uint64_t len_per_stride, void *buf, int use_aio);
 int bof_file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
                     uint64_t len_per_stride, const void *buf, int use_aio);
+/* Unaligned requests on an O_DIRECT descriptor go through a cached buffered descriptor of
+ * the same file; call this before close(fd) so that it is closed too
+ * (FlashFileHandle::close does). */
+int bof_file_forget(int fd);
 
 /* ---- synthetic inputs generated in HBM (bench / tests) ---------------------- */
 /* misc/dense_create.cpp:28-37: mode 's' -> x[i] = (first+i) % 10, 'z' -> 0;
