@@ -241,6 +241,298 @@ def csr_secondary_sharded(bofhip, torch, dev, st, rank, n_gpus):
     return res
 
 
+# =====================================================================================
+# End-to-end legs: the SSD-resident configurations themselves (BASELINE configs[1], [2]).
+# Files are created under $BOF_BENCH_DIR / $TMPDIR, the library call is timed the way the
+# reference's drivers time it (wall clock around flash::gemm / flash::csrmm, flush included:
+# drivers/gemm.cpp:57-62, drivers/csrmm.cpp:62-65), and the WHOLE output file is verified.
+# =====================================================================================
+CFG3_C_SHA256 = "d08df7c04907bec66f4638df05ffe2bbfb447c2a01e2bc03e5e6fd1d8daf2382"
+
+
+def _open(path, direct):
+    if direct:
+        try:
+            return os.open(path, os.O_RDWR | os.O_DIRECT), True
+        except OSError:
+            pass
+    return os.open(path, os.O_RDWR), False
+
+
+def _fs_of(path):
+    best = ("", "?")
+    try:
+        rp = os.path.realpath(path)
+        for ln in open("/proc/mounts"):
+            f = ln.split()
+            if rp.startswith(f[1]) and len(f[1]) >= len(best[0]):
+                best = (f[1], f[2])
+    except OSError:
+        pass
+    return best[1]
+
+
+def _write_device_tensor(bofhip, t, path, direct, opts, st):
+    """HBM -> file through the library's own writer (n_io_threads workers, 32 MiB chunks);
+    O_DIRECT when the file system takes it, so the page cache holds nothing of the inputs."""
+    with open(path, "wb") as f:
+        f.truncate(t.numel() * t.element_size())
+    fd, is_direct = _open(path, direct)
+    try:
+        o = bofhip.default_options(n_io_threads=opts.n_io_threads, use_odirect=1 if is_direct else 0)
+        bofhip.device_to_file(bofhip.FPtr(fd, 0), t.numel() * t.element_size(), t.data_ptr(), o, st)
+        os.fsync(fd)
+    finally:
+        bofhip.lib().bof_file_forget(fd)
+        os.close(fd)
+
+
+def _drop_cache(paths):
+    for p in paths:
+        fd = os.open(p, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        finally:
+            os.close(fd)
+
+
+def _leg_summary(runs, flops, kernel_s, compulsory_rd, compulsory_wr, units):
+    best = min(runs, key=lambda r: r["seconds"])
+    s = best["seconds"]
+    st = best["stats"]
+    return {"seconds_all": [round(r["seconds"], 3) for r in runs], "seconds": round(s, 3),
+            "gflops": round(flops / s / 1e9, 1),
+            "read_GBps": round(st["bytes_read"] / s / 1e9, 2), "write_GBps": round(st["bytes_written"] / s / 1e9, 2),
+            "h2d_GBps": round(st["bytes_h2d"] / s / 1e9, 2), "d2h_GBps": round(st["bytes_d2h"] / s / 1e9, 2),
+            "read_amplification": round(st["bytes_read"] / compulsory_rd, 3),
+            "write_amplification": round(st["bytes_written"] / compulsory_wr, 3),
+            "read_requests": st["read_ops"], "write_requests": st["write_ops"],
+            "requests_per_unit": round((st["read_ops"] + st["write_ops"]) / max(units, 1), 1),
+            "overlap_kernel_over_e2e": round(kernel_s / s, 3) if kernel_s else None}
+
+
+def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps):
+    """cfg2 through bof_flash_gemm on three n*n*4-byte files (A, B mode 's'; C zeros)."""
+    import numpy as np
+    nbytes = n * n * 4
+    pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
+    wopts = bofhip.default_options(n_io_threads=io_threads)
+    t0 = time.perf_counter()
+    t = torch.empty(n * n, dtype=torch.float32, device=dev)
+    for path in (pa, pb):
+        bofhip.gen_dense(t.data_ptr(), 0, n * n, "s", 0, st)          # dense_create mode s
+        _write_device_tensor(bofhip, t, path, True, wopts, st)
+    t.zero_()
+    _write_device_tensor(bofhip, t, pc, True, wopts, st)                # dense_create mode z
+    create_s = time.perf_counter() - t0
+    # closed form (SURVEY App. A-3): C[i,j] depends on (i mod 10, j mod 10) only
+    ii = np.arange(10, dtype=np.int64)[:, None]
+    kk = np.arange(n, dtype=np.int64)
+    a10 = (ii * n + kk[None, :]) % 10                                    # 10 x n
+    b10 = (kk[:, None] * n + np.arange(10, dtype=np.int64)[None, :]) % 10  # n x 10
+    pat = torch.from_numpy((a10 @ b10).astype(np.float32)).to(dev)       # exact: all sums < 2^24
+    idx = torch.arange(n, device=dev)
+    rowpat = pat[:, idx % 10]                                            # 10 x n
+
+    def verify():
+        """whole C file -> HBM -> compared with the closed form, every element."""
+        fd, _ = _open(pc, False)
+        try:
+            bofhip.file_to_device(bofhip.FPtr(fd, 0), nbytes, t.data_ptr(), bofhip.default_options(use_odirect=0), st)
+        finally:
+            os.close(fd)
+        C = t.view(n, n)
+        rows = max(1, (1 << 27) // n)
+        for r0 in range(0, n, rows):
+            r1 = min(n, r0 + rows)
+            if not torch.equal(C[r0:r1], rowpat[idx[r0:r1] % 10]):
+                return False
+        return True
+
+    def reset_c():
+        fd, d = _open(pc, True)
+        try:
+            z = torch.zeros(1 << 24, dtype=torch.float32, device=dev)
+            o = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if d else 0)
+            for off in range(0, nbytes, z.numel() * 4):
+                bofhip.device_to_file(bofhip.FPtr(fd, off), min(z.numel() * 4, nbytes - off), z.data_ptr(), o, st)
+        finally:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+
+    flops = 2.0 * n ** 3
+    tiles = 3 * (n // blk) ** 2
+    out = {"workload": f"flash _gemm fp32 {n}x{n}x{n}, {blk}-tile, A/B/C as {nbytes / 2**30:.0f} GiB files "
+                       f"(BASELINE configs[1]); wall clock around bof_flash_gemm incl. write-back",
+           "file_system": _fs_of(workdir), "create_files_s": round(create_s, 1), "io_threads": io_threads}
+    for mode in ("odirect", "buffered"):
+        fds = []
+        ok_direct = True
+        for p in (pa, pb, pc):
+            fd, d = _open(p, mode == "odirect")
+            fds.append(fd)
+            ok_direct = ok_direct and d
+        if mode == "odirect" and not ok_direct:
+            out[mode] = {"skipped": "file system refuses O_DIRECT"}
+            for fd in fds:
+                os.close(fd)
+            continue
+        opts = bofhip.default_options(gemm_blk=blk, n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0)
+        runs = []
+        verified = True
+        for rep in range(reps + (1 if mode == "buffered" else 0)):
+            if mode == "odirect":
+                _drop_cache((pa, pb, pc))
+            t0 = time.perf_counter()
+            bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                              bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
+            dt = time.perf_counter() - t0
+            runs.append({"seconds": dt, "stats": bofhip.flash_last_stats()})
+            if rep == 0:
+                verified = verified and verify()
+                if reps > 1 or mode == "buffered":
+                    reset_c()        # later runs must produce C again, not find it
+        verified = verified and verify()
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+        if mode == "buffered":
+            cold = runs.pop(0)       # first buffered run also fills the page cache
+        leg = _leg_summary(runs, flops, kernel_s, 2.0 * nbytes, 1.0 * nbytes, tiles)
+        if mode == "buffered":
+            leg["first_run_cold_cache_s"] = round(cold["seconds"], 3)
+            leg["note"] = "files in the page cache (DRAM-resident): the I/O stack without the device"
+        leg["whole_C_file_matches_closed_form"] = bool(verified)
+        out[mode] = leg
+    for p in (pa, pb, pc):
+        os.remove(p)
+    del t
+    torch.cuda.empty_cache()
+    return out
+
+
+def e2e_csrmm(bofhip, torch, dev, st, workdir, kernel_s, io_threads, reps):
+    """cfg3 through bof_flash_csrmm: sparse_create(10M, 1M, 1e-4) x dense_create(1M, 128, 's'),
+    C = 10M x 128; sha256 of the C file against the hash both reference drivers produced."""
+    import hashlib
+    m, n, k, npr = 10_000_000, 1_000_000, 128, 100
+    nnz = m * npr
+    p = {x: os.path.join(workdir, x) for x in ("A.csr", "A.col", "A.off", "B.bin", "C.bin")}
+    wopts = bofhip.default_options(n_io_threads=io_threads)
+    t0 = time.perf_counter()
+    val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 1_000_000):
+        bofhip.gen_sparse_rows(r0, 1_000_000, n, npr, val.data_ptr() + 4 * r0 * npr,
+                               col.data_ptr() + 8 * r0 * npr, off.data_ptr() + 8 * r0, st)
+    b = torch.empty(n * k, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(b.data_ptr(), 0, n * k, "s", 0, st)
+    for t, name in ((val, "A.csr"), (col, "A.col"), (off, "A.off"), (b, "B.bin")):
+        _write_device_tensor(bofhip, t, p[name], True, wopts, st)
+    del val, col, off, b
+    c = torch.zeros(m * k, dtype=torch.float32, device=dev)
+    _write_device_tensor(bofhip, c, p["C.bin"], True, wopts, st)
+    create_s = time.perf_counter() - t0
+    flops = 2.0 * nnz * k
+    rd = nnz * 12 + (m + 1) * 8 + 4 * n * k
+    wr = 4 * m * k
+    out = {"workload": "flash _csrmm 10M x 1M CSR (1e9 nnz: 4 GB values, 8 GB int64 indices, 80 MB offsets) x 1M x 128 "
+                       "(512 MB) -> C 5.12 GB, all files (BASELINE configs[2]); wall clock around bof_flash_csrmm",
+           "file_system": _fs_of(workdir), "create_files_s": round(create_s, 1), "io_threads": io_threads}
+    names = ("A.csr", "A.off", "A.col", "B.bin", "C.bin")
+    sums_ok = True
+    for mode in ("odirect", "buffered"):
+        fds, ok_direct = {}, True
+        for x in names:
+            fds[x], d = _open(p[x], mode == "odirect")
+            ok_direct = ok_direct and d
+        if mode == "odirect" and not ok_direct:
+            out[mode] = {"skipped": "file system refuses O_DIRECT"}
+            for fd in fds.values():
+                os.close(fd)
+            continue
+        opts = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0)
+        runs = []
+        for rep in range(reps + (1 if mode == "buffered" else 0)):
+            if mode == "odirect":
+                _drop_cache(p.values())
+            F = lambda x: bofhip.FPtr(fds[x], 0)                                        # noqa: E731
+            t0 = time.perf_counter()
+            bofhip.flash_csrmm("N", m, n, k, 1.0, 0.0, F("A.csr"), F("A.off"), F("A.col"), "R", F("B.bin"),
+                               F("C.bin"), opts)
+            dt = time.perf_counter() - t0
+            runs.append({"seconds": dt, "stats": bofhip.flash_last_stats()})
+        for fd in fds.values():
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+        # whole C file back into HBM: total must be the known 2879999461076 (App. A-3)
+        fd, _ = _open(p["C.bin"], False)
+        try:
+            bofhip.file_to_device(bofhip.FPtr(fd, 0), m * k * 4, c.data_ptr(), bofhip.default_options(use_odirect=0), st)
+        finally:
+            os.close(fd)
+        total = float(c.double().sum().item())
+        sums_ok = sums_ok and total == 2879999461076.0
+        if mode == "buffered":
+            cold = runs.pop(0)
+        leg = _leg_summary(runs, flops, kernel_s, float(rd), float(wr), 100)
+        if mode == "buffered":
+            leg["first_run_cold_cache_s"] = round(cold["seconds"], 3)
+        leg["C_total_matches_reference"] = bool(total == 2879999461076.0)
+        out[mode] = leg
+    h = hashlib.sha256()
+    with open(p["C.bin"], "rb") as f:
+        while True:
+            chunk = f.read(1 << 26)
+            if not chunk:
+                break
+            h.update(chunk)
+    out["sha256_C_file"] = h.hexdigest()
+    out["sha256_matches_reference_drivers"] = bool(h.hexdigest() == CFG3_C_SHA256)
+    for x in p.values():
+        os.remove(x)
+    del c
+    torch.cuda.empty_cache()
+    return out
+
+
+def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s):
+    import shutil
+    import tempfile
+    base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    out = {"what": "out-of-core legs: files -> pinned ring -> HBM -> kernels -> files, timed like the reference's "
+                   "drivers; odirect = O_DIRECT descriptors with the page cache dropped before every call"}
+    try:
+        workdir = tempfile.mkdtemp(prefix="bof_bench_", dir=base)
+    except OSError as e:
+        return {"error": f"no scratch directory under {base}: {e}"}
+    try:
+        free = shutil.disk_usage(workdir).free
+        out["scratch_dir_free_GB"] = round(free / 1e9, 1)
+        n = args.e2e_size
+        bofhip.lib().bof_flash_release()
+        if free > 3 * n * n * 4 + (2 << 30):
+            out["gemm"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s, args.io_threads,
+                                   args.e2e_reps)
+        else:
+            out["gemm"] = {"skipped": "not enough free disk for three matrix files"}
+        bofhip.lib().bof_flash_release()
+        if args.no_csr or args.e2e_size != 32768:
+            pass
+        elif free > 19e9:
+            out["csrmm"] = e2e_csrmm(bofhip, torch, dev, st, workdir, csrmm_kernel_s, args.io_threads, args.e2e_reps)
+        else:
+            out["csrmm"] = {"skipped": "not enough free disk for the cfg3 files (17.7 GB)"}
+        bofhip.lib().bof_flash_release()
+    except Exception as e:  # the headline line must still be printed
+        out["error"] = f"{type(e).__name__}: {str(e)[:300]}"
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +550,11 @@ def main():
                     help="debug: run rank 0's slab of the N-GPU workload on one GPU")
     ap.add_argument("--no-csr", action="store_true",
                     help="skip the CSRMM (cfg3) / CSRGEMV (cfg5-size) secondary measurements")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-resident (out-of-core) legs")
+    ap.add_argument("--e2e-dir", default="", help="directory for the matrix files (default $BOF_BENCH_DIR, $TMPDIR, /tmp)")
+    ap.add_argument("--e2e-size", type=int, default=32768, help="edge of the file-resident GEMM")
+    ap.add_argument("--e2e-reps", type=int, default=2)
+    ap.add_argument("--io-threads", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -428,6 +725,15 @@ def main():
                 out["secondary"] = csr_secondary(bofhip, torch, dev, st)
             except Exception as e:  # the headline line must still be printed
                 out["secondary"] = {"error": str(e)[:200]}
+        if not args.no_e2e and n_gpus == 1 and world == 1 and not shard_of:
+            try:
+                del a, b, c
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            csr_ms = (out.get("secondary") or {}).get("csrmm", {}).get("ms")
+            out["e2e"] = e2e_block(bofhip, torch, dev, st, args, dt / args.steps if not args.size else None,
+                                   csr_ms * 1e-3 if csr_ms else None)
         if sharded is not None:
             sec = {"scaling": "strong (the BASELINE matrices row-sharded over the ranks; max over ranks)",
                    "ok": sharded["ok"]}

@@ -40,7 +40,7 @@ class FPtr(C.Structure):
 class FlashStats(C.Structure):
     _fields_ = [("bytes_read", u64), ("bytes_written", u64), ("bytes_h2d", u64),
                 ("bytes_d2h", u64), ("tasks", u64), ("tile_hits", u64), ("tile_misses", u64),
-                ("seconds", C.c_double)]
+                ("seconds", C.c_double), ("read_ops", u64), ("write_ops", u64)]
 
 
 # every symbol include/bof_hip.h declares: (name, restype, argtypes)

@@ -24,6 +24,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -40,6 +41,13 @@ static constexpr unsigned kAioEvents = 1024;
 static constexpr int kIoRetries = 5;                // reference submit_and_reap retries
 
 static inline bool al(uint64_t v) { return (v % kSector) == 0; }
+
+// requests handed to the kernel (iocbs + pread/pwrite calls), process-wide
+static std::atomic<uint64_t> g_rd_ops{0}, g_wr_ops{0};
+void file_io_ops(uint64_t *reads, uint64_t *writes) {
+  *reads = g_rd_ops.load();
+  *writes = g_wr_ops.load();
+}
 
 // ---- per-thread AIO context -------------------------------------------------------
 struct AioCtx {
@@ -140,6 +148,7 @@ static int rw_full(int fd, bool wr, char *buf, uint64_t len, uint64_t off) {
   while (done < len) {
     ssize_t r = wr ? ::pwrite(fd, buf + done, len - done, (off_t) (off + done))
                    : ::pread(fd, buf + done, len - done, (off_t) (off + done));
+    (wr ? g_wr_ops : g_rd_ops)++;
     if (r < 0) {
       if ((errno == EINTR || errno == EAGAIN) && ++retries <= kIoRetries) continue;
       return -errno;
@@ -181,7 +190,10 @@ static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_
       }
     }
     const int rc = aio_run(cbs);
-    if (rc != -ENOSYS) return rc;
+    if (rc != -ENOSYS) {
+      (wr ? g_wr_ops : g_rd_ops) += cbs.size();
+      return rc;
+    }
   }
   for (uint64_t s = 0; s < n_strides; s++) {
     const int rc = rw_full(fd, wr, p + s * len, len, offset + s * stride);

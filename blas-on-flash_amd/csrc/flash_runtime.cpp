@@ -56,6 +56,8 @@ static std::mutex g_stats_mu;
 
 struct Counters {
   std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0};
+  uint64_t ops0[2];  // file_io_ops() when the call began
+  Counters() { file_io_ops(&ops0[0], &ops0[1]); }
 };
 
 template <class T>
@@ -173,6 +175,9 @@ static void publish_stats(const Counters &c, double seconds) {
   g_last_stats.bytes_h2d = c.h2d; g_last_stats.bytes_d2h = c.d2h;
   g_last_stats.tasks = c.tasks; g_last_stats.tile_hits = c.hits;
   g_last_stats.tile_misses = c.misses; g_last_stats.seconds = seconds;
+  uint64_t r = 0, w = 0;
+  file_io_ops(&r, &w);
+  g_last_stats.read_ops = r - c.ops0[0]; g_last_stats.write_ops = w - c.ops0[1];
 }
 
 // =====================================================================================

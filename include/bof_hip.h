@@ -231,6 +231,8 @@ typedef struct {
   uint64_t tasks;                     /* tile tasks executed           */
   uint64_t tile_hits, tile_misses;    /* HBM tile cache                */
   double seconds;                     /* wall time of the call         */
+  uint64_t read_ops, write_ops;       /* requests handed to the kernel
+                                         (iocbs + pread/pwrite calls)  */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
 /* Dry run of bof_flash_gemm's schedule (task order, HBM tile-slot replacement, write-back)
