@@ -309,10 +309,11 @@ def _leg_summary(runs, flops, kernel_s, compulsory_rd, compulsory_wr, units):
             "write_amplification": round(st["bytes_written"] / compulsory_wr, 3),
             "read_requests": st["read_ops"], "write_requests": st["write_ops"],
             "requests_per_unit": round((st["read_ops"] + st["write_ops"]) / max(units, 1), 1),
-            "overlap_kernel_over_e2e": round(kernel_s / s, 3) if kernel_s else None}
+            "overlap_kernel_over_e2e": round(kernel_s / s, 3) if kernel_s else None, "stats": st}
 
 
-def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps):
+def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps, modes=("odirect", "buffered"),
+             **extra_opts):
     """cfg2 through bof_flash_gemm on three n*n*4-byte files (A, B mode 's'; C zeros)."""
     import numpy as np
     nbytes = n * n * 4
@@ -366,7 +367,7 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
     out = {"workload": f"flash _gemm fp32 {n}x{n}x{n}, {blk}-tile, A/B/C as {nbytes / 2**30:.0f} GiB files "
                        f"(BASELINE configs[1]); wall clock around bof_flash_gemm incl. write-back",
            "file_system": _fs_of(workdir), "create_files_s": round(create_s, 1), "io_threads": io_threads}
-    for mode in ("odirect", "buffered"):
+    for mode in modes:
         fds = []
         ok_direct = True
         for p in (pa, pb, pc):
@@ -378,7 +379,8 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
             for fd in fds:
                 os.close(fd)
             continue
-        opts = bofhip.default_options(gemm_blk=blk, n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0)
+        opts = bofhip.default_options(gemm_blk=blk, n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0,
+                                      **extra_opts)
         runs = []
         verified = True
         for rep in range(reps + (1 if mode == "buffered" else 0)):

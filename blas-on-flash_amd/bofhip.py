@@ -23,7 +23,8 @@ class Options(C.Structure):
     """bof_options (reference compile-time tunables, CMakeLists.txt:38-63)."""
     _fields_ = [("gemm_blk", i64), ("max_nnzs", i64), ("csrmm_rblk", i64), ("csrmm_cblk", i64),
                 ("hbm_budget", i64), ("n_io_threads", C.c_int32), ("n_streams", C.c_int32),
-                ("use_odirect", C.c_int32), ("pinned_slots", C.c_int32)]
+                ("use_odirect", C.c_int32), ("pinned_slots", C.c_int32), ("gemm_path", C.c_int32),
+                ("io_chunk_mib", C.c_int32)]
 
 
 class GemmTask(C.Structure):

@@ -36,6 +36,8 @@ bof_options resolved(const bof_options *o) {
   if (o->n_streams > 0) r.n_streams = o->n_streams > 16 ? 16 : o->n_streams;
   r.use_odirect = o->use_odirect;
   if (o->pinned_slots > 0) r.pinned_slots = o->pinned_slots;
+  if (o->gemm_path >= 0 && o->gemm_path <= 2) r.gemm_path = o->gemm_path;
+  if (o->io_chunk_mib > 0) r.io_chunk_mib = o->io_chunk_mib > 1024 ? 1024 : o->io_chunk_mib;
   return r;
 }
 
@@ -124,6 +126,8 @@ void bof_default_options(bof_options *o) {
   o->n_streams = 4;
   o->use_odirect = 1;
   o->pinned_slots = 8;
+  o->gemm_path = 0;
+  o->io_chunk_mib = 32;
 }
 
 int bof_device_count(void) {

@@ -129,6 +129,7 @@ static int buffered_twin(int fd) {
   g_twin[fd] = t;
   return t;
 }
+int file_buffered_fd(int fd) { return file_is_direct(fd) ? buffered_twin(fd) : fd; }
 void file_forget(int fd) {
   std::lock_guard<std::mutex> lk(g_twin_mu);
   auto it = g_twin.find(fd);

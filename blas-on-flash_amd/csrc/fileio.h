@@ -8,6 +8,8 @@ int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uin
 int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
                 const void *buf, bool use_aio);
 bool file_is_direct(int fd);
+// a buffered descriptor of the same file (fd itself unless it is O_DIRECT; cached; -1 on failure)
+int file_buffered_fd(int fd);
 void file_io_ops(uint64_t *reads, uint64_t *writes);  // requests issued so far (process-wide)
 void file_forget(int fd);  // drop the cached buffered twin of fd (call before close)
 }  // namespace bof

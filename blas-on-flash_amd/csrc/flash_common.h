@@ -1,0 +1,136 @@
+// flash_common.h -- pieces shared by the level-3 pipelines (flash_runtime.cpp: tile cache, CSR
+// row-block ring, transposition; flash_gemm_panels.cpp: panel pipeline of flash::gemm).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <vector>
+
+#include "bof_hip.h"
+#include "bof_internal.h"
+#include "fileio.h"
+
+namespace bof {
+
+struct Counters {
+  std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0};
+  uint64_t ops0[2];  // file_io_ops() when the call began
+  Counters() { file_io_ops(&ops0[0], &ops0[1]); }
+};
+
+template <class T>
+class WorkQueue {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<T> q;
+  bool closed = false;
+
+ public:
+  void push(const T &v) {
+    { std::lock_guard<std::mutex> lk(mu); q.push_back(v); }
+    cv.notify_one();
+  }
+  bool pop(T &out) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return closed || !q.empty(); });
+    if (q.empty()) return false;
+    out = q.front();
+    q.pop_front();
+    return true;
+  }
+  void close() {
+    { std::lock_guard<std::mutex> lk(mu); closed = true; }
+    cv.notify_all();
+  }
+};
+
+// Pinned staging ring.  A slot handed out by acquire() is safe to overwrite: the GPU
+// copy that last referenced it (mark_busy) has completed.
+class PinnedRing {
+  std::vector<void *> slots;
+  std::vector<hipEvent_t> ev;
+  std::vector<char> ev_set;
+  std::deque<int> free_;
+  std::mutex mu;
+  std::condition_variable cv;
+
+ public:
+  size_t bytes = 0;
+  int count() const { return (int) slots.size(); }
+  int init(int n, size_t nbytes) {
+    if ((int) slots.size() == n && bytes == nbytes) {  // reuse a cached ring as is
+      free_.clear();
+      for (int i = 0; i < n; i++) free_.push_back(i);
+      return BOF_OK;
+    }
+    destroy();
+    bytes = nbytes;
+    for (int i = 0; i < n; i++) {
+      void *p = nullptr;
+      BOF_HIP_TRY(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
+      hipEvent_t e;
+      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      slots.push_back(p); ev.push_back(e); ev_set.push_back(0); free_.push_back(i);
+    }
+    return BOF_OK;
+  }
+  void destroy() {
+    for (size_t i = 0; i < slots.size(); i++) {
+      if (ev_set[i]) (void) hipEventSynchronize(ev[i]);
+      (void) hipHostFree(slots[i]);
+      (void) hipEventDestroy(ev[i]);
+    }
+    slots.clear(); ev.clear(); ev_set.clear(); free_.clear();
+  }
+  int acquire() {
+    int idx;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !free_.empty(); });
+      idx = free_.front();
+      free_.pop_front();
+    }
+    if (ev_set[idx]) { (void) hipEventSynchronize(ev[idx]); ev_set[idx] = 0; }
+    return idx;
+  }
+  void release(int idx) {
+    { std::lock_guard<std::mutex> lk(mu); free_.push_back(idx); }
+    cv.notify_one();
+  }
+  int mark_busy(int idx, hipStream_t st) {
+    BOF_HIP_TRY(hipEventRecord(ev[idx], st));
+    ev_set[idx] = 1;
+    return BOF_OK;
+  }
+  hipEvent_t event(int idx) { return ev[idx]; }
+  void *ptr(int idx) { return slots[idx]; }
+};
+
+static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// Runs the registered releases in reverse order when the call returns, on every path.
+struct Cleanup {
+  std::vector<std::function<void()>> fns;
+  void add(std::function<void()> f) { fns.push_back(std::move(f)); }
+  ~Cleanup() {
+    for (auto it = fns.rbegin(); it != fns.rend(); ++it) (*it)();
+  }
+};
+
+int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
+void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
+
+// flash::gemm through whole row panels kept in HBM in FILE layout (flash_gemm_panels.cpp).
+// Returns BOF_OK / an error, or +1 when the call is not eligible (layout, budget) and the tile
+// cache of flash_runtime.cpp must take it.
+int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
+                      bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
+                      const bof_options &o);
+void panel_resources_release();
+
+}  // namespace bof

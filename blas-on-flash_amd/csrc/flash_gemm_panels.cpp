@@ -1,0 +1,521 @@
+// flash_gemm_panels.cpp -- flash::gemm on file-resident matrices through ROW PANELS.
+//
+// What it replaces: the reference moves every 64 MiB tile as 4096 strided 16 KiB requests
+// (one iocb per tile row, src/file_handles/flash_file_handle.cpp:444-460) and packs it into
+// its own buffer (src/blas/gemm.cpp:117-120).  But a block row of a stored matrix -- `blk`
+// stored rows x the full stored width -- is ONE contiguous extent of the file.  With 288 GB of
+// HBM per GPU the natural unit of the program cache is therefore that panel, kept in HBM in
+// FILE layout (leading dimension = the file's):
+//   * reads and writes are a handful of large sequential requests per panel (io_chunk_mib,
+//     default 32 MiB) instead of thousands of row requests per tile; every request lands in a
+//     pinned staging slot and crosses PCIe as one linear SDMA copy;
+//   * no packing anywhere: a tile task is `pointer into a panel + leading dimension`, exactly
+//     what the level-2 tile DAG passes to the kernel;
+//   * C panels are written back as they complete, while the next panels compute.
+//
+// Schedule (same tasks, same k-order per accumulate chain as src/blas/gemm.cpp:83-129, so
+// the result is bit-identical to the tile path): C panels are processed in groups of
+// `group` (default 1); inside a group tasks go l-major.  Let D be the dimension along which
+// C is paneled (m for row-major C, n for column-major).  The operand that does not contain D
+// ("Y": B for row-major) is needed whole by every group and stays resident; the other one
+// ("X": A) is resident too when it is paneled along k, else its panels stream through a small
+// ring, one group ahead.  If that working set does not fit opts->hbm_budget, or C's rows are
+// not contiguous in its file (ldc != stored width: writing whole panels would clobber what
+// lies between the rows), the call is handed to the tile cache of flash_runtime.cpp.
+//
+// Threads: n_io_threads readers (file -> pinned slot -> H2D), the caller as dispatcher (tile
+// launches on n_streams compute streams), one flusher (HBM -> pinned, chunk by chunk) and
+// writers (pinned -> file).  Everything is ordered by hipEvents and two condition variables;
+// nothing polls.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "flash_common.h"
+
+namespace bof {
+namespace {
+
+struct Panel {
+  int64_t r0 = 0, nr = 0;       // stored rows [r0, r0 + nr)
+  uint64_t bytes = 0;           // extent: (nr-1)*ld + cols elements
+  int state = 0;                // 0 idle, 1 being read, 2 usable            (guarded by mu)
+  int remaining = 0;            // chunks whose H2D copy is not enqueued yet  (guarded by mu)
+  bool retired = false;         // consumers launched / write-back enqueued   (guarded by mu)
+  hipEvent_t ready = nullptr;   // recorded on the H2D stream behind the panel's last copy
+  hipEvent_t d2h_done = nullptr;
+  std::vector<hipEvent_t> retire_ev;  // what the slot's next occupant must wait for
+};
+
+struct Mat {
+  bof_fptr f{-1, 0};
+  int fd = -1;                  // descriptor every request of this call uses (O_DIRECT or twin)
+  bool aio = false;
+  int rdim = 0, cdim = 0;
+  int64_t rows = 0, cols = 0, ld = 0, blk_r = 0, blk_c = 0;
+  std::vector<Panel> panels;
+  bool natural = false;         // whole matrix resident at its file offsets
+  int n_slots = 0;
+  size_t slot_bytes = 0, total_bytes = 0;
+  char *base = nullptr;
+  char *panel_ptr(int p) const {
+    return natural ? base + (size_t) panels[(size_t) p].r0 * (size_t) ld * 4
+                   : base + (size_t) (p % n_slots) * slot_bytes;
+  }
+  uint64_t file_off(int p) const { return f.foffset + (uint64_t) panels[(size_t) p].r0 * (uint64_t) ld * 4; }
+};
+
+struct ChunkReq { int mat, panel; uint64_t off, bytes; };
+struct WriteReq { int wslot; uint64_t file_off, bytes; };
+
+struct PanelResources {
+  PinnedRing rring, wring;
+  char *slab[3] = {nullptr, nullptr, nullptr};
+  size_t slab_bytes[3] = {0, 0, 0};
+};
+std::mutex g_pres_mu;
+PanelResources *g_pres[64];
+
+bool trace_on() {
+  static const bool on = getenv("BOF_TRACE") != nullptr;
+  return on;
+}
+
+struct PanelRun {
+  bof_options o;
+  GemmGeometry g;
+  Mat mat[3];
+  int xmat = 0, ymat = 1;       // streamed-or-resident operand / always-resident operand
+  bool c_read = false;
+  size_t chunk = 32u << 20;
+  PanelResources *res = nullptr;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  StreamSet *ss = nullptr;
+  WorkQueue<ChunkReq> fetch_q;
+  WorkQueue<int> flush_q;
+  WorkQueue<WriteReq> write_q;
+  std::vector<std::pair<int, int>> order;  // (mat, panel) in order of first use
+  size_t next_fetch = 0;
+  std::vector<std::vector<hipEvent_t>> group_ev;  // per group: one event per compute stream
+  std::vector<int> group_of;                      // C panel -> group
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<int> io_error{0};
+  Counters cnt;
+  int dev = 0;
+  std::chrono::steady_clock::time_point t_begin;
+
+  void trace(const char *label) const {
+    if (trace_on())
+      fprintf(stderr, "[bof trace] %-34s %8.3f ms\n", label,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  }
+  void fail_io(int code) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      int none = 0;
+      io_error.compare_exchange_strong(none, code);
+    }
+    cv.notify_all();
+  }
+
+  // Push the chunk requests of every panel, in first-use order, whose HBM slot is free: the
+  // whole-matrix images always are, a ring slot once its previous occupant has retired.
+  // Strictly in order, so the readers always work on what is needed soonest.  Caller holds mu.
+  void pump_fetches() {
+    while (next_fetch < order.size()) {
+      const int x = order[next_fetch].first, p = order[next_fetch].second;
+      Mat &M = mat[x];
+      Panel &P = M.panels[(size_t) p];
+      const int prev = M.natural ? -1 : p - M.n_slots;
+      if (prev >= 0 && !M.panels[(size_t) prev].retired) break;
+      const int n_chunks = (int) ((P.bytes + chunk - 1) / chunk);
+      P.state = 1;
+      P.remaining = n_chunks;
+      for (int c = 0; c < n_chunks; c++) {
+        const uint64_t off = (uint64_t) c * chunk;
+        fetch_q.push(ChunkReq{x, p, off, std::min<uint64_t>(chunk, P.bytes - off)});
+      }
+      cnt.misses++;
+      next_fetch++;
+    }
+  }
+
+  void reader_main() {
+    (void) hipSetDevice(dev);
+    ChunkReq rq;
+    while (fetch_q.pop(rq)) {
+      Mat &M = mat[rq.mat];
+      Panel &P = M.panels[(size_t) rq.panel];
+      const int ps = res->rring.acquire();
+      int rc = 0;
+      if (!io_error.load())
+        rc = file_sread(M.fd, M.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, res->rring.ptr(ps), M.aio);
+      if (rc) fail_io(rc);
+      hipError_t e = hipSuccess;
+      const int prev = M.natural ? -1 : rq.panel - M.n_slots;
+      if (prev >= 0)  // WAR: the slot's previous occupant (its events were recorded before it retired)
+        for (hipEvent_t w : M.panels[(size_t) prev].retire_ev)
+          if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
+      if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, res->rring.ptr(ps), rq.bytes, hipMemcpyHostToDevice, h2d);
+      if (e == hipSuccess) (void) res->rring.mark_busy(ps, h2d);
+      res->rring.release(ps);
+      cnt.rd += rq.bytes;
+      cnt.h2d += rq.bytes;
+      {
+        // the copy above is enqueued before this decrement, so whoever brings the count to
+        // zero records `ready` behind every copy of the panel
+        std::lock_guard<std::mutex> lk(mu);
+        if (--P.remaining == 0) {
+          if (e == hipSuccess) e = hipEventRecord(P.ready, h2d);
+          P.state = 2;
+        }
+      }
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
+      cv.notify_all();
+    }
+  }
+
+  // HBM -> pinned ring, chunk by chunk, for every finished C panel; then the panel's slot is
+  // free for a later one.
+  void flusher_main() {
+    (void) hipSetDevice(dev);
+    int pc;
+    while (flush_q.pop(pc)) {
+      Mat &C = mat[2];
+      Panel &P = C.panels[(size_t) pc];
+      hipError_t e = hipSuccess;
+      for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
+        if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
+      for (uint64_t off = 0; off < P.bytes && e == hipSuccess && !io_error.load(); off += chunk) {
+        const uint64_t len = std::min<uint64_t>(chunk, P.bytes - off);
+        const int ws = res->wring.acquire();
+        e = hipMemcpyAsync(res->wring.ptr(ws), C.panel_ptr(pc) + off, len, hipMemcpyDeviceToHost, d2h);
+        if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
+        if (e != hipSuccess) { res->wring.release(ws); break; }
+        cnt.d2h += len;
+        write_q.push(WriteReq{ws, C.file_off(pc) + off, len});
+      }
+      if (e == hipSuccess) e = hipEventRecord(P.d2h_done, d2h);
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        P.retire_ev.assign(1, P.d2h_done);
+        P.retired = true;
+        pump_fetches();
+      }
+      cv.notify_all();
+    }
+  }
+
+  void writer_main() {
+    (void) hipSetDevice(dev);
+    WriteReq rq;
+    while (write_q.pop(rq)) {
+      hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
+      int rc = 0;
+      if (!io_error.load())
+        rc = file_swrite(mat[2].fd, rq.file_off, 0, 1, rq.bytes, res->wring.ptr(rq.wslot), mat[2].aio);
+      if (rc) fail_io(rc);
+      cnt.wr += rq.bytes;
+      res->wring.release(rq.wslot);
+    }
+  }
+};
+
+// One descriptor mode per file per call: O_DIRECT only if EVERY request of the call is sector
+// aligned; otherwise every request goes through the buffered twin.  Mixing the two on one file
+// lets a direct write and a buffered write of neighbouring regions meet in one page.
+void pick_descriptor(Mat &M, bool use_odirect, size_t chunk) {
+  bool aligned = (M.f.foffset % 512) == 0 && (chunk % 512) == 0;
+  for (const Panel &P : M.panels)
+    aligned = aligned && (P.bytes % 512) == 0 && (((uint64_t) P.r0 * (uint64_t) M.ld * 4) % 512) == 0;
+  M.fd = M.f.fd;
+  M.aio = false;
+  if (file_is_direct(M.f.fd)) {
+    if (aligned && use_odirect) M.aio = true;
+    else if (aligned) M.aio = false;               // direct descriptor, synchronous requests
+    else M.fd = file_buffered_fd(M.f.fd);
+  }
+}
+
+}  // namespace
+
+void panel_resources_release() {
+  std::lock_guard<std::mutex> lk(g_pres_mu);
+  for (int d = 0; d < 64; d++) {
+    PanelResources *r = g_pres[d];
+    if (!r) continue;
+    r->rring.destroy();
+    r->wring.destroy();
+    for (int x = 0; x < 3; x++)
+      if (r->slab[x]) (void) hipFree(r->slab[x]);
+    delete r;
+    g_pres[d] = nullptr;
+  }
+}
+
+int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
+                      bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
+                      const bof_options &o) {
+  PanelRun R;
+  R.t_begin = std::chrono::steady_clock::now();
+  R.o = o;
+  R.g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
+  const GemmGeometry &g = R.g;
+  const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
+  if (Nm * Nn == 0 || Nk == 0) return 1;
+  R.chunk = (size_t) std::max(1, o.io_chunk_mib) << 20;
+  R.c_read = beta != 0.0f;
+  BOF_HIP_TRY(hipGetDevice(&R.dev));
+
+  // ---- panels -----------------------------------------------------------------------------
+  const bof_fptr fp[3] = {fa, fb, fc};
+  for (int x = 0; x < 3; x++) {
+    Mat &M = R.mat[x];
+    M.f = fp[x];
+    M.rdim = g.rdim[x]; M.cdim = g.cdim[x];
+    M.rows = g.size[M.rdim]; M.cols = g.size[M.cdim]; M.ld = g.ld[x];
+    M.blk_r = g.blk[M.rdim]; M.blk_c = g.blk[M.cdim];
+    if (M.ld < M.cols) return 1;                       // malformed: let the tile path report it
+    if (x < 2 && M.cols * 2 < M.ld) return 1;          // a narrow view of a wide matrix: mostly gaps
+    M.panels.resize((size_t) g.nblk[M.rdim]);
+    for (int64_t p = 0; p < g.nblk[M.rdim]; p++) {
+      Panel &P = M.panels[(size_t) p];
+      P.r0 = p * M.blk_r;
+      P.nr = (p == g.nblk[M.rdim] - 1) ? M.rows - P.r0 : M.blk_r;
+      P.bytes = ((uint64_t) (P.nr - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4;
+      M.slot_bytes = std::max<size_t>(M.slot_bytes, (size_t) round_up(P.bytes, 2u << 20));
+    }
+    M.total_bytes = (size_t) (((uint64_t) (M.rows - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4);
+  }
+  if (R.mat[2].ld != R.mat[2].cols) return 1;  // gaps between C's rows belong to someone else
+
+  // ---- who is resident, who streams; does it fit? -----------------------------------------
+  const int dC = g.rdim[2];                    // 0: C paneled along m, 2: along n
+  R.xmat = dC == 0 ? 0 : 1;
+  R.ymat = 1 - R.xmat;
+  const bool x_streams = g.rdim[R.xmat] == dC;
+  const char *genv = getenv("BOF_PANEL_GROUP");
+  const int64_t NpC = g.nblk[dC];
+  const int64_t group = std::max<int64_t>(1, std::min<int64_t>(genv ? atoll(genv) : 1, NpC));
+  size_t free_b = 0, total_b = 0;
+  BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  {
+    std::lock_guard<std::mutex> lk(g_pres_mu);
+    if (!g_pres[R.dev & 63]) g_pres[R.dev & 63] = new PanelResources();
+    R.res = g_pres[R.dev & 63];
+  }
+  for (int x = 0; x < 3; x++) free_b += R.res->slab_bytes[x];  // what we already hold counts as free
+  size_t budget = o.hbm_budget > 0 ? (size_t) o.hbm_budget : (size_t) (free_b * 0.8);
+  budget = std::min(budget, (size_t) (free_b * 0.95));
+  Mat &X = R.mat[R.xmat], &Y = R.mat[R.ymat], &C = R.mat[2];
+  Y.natural = true;
+  Y.n_slots = (int) Y.panels.size();
+  X.natural = !x_streams;
+  X.n_slots = X.natural ? (int) X.panels.size() : (int) std::min<int64_t>((int64_t) X.panels.size(), 2 * group);
+  C.natural = false;
+  C.n_slots = (int) std::min<int64_t>(NpC, 2 * group + 1);
+  auto need_of = [](const Mat &M) { return M.natural ? round_up(M.total_bytes, 2u << 20) : (size_t) M.n_slots * M.slot_bytes; };
+  size_t need = need_of(X) + need_of(Y) + need_of(C);
+  if (need > budget) return 1;
+  // spare budget: a deeper C ring lets compute run ahead of a slow write-back
+  while (C.n_slots < NpC && need + C.slot_bytes <= budget && C.n_slots < 2 * group + 4) { C.n_slots++; need += C.slot_bytes; }
+  if ((int64_t) C.n_slots == NpC && need_of(C) >= round_up(C.total_bytes, 2u << 20)) C.natural = true;
+
+  // ---- task list in execution order, panels in first-use order ------------------------------
+  std::vector<bof_gemm_task> tasks;
+  tasks.reserve((size_t) (Nm * Nk * Nn));
+  R.group_of.assign((size_t) NpC, 0);
+  std::vector<std::vector<char>> seen(3);
+  for (int x = 0; x < 3; x++) seen[x].assign(R.mat[x].panels.size(), 0);
+  const int64_t Nq = dC == 0 ? Nn : Nm;        // C tiles per panel
+  int n_groups = 0;
+  std::vector<size_t> group_end;               // task index one past each group
+  for (int64_t G0 = 0; G0 < NpC; G0 += group, n_groups++) {
+    const int64_t G1 = std::min(NpC, G0 + group);
+    for (int64_t l = 0; l < Nk; l++)
+      for (int64_t pc = G0; pc < G1; pc++) {
+        R.group_of[(size_t) pc] = n_groups;
+        for (int64_t q = 0; q < Nq; q++) {
+          const int64_t i = dC == 0 ? pc : q, j = dC == 0 ? q : pc;
+          bof_gemm_task t;
+          gemm_task_at(g, l, i, j, beta, &t);
+          tasks.push_back(t);
+          const int64_t idx[3] = {i, l, j};
+          for (int x = 0; x < 3; x++) {
+            const int p = (int) idx[R.mat[x].rdim];
+            if (seen[x][(size_t) p]) continue;
+            seen[x][(size_t) p] = 1;
+            if (x < 2 || R.c_read) R.order.emplace_back(x, p);
+          }
+        }
+      }
+    group_end.push_back(tasks.size());
+  }
+
+  // ---- descriptors, HBM, rings, streams, events -----------------------------------------------
+  for (int x = 0; x < 3; x++) {
+    pick_descriptor(R.mat[x], o.use_odirect != 0, R.chunk);
+    if (R.mat[x].fd < 0) { set_error("bof_flash_gemm: cannot open a buffered descriptor of an unaligned matrix file"); return BOF_EIO; }
+  }
+  for (int x = 0; x < 3; x++) {
+    Mat &M = R.mat[x];
+    const size_t bytes = need_of(M);
+    if (R.res->slab_bytes[x] < bytes) {
+      if (R.res->slab[x]) (void) hipFree(R.res->slab[x]);
+      R.res->slab[x] = nullptr;
+      R.res->slab_bytes[x] = 0;
+      BOF_HIP_TRY(hipMalloc((void **) &R.res->slab[x], bytes));
+      R.res->slab_bytes[x] = bytes;
+    }
+    M.base = R.res->slab[x];
+  }
+  R.trace("plan + HBM panels");
+  Cleanup guard;
+  guard.add([&R] {
+    for (auto &M : R.mat)
+      for (auto &P : M.panels) {
+        if (P.ready) (void) hipEventDestroy(P.ready);
+        if (P.d2h_done) (void) hipEventDestroy(P.d2h_done);
+      }
+    for (auto &v : R.group_ev)
+      for (hipEvent_t e : v) (void) hipEventDestroy(e);
+    if (R.h2d) (void) hipStreamDestroy(R.h2d);
+    if (R.d2h) (void) hipStreamDestroy(R.d2h);
+  });
+  for (int x = 0; x < 3; x++)
+    for (auto &P : R.mat[x].panels) {
+      BOF_HIP_TRY(hipEventCreateWithFlags(&P.ready, hipEventDisableTiming));
+      if (x == 2) BOF_HIP_TRY(hipEventCreateWithFlags(&P.d2h_done, hipEventDisableTiming));
+    }
+  R.ss = stream_set(o.n_streams);
+  if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
+  R.group_ev.assign((size_t) n_groups, std::vector<hipEvent_t>());
+  for (auto &v : R.group_ev)
+    for (int s = 0; s < R.ss->n; s++) {
+      hipEvent_t e;
+      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      v.push_back(e);
+    }
+  int rc = R.res->rring.init(std::max(2, o.pinned_slots), R.chunk);
+  if (rc) return rc;
+  rc = R.res->wring.init(std::max(2, o.pinned_slots), R.chunk);
+  if (rc) return rc;
+  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
+  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
+  R.trace("rings/streams ready");
+
+  std::vector<std::thread> readers, writers;
+  const int n_readers = std::max(1, o.n_io_threads);
+  const int n_writers = std::max(2, std::min(8, o.n_io_threads / 2));
+  for (int i = 0; i < n_readers; i++) readers.emplace_back([&R] { R.reader_main(); });
+  for (int i = 0; i < n_writers; i++) writers.emplace_back([&R] { R.writer_main(); });
+  std::thread flusher([&R] { R.flusher_main(); });
+  {
+    std::lock_guard<std::mutex> lk(R.mu);
+    R.pump_fetches();
+  }
+
+  // ---- dispatch ---------------------------------------------------------------------------------
+  hipError_t herr = hipSuccess;
+  int fail = 0;
+  // per (matrix, stream): the panel whose events that stream has already been told to wait for
+  std::vector<int> waited((size_t) 3 * (size_t) R.ss->n, -1);
+  size_t t = 0;
+  for (int gi = 0; gi < n_groups && !fail && herr == hipSuccess; gi++) {
+    for (; t < group_end[(size_t) gi]; t++) {
+      const bof_gemm_task &tk = tasks[t];
+      const int64_t idx[3] = {tk.i, tk.l, tk.j};
+      int pn[3];
+      for (int x = 0; x < 3; x++) pn[x] = (int) idx[R.mat[x].rdim];
+      const int cprev = C.natural ? -1 : pn[2] - C.n_slots;
+      {
+        std::unique_lock<std::mutex> lk(R.mu);
+        R.cv.wait(lk, [&] {
+          if (R.io_error.load()) return true;
+          if (R.mat[0].panels[(size_t) pn[0]].state != 2 || R.mat[1].panels[(size_t) pn[1]].state != 2) return false;
+          if (R.c_read) return C.panels[(size_t) pn[2]].state == 2;
+          return cprev < 0 || C.panels[(size_t) cprev].retired;   // the slot's write-back is on its way
+        });
+      }
+      if (R.io_error.load()) { fail = BOF_EIO; break; }
+      const int64_t q = dC == 0 ? tk.j : tk.i;
+      const int sidx = (int) (((int64_t) pn[2] * Nq + q) % R.ss->n);   // chain -> stream: FIFO = parent dependency
+      hipStream_t st = R.ss->s[sidx];
+      for (int x = 0; x < 3 && herr == hipSuccess; x++) {
+        int &w = waited[(size_t) x * (size_t) R.ss->n + (size_t) sidx];
+        if (w == pn[x]) continue;
+        w = pn[x];
+        if (x < 2 || R.c_read) herr = hipStreamWaitEvent(st, R.mat[x].panels[(size_t) pn[x]].ready, 0);
+        else if (cprev >= 0)
+          for (hipEvent_t e : C.panels[(size_t) cprev].retire_ev)
+            if (herr == hipSuccess) herr = hipStreamWaitEvent(st, e, 0);
+      }
+      if (herr != hipSuccess) break;
+      const float *pa = (const float *) R.mat[0].panel_ptr(pn[0]) + idx[R.mat[0].cdim] * R.mat[0].blk_c;
+      const float *pb = (const float *) R.mat[1].panel_ptr(pn[1]) + idx[R.mat[1].cdim] * R.mat[1].blk_c;
+      float *pcp = (float *) C.panel_ptr(pn[2]) + idx[C.cdim] * C.blk_c;
+      herr = sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, pa, R.mat[0].ld, pb, R.mat[1].ld, tk.beta, pcp, C.ld, st);
+      if (herr != hipSuccess) break;
+      R.cnt.tasks++;
+    }
+    if (fail || herr != hipSuccess) break;
+    // group finished on the host side: mark where every stream stands, hand its C panels to the
+    // flusher and let the streamed operand's panels of this group go
+    for (int s = 0; s < R.ss->n && herr == hipSuccess; s++) herr = hipEventRecord(R.group_ev[(size_t) gi][(size_t) s], R.ss->s[s]);
+    if (herr != hipSuccess) break;
+    const int64_t G0 = (int64_t) gi * group, G1 = std::min(NpC, G0 + group);
+    {
+      std::lock_guard<std::mutex> lk(R.mu);
+      if (!X.natural)
+        for (int64_t pc = G0; pc < G1; pc++) {
+          Panel &P = X.panels[(size_t) pc];
+          P.retire_ev = R.group_ev[(size_t) gi];
+          P.retired = true;
+        }
+      R.pump_fetches();
+    }
+    for (int64_t pc = G0; pc < G1; pc++) R.flush_q.push((int) pc);
+    if (trace_on()) {
+      char lbl[64];
+      snprintf(lbl, sizeof(lbl), "group %d dispatched", gi);
+      R.trace(lbl);
+    }
+  }
+
+  // ---- drain ------------------------------------------------------------------------------------
+  if (herr != hipSuccess || fail) R.fail_io(-EIO);
+  R.fetch_q.close();
+  for (auto &th : readers) th.join();
+  R.flush_q.close();
+  flusher.join();
+  R.write_q.close();
+  for (auto &th : writers) th.join();
+  (void) hipDeviceSynchronize();
+  R.trace("drained (writes done)");
+  if (herr != hipSuccess && !fail) fail = hip_fail(herr, "bof_flash_gemm (panels) dispatch");
+  if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
+    const int e = R.io_error.load();
+    set_error("bof_flash_gemm: I/O pipeline failed: " +
+              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
+    fail = BOF_EIO;
+  }
+  R.cnt.hits = 3 * R.cnt.tasks.load() - std::min<uint64_t>(R.cnt.misses.load(), 3 * R.cnt.tasks.load());
+  publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - R.t_begin).count());
+  return fail;
+}
+
+}  // namespace bof

@@ -41,6 +41,7 @@
 #include "bof_hip.h"
 #include "bof_internal.h"
 #include "fileio.h"
+#include "flash_common.h"
 
 namespace bof {
 
@@ -54,112 +55,7 @@ std::recursive_mutex &device_call_mutex() {
 static bof_flash_stats g_last_stats;
 static std::mutex g_stats_mu;
 
-struct Counters {
-  std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0};
-  uint64_t ops0[2];  // file_io_ops() when the call began
-  Counters() { file_io_ops(&ops0[0], &ops0[1]); }
-};
-
-template <class T>
-class WorkQueue {
-  std::mutex mu;
-  std::condition_variable cv;
-  std::deque<T> q;
-  bool closed = false;
-
- public:
-  void push(const T &v) {
-    { std::lock_guard<std::mutex> lk(mu); q.push_back(v); }
-    cv.notify_one();
-  }
-  bool pop(T &out) {
-    std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return closed || !q.empty(); });
-    if (q.empty()) return false;
-    out = q.front();
-    q.pop_front();
-    return true;
-  }
-  void close() {
-    { std::lock_guard<std::mutex> lk(mu); closed = true; }
-    cv.notify_all();
-  }
-};
-
-// Pinned staging ring.  A slot handed out by acquire() is safe to overwrite: the GPU
-// copy that last referenced it (mark_busy) has completed.
-class PinnedRing {
-  std::vector<void *> slots;
-  std::vector<hipEvent_t> ev;
-  std::vector<char> ev_set;
-  std::deque<int> free_;
-  std::mutex mu;
-  std::condition_variable cv;
-
- public:
-  size_t bytes = 0;
-  int count() const { return (int) slots.size(); }
-  int init(int n, size_t nbytes) {
-    if ((int) slots.size() == n && bytes == nbytes) {  // reuse a cached ring as is
-      free_.clear();
-      for (int i = 0; i < n; i++) free_.push_back(i);
-      return BOF_OK;
-    }
-    destroy();
-    bytes = nbytes;
-    for (int i = 0; i < n; i++) {
-      void *p = nullptr;
-      BOF_HIP_TRY(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
-      hipEvent_t e;
-      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      slots.push_back(p); ev.push_back(e); ev_set.push_back(0); free_.push_back(i);
-    }
-    return BOF_OK;
-  }
-  void destroy() {
-    for (size_t i = 0; i < slots.size(); i++) {
-      if (ev_set[i]) (void) hipEventSynchronize(ev[i]);
-      (void) hipHostFree(slots[i]);
-      (void) hipEventDestroy(ev[i]);
-    }
-    slots.clear(); ev.clear(); ev_set.clear(); free_.clear();
-  }
-  int acquire() {
-    int idx;
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return !free_.empty(); });
-      idx = free_.front();
-      free_.pop_front();
-    }
-    if (ev_set[idx]) { (void) hipEventSynchronize(ev[idx]); ev_set[idx] = 0; }
-    return idx;
-  }
-  void release(int idx) {
-    { std::lock_guard<std::mutex> lk(mu); free_.push_back(idx); }
-    cv.notify_one();
-  }
-  int mark_busy(int idx, hipStream_t st) {
-    BOF_HIP_TRY(hipEventRecord(ev[idx], st));
-    ev_set[idx] = 1;
-    return BOF_OK;
-  }
-  hipEvent_t event(int idx) { return ev[idx]; }
-  void *ptr(int idx) { return slots[idx]; }
-};
-
-static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
-
-// Runs the registered releases in reverse order when the call returns, on every path.
-struct Cleanup {
-  std::vector<std::function<void()>> fns;
-  void add(std::function<void()> f) { fns.push_back(std::move(f)); }
-  ~Cleanup() {
-    for (auto it = fns.rbegin(); it != fns.rend(); ++it) (*it)();
-  }
-};
-
-static int device_ready() {
+int device_ready() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     (void) hipGetLastError();
@@ -169,7 +65,7 @@ static int device_ready() {
   return BOF_OK;
 }
 
-static void publish_stats(const Counters &c, double seconds) {
+void publish_stats(const Counters &c, double seconds) {
   std::lock_guard<std::mutex> lk(g_stats_mu);
   g_last_stats.bytes_read = c.rd; g_last_stats.bytes_written = c.wr;
   g_last_stats.bytes_h2d = c.h2d; g_last_stats.bytes_d2h = c.d2h;
@@ -338,6 +234,12 @@ struct GemmRun {
   Counters cnt;
   int dev = 0;
   bool use_aio = true;
+  // One descriptor mode per file per call: O_DIRECT + AIO only if EVERY tile region of that
+  // matrix is sector aligned, else every request of the call goes through the buffered twin.
+  // (A direct write and a buffered write of neighbouring tiles must never meet in one page:
+  // the case the reference serialises in io_executor.cpp:28-156.)
+  int fd_io[3] = {-1, -1, -1};
+  bool aio_io[3] = {false, false, false};
 
   size_t tile_bytes(const Tile &t) const { return (size_t) t.nrows * t.ncols * sizeof(float); }
 
@@ -360,8 +262,8 @@ struct GemmRun {
       const int ps = res->rring.acquire();
       int rc = 0;
       if (!io_error.load())
-        rc = file_sread(f[t.mat].fd, f[t.mat].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
-                        (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->rring.ptr(ps), use_aio);
+        rc = file_sread(fd_io[t.mat], f[t.mat].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
+                        (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->rring.ptr(ps), aio_io[t.mat]);
       if (rc) fail_io(rc);
       cnt.rd += tile_bytes(t);
       DevSlot &s = slots[rq.slot];
@@ -389,8 +291,8 @@ struct GemmRun {
       if (e != hipSuccess) fail_io(-1000 - (int) e);
       int rc = 0;
       if (!io_error.load())
-        rc = file_swrite(f[2].fd, f[2].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
-                         (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->wring.ptr(rq.wslot), use_aio);
+        rc = file_swrite(fd_io[2], f[2].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
+                         (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->wring.ptr(rq.wslot), aio_io[2]);
       if (rc) fail_io(rc);
       cnt.wr += tile_bytes(t);
       res->wring.release(rq.wslot);
@@ -456,10 +358,36 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   if (Nm * Nn == 0) return BOF_OK;
   if (Nk == 0) { set_error("bof_flash_gemm: k == 0 is not supported on the file path"); return BOF_EINVAL; }
 
+  // ---- large working budgets: whole row panels in file layout, big sequential requests ----
+  if (R.o.gemm_path != 1) {
+    rc = flash_gemm_panels(ord, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, R.o);
+    if (rc <= 0) return rc;
+    if (R.o.gemm_path == 2) {
+      set_error("bof_flash_gemm: gemm_path = 2 (panels) but the call is not eligible: C rows must be "
+                "contiguous in the file (ldc = stored width) and B, two A panels and three C panels must "
+                "fit hbm_budget");
+      return BOF_ENOMEM;
+    }
+  }
+
   // ---- tiles ------------------------------------------------------------------------
   size_t max_tile = 0;
   build_tiles(g, beta, R.tiles, max_tile);
   R.slot_bytes = round_up(max_tile, 4096);
+  for (int x = 0; x < 3; x++) {
+    bool aligned = (R.f[x].foffset % 512) == 0;
+    for (const Tile &t : R.tiles)
+      if (t.mat == x)
+        aligned = aligned && ((uint64_t) t.off * 4) % 512 == 0 && ((uint64_t) t.ncols * 4) % 512 == 0 &&
+                  (t.nrows <= 1 || ((uint64_t) t.ld * 4) % 512 == 0);
+    R.fd_io[x] = R.f[x].fd;
+    R.aio_io[x] = false;
+    if (file_is_direct(R.f[x].fd)) {
+      if (aligned) R.aio_io[x] = R.use_aio;
+      else R.fd_io[x] = file_buffered_fd(R.f[x].fd);
+      if (R.fd_io[x] < 0) { set_error("bof_flash_gemm: cannot open a buffered descriptor of an unaligned matrix file"); return BOF_EIO; }
+    }
+  }
 
   // ---- HBM budget -> slot count -> C super-block (gi x gj chains per pass) --------------
   size_t free_b = 0, total_b = 0;
@@ -1601,6 +1529,7 @@ int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_o
 
 int bof_flash_release(void) {
   scratch_release_all();
+  panel_resources_release();
   std::lock_guard<std::mutex> lk(g_res_mu);
   for (int d = 0; d < 64; d++) {
     GemmResources *r = g_res[d];

@@ -51,6 +51,8 @@ namespace flash {
     o.n_io_threads = (int32_t) sched.n_io_threads();
     o.n_streams = (int32_t) sched.n_compute_threads();
     o.use_odirect = sched.use_odirect ? 1 : 0;
+    o.gemm_path = (int32_t) env_long("BOF_GEMM_PATH", 0);       // 0 choose, 1 tile cache, 2 panels
+    o.io_chunk_mib = (int32_t) env_long("BOF_IO_CHUNK_MIB", 0);
     return o;
   }
 

@@ -71,6 +71,12 @@ typedef struct {
   int32_t n_streams;     /* compute streams (N_COMPUTE_THR analogue) default 4    */
   int32_t use_odirect;   /* 1 = O_DIRECT + kernel AIO (default), 0 = buffered     */
   int32_t pinned_slots;  /* pinned staging ring slots  default 8                  */
+  int32_t gemm_path;     /* bof_flash_gemm: 0 = choose (default), 1 = tile cache
+                            (packed tiles, Belady replacement: any budget, any
+                            layout), 2 = row panels kept in HBM in file layout,
+                            read/written as large contiguous requests (needs B,
+                            two A panels and three C panels inside hbm_budget)    */
+  int32_t io_chunk_mib;  /* size of one panel read/write request  default 32      */
 } bof_options;
 void bof_default_options(bof_options *o);
 

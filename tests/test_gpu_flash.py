@@ -52,10 +52,12 @@ class Files:
             os.close(fd)
 
 
+@pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
-def test_flash_gemm_layouts_unaligned(dev, tmp_path, ord_, ta, tb):
+def test_flash_gemm_layouts_unaligned(dev, tmp_path, ord_, ta, tb, path):
     """SURVEY 8c trust-matrix shape: 640x600x500 with unaligned leading dims, tile
-    256 (separate tail, merged tail), alpha=0.5, beta=2, random C, all 8 layouts."""
+    256 (separate tail, merged tail), alpha=0.5, beta=2, random C, all 8 layouts; through the
+    tile cache (path 1) and through the row-panel pipeline (path 2)."""
     m, k, n, blk = 640, 600, 500, 256
     rng = np.random.default_rng(11)
     sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
@@ -65,7 +67,8 @@ def test_flash_gemm_layouts_unaligned(dev, tmp_path, ord_, ta, tb):
     ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk)
     F = Files(tmp_path, a=a, b=b, c=c0)
     try:
-        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=3, pinned_slots=4)
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=3, pinned_slots=4,
+                                      gemm_path=path, io_chunk_mib=1)
         bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"),
                           0, 0, 0, opts)
         got = F.read("c", np.float32, sc)
@@ -74,6 +77,94 @@ def test_flash_gemm_layouts_unaligned(dev, tmp_path, ord_, ta, tb):
         assert st["tasks"] == 12
         assert st["bytes_read"] == 4 * (a.size + b.size + c0.size)   # every tile read once
         assert st["bytes_written"] == 4 * c0.size                    # C written once
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_flash_gemm_mixed_alignment_stress(dev, tmp_path, ord_, ta, tb):
+    """Aligned leading dimension (640 floats = 5 sectors) + a tail-merged tile whose width is not a
+    multiple of 128 (600 = 256 + 344): some tile regions of every file are sector aligned and some
+    are not, and neighbouring C tiles share 4 KiB pages.  The reference serialises such writes
+    (src/scheduler/io_executor.cpp:28-156); here every request of the call on such a file goes
+    through ONE descriptor mode (the buffered twin), never O_DIRECT and buffered side by side.
+    beta != 0, 4 writer threads, repeated: any lost update shows up as a mismatch."""
+    m = n = k = 600
+    ld, blk = 640, 256
+    rng = np.random.default_rng(31)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+
+    def padded(shape):
+        x = rng.uniform(-1, 1, (shape[0], ld)).astype(np.float32)
+        return x
+    a, b, c0 = padded(sa), padded(sb), padded(sc)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), ld, ld, ld, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=4, n_io_threads=8, pinned_slots=6)
+        for rep in range(12):
+            bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"),
+                              ld, ld, ld, opts)
+            got = F.read("c", np.float32, c0.shape)
+            assert np.array_equal(got, ref), rep        # incl. the padding columns: untouched
+            c0.tofile(F.paths["c"])                     # restore C for the next round
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("ord_,ta,tb,beta", [("R", "N", "N", 0.0), ("R", "N", "N", 1.5), ("R", "T", "N", 1.5),
+                                             ("C", "N", "T", 0.0), ("C", "T", "T", 1.5), ("R", "N", "T", 0.0)])
+def test_flash_gemm_panels_ring_reuse(dev, tmp_path, monkeypatch, ord_, ta, tb, beta, group):
+    """Panel pipeline with an HBM budget that holds the resident operand(s) plus the minimum
+    rings (2*group panels of the streamed operand, 2*group+1 of C): every ring slot is reused several
+    times, so the write-after-read (operand panels) and write-back-before-refill (C panels, read
+    again when beta != 0) orderings are all exercised.  Tail-merged last panels in m and k."""
+    monkeypatch.setenv("BOF_PANEL_GROUP", str(group))
+    m, k, n, blk = 1100, 900, 1024, 128          # m: 8 panels + merged tail (76), k: 7 + separate... 900 = 7*128+4 -> merged
+    rng = np.random.default_rng(7)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.75, beta, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        # slots are rounded to 2 MiB: resident operands 4 MiB each at most, rings 2 MiB per panel
+        budget = (2 * 6 + (2 * group + 2 * group + 1) * 2) << 20
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=4, pinned_slots=3, gemm_path=2,
+                                      io_chunk_mib=1, hbm_budget=budget)
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.75, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+        st = bofhip.flash_last_stats()
+        nt = bofhip.gemm_plan(ord_, ta, tb, m, n, k, beta, 0, 0, 0, blk)[0]
+        assert st["tasks"] == len(nt)
+        assert st["bytes_read"] == 4 * (a.size + b.size + (c0.size if beta else 0))   # everything once
+        assert st["bytes_written"] == 4 * c0.size
+        # big sequential requests: a handful per panel instead of one per tile row
+        assert st["read_ops"] + st["write_ops"] < 3 * (st["bytes_read"] + st["bytes_written"]) / (1 << 20) + 64
+    finally:
+        F.close()
+
+
+def test_flash_gemm_panels_not_eligible_falls_back(dev, tmp_path):
+    """ldc > n (the gaps between C's rows are not ours to rewrite) and tiny budgets go to the tile
+    cache; gemm_path = 2 makes that an error instead of a silent change of path."""
+    m, k, n, blk = 512, 384, 256, 128
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n + 128)).astype(np.float32)
+    ref = orc.flash_gemm("R", "N", "N", m, n, k, 1.0, 1.0, a, b, c0.copy(), 0, 0, n + 128, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        bofhip.flash_gemm("R", "N", "N", m, n, k, 1.0, 1.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, n + 128,
+                          bofhip.default_options(gemm_blk=blk))
+        assert np.array_equal(F.read("c", np.float32, c0.shape), ref)
+        with pytest.raises(bofhip.BofError):
+            bofhip.flash_gemm("R", "N", "N", m, n, k, 1.0, 1.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, n + 128,
+                              bofhip.default_options(gemm_blk=blk, gemm_path=2))
     finally:
         F.close()
 

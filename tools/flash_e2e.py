@@ -1,101 +1,55 @@
 #!/usr/bin/env python3
-"""End-to-end FILE-resident runs (level 3) at sizes that fit the GPU box's disk: reports the
-disk/PCIe-inclusive rate that DESIGN.md quotes next to the HBM-resident bench value."""
+"""End-to-end FILE-resident flash::gemm (level 3) at a chosen size: the same measurement and the same
+whole-file verification as bench.py's `e2e.gemm` block (bench.e2e_gemm), with the knobs exposed:
+size, tile, descriptor mode, I/O path (tile cache / row panels), HBM budget."""
 import argparse
 import json
 import os
+import shutil
 import sys
-import time
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "blas-on-flash_amd"))
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import bofhip  # noqa: E402
-
-
-def write_dense(path, rows, cols, mode, dev):
-    t = torch.empty(rows * cols, dtype=torch.float32, device=dev)
-    bofhip.gen_dense(t.data_ptr(), 0, t.numel(), mode, 7, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    with open(path, "wb") as f:
-        step = 1 << 28
-        for i in range(0, t.numel(), step):
-            f.write(t[i:i + step].cpu().numpy().tobytes())
-    del t
-
-
-def open_fd(path, direct):
-    if direct:
-        try:
-            return os.open(path, os.O_RDWR | os.O_DIRECT)
-        except OSError:
-            print("O_DIRECT open failed, falling back to buffered", file=sys.stderr)
-    return os.open(path, os.O_RDWR)
+import bench  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dir", default="/tmp/bof_e2e")
+    ap.add_argument("--dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--blk", type=int, default=4096)
-    ap.add_argument("--direct", type=int, default=1)
+    ap.add_argument("--direct", type=int, default=-1, help="1 O_DIRECT only, 0 buffered only, -1 both")
     ap.add_argument("--io-threads", type=int, default=8)
     ap.add_argument("--pinned", type=int, default=8)
-    ap.add_argument("--drop-cache", type=int, default=0)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--path", type=int, default=0, help="0 choose, 1 tile cache, 2 row panels")
+    ap.add_argument("--chunk-mib", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--budget-gib", type=float, default=0.0,
-                    help="HBM tile budget (0 = library default: most of the free HBM); 8 = the reference's PROGRAM_BUDGET")
+                    help="HBM budget (0 = library default: most of the free HBM); 8 = the reference's PROGRAM_BUDGET")
     args = ap.parse_args()
-    os.makedirs(args.dir, exist_ok=True)
+    bofhip.require_device()
     dev = torch.device("cuda:0")
-    n = args.n
-    pa, pb, pc = (os.path.join(args.dir, x) for x in ("A.bin", "B.bin", "C.bin"))
-    t0 = time.time()
-    write_dense(pa, n, n, "s", dev)
-    write_dense(pb, n, n, "s", dev)
-    with open(pc, "wb") as f:
-        f.truncate(n * n * 4)
-    os.sync()
-    print(f"wrote 3 x {n * n * 4 / 2**30:.1f} GiB in {time.time() - t0:.1f} s", flush=True)
-    fds = [open_fd(p, args.direct) for p in (pa, pb, pc)]
-    if args.direct:  # drop the page cache copies the writes left behind
-        for fd in fds:
-            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
-    opts = bofhip.default_options(gemm_blk=args.blk, n_io_threads=args.io_threads,
-                                  pinned_slots=args.pinned, use_odirect=args.direct, n_streams=4,
-                                  hbm_budget=int(args.budget_gib * 2**30))
-    for rep in range(args.reps):
-        t0 = time.time()
-        bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
-                          bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
-        dt = time.time() - t0
-        print(f"call {rep}: {dt:.3f} s  {2.0 * n ** 3 / dt / 1e9:.0f} GFLOP/s", flush=True)
-    st = bofhip.flash_last_stats()
-    for fd in fds:
-        os.close(fd)
-    # closed form check on the first 16 rows: B[k,j] = (k*n + j) % 10 has period 10 in j, so
-    # C[i, j] = C[i, j % 10]; 10 reference columns are enough
-    c = np.fromfile(pc, np.float32, count=n * 16).reshape(16, n)
-    a64 = ((np.arange(16)[:, None] * n + np.arange(n)[None, :]) % 10).astype(np.float64)
-    b64 = ((np.arange(n)[:, None] * n + np.arange(10)[None, :]) % 10).astype(np.float64)
-    ref = a64 @ b64
-    ok = bool(np.array_equal(c.astype(np.float64), ref[:, np.arange(n) % 10]))
-    sim = None
-    if args.budget_gib > 0:
+    st = torch.cuda.current_stream().cuda_stream
+    work = tempfile.mkdtemp(prefix="bof_e2e_", dir=args.dir)
+    modes = {1: ("odirect",), 0: ("buffered",), -1: ("odirect", "buffered")}[args.direct]
+    try:
+        out = bench.e2e_gemm(bofhip, torch, dev, st, work, args.n, args.blk, None, args.io_threads, args.reps,
+                             modes=modes, gemm_path=args.path, io_chunk_mib=args.chunk_mib, n_streams=args.streams,
+                             pinned_slots=args.pinned, hbm_budget=int(args.budget_gib * 2**30))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out["args"] = vars(args)
+    if args.budget_gib > 0 and args.path == 1:
         slot = args.blk * args.blk * 4
-        sim = bofhip.flash_gemm_simulate("R", "N", "N", n, n, n, 0.0, args.blk, int(args.budget_gib * 2**30) // slot)
-    out = {"what": "flash_gemm end-to-end (files -> pinned ring -> HBM -> kernels -> files)",
-           "n": n, "tile": args.blk, "odirect": args.direct, "seconds": round(dt, 3),
-           "gflops": round(2.0 * n ** 3 / dt / 1e9, 1), "first_16_rows_exact": ok,
-           "read_GBps": round(st["bytes_read"] / dt / 1e9, 2),
-           "write_GBps": round(st["bytes_written"] / dt / 1e9, 2), "stats": st,
-           "budget_gib": args.budget_gib, "compulsory_read_bytes": 2 * n * n * 4,
-           "read_amplification": round(st["bytes_read"] / (2.0 * n * n * 4), 3),
-           "write_amplification": round(st["bytes_written"] / (1.0 * n * n * 4), 3), "simulated": sim}
+        out["simulated"] = bofhip.flash_gemm_simulate("R", "N", "N", args.n, args.n, args.n, 0.0, args.blk,
+                                                      int(args.budget_gib * 2**30) // slot,
+                                                      lookahead=2 * args.pinned)
     print(json.dumps(out), flush=True)
-    for p in (pa, pb, pc):
-        os.remove(p)
 
 
 if __name__ == "__main__":
