@@ -92,6 +92,7 @@ SYMBOLS = [
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_forget", C.c_int, [C.c_int]),
+    ("bof_file_set_request_bytes", C.c_int, [u64]),
     ("bof_gen_dense", C.c_int, [P, i64, i64, chr_, u64, P]),
     ("bof_gen_sparse_rows", C.c_int, [i64, i64, i64, i64, P, P, P, P]),
 ]

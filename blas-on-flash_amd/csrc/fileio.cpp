@@ -18,6 +18,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <linux/aio_abi.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
@@ -37,6 +38,20 @@ namespace bof {
 
 static constexpr uint64_t kSector = 512;
 static constexpr uint64_t kMaxChunk = 32ull << 20;  // reference MAX_CHUNK_SIZE
+// A contiguous O_DIRECT transfer is cut into requests of this size, all submitted together:
+// several medium requests in flight beat one huge one on every device measured so far
+// (profiles/r2/iobench_*.json).  BOF_IO_REQUEST_KIB / bof_file_set_request_bytes override.
+static std::atomic<uint64_t> g_req_bytes{0};
+static uint64_t request_bytes() {
+  uint64_t v = g_req_bytes.load(std::memory_order_relaxed);
+  if (v == 0) {
+    const char *e = getenv("BOF_IO_REQUEST_KIB");
+    v = e && atoll(e) > 0 ? (uint64_t) atoll(e) << 10 : (4ull << 20);
+    v = std::min(std::max<uint64_t>(v / kSector * kSector, kSector), kMaxChunk);
+    g_req_bytes.store(v);
+  }
+  return v;
+}
 static constexpr unsigned kAioEvents = 1024;
 static constexpr int kIoRetries = 5;                // reference submit_and_reap retries
 
@@ -177,15 +192,16 @@ static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_
   char *p = static_cast<char *>(buf);
   if (direct && aligned && use_aio && tls_ctx().ok) {
     std::vector<struct iocb> cbs;
-    cbs.reserve(n_strides == 1 ? (size_t) (len / kMaxChunk + 1) : (size_t) n_strides);
+    const uint64_t piece = request_bytes();
+    cbs.reserve(n_strides == 1 ? (size_t) (len / piece + 1) : (size_t) n_strides);
     for (uint64_t s = 0; s < n_strides; s++) {
-      for (uint64_t o = 0; o < len; o += kMaxChunk) {
+      for (uint64_t o = 0; o < len; o += piece) {
         struct iocb cb;
         memset(&cb, 0, sizeof(cb));
         cb.aio_fildes = (uint32_t) fd;
         cb.aio_lio_opcode = wr ? IOCB_CMD_PWRITE : IOCB_CMD_PREAD;
         cb.aio_buf = reinterpret_cast<uint64_t>(p + s * len + o);
-        cb.aio_nbytes = std::min(kMaxChunk, len - o);
+        cb.aio_nbytes = std::min(piece, len - o);
         cb.aio_offset = (int64_t) (offset + s * stride + o);
         cbs.push_back(cb);
       }
@@ -214,6 +230,11 @@ int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, ui
 
 }  // namespace bof
 
+extern "C" int bof_file_set_request_bytes(uint64_t bytes) {
+  if (bytes < 512 || bytes % 512) { bof::set_error("bof_file_set_request_bytes: need a multiple of 512"); return BOF_EINVAL; }
+  bof::g_req_bytes.store(std::min<uint64_t>(bytes, bof::kMaxChunk));
+  return BOF_OK;
+}
 extern "C" int bof_file_forget(int fd) {
   bof::file_forget(fd);
   return BOF_OK;

@@ -122,6 +122,12 @@ struct Cleanup {
   }
 };
 
+// Pins the calling thread to the CPUs of the NUMA node the HIP device hangs off (PCI bus id ->
+// /sys/bus/pci/devices/*/numa_node -> node cpulist), intersected with the CPUs the process is
+// allowed on.  Reader / writer / flusher threads call it so that page-cache copies and the
+// pinned staging rings stay on the GPU's socket.  No-op when the topology is
+// unknown or BOF_NUMA_BIND=0.  Returns the node or -1.
+int bind_thread_near_device(int dev);
 int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
 void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
 

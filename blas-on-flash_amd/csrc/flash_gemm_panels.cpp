@@ -153,6 +153,7 @@ struct PanelRun {
 
   void reader_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     ChunkReq rq;
     while (fetch_q.pop(rq)) {
       Mat &M = mat[rq.mat];
@@ -191,6 +192,7 @@ struct PanelRun {
   // free for a later one.
   void flusher_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     int pc;
     while (flush_q.pop(pc)) {
       Mat &C = mat[2];
@@ -221,6 +223,7 @@ struct PanelRun {
 
   void writer_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     WriteReq rq;
     while (write_q.pop(rq)) {
       hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));

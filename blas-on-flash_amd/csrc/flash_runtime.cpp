@@ -23,7 +23,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -50,6 +52,72 @@ std::recursive_mutex &device_call_mutex() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = 0; }
   return g_call_mu[dev & 63];
+}
+
+// ---- NUMA placement of the I/O threads -------------------------------------------------------
+namespace {
+struct NodeCpus { int node = -2; cpu_set_t set; };   // -2 not looked up yet, -1 unknown
+std::mutex g_numa_mu;
+NodeCpus g_numa[64];
+
+bool parse_cpulist(const char *txt, cpu_set_t *set) {
+  CPU_ZERO(set);
+  int n = 0;
+  const char *p = txt;
+  while (*p) {
+    char *end = nullptr;
+    long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int) c, set); n++; }
+    while (*p == ',' || *p == ' ' || *p == '\n') p++;
+  }
+  return n > 0;
+}
+bool read_small(const std::string &path, char *buf, size_t cap) {
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return false;
+  const size_t n = fread(buf, 1, cap - 1, f);
+  fclose(f);
+  buf[n] = 0;
+  return n > 0;
+}
+}  // namespace
+
+int bind_thread_near_device(int dev) {
+  static const bool enabled = !getenv("BOF_NUMA_BIND") || atoi(getenv("BOF_NUMA_BIND")) != 0;
+  if (!enabled || dev < 0 || dev >= 64) return -1;
+  NodeCpus nc;
+  {
+    std::lock_guard<std::mutex> lk(g_numa_mu);
+    NodeCpus &c = g_numa[dev];
+    if (c.node == -2) {
+      c.node = -1;
+      char bus[64] = {0}, buf[4096];
+      if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), dev) == hipSuccess) {
+        for (char *q = bus; *q; q++) *q = (char) tolower(*q);
+        if (read_small(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", buf, sizeof(buf))) {
+          const int node = atoi(buf);
+          if (node >= 0 &&
+              read_small("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", buf, sizeof(buf)) &&
+              parse_cpulist(buf, &c.set)) {
+            cpu_set_t allowed, both;
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+              CPU_AND(&both, &allowed, &c.set);
+              if (CPU_COUNT(&both) > 0) { c.set = both; c.node = node; }
+            }
+          }
+        }
+      } else {
+        (void) hipGetLastError();
+      }
+    }
+    nc = c;
+  }
+  if (nc.node < 0) return -1;
+  return sched_setaffinity(0, sizeof(nc.set), &nc.set) == 0 ? nc.node : -1;
 }
 
 static bof_flash_stats g_last_stats;
@@ -256,6 +324,7 @@ struct GemmRun {
 
   void reader_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     FetchReq rq;
     while (fetch_q.pop(rq)) {
       Tile &t = tiles[rq.tile];
@@ -284,6 +353,7 @@ struct GemmRun {
 
   void writer_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     WriteReq rq;
     while (write_q.pop(rq)) {
       Tile &t = tiles[rq.tile];
@@ -630,6 +700,7 @@ struct CsrRun {
 
   void reader_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     const int64_t nb = (int64_t) st.size();
     for (;;) {
       const int64_t b = next_blk.fetch_add(1);
@@ -688,6 +759,7 @@ struct CsrRun {
   // retires blocks in order: waits for the block's last GPU op, writes C (csrmm), frees ctx
   void retire_main() {
     (void) hipSetDevice(dev);
+    (void) bind_thread_near_device(dev);
     int64_t b;
     while (done_q.pop(b)) {
       CsrCtx &c = ctx[b % depth];
@@ -754,7 +826,7 @@ int stream_file(const bof_fptr &f, uint64_t bytes, char *dptr, bool to_device, h
   std::atomic<int> fail{0};
   int dev = 0;
   BOF_HIP_TRY(hipGetDevice(&dev));
-  auto worker = [&] {
+  auto worker = [&, dev] {
     (void) hipSetDevice(dev);
     PinnedRing ring;
     if (ring.init(2, chunk)) { fail.store(-1000); return; }

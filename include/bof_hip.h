@@ -260,6 +260,10 @@ int bof_file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
                    uint64_t len_per_stride, void *buf, int use_aio);
 int bof_file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides,
                     uint64_t len_per_stride, const void *buf, int use_aio);
+/* Size of the requests a contiguous O_DIRECT transfer is cut into (all submitted together);
+ * default 4 MiB or $BOF_IO_REQUEST_KIB.  Multiple of 512, at most 32 MiB (the reference's
+ * MAX_CHUNK_SIZE, flash_file_handle.cpp:25). */
+int bof_file_set_request_bytes(uint64_t bytes);
 /* Unaligned requests on an O_DIRECT descriptor go through a cached buffered descriptor of
  * the same file; call this before close(fd) so that it is closed too
  * (FlashFileHandle::close does). */

@@ -136,15 +136,47 @@ def main():
 
     if direct:
         od = {}
-        for nthr in (1, 2, 4, 8, 16):
-            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
-            od[f"read_contig32M_{nthr}thr"] = round(reader(fd, nthr, 32 << 20, "contig", 1), 2)
-        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
-        od["read_contig4M_8thr"] = round(reader(fd, 8, 4 << 20, "contig", 1), 2)
+        # one 32 MiB transfer per call, cut into `req`-sized requests that are submitted together
+        for req_mib in (1, 2, 4, 8, 16, 32):
+            L.bof_file_set_request_bytes(req_mib << 20)
+            for nthr in (2, 4, 8, 16):
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                od[f"read_32M_as_{req_mib}M_requests_{nthr}thr"] = round(reader(fd, nthr, 32 << 20, "contig", 1), 2)
+        L.bof_file_set_request_bytes(4 << 20)
         os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
         od["read_tile16K_rows_8thr"] = round(reader(fd, 8, 0, "tile", 1), 2)
-        for nthr in (1, 4, 8, 16):
-            od[f"write_contig32M_{nthr}thr"] = round(writer(fd, nthr, 32 << 20, 1), 2)
+        for req_mib in (1, 4, 8, 32):
+            L.bof_file_set_request_bytes(req_mib << 20)
+            for nthr in (2, 4, 8, 16):
+                od[f"write_32M_as_{req_mib}M_requests_{nthr}thr"] = round(writer(fd, nthr, 32 << 20, 1), 2)
+        L.bof_file_set_request_bytes(4 << 20)
+        # reads and writes at the same time (the pipeline's steady state): 8 readers + 4 writers
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        both = {}
+
+        def rd_side():
+            both["read"] = reader(fd, 8, 32 << 20, "contig", 1)
+
+        def wr_side():
+            nchunks = size // slot
+
+            def work(i):
+                for cidx in range(i, nchunks, 4):
+                    L.bof_file_swrite(fd2, cidx * slot, 0, 1, 32 << 20, hbuf[8 + i], 1)
+                    L.bof_file_swrite(fd2, cidx * slot + (32 << 20), 0, 1, 32 << 20, hbuf[8 + i] + (32 << 20), 1)
+            both["write"] = size / run_threads(4, work) / 1e9
+        path2 = path + ".2"
+        with open(path2, "wb") as f:
+            f.truncate(size)
+        fd2 = os.open(path2, os.O_RDWR | os.O_DIRECT)
+        bofhip.device_to_file(bofhip.FPtr(fd2, 0), size, t.data_ptr(), bofhip.default_options(use_odirect=1), st)
+        ta = threading.Thread(target=rd_side)
+        tb = threading.Thread(target=wr_side)
+        ta.start(); tb.start(); ta.join(); tb.join()
+        od["concurrent_read_8thr"] = round(both["read"], 2)
+        od["concurrent_write_4thr"] = round(both["write"], 2)
+        os.close(fd2)
+        os.remove(path2)
         res["o_direct_GBps"] = od
     os.close(fd)
 
