@@ -230,3 +230,57 @@ def test_gemm_4096_generator_known_answer(dev):
     A64 = (np.arange(5 * n, dtype=np.int64) % 10).reshape(5, n).astype(np.float64)
     B64 = ((np.arange(n)[:, None] * n + np.arange(10)[None, :]) % 10).astype(np.float64)
     assert np.array_equal(pat.cpu().numpy().astype(np.float64), A64 @ B64)
+
+
+@pytest.fixture(scope="module")
+def golden_big():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return np.load(os.path.join(root, "tests", "golden", "mkl_golden_big.npz"))
+
+
+def test_gen_dense_u_matches_numpy_restatement(dev):
+    """The inputs of mkl_golden_big.npz are regenerated, not stored: device generator == numpy."""
+    from gen_u import dense_u
+    for first, count, seed in [(0, 1 << 20, 11), (123456789, 300000, 12), (2 ** 33 + 5, 4096, 13)]:
+        t = torch.empty(count, dtype=torch.float32, device=dev)
+        bofhip.gen_dense(ptr(t), first, count, "u", seed, stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), dense_u(first, count, seed))
+
+
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_big_kernels_vs_mkl_random(dev, golden_big, ord_, ta, tb):
+    """4096 x 2048 x 1024, uniform [-1,1) inputs, alpha = 0.5, beta = 2: the 256x256 MFMA kernels
+    (LDS-DMA staging for k-major x k-major operands, register staging otherwise) and the level-2
+    tile DAG with 1024-tiles (one task per accumulate chain) and 256-tiles (512 tasks, chains of
+    4) against cblas_sgemm (MKL 2021.4) sub-blocks, 1e-4 relative (BASELINE north_star)."""
+    meta = str(golden_big["meta"][1]).split()
+    m, n, k = int(meta[1]), int(meta[2]), int(meta[3])
+    alpha, beta = float(meta[5]), float(meta[7])
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = torch.empty(sa[0] * sa[1], dtype=torch.float32, device=dev)
+    b = torch.empty(sb[0] * sb[1], dtype=torch.float32, device=dev)
+    c0 = torch.empty(sc[0] * sc[1], dtype=torch.float32, device=dev)
+    bofhip.gen_dense(ptr(a), 0, a.numel(), "u", 11, stream())
+    bofhip.gen_dense(ptr(b), 0, b.numel(), "u", 12, stream())
+    bofhip.gen_dense(ptr(c0), 0, c0.numel(), "u", 13, stream())
+    want = golden_big[f"{ord_}{ta}{tb}"]
+    blocks = golden_big["blocks"]
+
+    def check(c, what):
+        C = c.view(sc).cpu().numpy()
+        L = C if ord_ == "R" else C.T
+        for (r, q), ref in zip(blocks, want):
+            assert rel_err(L[r:r + 64, q:q + 64], ref) < TOL, (what, int(r), int(q))
+
+    c = c0.clone()
+    bofhip.sgemm(ord_, ta, tb, m, n, k, alpha, ptr(a), sa[1], ptr(b), sb[1], beta, ptr(c), sc[1], stream())
+    torch.cuda.synchronize()
+    check(c, "bof_sgemm")
+    for blk in (1024, 256):
+        c = c0.clone()
+        bofhip.gemm_resident(ord_, ta, tb, m, n, k, alpha, beta, ptr(a), ptr(b), ptr(c), 0, 0, 0,
+                             bofhip.default_options(gemm_blk=blk), stream())
+        torch.cuda.synchronize()
+        check(c, f"bof_gemm_resident blk={blk}")

@@ -270,3 +270,34 @@ def test_oracle_transposition_exact_hashes(golden_tr):
     c = np.zeros((2048, 128), np.float32)
     orc.scsrmm_t(4096, 2048, 128, 1.0, val, ia, ja, b, 128, 0.0, c, 128)
     assert hashlib.sha256(c.tobytes()).hexdigest() == want["gen_csrmmT_c"]
+
+
+def test_oracle_vs_mkl_big_random_blocks():
+    """The oracle's sgemm against cblas_sgemm on the 4096 x 2048 x 1024 uniform-random problems of
+    tests/golden/mkl_golden_big.npz (the inputs are regenerated by tests/gen_u.py): only the rows /
+    columns of the stored 64 x 64 sub-blocks are computed."""
+    from gen_u import dense_u
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mkl_golden_big.npz"))
+    meta = str(g["meta"][1]).split()
+    m, n, k = int(meta[1]), int(meta[2]), int(meta[3])
+    alpha, beta = float(meta[5]), float(meta[7])
+    # KAT of the generator restatement itself (values computed once from the formula by hand)
+    u = dense_u(0, 4, 11)
+    assert u.dtype == np.float32 and np.all(u >= -1) and np.all(u < 1)
+    assert len({float(x) for x in dense_u(0, 1000, 11)}) > 990
+    for ord_, ta, tb in [("R", "N", "N"), ("R", "T", "T"), ("C", "N", "T"), ("C", "T", "N")]:
+        sa = (m, k) if (ta == "T") == (ord_ == "C") else (k, m)
+        sb = (k, n) if (tb == "T") == (ord_ == "C") else (n, k)
+        sc = (m, n) if ord_ == "R" else (n, m)
+        a = dense_u(0, sa[0] * sa[1], 11).reshape(sa)
+        b = dense_u(0, sb[0] * sb[1], 12).reshape(sb)
+        c0 = dense_u(0, sc[0] * sc[1], 13).reshape(sc)
+        al = a if sa == (m, k) else a.T          # logical m x k
+        bl = b if sb == (k, n) else b.T          # logical k x n
+        cl = c0 if ord_ == "R" else c0.T
+        for (r, q), ref in zip(g["blocks"], g[f"{ord_}{ta}{tb}"]):
+            asub = np.ascontiguousarray(al[r:r + 64])
+            bsub = np.ascontiguousarray(bl[:, q:q + 64])
+            c = np.ascontiguousarray(cl[r:r + 64, q:q + 64]).copy()
+            orc.sgemm("R", "N", "N", 64, 64, k, alpha, asub, k, bsub, 64, beta, c, 64)
+            assert np.abs(c - ref).max() / np.abs(ref).max() < 1e-4
