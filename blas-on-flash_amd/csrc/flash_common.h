@@ -128,6 +128,15 @@ struct Cleanup {
 // pinned staging rings stay on the GPU's socket.  No-op when the topology is
 // unknown or BOF_NUMA_BIND=0.  Returns the node or -1.
 int bind_thread_near_device(int dev);
+// Named ranges for rocprofv3 --marker-trace (roctx): resolved from librocprofiler-sdk-roctx /
+// libroctx64 at first use, silently absent otherwise.  BOF_TRACE=1 additionally prints a
+// wall-clock timeline to stderr.
+void trace_push(const char *name);
+void trace_pop();
+struct TraceRange {
+  explicit TraceRange(const char *name) { trace_push(name); }
+  ~TraceRange() { trace_pop(); }
+};
 int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
 void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
 

@@ -160,8 +160,10 @@ struct PanelRun {
       Panel &P = M.panels[(size_t) rq.panel];
       const int ps = res->rring.acquire();
       int rc = 0;
-      if (!io_error.load())
+      if (!io_error.load()) {
+        TraceRange r("panel chunk read");
         rc = file_sread(M.fd, M.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, res->rring.ptr(ps), M.aio);
+      }
       if (rc) fail_io(rc);
       hipError_t e = hipSuccess;
       const int prev = M.natural ? -1 : rq.panel - M.n_slots;
@@ -229,8 +231,10 @@ struct PanelRun {
       hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
       if (e != hipSuccess) fail_io(-1000 - (int) e);
       int rc = 0;
-      if (!io_error.load())
+      if (!io_error.load()) {
+        TraceRange r("panel chunk write");
         rc = file_swrite(mat[2].fd, rq.file_off, 0, 1, rq.bytes, res->wring.ptr(rq.wslot), mat[2].aio);
+      }
       if (rc) fail_io(rc);
       cnt.wr += rq.bytes;
       res->wring.release(rq.wslot);
@@ -439,6 +443,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   std::vector<int> waited((size_t) 3 * (size_t) R.ss->n, -1);
   size_t t = 0;
   for (int gi = 0; gi < n_groups && !fail && herr == hipSuccess; gi++) {
+    TraceRange grange("panel group dispatch");
     for (; t < group_end[(size_t) gi]; t++) {
       const bof_gemm_task &tk = tasks[t];
       const int64_t idx[3] = {tk.i, tk.l, tk.j};

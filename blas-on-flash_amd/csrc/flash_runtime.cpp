@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/stat.h>
@@ -52,6 +53,32 @@ std::recursive_mutex &device_call_mutex() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = 0; }
   return g_call_mu[dev & 63];
+}
+
+// ---- roctx ranges -------------------------------------------------------------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve() {
+  for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+    void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    g_roctx_push = (roctx_push_fn) dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_fn) dlsym(h, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) return;
+    g_roctx_push = nullptr; g_roctx_pop = nullptr;
+  }
+}
+}  // namespace
+void trace_push(const char *name) {
+  std::call_once(g_roctx_once, roctx_resolve);
+  if (g_roctx_push) (void) g_roctx_push(name);
+}
+void trace_pop() {
+  if (g_roctx_pop) (void) g_roctx_pop();
 }
 
 // ---- NUMA placement of the I/O threads -------------------------------------------------------
@@ -416,6 +443,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   int rc = device_ready();
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
+  TraceRange range("bof_flash_gemm");
   GemmRun R;
   R.o = resolved(opts);
   R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
@@ -1166,6 +1194,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   int rc = device_ready();
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
+  TraceRange range(is_mm ? "bof_flash_csrmm" : "bof_flash_csrgemv");
   CsrRun R;
   if (carry) {  // bytes moved by the transposition that produced `res`
     R.cnt.rd += carry->rd.load(); R.cnt.h2d += carry->h2d.load(); R.cnt.d2h += carry->d2h.load();

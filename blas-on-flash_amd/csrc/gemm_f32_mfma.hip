@@ -116,7 +116,7 @@ __device__ __forceinline__ f32x4 s2op(const float *__restrict__ s, int x, int q,
 //        kt is multiplied out of buffer kt&1, slab kt+1 (fetched one slab earlier) is
 //        written to the other buffer and slab kt+2's global loads are in flight.
 template <int BM, int BN, int WM, int WN, bool DBUF, int AMODE, int BMODE, bool GUARD>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : (BM * BN == 65536 ? 1 : 3))
+__global__ void __launch_bounds__(64 * WM * WN, 3)
 sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                   int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
                   float alpha, float beta, int tiles_m, int tiles_n) {
@@ -241,6 +241,33 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
     }
 }
 
+// Epilogue shared by the one-wave-per-SIMD 256 x 256 kernels: the wave's 128 x 128 tile (4 x 4
+// accumulators of 32 x 32; lane (i, h) holds rows 8q + 4h' ... of column i, the MFMA output
+// layout) goes out as c = beta == 0 ? alpha*acc : fmaf(alpha, acc, beta*c).
+__device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64_t ldc, int m0, int n0, int wm,
+                                                    int wn, int h, int i, const f32x16 (&acc)[4][4], float alpha,
+                                                    float beta) {
+  float *ctile = C + (int64_t) m0 * ldc + n0;
+  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+      f32x16 old;
+      if (beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
+        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 256 x 256 x 32 block tile, ONE wave per SIMD (4 waves, wave tile 128 x 128 = 16
 // accumulators = 256 AGPRs), double-buffered LDS, one barrier per slab.
@@ -295,16 +322,6 @@ __device__ __forceinline__ f32x4 ld_stage(const float *__restrict__ origin, int6
   return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(u) + goff);
 }
 
-// LDS-DMA staging of one float4-per-lane piece of a KMAJOR slab (1 KiB per wave-instruction =
-// one k-row of 256 floats): no VGPR round trip, no ds_write.  `dst` is the wave-uniform LDS
-// address of the piece (the hardware adds lane*16).
-__device__ __forceinline__ void dma_piece(const float *__restrict__ origin, int64_t ld, int k0, int p,
-                                          unsigned goff, float *dst) {
-  const float *u = origin + (int64_t) (k0 + 4 * p) * ld;
-  __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(u) + goff,
-                                   (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
-}
-
 // K-tail version (only the last, partial slab is fetched with it): elements at k >= K read as 0,
 // which leaves every fmaf chain unchanged.
 template <int MODE>
@@ -326,12 +343,11 @@ __device__ __forceinline__ f32x4 ld_stage_tail(const float *__restrict__ origin,
   return v;
 }
 
-template <int AMODE, int BMODE, bool W, bool L, bool DMA = false, bool TAIL = false>
+template <int AMODE, int BMODE, bool W, bool L, bool TAIL = false>
 __device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restrict__ Ao, int64_t lda,
                                          const float *__restrict__ Bo, int64_t ldb, int k2,
                                          unsigned a_goff, unsigned b_goff, Stage<8> &ra, Stage<8> &rb,
-                                         f32x16 (&acc)[4][4], float *a_dma = nullptr,
-                                         float *b_dma = nullptr, int K = 0, int t = 0) {
+                                         f32x16 (&acc)[4][4], int K = 0, int t = 0) {
   f32x4 a[2][4], b[2][4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
@@ -356,15 +372,7 @@ __device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restri
         }
       }
       const int s = 4 * q + c;
-      if (DMA) {  // k2 is the NEXT slab here: the piece lands directly in the other LDS buffer
-        if (W && s < 4) {  // all 16 pieces go out in the first quarter of the slab so that the
-                           // vmcnt(0) before the barrier finds them landed
-          dma_piece(Ao, lda, k2, 2 * s, a_goff, a_dma + (2 * s) * 4 * 256);
-          dma_piece(Bo, ldb, k2, 2 * s, b_goff, b_dma + (2 * s) * 4 * 256);
-          dma_piece(Ao, lda, k2, 2 * s + 1, a_goff, a_dma + (2 * s + 1) * 4 * 256);
-          dma_piece(Bo, ldb, k2, 2 * s + 1, b_goff, b_dma + (2 * s + 1) * 4 * 256);
-        }
-      } else if (s < 8) {
+      if (s < 8) {
         if (W) wr_stage<AMODE>(bs.a_wr, ra.v[s], s);
         if (L) ra.v[s] = TAIL ? ld_stage_tail<AMODE>(Ao, lda, k2, s, a_goff, K, t)
                               : ld_stage<AMODE>(Ao, lda, k2, s, a_goff);
@@ -465,8 +473,8 @@ sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *
   }
   if (KTAIL) {  // slab nkt-3: the slab fetched now is the partial one
     const Bases1w bs = (kt & 1) ? b1 : b0;
-    slab_1w2<AMODE, BMODE, true, true, false, true>(bs, Ao, lda, Bo, ldb, (kt + 2) * BK, a_goff, b_goff, ra,
-                                                    rb, acc, nullptr, nullptr, K, t);
+    slab_1w2<AMODE, BMODE, true, true, true>(bs, Ao, lda, Bo, ldb, (kt + 2) * BK, a_goff, b_goff, ra, rb, acc,
+                                             K, t);
     __syncthreads();
     kt++;
   }
@@ -481,114 +489,9 @@ sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *
     slab_1w2<AMODE, BMODE, false, false>(bs, Ao, lda, Bo, ldb, 0, a_goff, b_goff, ra, rb, acc);
   }
 
-  float *ctile = C + (int64_t) m0 * ldc + n0;
-  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
-#pragma unroll
-  for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
-      f32x16 old;
-      if (beta != 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
-      }
-    }
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta);
 }
 
-// Variant 3: both operands KMAJOR ('T','N' in row-major terms), staged exclusively by LDS-DMA.
-__global__ void __launch_bounds__(256, 1)
-sgemm_tile256_dma_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
-                         int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
-                         float alpha, float beta, int tiles_m, int tiles_n) {
-  constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;
-  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_BUF];
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  constexpr int GROUP_M = 4;
-  const int per_group = GROUP_M * tiles_n;
-  const int gid = bid / per_group;
-  const int first_m = gid * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (bid % per_group) % gsz;
-  const int tn = (bid % per_group) / gsz;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int a_rd = h * 256 + wm * 128 + i;
-  const int b_rd = LDS_A + h * 256 + wn * 128 + i;
-  const unsigned a_goff = 4u * (unsigned) ((t >> 6) * (int) lda + 4 * (t & 63));
-  const unsigned b_goff = 4u * (unsigned) ((t >> 6) * (int) ldb + 4 * (t & 63));
-  const float *Ao = A + m0, *Bo = B + n0;
-  // wave-uniform DMA destinations (k-row `wave` of each 4-row piece), per buffer
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  float *a_dma0 = lds + wv * 256, *b_dma0 = lds + LDS_A + wv * 256;
-  float *a_dma1 = a_dma0 + LDS_BUF, *b_dma1 = b_dma0 + LDS_BUF;
-  Bases1w b0, b1;
-  b0.a_rd = lds + a_rd;           b0.b_rd = lds + b_rd;           b0.a_wr = b0.b_wr = nullptr;
-  b1.a_rd = lds + LDS_BUF + a_rd; b1.b_rd = lds + LDS_BUF + b_rd; b1.a_wr = b1.b_wr = nullptr;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-
-  const int nkt = K / BK;
-  Stage<8> ra, rb;  // unused by the DMA path
-#pragma unroll
-  for (int p = 0; p < 8; p++) {
-    dma_piece(Ao, lda, 0, p, a_goff, a_dma0 + p * 4 * 256);
-    dma_piece(Bo, ldb, 0, p, b_goff, b_dma0 + p * 4 * 256);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nkt; kt++) {
-    const bool odd = kt & 1;
-    slab_1w2<KMAJOR, KMAJOR, true, false, true>(odd ? b1 : b0, Ao, lda, Bo, ldb, (kt + 1) * BK, a_goff,
-                                                b_goff, ra, rb, acc, odd ? a_dma0 : a_dma1,
-                                                odd ? b_dma0 : b_dma1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-    __syncthreads();
-  }
-  slab_1w2<KMAJOR, KMAJOR, false, false, true>((kt & 1) ? b1 : b0, Ao, lda, Bo, ldb, 0, a_goff, b_goff, ra,
-                                               rb, acc);
-
-  float *ctile = C + (int64_t) m0 * ldc + n0;
-  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
-#pragma unroll
-  for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
-      f32x16 old;
-      if (beta != 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
-      }
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // Variant 4: variant 3 with the two remaining sources of VALU work in the slab loop removed.
@@ -763,25 +666,7 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead fragment reads of the last slab
 
-  float *ctile = C + (int64_t) m0 * ldc + n0;
-  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
-#pragma unroll
-  for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
-      f32x16 old;
-      if (beta != 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
-      }
-    }
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1010,25 +895,7 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // look-ahead loads/reads of the last slabs
 
-  float *ctile = C + (int64_t) m0 * ldc + n0;
-  const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
-#pragma unroll
-  for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) {
-      f32x16 old;
-      if (beta != 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
-      }
-    }
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta);
 }
 
 template <int AMODE, int BMODE>
@@ -1051,35 +918,26 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
                       ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   const bool vec_ok = vec_ld && (K % BK == 0) && (K > 0);
-  // 256x256 kernels for the tile-aligned part of the problem:
-  //   4 (default): hand-scheduled slab loops (explicit LDS reads/writes with immediate offsets,
+  // 256x256 kernels (one wave per SIMD) for the tile-aligned part of the problem:
+  //   K % 64 == 0: hand-scheduled slab loops (explicit LDS reads/writes with immediate offsets,
   //      scalar-addressed global loads / DMA, barrier in front of the last k-group): 'T','N'
-  //      through LDS-DMA (147.6-149.5 TFLOP/s at 4096^3, 149.7 at K = 16384), the layouts with an
-  //      x-major operand through registers (NN 145.0, TT 145.4, NT 141.8); needs K % 64 == 0,
-  //      otherwise 3
-  //   3: one wave per SIMD; KMAJOR x KMAJOR staged purely by LDS-DMA (143.3 TFLOP/s at
-  //      4096^3), every other layout through variant 2 (140.6-141.3)
-  //   2: one wave per SIMD, register staging, constant-offset addressing
-  //   0: 8 waves, 2 per SIMD (137-138)   (a variant 1 -- variant 2 with per-access address
-  //      arithmetic, 138.5 -- existed earlier in the round)
-  static const int big_tile_variant = getenv("BOF_GEMM_VARIANT") ? atoi(getenv("BOF_GEMM_VARIANT")) : 4;
-
+  //      through LDS-DMA (sgemm_tile256_dma2_kernel: 147.6-149.5 TFLOP/s at 4096^3, 149.7 at
+  //      K = 16384), the layouts with an x-major operand through registers
+  //      (sgemm_tile256_1w3_kernel: NN 145.0, TT 145.4, NT 141.8);
+  //   any other K: the compiler-scheduled register-staging loop (sgemm_tile256_1w2_kernel,
+  //      140.6-141.3), its last partial slab fetched with guarded loads when K % 32 != 0.
   // Ragged sizes (tail-merged tiles of 4096+r, unaligned problem edges): the largest
   // 256-aligned interior runs on the big-tile kernel (its last K slab guarded when K % 32 != 0),
   // the right and bottom strips on the guarded 128x128 kernel.  Every output element is still
   // produced by one kernel as one k-ordered chain, so the split does not change a single bit.
   const int Mi = M - M % 256, Ni = N - N % 256;
   const bool k_ok = (K % BK == 0) ? (K >= 2 * BK) : (K >= 3 * BK);
-  if (big_tile_variant >= 2 && vec_ld && k_ok && (int64_t) (Mi / 256) * (Ni / 256) >= 128 &&
-      lda < (1 << 22) && ldb < (1 << 22)) {
+  if (vec_ld && k_ok && (int64_t) (Mi / 256) * (Ni / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
     const int tiles_m = Mi / 256, tiles_n = Ni / 256;
-    if (big_tile_variant == 4 && AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
+    if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
       hipLaunchKernelGGL(sgemm_tile256_dma2_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                          ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
-    else if (big_tile_variant >= 3 && AMODE == KMAJOR && BMODE == KMAJOR && K % BK == 0)
-      hipLaunchKernelGGL(sgemm_tile256_dma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
-                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
-    else if (big_tile_variant == 4 && K % (2 * BK) == 0)
+    else if (K % (2 * BK) == 0)
       hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
                          A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
     else if (K % BK == 0)
@@ -1101,13 +959,6 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
                                        beta, st);
     }
     return e;
-  }
-  if (vec_ok && M % 256 == 0 && N % 256 == 0 && (int64_t) (M / 256) * (N / 256) >= 128) {
-    const int tiles_m = M / 256, tiles_n = N / 256;
-    hipLaunchKernelGGL((sgemm_tile_kernel<256, 256, 2, 4, true, AMODE, BMODE, false>),
-                       dim3(tiles_m * tiles_n), dim3(512), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
-                       alpha, beta, tiles_m, tiles_n);
-    return hipGetLastError();
   }
   const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
   dim3 grid(tiles_m * tiles_n), block(256);

@@ -85,17 +85,6 @@ def test_sgemm_bit_exact_vs_oracle(dev, ord_, ta, tb, m, n, k, alpha, beta):
     assert rel_err(gotl, full) < TOL
 
 
-@pytest.mark.parametrize("variant", ["0", "2", "3"])
-def test_sgemm_big_tile_other_variants_subprocess(dev, variant):
-    """The non-default shapes of the 256x256 kernel (BOF_GEMM_VARIANT, read once at library
-    load) stay bit-exact too; each is checked in a child process."""
-    import subprocess, sys, os
-    env = dict(os.environ, BOF_GEMM_VARIANT=variant)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
-                        "big_tile_kernel_bit_exact"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:]
-
-
 @pytest.mark.parametrize("ta,tb", list(itertools.product("NT", "NT")))
 def test_sgemm_big_tile_kernel_bit_exact(dev, ta, tb):
     """4096 x 2048 x 96 is 16 x 8 = 128 blocks of 256 x 256: the double-buffered 8-wave

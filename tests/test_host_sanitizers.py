@@ -14,7 +14,7 @@ def test_plan_fileio_and_schedule_under_asan_ubsan(tmp_path):
            os.path.join(csrc, "plan.cpp"), os.path.join(csrc, "fileio.cpp"), os.path.join(csrc, "flash_runtime.cpp"),
            os.path.join(csrc, "flash_gemm_panels.cpp"),
            os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64",
-           "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+           "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300,
