@@ -139,6 +139,52 @@ def pmc_traffic():
         return None, None
 
 
+def check_tile_row_float64(torch, a_rows, b, c_rows, k, n, col_chunk=8192):
+    """max |C - A B| / max |A B| over a full tile-row of C (rows x n outputs) against a float64
+    product (torch.mm in fp64 is only the checker here), column block by column block."""
+    rows = a_rows.numel() // k
+    a64 = a_rows.view(rows, k).double()
+    worst, scale = 0.0, 0.0
+    for j0 in range(0, n, col_chunk):
+        j1 = min(n, j0 + col_chunk)
+        ref = a64 @ b.view(k, n)[:, j0:j1].double()
+        got = c_rows.view(rows, n)[:, j0:j1].double()
+        worst = max(worst, float((got - ref).abs().max().item()))
+        scale = max(scale, float(ref.abs().max().item()))
+        del ref, got
+    return worst / max(scale, 1e-30)
+
+
+def resident_gemm_line(bofhip, torch, dev, st, m_local, n, k, row0, blk, streams, steps, label):
+    """One more HBM-resident tile-DAG measurement (secondary line): generated inputs, `steps` timed
+    passes after one warm-up, first tile-row checked against float64."""
+    a = torch.empty(m_local * k, dtype=torch.float32, device=dev)
+    b = torch.empty(k * n, dtype=torch.float32, device=dev)
+    c = torch.empty(m_local * n, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(a.data_ptr(), row0 * k, a.numel(), "u", 1, st)
+    bofhip.gen_dense(b.data_ptr(), 0, b.numel(), "u", 2, st)
+    opts = bofhip.default_options(gemm_blk=blk, n_streams=streams)
+    run = lambda: bofhip.gemm_resident("R", "N", "N", m_local, n, k, 1.0, 0.0, a.data_ptr(), b.data_ptr(),   # noqa: E731
+                                       c.data_ptr(), 0, 0, 0, opts, st)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rows = min(m_local, blk)
+    rel = check_tile_row_float64(torch, a[:rows * k], b, c[:rows * n], k, n)
+    tasks = len(bofhip.gemm_plan("R", "N", "N", m_local, n, k, 0.0, 0, 0, 0, blk)[0])
+    del a, b, c
+    torch.cuda.empty_cache()
+    bofhip.lib().bof_flash_release()
+    flops = 2.0 * m_local * n * k
+    return {"workload": label, "ms_per_step": round(dt * 1e3, 2), "gflops": round(flops / dt / 1e9, 1),
+            "tile_tasks": tasks, "frac_of_mfma_peak": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "first_tile_row_rel_err_vs_float64": rel}
+
+
 def csr_secondary(bofhip, torch, dev, st):
     """Secondary lines of the metric: flash _csrmm at BASELINE configs[2] (10M x 1M CSR, 1e9 nnz,
     x 1M x 128 dense) and _csrgemv at the configs[4] size (50M x 50M, 5e8 nnz), HBM-resident,
@@ -700,15 +746,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- parity spot check on the timed output (size-independent property) -------
-    # linearity/closed form is covered in tests; here: C row 0 against float64 on 64 columns
-    import numpy as np
-    cols = 64
-    a0 = a[:k].double()
-    bsub = b.view(k, n)[:, :cols].double()
-    ref = (a0 @ bsub).cpu().numpy()
-    got = c.view(m_local, n)[0, :cols].double().cpu().numpy()
-    rel = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+    # ---- parity check on the timed output: a full tile-row of C against float64 --------------
+    rows = min(m_local, args.blk)
+    rel = check_tile_row_float64(torch, a[:rows * k], b, c[:rows * n], k, n)
 
     sharded = None
     if world > 1 and not args.no_csr and not args.size:
@@ -773,7 +813,7 @@ def main():
                          "flops_per_launch": flops_per_launch, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, PMC)",
                          "traffic_source": traffic_src},
-            "parity_spot_rel_err": rel,
+            "parity_first_tile_row_rel_err_vs_float64": rel,
         }
         if not args.no_cpu and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(bofhip, dev, st, with_csr=not args.no_csr and not args.size)
@@ -784,6 +824,17 @@ def main():
                 out["secondary"] = csr_secondary(bofhip, torch, dev, st)
             except Exception as e:  # the headline line must still be printed
                 out["secondary"] = {"error": str(e)[:200]}
+            # north_star's 64k x 64k x 64k at N = 1 (48 GiB resident), and the slab ONE rank of the
+            # 8-GPU run owns (BASELINE configs[3]): the same per-GPU workload the N = 8 line reports
+            try:
+                out["secondary"]["gemm_65536"] = resident_gemm_line(
+                    bofhip, torch, dev, st, 65536, 65536, 65536, 0, args.blk, args.streams, 1,
+                    "flash _gemm fp32 65536^3, 4096-tile, resident in HBM (48 GiB), 1xMI355X: 4096 tile tasks, 562.9 TFLOP")
+                out["secondary"]["gemm_65536_rank0_slab_of_8"] = resident_gemm_line(
+                    bofhip, torch, dev, st, 8192, 65536, 65536, 0, args.blk, args.streams, 2,
+                    "rank 0's row slab of BASELINE configs[3]: 8192 x 65536 x 65536 (512 tile tasks, 70.4 TFLOP), resident")
+            except Exception as e:
+                out["secondary"]["gemm_65536_error"] = str(e)[:200]
         if not args.no_e2e and n_gpus == 1 and world == 1 and not shard_of:
             try:
                 del a, b, c

@@ -58,21 +58,25 @@ def allreduce_partial(y, group=None):
 
 
 def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0, ldc=0, opts=None, group=None,
-                           device=None, one_gpu_debug=False):
-    """Multi-GPU flash::gemm('R','N','N') on FILE-resident matrices (BASELINE configs[3]; SURVEY 8f-4):
-    rank g owns the C rows [r0, r1) (tile-aligned, `row_shard`).  With 288 GB of HBM per GPU the
-    rank's A slab, its C slab and the whole of B are simply made resident:
+                           device=None, one_gpu_debug=False, b_once_per_node=False):
+    """Multi-GPU flash::gemm('R','N','N') on FILE-resident matrices (BASELINE configs[3]; SURVEY 8e):
+    rank g owns the C rows [r0, r1) (tile-aligned, `row_shard`).
 
-      * A[r0:r1, :] and (beta != 0) C[r0:r1, :] stream from the files into HBM;
-      * B is read from storage ONCE per node, not once per GPU: rank g reads the k-row panel
-        B[k0:k1, :] and one all-gather (RCCL over xGMI) assembles the full matrix on every
-        GPU -- the reference design would have every worker pull all of B through its own cache;
-      * the tile DAG runs over the resident slabs (bof_gemm_resident, same tiles, same k-order as
-        the single-GPU file path, so the C file is bit-identical);
-      * C[r0:r1, :] streams back into the file.
+    Default (no collective, as BASELINE configs[3] says): every rank simply calls the single-GPU
+    file pipeline on its slab -- bof_flash_gemm with the A and C pointers advanced to row r0.  In
+    level 3 that is the row-panel pipeline: the rank's A panels stream through a ring, B is read by
+    the rank itself (large sequential requests; from the page cache once another rank has touched
+    it), C panels are written back while later ones compute -- reads, PCIe copies, MFMA work and
+    write-back all overlap inside the library (flash_gemm_panels.cpp), nothing is staged in Python.
 
-    Returns {bytes_read, bytes_written} of this rank.  `one_gpu_debug` runs the collective
-    through host memory (gloo) so that two ranks can share one device on a single-GPU box."""
+    b_once_per_node=True: B is read from storage ONCE per node instead of once per
+    GPU: rank g reads the k-row panel B[k0:k1, :] and one all-gather (RCCL over xGMI) assembles the
+    full matrix on every GPU; A / C slabs are made resident and the level-2 tile DAG runs over them
+    (same tiles, same k-order, so the C file is bit-identical).  Pays when the storage, not PCIe, is
+    the bottleneck (8 x 16 GiB of B reads at cfg4).
+
+    Returns {bytes_read, bytes_written, rows, b_panel_rows} of this rank.  `one_gpu_debug` runs the
+    collective through host memory (gloo) so that two ranks can share one device."""
     import torch
     import torch.distributed as dist
     import bofhip
@@ -84,6 +88,15 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     tile = int(o.gemm_blk)
     r0, r1 = row_shard(m, world, rank, tile)
     rows = r1 - r0
+    if not b_once_per_node:
+        stats = {"bytes_read": 0, "bytes_written": 0, "rows": rows, "b_panel_rows": k if rows > 0 else 0}
+        if rows > 0:
+            bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, r0 * lda * 4),
+                              bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * ldc * 4), lda, ldb, ldc, o)
+            st_ = bofhip.flash_last_stats()
+            stats["bytes_read"], stats["bytes_written"] = st_["bytes_read"], st_["bytes_written"]
+            stats["seconds"] = st_["seconds"]
+        return stats
     st = torch.cuda.current_stream(dev).cuda_stream
     rd = wr = 0
     # --- B: this rank's k-row panel from the file, then all-gather ---------------------------

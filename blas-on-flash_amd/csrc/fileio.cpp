@@ -190,6 +190,19 @@ static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_
     if (fd < 0) return -EBADF;
   }
   char *p = static_cast<char *>(buf);
+  static const bool use_uring = getenv("BOF_IO_ENGINE") && !strcmp(getenv("BOF_IO_ENGINE"), "uring");
+  if (direct && aligned && use_aio && use_uring) {
+    std::vector<IoPiece> pieces;
+    const uint64_t piece = request_bytes();
+    for (uint64_t s = 0; s < n_strides; s++)
+      for (uint64_t o = 0; o < len; o += piece)
+        pieces.push_back(IoPiece{fd, wr, p + s * len + o, std::min(piece, len - o), offset + s * stride + o});
+    const int rc = uring_run(pieces);
+    if (rc != -ENOSYS) {
+      (wr ? g_wr_ops : g_rd_ops) += pieces.size();
+      return rc;
+    }
+  }
   if (direct && aligned && use_aio && tls_ctx().ok) {
     std::vector<struct iocb> cbs;
     const uint64_t piece = request_bytes();

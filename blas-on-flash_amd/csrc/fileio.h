@@ -1,6 +1,9 @@
 // fileio.h -- strided file <-> packed host buffer transfers (fileio.cpp)
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
+
+#include <vector>
 namespace bof {
 // return 0 or -errno
 int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
@@ -12,4 +15,11 @@ bool file_is_direct(int fd);
 int file_buffered_fd(int fd);
 void file_io_ops(uint64_t *reads, uint64_t *writes);  // requests issued so far (process-wide)
 void file_forget(int fd);  // drop the cached buffered twin of fd (call before close)
+// ---- io_uring engine (uring_io.cpp); BOF_IO_ENGINE=uring selects it for aligned O_DIRECT I/O ----
+struct IoPiece { int fd; bool wr; void *buf; uint64_t len; uint64_t off; };
+int uring_run(const std::vector<IoPiece> &pieces);   // 0 / -errno; -ENOSYS: no io_uring here
+// pinned staging slots registered as io_uring FIXED buffers (PinnedRing does this)
+void file_buffers_add(void *ptr, size_t bytes);
+void file_buffers_remove(void *ptr);
+void uring_op_counts(uint64_t *fixed, uint64_t *plain);
 }  // namespace bof

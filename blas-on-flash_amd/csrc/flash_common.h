@@ -75,6 +75,7 @@ class PinnedRing {
       BOF_HIP_TRY(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
       hipEvent_t e;
       BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      file_buffers_add(p, nbytes);   // io_uring fixed buffer (no effect on the AIO engine)
       slots.push_back(p); ev.push_back(e); ev_set.push_back(0); free_.push_back(i);
     }
     return BOF_OK;
@@ -82,6 +83,7 @@ class PinnedRing {
   void destroy() {
     for (size_t i = 0; i < slots.size(); i++) {
       if (ev_set[i]) (void) hipEventSynchronize(ev[i]);
+      file_buffers_remove(slots[i]);
       (void) hipHostFree(slots[i]);
       (void) hipEventDestroy(ev[i]);
     }

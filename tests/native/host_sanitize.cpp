@@ -95,6 +95,10 @@ static void files(const char *dir) {
     void *buf = nullptr;
     CHECK(posix_memalign(&buf, 4096, rows * cols * 4 + 4096) == 0);
     float *p = (float *) buf;
+    // with BOF_IO_ENGINE=uring the aligned O_DIRECT requests below go through io_uring; this buffer
+    // is registered as a FIXED buffer (what PinnedRing does with its slots), the per-thread ones
+    // further down are not and take the plain READ opcode
+    bof::file_buffers_add(buf, rows * cols * 4 + 4096);
     // aligned strided tile (AIO path when direct)
     CHECK(bof::file_sread(fd, 128 * 4, ld * 4, rows, cols * 4, p, true) == 0);
     for (uint64_t r = 0; r < rows; r += 37) CHECK(p[r * cols + 5] == img[r * ld + 128 + 5]);
@@ -122,11 +126,37 @@ static void files(const char *dir) {
       });
     for (auto &x : th) x.join();
     for (int t = 0; t < 8; t++) CHECK(rc[t] == 0);
+    // a large contiguous transfer cut into many requests (more than the ring holds at once)
+    {
+      const uint64_t big = 24u << 20;
+      void *bb = nullptr;
+      CHECK(posix_memalign(&bb, 4096, big) == 0);
+      unsigned char *q = (unsigned char *) bb;
+      for (uint64_t i = 0; i < big; i++) q[i] = (unsigned char) (i * 2654435761u >> 24);
+      const std::string p2 = std::string(dir) + "/san_big.bin";
+      int f2 = open(p2.c_str(), O_RDWR | O_CREAT | O_TRUNC | (direct ? O_DIRECT : 0), 0600);
+      CHECK(f2 >= 0);
+      CHECK(ftruncate(f2, (off_t) big) == 0);
+      CHECK(bof_file_set_request_bytes(64 << 10) == BOF_OK);       // 384 requests
+      CHECK(bof::file_swrite(f2, 0, 0, 1, big, bb, true) == 0);
+      memset(bb, 0, big);
+      CHECK(bof::file_sread(f2, 0, 0, 1, big, bb, true) == 0);
+      for (uint64_t i = 0; i < big; i += 4099) CHECK(q[i] == (unsigned char) (i * 2654435761u >> 24));
+      CHECK(bof_file_set_request_bytes(4 << 20) == BOF_OK);
+      bof::file_forget(f2);
+      close(f2);
+      unlink(p2.c_str());
+      free(bb);
+    }
+    bof::file_buffers_remove(buf);
     bof::file_forget(fd);
     close(fd);
     free(buf);
   }
   unlink(path.c_str());
+  uint64_t fixed = 0, plain = 0;
+  bof::uring_op_counts(&fixed, &plain);
+  printf("io_uring requests: %llu fixed-buffer, %llu plain\n", (unsigned long long) fixed, (unsigned long long) plain);
 }
 
 // the level-3 schedule (tile list, task order, Belady slot replacement) as a dry run

@@ -512,12 +512,14 @@ def test_csrcsc_driver_and_csrmm_driver_trans(dev, tmp_path, golden_tr):
     assert h("C", np.float32) == want["gen_csrmmT_c"]
 
 
+@pytest.mark.parametrize("b_once", ["0", "1"])
 @pytest.mark.parametrize("nproc", [1, 2])
-def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc):
-    """Multi-GPU file path: every rank makes its A / C row slabs resident, B is
-    read once per node (one k-row panel per rank + all-gather) and the tile DAG runs over the
-    resident slabs; the C file equals the restated flash::gemm bit for bit.  nproc = 2 shares
-    cuda:0 between the ranks and routes the collective through gloo (single-GPU box)."""
+def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc, b_once):
+    """Multi-GPU file path.  b_once = 0: every rank runs the level-3 pipeline on its
+    row slab (flash_ptr + offset), no collective.  b_once = 1: A / C row slabs resident, B read once
+    per node (one k-row panel per rank + all-gather), tile DAG over the resident slabs.  Either way
+    the C file equals the restated flash::gemm bit for bit.  nproc = 2 shares cuda:0 between the
+    ranks and routes the collective through gloo (single-GPU box)."""
     import json
     import sys
     m, k, n, blk = 1100, 600, 500, 256
@@ -536,14 +538,17 @@ def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc):
         cmd = [sys.executable, tool]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", "29577", tool]
+               "--master-addr", "127.0.0.1", "--master-port", str(29577 + int(b_once)), tool]
     r = subprocess.run(cmd + [str(x) for x in args], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, BOF_BENCH_ONE_GPU="1"))
+                       env=dict(os.environ, BOF_BENCH_ONE_GPU="1", BOF_B_ONCE=b_once))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(recs) == nproc
     assert sum(x["rows"] for x in recs) == m
-    assert sum(x["b_panel_rows"] for x in recs) == k          # B read from storage exactly once
+    if b_once == "1":
+        assert sum(x["b_panel_rows"] for x in recs) == k      # B read from storage exactly once
+    else:
+        assert all(x["b_panel_rows"] == k for x in recs)      # every rank streams B itself
     got = np.fromfile(pc, np.float32).reshape(m, ldc)
     assert np.array_equal(got, ref)
 

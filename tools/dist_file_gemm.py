@@ -42,8 +42,11 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.time()
+    # BOF_B_ONCE=1: B is read from storage once per node (k-row panel per rank + all-gather);
+    # default: every rank runs the level-3 file pipeline on its slab, no collective
     st = bof_dist.flash_gemm_row_sharded(m, n, k, alpha, beta, fds[0], fds[1], fds[2], lda, ldb, ldc, opts,
-                                         one_gpu_debug=one_gpu)
+                                         one_gpu_debug=one_gpu,
+                                         b_once_per_node=os.environ.get("BOF_B_ONCE", "0") == "1")
     for fd in fds:
         os.fsync(fd)
         os.close(fd)
