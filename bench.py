@@ -603,6 +603,165 @@ def e2e_csrmm(bofhip, torch, dev, st, workdir, kernel_s, io_threads, reps):
     return out
 
 
+def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local, n, k, kernel_s):
+    """N > 1: BASELINE configs[3] as files.  One A, B and C file shared by the ranks (written by them
+    in parallel, slab by slab); rank g then runs the level-3 pipeline on its C rows
+    [g*m_local, (g+1)*m_local) -- bof_flash_gemm with the A and C pointers advanced to its slab, B
+    read by every rank itself, no collective -- between two barriers; max over ranks.  Every rank
+    checks every element of its C slab against the closed form.  Local work runs inside `phase`,
+    which ends in a collective every rank reaches whatever happened locally, so one failing rank
+    ends the leg on all of them instead of leaving the others in a barrier."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch.distributed as dist
+    out = {"what": f"{m_local * world}x{k}x{n} fp32 flash _gemm on files, row-block sharded over {world} ranks "
+                   f"(each: {m_local} C rows; B streamed by every rank; no collective), wall clock between barriers"}
+
+    def phase(fn):
+        """run fn locally; (all ranks ok?, max seconds over ranks, local error text)"""
+        err = ""
+        t0 = time.perf_counter()
+        try:
+            fn()
+        except Exception as e:
+            err = f"{type(e).__name__}: {str(e)[:200]}"
+        v = torch.tensor([0.0 if err else 1.0, -(time.perf_counter() - t0)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(v[0].item() == 1.0), -float(v[1].item()), err
+
+    base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    m = m_local * world
+    box = [None]
+    if rank == 0:
+        try:
+            d = tempfile.mkdtemp(prefix="bof_bench_sharded_", dir=base)
+            need = 4 * (m * k + k * n + m * n) + (2 << 30)
+            if shutil.disk_usage(d).free > need:
+                box[0] = d
+                for name, sz in (("A.bin", m * k * 4), ("B.bin", k * n * 4), ("C.bin", m * n * 4)):
+                    with open(os.path.join(d, name), "wb") as f:
+                        f.truncate(sz)
+            else:
+                box[0] = "!not enough free disk"
+                shutil.rmtree(d, ignore_errors=True)
+        except OSError as e:
+            box[0] = f"!{e}"
+    dist.broadcast_object_list(box, src=0)
+    if box[0].startswith("!"):
+        out["skipped"] = box[0][1:]
+        return out
+    workdir = box[0]
+    pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
+    r0 = rank * m_local
+    kb = (k + world - 1) // world
+    k0, k1 = min(k, rank * kb), min(k, (rank + 1) * kb)
+    state = {}
+
+    def put(path, off_elems, count, first, mode):
+        if count <= 0:
+            return
+        t = state["t"]
+        bofhip.gen_dense(t.data_ptr(), first, count, mode, 0, st)
+        fd, d = _open(path, True)
+        try:
+            bofhip.device_to_file(bofhip.FPtr(fd, off_elems * 4), count * 4, t.data_ptr(),
+                                  bofhip.default_options(n_io_threads=args.io_threads, use_odirect=1 if d else 0), st)
+            os.fsync(fd)
+        finally:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+
+    def create():
+        state["t"] = torch.empty(max(m_local * max(k, n), (k1 - k0) * n), dtype=torch.float32, device=dev)
+        put(pa, r0 * k, m_local * k, r0 * k, "s")          # dense_create mode s, this rank's rows
+        put(pb, k0 * n, (k1 - k0) * n, k0 * n, "s")        # 1/world of B
+        put(pc, r0 * n, m_local * n, 0, "z")
+        kk = np.arange(k, dtype=np.int64)
+        a10 = (np.arange(10, dtype=np.int64)[:, None] * k + kk[None, :]) % 10
+        b10 = (kk[:, None] * n + np.arange(10, dtype=np.int64)[None, :]) % 10
+        pat = torch.from_numpy((a10 @ b10).astype(np.float32)).to(dev)
+        state["rowpat"] = pat[:, torch.arange(n, device=dev) % 10]
+
+    good, secs, err = phase(create)
+    out["create_files_s"] = round(secs, 1)
+    flops = 2.0 * m * n * k
+    for mode in ("odirect", "buffered"):
+        if not good:
+            break
+        fds = []
+
+        def opening():
+            for p in (pa, pb, pc):
+                fd, d = _open(p, mode == "odirect")
+                fds.append(fd)
+                if mode == "odirect" and not d:
+                    raise OSError("file system refuses O_DIRECT")
+        can, _, e1 = phase(opening)
+        if not can:
+            out[mode] = {"skipped": e1 or "another rank could not open the files"}
+            for fd in fds:
+                os.close(fd)
+            continue
+        opts = bofhip.default_options(gemm_blk=args.blk, n_io_threads=args.io_threads,
+                                      use_odirect=1 if mode == "odirect" else 0)
+
+        def run():
+            bofhip.flash_gemm("R", "N", "N", m_local, n, k, 1.0, 0.0, bofhip.FPtr(fds[0], r0 * k * 4),
+                              bofhip.FPtr(fds[1], 0), bofhip.FPtr(fds[2], r0 * n * 4), 0, 0, 0, opts)
+        times = []
+        for rep in range(2):
+            if mode == "odirect" and rank == 0:
+                _drop_cache((pa, pb, pc))
+            dist.barrier()
+            good, secs, err = phase(run)
+            times.append(secs)
+            if not good:
+                break
+        stats = bofhip.flash_last_stats()
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+        if not good:
+            break
+
+        def verify():
+            t = state["t"]
+            fd, _ = _open(pc, False)
+            try:
+                bofhip.file_to_device(bofhip.FPtr(fd, r0 * n * 4), m_local * n * 4, t.data_ptr(),
+                                      bofhip.default_options(use_odirect=0), st)
+            finally:
+                os.close(fd)
+            C = t[:m_local * n].view(m_local, n)
+            rows = max(1, (1 << 27) // n)
+            for q0 in range(0, m_local, rows):
+                q1 = min(m_local, q0 + rows)
+                gi = torch.arange(r0 + q0, r0 + q1, device=dev)
+                if not torch.equal(C[q0:q1], state["rowpat"][gi % 10]):
+                    raise AssertionError(f"C rows [{r0 + q0}, {r0 + q1}) differ from the closed form")
+        match, _, verr = phase(verify)
+        best = min(times) if mode == "odirect" else times[-1]
+        out[mode] = {"seconds_all": [round(x, 3) for x in times], "seconds": round(best, 3),
+                     "gflops": round(flops / best / 1e9, 1),
+                     "rank0_read_GBps": round(stats["bytes_read"] / best / 1e9, 2),
+                     "rank0_write_GBps": round(stats["bytes_written"] / best / 1e9, 2),
+                     "rank0_requests": stats["read_ops"] + stats["write_ops"],
+                     "overlap_kernel_over_e2e": round(kernel_s / best, 3),
+                     "every_C_slab_matches_closed_form": match}
+        if verr:
+            out[mode]["rank0_verify_error"] = verr
+    if not good:
+        out["error"] = err or "another rank failed"
+    state.clear()
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(workdir, ignore_errors=True)
+    torch.cuda.empty_cache()
+    bofhip.lib().bof_flash_release()
+    return out
+
+
 def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s):
     import shutil
     import tempfile
@@ -769,18 +928,46 @@ def main():
         lo = hi.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        # csrgemv 'T': the one real exchange of the path -- all-reduce(sum) of the partial vectors
+        # csrgemv 'T': the one real exchange of the path -- sum of the per-rank partial vectors.
+        # Warm-up on a small tensor (communicator set-up is not part of the exchange), then both
+        # forms are timed on copies: one all-reduce, and reduce-scatter + all-gather (7 xGMI links
+        # at once on the fully connected mesh); the result of the faster one is kept.
+        import bof_dist
         part_r = part.cpu() if one_gpu else part
-        dist.barrier()
-        torch.cuda.synchronize()
-        t_red = time.perf_counter()
-        dist.all_reduce(part_r, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-        red_ms = torch.tensor([(time.perf_counter() - t_red) * 1e3], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(red_ms, op=dist.ReduceOp.MAX)
-        ysum = float(part_r.double().sum().item())
+        warm = torch.ones(1 << 16, dtype=torch.float32, device=part_r.device)
+        dist.all_reduce(warm)
+        bof_dist.allreduce_partial(warm, algo="rs_ag")
+        red = {}
+        for algo in ("allreduce", "rs_ag"):
+            best = None
+            for _ in range(2):
+                buf = part_r.clone()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_red = time.perf_counter()
+                bof_dist.allreduce_partial(buf, algo=algo)
+                torch.cuda.synchronize()
+                tt = torch.tensor([(time.perf_counter() - t_red) * 1e3], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                best = float(tt.item()) if best is None else min(best, float(tt.item()))
+            red[algo] = best
+            if algo == "allreduce":
+                result = buf
+        ysum = float(result.double().sum().item())
         sharded = {"ok": bool(lo.min().item() >= 0), "max_ms": dict(zip(keys, [float(v) for v in hi.tolist()])),
-                   "allreduce_ms": float(red_ms.item()), "y_T_sum": ysum}
+                   "allreduce_ms": min(red.values()), "reduce_ms_by_algo": red, "y_T_sum": ysum}
+        del part, part_r, result, buf
+        torch.cuda.empty_cache()
+
+    e2e_sharded = None
+    if world > 1 and not args.no_e2e:
+        try:
+            del a, b, c
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        e2e_sharded = e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local, n, k,
+                                       dt / args.steps)
 
     if rank == 0:
         if shard_of > 1:
@@ -860,10 +1047,13 @@ def main():
                 sec["csrgemv_T"] = {"workload": "flash _csrgemv 'T': per-rank partial + one all-reduce(sum) of 200 MB",
                                     "local_ms": round(ms["csrgemv_T_local_ms"], 3),
                                     "allreduce_ms": round(sharded["allreduce_ms"], 3),
+                                    "reduce_ms_by_algo": sharded["reduce_ms_by_algo"],
                                     "gflops": round(2.0 * nnz5 / t_ms / 1e6, 1),
                                     # known answer of the full product: sum(y) = 11249999940
                                     "sum_y": sharded["y_T_sum"], "sum_y_expected": 11249999940.0}
             out["secondary"] = sec
+        if e2e_sharded is not None:
+            out["e2e"] = e2e_sharded
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

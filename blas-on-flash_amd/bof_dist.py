@@ -48,12 +48,34 @@ def gemm_shard_args(m, n, k, lda, ldc, world, rank, tile):
     return r1 - r0, r0 * (lda or k), r0 * (ldc or n)
 
 
-def allreduce_partial(y, group=None):
-    """Sum the per-rank partial vectors of CSRGEMV 'T' in place (RCCL all-reduce over
-    xGMI for device tensors).  fp32; exact for the integer-valued generator data."""
+def allreduce_partial(y, group=None, algo="allreduce"):
+    """Sum the per-rank partial vectors of CSRGEMV 'T' in place (RCCL over xGMI for device tensors).
+    fp32; exact for the integer-valued generator data.
+
+    algo "allreduce": one all-reduce (RCCL picks ring / tree).  algo "rs_ag": reduce-scatter then
+    all-gather -- on the fully connected xGMI mesh (7 point-to-point links per GPU) every rank sends
+    its 7 foreign chunks of S/8 over 7 different links at once, so the step is bound by S/8 per
+    link instead of a ring's 2 (N-1)/N S over one.  The vector length is padded
+    to a multiple of the world size in a scratch tensor when needed."""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return y
+    world = dist.get_world_size(group)
+    if algo != "rs_ag":
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+    n = y.numel()
+    per = (n + world - 1) // world
+    src = y
+    if per * world != n:
+        src = torch.zeros(per * world, dtype=y.dtype, device=y.device)
+        src[:n] = y
+    mine = torch.empty(per, dtype=y.dtype, device=y.device)
+    dist.reduce_scatter_tensor(mine, src, op=dist.ReduceOp.SUM, group=group)
+    dist.all_gather_into_tensor(src, mine, group=group)
+    if src is not y:
+        y.copy_(src[:n])
     return y
 
 

@@ -76,7 +76,7 @@ struct Mat {
 };
 
 struct ChunkReq { int mat, panel; uint64_t off, bytes; };
-struct WriteReq { int wslot; uint64_t file_off, bytes; };
+struct WriteReq { int wslot; uint64_t file_off, bytes; int panel; bool last; };
 
 struct PanelResources {
   PinnedRing rring, wring;
@@ -86,10 +86,11 @@ struct PanelResources {
 std::mutex g_pres_mu;
 PanelResources *g_pres[64];
 
-bool trace_on() {
-  static const bool on = getenv("BOF_TRACE") != nullptr;
-  return on;
+int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel read / flush / write
+  static const int lvl = getenv("BOF_TRACE") ? std::max(1, atoi(getenv("BOF_TRACE"))) : 0;
+  return lvl;
 }
+bool trace_on() { return trace_level() >= 1; }
 
 struct PanelRun {
   bof_options o;
@@ -115,6 +116,13 @@ struct PanelRun {
   int dev = 0;
   std::chrono::steady_clock::time_point t_begin;
 
+  void trace2(const char *what, int x, int p) const {
+    if (trace_level() >= 2) {
+      char lbl[64];
+      snprintf(lbl, sizeof(lbl), "%s %c%d", what, "ABC"[x], p);
+      trace(lbl);
+    }
+  }
   void trace(const char *label) const {
     if (trace_on())
       fprintf(stderr, "[bof trace] %-34s %8.3f ms\n", label,
@@ -183,6 +191,7 @@ struct PanelRun {
         if (--P.remaining == 0) {
           if (e == hipSuccess) e = hipEventRecord(P.ready, h2d);
           P.state = 2;
+          trace2("read + H2D queued:", rq.mat, rq.panel);
         }
       }
       if (e != hipSuccess) fail_io(-1000 - (int) e);
@@ -209,10 +218,11 @@ struct PanelRun {
         if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
         if (e != hipSuccess) { res->wring.release(ws); break; }
         cnt.d2h += len;
-        write_q.push(WriteReq{ws, C.file_off(pc) + off, len});
+        write_q.push(WriteReq{ws, C.file_off(pc) + off, len, pc, off + len >= P.bytes});
       }
       if (e == hipSuccess) e = hipEventRecord(P.d2h_done, d2h);
       if (e != hipSuccess) fail_io(-1000 - (int) e);
+      trace2("D2H queued:", 2, pc);
       {
         std::lock_guard<std::mutex> lk(mu);
         P.retire_ev.assign(1, P.d2h_done);
@@ -238,6 +248,7 @@ struct PanelRun {
       if (rc) fail_io(rc);
       cnt.wr += rq.bytes;
       res->wring.release(rq.wslot);
+      if (rq.last) trace2("last chunk written:", 2, rq.panel);
     }
   }
 };
@@ -408,7 +419,12 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       BOF_HIP_TRY(hipEventCreateWithFlags(&P.ready, hipEventDisableTiming));
       if (x == 2) BOF_HIP_TRY(hipEventCreateWithFlags(&P.d2h_done, hipEventDisableTiming));
     }
-  R.ss = stream_set(o.n_streams);
+  // A 4096^2 tile launch is 256 workgroups = the whole chip, so more than two compute streams only
+  // interleave whole-chip kernels of different chains and starve the copy queues: measured on
+  // cfg2 files (page cache) 0.70 s with 4 streams, 0.58 s with 2, 0.59 s with 1
+  // (profiles/r2/e2e_sweep_*.txt).  BOF_PANEL_STREAMS overrides.
+  const char *senv = getenv("BOF_PANEL_STREAMS");
+  R.ss = stream_set(senv && atoi(senv) > 0 ? std::min(atoi(senv), 16) : std::min(o.n_streams, 2));
   if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
   R.group_ev.assign((size_t) n_groups, std::vector<hipEvent_t>());
   for (auto &v : R.group_ev)
@@ -427,7 +443,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
 
   std::vector<std::thread> readers, writers;
   const int n_readers = std::max(1, o.n_io_threads);
-  const int n_writers = std::max(2, std::min(8, o.n_io_threads / 2));
+  const char *wenv = getenv("BOF_PANEL_WRITERS");
+  const int n_writers = wenv && atoi(wenv) > 0 ? atoi(wenv) : std::max(2, std::min(8, o.n_io_threads / 2));
   for (int i = 0; i < n_readers; i++) readers.emplace_back([&R] { R.reader_main(); });
   for (int i = 0; i < n_writers; i++) writers.emplace_back([&R] { R.writer_main(); });
   std::thread flusher([&R] { R.flusher_main(); });
