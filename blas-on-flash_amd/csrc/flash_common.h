@@ -23,6 +23,13 @@ struct Counters {
   Counters() { file_io_ops(&ops0[0], &ops0[1]); }
 };
 
+// Pinned host blocks are expensive to create and destroy (page pinning: ~0.1 s per GB each way),
+// so the level-3 pipelines take them from a per-process cache: a freed block is kept (up to
+// 4 GiB in total) and handed to the next request of a similar size; bof_flash_release empties it.
+int pinned_alloc(void **p, size_t bytes);   // BOF_OK / BOF_EHIP; the block has at least `bytes`
+void pinned_free(void *p);
+void pinned_cache_release();
+
 template <class T>
 class WorkQueue {
   std::mutex mu;
@@ -72,7 +79,8 @@ class PinnedRing {
     bytes = nbytes;
     for (int i = 0; i < n; i++) {
       void *p = nullptr;
-      BOF_HIP_TRY(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
+      const int rc = pinned_alloc(&p, nbytes);
+      if (rc) return rc;
       hipEvent_t e;
       BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       file_buffers_add(p, nbytes);   // io_uring fixed buffer (no effect on the AIO engine)
@@ -84,7 +92,7 @@ class PinnedRing {
     for (size_t i = 0; i < slots.size(); i++) {
       if (ev_set[i]) (void) hipEventSynchronize(ev[i]);
       file_buffers_remove(slots[i]);
-      (void) hipHostFree(slots[i]);
+      pinned_free(slots[i]);
       (void) hipEventDestroy(ev[i]);
     }
     slots.clear(); ev.clear(); ev_set.clear(); free_.clear();

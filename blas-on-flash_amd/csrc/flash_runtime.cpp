@@ -36,9 +36,11 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "bof_hip.h"
@@ -53,6 +55,69 @@ std::recursive_mutex &device_call_mutex() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = 0; }
   return g_call_mu[dev & 63];
+}
+
+// ---- cache of pinned host blocks -------------------------------------------------------------------
+namespace {
+struct PinnedCache {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_;          // size -> block
+  std::unordered_map<void *, size_t> live;      // handed out
+  size_t cached_bytes = 0;
+} g_pin;
+constexpr size_t kPinnedCacheCap = 4ull << 30;
+}  // namespace
+
+int pinned_alloc(void **p, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  {
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    auto it = g_pin.free_.lower_bound(bytes);
+    if (it != g_pin.free_.end() && it->first <= std::max(2 * bytes, bytes + (4u << 20))) {
+      *p = it->second;
+      g_pin.live[*p] = it->first;
+      g_pin.cached_bytes -= it->first;
+      g_pin.free_.erase(it);
+      return BOF_OK;
+    }
+  }
+  const size_t rounded = (bytes + 4095) / 4096 * 4096;
+  hipError_t e = hipHostMalloc(p, rounded, hipHostMallocDefault);
+  if (e != hipSuccess) {  // the cache may be what is in the way
+    pinned_cache_release();
+    e = hipHostMalloc(p, rounded, hipHostMallocDefault);
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (pinned staging block)");
+  std::lock_guard<std::mutex> lk(g_pin.mu);
+  g_pin.live[*p] = rounded;
+  return BOF_OK;
+}
+void pinned_free(void *p) {
+  if (!p) return;
+  size_t sz = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    auto it = g_pin.live.find(p);
+    if (it == g_pin.live.end()) return;
+    sz = it->second;
+    g_pin.live.erase(it);
+    if (g_pin.cached_bytes + sz <= kPinnedCacheCap) {
+      g_pin.free_.emplace(sz, p);
+      g_pin.cached_bytes += sz;
+      return;
+    }
+  }
+  (void) hipHostFree(p);
+}
+void pinned_cache_release() {
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pin.mu);
+    for (auto &kv : g_pin.free_) blocks.push_back(kv.second);
+    g_pin.free_.clear();
+    g_pin.cached_bytes = 0;
+  }
+  for (void *b : blocks) (void) hipHostFree(b);
 }
 
 // ---- roctx ranges -------------------------------------------------------------------------------
@@ -784,7 +849,8 @@ struct CsrRun {
     }
   }
 
-  // retires blocks in order: waits for the block's last GPU op, writes C (csrmm), frees ctx
+  // retires a block: waits for its last GPU op, writes C (csrmm), hands its context to block b + depth
+  // (run by a small pool: blocks in flight always sit in different contexts)
   void retire_main() {
     (void) hipSetDevice(dev);
     (void) bind_thread_near_device(dev);
@@ -1246,9 +1312,9 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   guard.add([&] {
     for (auto &c : R.ctx) {
       (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c); (void) hipFree(c.d_c_rm);
-      if (c.h_idx) (void) hipHostFree(c.h_idx);
-      if (c.h_val) (void) hipHostFree(c.h_val);
-      if (c.h_c) (void) hipHostFree(c.h_c);
+      pinned_free(c.h_idx);
+      pinned_free(c.h_val);
+      pinned_free(c.h_c);
       if (c.ready) (void) hipEventDestroy(c.ready);
       if (c.done) (void) hipEventDestroy(c.done);
     }
@@ -1296,20 +1362,26 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   BOF_HIP_TRY(hipEventCreateWithFlags(&resident_ev, hipEventDisableTiming));
   BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
 
-  R.depth = (int) std::min<int64_t>(std::max(2, R.o.pinned_slots / 2), nb);
+  // one context = one row block in flight (index + value segments, C block); the device delivers
+  // its sequential rate only with several large requests queued, so as many blocks are in flight
+  // as there are staging slots, each read by its own thread, and retired (C written back) by a
+  // small pool instead of one thread
+  R.depth = (int) std::min<int64_t>(std::max(2, R.o.pinned_slots), nb);
   R.ctx.resize((size_t) R.depth);
   for (int i = 0; i < R.depth; i++) {
     CsrCtx &c = R.ctx[i];
     if (!res) {
       BOF_HIP_TRY(hipMalloc((void **) &c.d_idx, max_idx));
       BOF_HIP_TRY(hipMalloc((void **) &c.d_val, max_val));
-      BOF_HIP_TRY(hipHostMalloc((void **) &c.h_idx, max_idx, hipHostMallocDefault));
-      BOF_HIP_TRY(hipHostMalloc((void **) &c.h_val, max_val, hipHostMallocDefault));
+      rc = pinned_alloc((void **) &c.h_idx, max_idx);
+      if (!rc) rc = pinned_alloc((void **) &c.h_val, max_val);
+      if (rc) return rc;
     }
     if (is_mm) {
       BOF_HIP_TRY(hipMalloc((void **) &c.d_c, max_c));
       if (ord_b == 'C') BOF_HIP_TRY(hipMalloc((void **) &c.d_c_rm, max_c));
-      BOF_HIP_TRY(hipHostMalloc((void **) &c.h_c, max_c, hipHostMallocDefault));
+      rc = pinned_alloc((void **) &c.h_c, max_c);
+      if (rc) return rc;
     }
     BOF_HIP_TRY(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
     BOF_HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
@@ -1322,7 +1394,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   std::vector<std::thread> readers;
   for (int i = 0; i < std::max(1, std::min<int>(R.o.n_io_threads, R.depth)); i++)
     readers.emplace_back([&R] { R.reader_main(); });
-  std::thread retire([&R] { R.retire_main(); });
+  std::vector<std::thread> retirers;
+  for (int i = 0; i < std::max(1, std::min(4, R.depth / 2)); i++) retirers.emplace_back([&R] { R.retire_main(); });
 
   hipError_t herr = hipSuccess;
   int fail = 0;
@@ -1385,7 +1458,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   if (herr != hipSuccess || fail) R.fail_io(-EIO);  // releases readers parked on a context hand-over
   for (auto &th : readers) th.join();
   R.done_q.close();
-  retire.join();
+  for (auto &th : retirers) th.join();
   (void) hipDeviceSynchronize();
   if (!is_mm && !fail && herr == hipSuccess) {
     herr = hipMemcpy(hc, d_y, (size_t) ylen * 4, hipMemcpyDeviceToHost);
@@ -1641,6 +1714,7 @@ int bof_flash_release(void) {
     delete r;
     g_res[d] = nullptr;
   }
+  pinned_cache_release();
   return BOF_OK;
 }
 

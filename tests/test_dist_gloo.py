@@ -61,7 +61,18 @@ def _worker(rank, world, port, out_dir):
     # shard = offset `ia` pointer; val/ja stay whole-file (absolute offsets, as flash_ptr + r0)
     orc.flash_csrgemv("T", r1 - r0, n, val, ia[r0:r1 + 1], ja, x[r0:r1], part, 1000, 5000)
     y = torch.from_numpy(part)
+    # the reduce-scatter + all-gather form must give the same vector (gloo builds without
+    # reduce_scatter are skipped on that leg); n + 1 elements exercise the padding path
+    y2 = torch.cat([y.clone(), torch.full((1,), float(rank + 1))])
+    try:
+        bof_dist.allreduce_partial(y2, algo="rs_ag")
+        rs_ok = True
+    except (RuntimeError, NotImplementedError):
+        rs_ok = False
     bof_dist.allreduce_partial(y)
+    if rs_ok:
+        assert torch.equal(y2[:-1], y) and float(y2[-1]) == world * (world + 1) / 2
+    np.save(os.path.join(out_dir, f"rs_{rank}.npy"), np.array([1 if rs_ok else 0]))
     # 'N' needs no collective: disjoint slices
     xn = (np.arange(n) % 10).astype(np.float32)
     yn = np.zeros(r1 - r0, np.float32)
@@ -78,6 +89,7 @@ def test_csrgemv_two_rank_reduce(tmp_path, golden):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
     for r in range(world):
+        assert int(np.load(tmp_path / f"rs_{r}.npy")[0]) == 1     # reduce-scatter + all-gather leg ran
         yT = np.load(tmp_path / f"T_{r}.npy")
         assert hashlib.sha256(yT.tobytes()).hexdigest() == want["gen_csrgemv_T"]
     parts = [np.load(tmp_path / f"N_{r}.npy") for r in range(world)]
