@@ -71,9 +71,42 @@ struct AioCtx {
   AioCtx() { ok = (syscall(SYS_io_setup, kAioEvents, &ctx) == 0); }
   ~AioCtx() { if (ok) syscall(SYS_io_destroy, ctx); }
 };
+// Contexts are leased, not owned, by threads.  io_setup / io_destroy are expensive on a large
+// machine (io_destroy waits for an RCU grace period: the twelve I/O threads of one level-3 call
+// spent 0.5 s of a 1.4 s cfg2 run just exiting, profiles/r2/e2e_panels_trace_level2_aio.txt), and
+// the pipelines start fresh reader / writer threads per call.  A thread takes a context from the
+// pool at its first request and hands it back when it exits; aio_run never returns with
+// requests in flight, so a pooled context is always idle.
+struct AioPool {
+  std::mutex mu;
+  std::vector<AioCtx *> idle;
+  AioCtx *get() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!idle.empty()) { AioCtx *c = idle.back(); idle.pop_back(); return c; }
+    }
+    return new AioCtx();
+  }
+  void put(AioCtx *c) {
+    std::lock_guard<std::mutex> lk(mu);
+    idle.push_back(c);
+  }
+  ~AioPool() {
+    for (AioCtx *c : idle) delete c;
+  }
+};
+static AioPool &aio_pool() {
+  static AioPool p;
+  return p;
+}
+struct AioLease {
+  AioCtx *c;
+  AioLease() : c(aio_pool().get()) {}
+  ~AioLease() { aio_pool().put(c); }
+};
 static AioCtx &tls_ctx() {
-  static thread_local AioCtx c;
-  return c;
+  static thread_local AioLease l;
+  return *l.c;
 }
 
 static int aio_run(std::vector<struct iocb> &cbs) {

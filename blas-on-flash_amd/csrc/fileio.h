@@ -22,4 +22,5 @@ int uring_run(const std::vector<IoPiece> &pieces);   // 0 / -errno; -ENOSYS: no 
 void file_buffers_add(void *ptr, size_t bytes);
 void file_buffers_remove(void *ptr);
 void uring_op_counts(uint64_t *fixed, uint64_t *plain);
+void uring_release_buffers();   // idle rings give up their fixed-buffer registrations
 }  // namespace bof

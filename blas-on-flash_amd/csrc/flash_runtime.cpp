@@ -1714,6 +1714,7 @@ int bof_flash_release(void) {
     delete r;
     g_res[d] = nullptr;
   }
+  uring_release_buffers();
   pinned_cache_release();
   return BOF_OK;
 }

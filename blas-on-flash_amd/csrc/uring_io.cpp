@@ -111,9 +111,41 @@ struct Uring {
   }
 };
 
+// Rings are leased from a pool for the same reason as the AIO contexts of fileio.cpp: the
+// pipelines start fresh I/O threads per call, and a ring is expensive to build (three mappings
+// plus the registration -- i.e. long-term pinning -- of every staging slot) and to tear down.
+// A pooled ring keeps its buffer registration across calls; uring_run never returns with
+// requests in flight, so a pooled ring is always idle.
+struct RingPool {
+  std::mutex mu;
+  std::vector<Uring *> idle;
+  Uring *get() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!idle.empty()) { Uring *r = idle.back(); idle.pop_back(); return r; }
+    }
+    return new Uring();
+  }
+  void put(Uring *r) {
+    std::lock_guard<std::mutex> lk(mu);
+    idle.push_back(r);
+  }
+  ~RingPool() {
+    for (Uring *r : idle) delete r;
+  }
+};
+RingPool &ring_pool() {
+  static RingPool p;
+  return p;
+}
+struct RingLease {
+  Uring *r;
+  RingLease() : r(ring_pool().get()) {}
+  ~RingLease() { ring_pool().put(r); }
+};
 Uring &tls_ring() {
-  static thread_local Uring r;
-  return r;
+  static thread_local RingLease l;
+  return *l.r;
 }
 
 std::atomic<uint64_t> g_fixed_ops{0}, g_plain_ops{0};
@@ -135,6 +167,19 @@ void file_buffers_remove(void *ptr) {
       g_tab.bufs.erase(g_tab.bufs.begin() + (long) i);
       g_tab.gen++;
       return;
+    }
+}
+// drop the buffer registration (= the long-term page pins) of every idle ring: called when the
+// staging memory itself is being given back (bof_flash_release)
+void uring_release_buffers() {
+  RingPool &p = ring_pool();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (Uring *r : p.idle)
+    if (r->ok && r->fixed) {
+      (void) syscall(__NR_io_uring_register, r->fd, IORING_UNREGISTER_BUFFERS, nullptr, 0);
+      r->fixed = false;
+      r->reg.clear();
+      r->reg_gen = 0;
     }
 }
 void uring_op_counts(uint64_t *fixed, uint64_t *plain) {

@@ -179,8 +179,8 @@ def test_cfg2_flash_gemm_files_end_to_end(dev, tmp_path, path):
     st = leg["stats"]
     assert st["tasks"] == 512 and st["bytes_read"] == 2 * 4 * 32768 ** 2 and st["bytes_written"] == 4 * 32768 ** 2
     tiles = 3 * 8 * 8
-    if path == 2:    # 32 MiB requests: 2 per tile's worth of bytes
-        assert st["read_ops"] + st["write_ops"] <= 4 * tiles
+    if path == 2:    # sequential requests of a few MiB each (default 4): 16 per tile's worth of bytes
+        assert st["read_ops"] + st["write_ops"] <= (st["bytes_read"] + st["bytes_written"]) // (2 << 20)
     else:            # one request per 16 KiB tile row
         assert st["read_ops"] + st["write_ops"] >= 4096 * tiles
 
