@@ -185,6 +185,29 @@ def resident_gemm_line(bofhip, torch, dev, st, m_local, n, k, row0, blk, streams
             "first_tile_row_rel_err_vs_float64": rel}
 
 
+def csr_pmc():
+    """HBM-side bytes of one pass of the CSR kernels from the committed rocprofv3 PMC passes
+    (profiles/rNN/kbench_csr_pmc.json: FETCH_SIZE and WRITE_SIZE in KB summed over the launches of
+    one pass; fetch x2 is the gfx950 correction of MI355X_MICROARCH.md)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "kbench_csr_pmc.json")))
+    if not cands:
+        return {}, None
+    try:
+        d = json.load(open(cands[-1]))
+        out = {}
+        # (the committed 'T' counters belong to the per-block atomic kernel, not to the partitioned
+        #  form level 2 runs, so they are not quoted)
+        for key, name in (("csrmm_rowmajor", "csrmm"), ("csrgemv_n", "csrgemv_N")):
+            if key in d:
+                f = d[key]["FETCH_SIZE"]["sum_over_launches_of_one_pass"] * 1024.0 * 2.0
+                w = d[key]["WRITE_SIZE"]["sum_over_launches_of_one_pass"] * 1024.0
+                out[name] = f + w
+        return out, os.path.relpath(cands[-1], ROOT)
+    except Exception:
+        return {}, None
+
+
 def csr_secondary(bofhip, torch, dev, st):
     """Secondary lines of the metric: flash _csrmm at BASELINE configs[2] (10M x 1M CSR, 1e9 nnz,
     x 1M x 128 dense) and _csrgemv at the configs[4] size (50M x 50M, 5e8 nnz), HBM-resident,
@@ -202,6 +225,7 @@ def csr_secondary(bofhip, torch, dev, st):
         return e0.elapsed_time(e1) / iters
 
     out = {}
+    pmc, pmc_src = csr_pmc()
     opts = bofhip.default_options(n_streams=1)
     m, n, k, npr = 10_000_000, 1_000_000, 128, 100
     val = torch.empty(m * npr, dtype=torch.float32, device=dev)
@@ -226,7 +250,13 @@ def csr_secondary(bofhip, torch, dev, st):
                     "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
                                  "algorithmic_bytes": alg,
-                                 "gather_GBps": round(nnz * k * 4 / ms / 1e6, 1)}}
+                                 # what the kernel actually moves: one 512-byte B row per non-zero
+                                 "gather_bytes": nnz * k * 4, "gather_GBps": round(nnz * k * 4 / ms / 1e6, 1),
+                                 "gather_frac_of_hbm_peak": round(nnz * k * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                 "traffic": pmc.get("csrmm"), "traffic_source": pmc_src,
+                                 "traffic_over_algorithmic": round(pmc["csrmm"] / alg, 1) if "csrmm" in pmc else None,
+                                 "note": "bytes roofline 3 %: every non-zero fetches a B row from Infinity Cache/HBM "
+                                         "(L2 hit rate 2 %); the gather itself runs at the fabric's random-512-B-row rate"}}
     # transposition row on the same matrix: A -> A^T, and csrmm trans_a='T'
     vt = torch.empty_like(val)
     ct = torch.empty_like(col)
@@ -272,7 +302,11 @@ def csr_secondary(bofhip, torch, dev, st):
                                 "ms": round(ms, 3), "gflops": round(2.0 * nnz / ms / 1e6, 1),
                                 "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1),
                                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}}
+                                             "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                             "algorithmic_bytes": alg, "traffic": pmc.get("csrgemv_" + tr),
+                                             "traffic_source": pmc_src,
+                                             "traffic_over_algorithmic": round(pmc["csrgemv_" + tr] / alg, 1)
+                                             if ("csrgemv_" + tr) in pmc else None}}
     return out
 
 
