@@ -809,6 +809,9 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s):
     try:
         free = shutil.disk_usage(workdir).free
         out["scratch_dir_free_GB"] = round(free / 1e9, 1)
+        out["process_state"] = {"main_thread_allowed_cpus": len(os.sched_getaffinity(0)),
+                                "process_threads": len(os.listdir("/proc/self/task")),
+                                "loadavg_1min": round(os.getloadavg()[0], 1)}
         n = args.e2e_size
         bofhip.lib().bof_flash_release()
         if free > 3 * n * n * 4 + (2 << 30):

@@ -194,13 +194,8 @@ int bind_thread_near_device(int dev) {
           const int node = atoi(buf);
           if (node >= 0 &&
               read_small("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", buf, sizeof(buf)) &&
-              parse_cpulist(buf, &c.set)) {
-            cpu_set_t allowed, both;
-            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
-              CPU_AND(&both, &allowed, &c.set);
-              if (CPU_COUNT(&both) > 0) { c.set = both; c.node = node; }
-            }
-          }
+              parse_cpulist(buf, &c.set))
+            c.node = node;
         }
       } else {
         (void) hipGetLastError();
@@ -209,7 +204,12 @@ int bind_thread_near_device(int dev) {
     nc = c;
   }
   if (nc.node < 0) return -1;
-  return sched_setaffinity(0, sizeof(nc.set), &nc.set) == 0 ? nc.node : -1;
+  // The node's CPU list is requested as it is, NOT intersected with the creating thread's own
+  // mask: the caller may have been narrowed to one core by an OpenMP runtime (a BLAS call made
+  // earlier in the process is enough), and the I/O threads must not inherit that.  The kernel
+  // applies the cpuset of the container itself and refuses only an empty result.
+  if (sched_setaffinity(0, sizeof(nc.set), &nc.set) == 0) return nc.node;
+  return -1;
 }
 
 static bof_flash_stats g_last_stats;

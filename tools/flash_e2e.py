@@ -31,7 +31,17 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--budget-gib", type=float, default=0.0,
                     help="HBM budget (0 = library default: most of the free HBM); 8 = the reference's PROGRAM_BUDGET")
+    ap.add_argument("--cpu-warm", type=int, default=0,
+                    help="diagnostic: run a torch CPU sgemm of this edge first (what bench.py's cpu_baseline does)")
     args = ap.parse_args()
+    state = {"allowed_cpus_at_start": len(os.sched_getaffinity(0))}
+    if args.cpu_warm:
+        x = torch.rand(args.cpu_warm, args.cpu_warm)
+        torch.mm(x, x)
+        del x
+        state["allowed_cpus_after_cpu_sgemm"] = len(os.sched_getaffinity(0))
+        state["process_threads"] = len(os.listdir("/proc/self/task"))
+        state["loadavg"] = os.getloadavg()
     bofhip.require_device()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
@@ -44,6 +54,7 @@ def main():
     finally:
         shutil.rmtree(work, ignore_errors=True)
     out["args"] = vars(args)
+    out["process_state"] = state
     if args.budget_gib > 0 and args.path == 1:
         slot = args.blk * args.blk * 4
         out["simulated"] = bofhip.flash_gemm_simulate("R", "N", "N", args.n, args.n, args.n, 0.0, args.blk,
