@@ -41,11 +41,20 @@ bof_options resolved(const bof_options *o) {
   return r;
 }
 
+// The compute streams of a device are shared by every stream set: set(n) is the first n of
+// them.  (One private group of streams per n left up to 1 + 2 + 4 + ... streams alive; HIP maps
+// streams onto a handful of hardware queues, so every extra live stream makes it likelier that
+// two streams that should overlap end up in one queue.)
+static hipStream_t g_compute_stream[64][16];
 int StreamSet::init(int n_streams) {
   n = n_streams;
+  int dev = 0;
+  BOF_HIP_TRY(hipGetDevice(&dev));
   BOF_HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
   for (int i = 0; i < n; i++) {
-    BOF_HIP_TRY(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    hipStream_t &shared = g_compute_stream[dev & 63][i];
+    if (!shared) BOF_HIP_TRY(hipStreamCreateWithFlags(&shared, hipStreamNonBlocking));
+    s[i] = shared;
     BOF_HIP_TRY(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
   }
   return BOF_OK;

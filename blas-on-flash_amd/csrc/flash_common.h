@@ -147,6 +147,13 @@ struct TraceRange {
   explicit TraceRange(const char *name) { trace_push(name); }
   ~TraceRange() { trace_pop(); }
 };
+// Stream for H2D / D2H copies: non-blocking and of the HIGHEST priority.  HIP multiplexes its
+// streams onto a few hardware queues per priority level; a copy stream that lands on the same
+// queue as a compute stream is serialised behind whole-chip tile kernels (a leftover compute
+// stream of an earlier level-2 call was enough to turn a 0.575 s cfg2 file run into 0.77 s,
+// profiles/r2/e2e_stream_aliasing.txt).  High-priority streams get queues of their own, and the
+// D2H blit kernels (0.67 ms per 32 MiB) then go ahead of queued 0.95 ms tile kernels.
+hipError_t copy_stream_create(hipStream_t *s);
 int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
 void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
 

@@ -437,8 +437,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   if (rc) return rc;
   rc = R.res->wring.init(std::max(2, o.pinned_slots), R.chunk);
   if (rc) return rc;
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
+  BOF_HIP_TRY(copy_stream_create(&R.h2d));
+  BOF_HIP_TRY(copy_stream_create(&R.d2h));
   R.trace("rings/streams ready");
 
   std::vector<std::thread> readers, writers;

@@ -57,6 +57,15 @@ std::recursive_mutex &device_call_mutex() {
   return g_call_mu[dev & 63];
 }
 
+hipError_t copy_stream_create(hipStream_t *s) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+  }
+  (void) hipGetLastError();
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 // ---- cache of pinned host blocks -------------------------------------------------------------------
 namespace {
 struct PinnedCache {
@@ -609,8 +618,8 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   const int n_writers = std::max(2, std::min(4, R.o.n_io_threads / 2));
   rc = R.res->wring.init((int) std::min<int64_t>(gi * gj, 16) + 2, R.slot_bytes);
   if (rc) return rc;
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
+  BOF_HIP_TRY(copy_stream_create(&R.h2d));
+  BOF_HIP_TRY(copy_stream_create(&R.d2h));
   R.ss = stream_set(R.o.n_streams);
   if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
 
@@ -882,30 +891,6 @@ struct CsrRun {
 
 int read_host(const bof_fptr &f, uint64_t bytes, void *dst, bool use_aio) {
   return file_sread(f.fd, f.foffset, 0, 1, bytes, dst, use_aio);
-}
-
-// whole dense array file -> device, chunked through a pinned ring
-int load_dense_to_device(const bof_fptr &f, uint64_t bytes, char *dptr, hipStream_t st, bool use_aio,
-                         Counters &cnt) {
-  PinnedRing ring;
-  const size_t chunk = 64ull << 20;
-  int rc = ring.init(2, chunk);
-  if (rc) return rc;
-  int io = 0;
-  for (uint64_t o = 0; o < bytes && !io; o += chunk) {
-    const uint64_t len = std::min<uint64_t>(chunk, bytes - o);
-    const int s = ring.acquire();
-    io = file_sread(f.fd, f.foffset + o, 0, 1, len, ring.ptr(s), use_aio);
-    hipError_t e = hipSuccess;
-    if (!io) e = hipMemcpyAsync(dptr + o, ring.ptr(s), len, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) ring.mark_busy(s, st);
-    ring.release(s);
-    if (e != hipSuccess) { ring.destroy(); return hip_fail(e, "load_dense_to_device"); }
-    cnt.rd += len; cnt.h2d += len;
-  }
-  ring.destroy();
-  if (io) { set_error(std::string("dense load failed: ") + strerror(-io)); return BOF_EIO; }
-  return BOF_OK;
 }
 
 // Whole array <-> file with up to n_thr workers; each owns a 2-slot pinned ring and takes
@@ -1284,6 +1269,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
     R.cnt.rd += (uint64_t) (m + 1) * 8;
   }
+  BOF_TRACE_T("csr: offsets on the host");
   const int64_t nb = bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, nullptr, nullptr, 0);
   R.st.resize((size_t) nb); R.sz.resize((size_t) nb);
   bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
@@ -1324,8 +1310,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     if (R.h2d) (void) hipStreamDestroy(R.h2d);
     if (R.d2h) (void) hipStreamDestroy(R.d2h);
   });
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.h2d, hipStreamNonBlocking));
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&R.d2h, hipStreamNonBlocking));
+  BOF_HIP_TRY(copy_stream_create(&R.h2d));
+  BOF_HIP_TRY(copy_stream_create(&R.d2h));
   if (res) {
     d_ia = const_cast<int64_t *>(res->ia_dev);
   } else {
@@ -1342,7 +1328,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       BOF_HIP_TRY(hipMemcpyAsync(d_b, R.host_b, (size_t) n * k * 4, hipMemcpyHostToDevice, R.h2d));
       R.cnt.h2d += (uint64_t) n * k * 4;
     } else {
-      rc = load_dense_to_device(fb, (uint64_t) n * k * 4, d_b, R.h2d, R.use_aio, R.cnt);
+      rc = stream_file(fb, (uint64_t) n * k * 4, d_b, true, R.h2d, R.use_aio, R.o.n_io_threads, R.cnt);
       if (rc) return rc;
     }
     if (ord_b == 'C') {  // column-major B (n x k, ld = n) -> row-major copy used by the kernel
@@ -1361,6 +1347,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   }
   BOF_HIP_TRY(hipEventCreateWithFlags(&resident_ev, hipEventDisableTiming));
   BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
+  BOF_TRACE_T("csr: B / x resident (queued)");
 
   // one context = one row block in flight (index + value segments, C block); the device delivers
   // its sequential rate only with several large requests queued, so as many blocks are in flight
@@ -1391,6 +1378,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   if (!ss) { set_error("flash csr: stream creation failed"); return BOF_EHIP; }
   for (int i = 0; i < ss->n; i++) BOF_HIP_TRY(hipStreamWaitEvent(ss->s[i], resident_ev, 0));
 
+  BOF_TRACE_T("csr: block contexts ready");
   std::vector<std::thread> readers;
   for (int i = 0; i < std::max(1, std::min<int>(R.o.n_io_threads, R.depth)); i++)
     readers.emplace_back([&R] { R.reader_main(); });
@@ -1455,11 +1443,13 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     R.cnt.tasks++;
     R.done_q.push(b);
   }
+  BOF_TRACE_T("csr: all blocks dispatched");
   if (herr != hipSuccess || fail) R.fail_io(-EIO);  // releases readers parked on a context hand-over
   for (auto &th : readers) th.join();
   R.done_q.close();
   for (auto &th : retirers) th.join();
   (void) hipDeviceSynchronize();
+  BOF_TRACE_T("csr: drained (C written)");
   if (!is_mm && !fail && herr == hipSuccess) {
     herr = hipMemcpy(hc, d_y, (size_t) ylen * 4, hipMemcpyDeviceToHost);
     R.cnt.d2h += (uint64_t) ylen * 4;
@@ -1676,7 +1666,7 @@ static int region_transfer(bof_fptr f, uint64_t bytes, void *dptr, bool to_devic
   const bof_options o = resolved(opts);
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  BOF_HIP_TRY(copy_stream_create(&st));
   Cleanup guard;
   guard.add([&] {
     if (ev) (void) hipEventDestroy(ev);

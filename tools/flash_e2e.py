@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--budget-gib", type=float, default=0.0,
                     help="HBM budget (0 = library default: most of the free HBM); 8 = the reference's PROGRAM_BUDGET")
+    ap.add_argument("--pre", default="", help="diagnostic: alloc,resident,dgemm,release stages run first")
     ap.add_argument("--cpu-warm", type=int, default=0,
                     help="diagnostic: run a torch CPU sgemm of this edge first (what bench.py's cpu_baseline does)")
     args = ap.parse_args()
@@ -45,6 +46,35 @@ def main():
     bofhip.require_device()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
+    # diagnostic pre-stages (what bench.py does before its e2e block), comma separated
+    for stage in [x for x in args.pre.split(",") if x]:
+        if stage == "alloc":            # allocate and free 16 GiB through torch's allocator
+            ts = [torch.empty(1 << 30, dtype=torch.float32, device=dev) for _ in range(4)]
+            for t in ts:
+                t.zero_()
+            torch.cuda.synchronize()
+            del ts, t
+        elif stage == "resident":       # four passes of the resident cfg2 tile DAG
+            n = 32768
+            a = torch.empty(n * n, dtype=torch.float32, device=dev)
+            b = torch.empty(n * n, dtype=torch.float32, device=dev)
+            c = torch.empty(n * n, dtype=torch.float32, device=dev)
+            bofhip.gen_dense(a.data_ptr(), 0, n * n, "u", 1, st)
+            bofhip.gen_dense(b.data_ptr(), 0, n * n, "u", 2, st)
+            for _ in range(4):
+                bofhip.gemm_resident("R", "N", "N", n, n, n, 1.0, 0.0, a.data_ptr(), b.data_ptr(), c.data_ptr(), 0, 0, 0,
+                                     bofhip.default_options(n_streams=1), st)
+            torch.cuda.synchronize()
+            del a, b, c
+        elif stage == "dgemm":          # a float64 product through torch (rocBLAS)
+            x = torch.rand(4096, 8192, dtype=torch.float64, device=dev)
+            y = torch.rand(8192, 8192, dtype=torch.float64, device=dev)
+            (x @ y).sum().item()
+            del x, y
+        elif stage == "release":
+            bofhip.lib().bof_flash_release()
+        torch.cuda.empty_cache()
+        state.setdefault("pre", []).append(stage)
     work = tempfile.mkdtemp(prefix="bof_e2e_", dir=args.dir)
     modes = {1: ("odirect",), 0: ("buffered",), -1: ("odirect", "buffered")}[args.direct]
     try:
