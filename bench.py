@@ -196,10 +196,11 @@ def csr_pmc():
     try:
         d = json.load(open(cands[-1]))
         out = {}
-        # (the committed 'T' counters belong to the per-block atomic kernel, not to the partitioned
-        #  form level 2 runs, so they are not quoted)
-        for key, name in (("csrmm_rowmajor", "csrmm"), ("csrgemv_n", "csrgemv_N")):
-            if key in d:
+        # ('T' is quoted only from a file that measured the partitioned form level 2 runs; the
+        #  round-1 file holds the per-block atomic kernel under the key "csrgemv_t")
+        for key, name in (("csrmm_rowmajor", "csrmm"), ("csrgemv_n", "csrgemv_N"),
+                          ("csrgemv_t_partitioned", "csrgemv_T")):
+            if key in d and "FETCH_SIZE" in d[key] and "WRITE_SIZE" in d[key]:
                 f = d[key]["FETCH_SIZE"]["sum_over_launches_of_one_pass"] * 1024.0 * 2.0
                 w = d[key]["WRITE_SIZE"]["sum_over_launches_of_one_pass"] * 1024.0
                 out[name] = f + w

@@ -148,6 +148,18 @@ def test_flash_gemm_panels_ring_reuse(dev, tmp_path, monkeypatch, ord_, ta, tb, 
         F.close()
 
 
+def test_flash_gemm_io_uring_engine_subprocess(dev):
+    """The io_uring engine (BOF_IO_ENGINE is read once per process): the panel-ring and the 8-layout
+    file tests again in a child process whose aligned O_DIRECT requests go through io_uring with the
+    pinned staging slots registered as fixed buffers."""
+    import sys
+    env = dict(os.environ, BOF_IO_ENGINE="uring")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "panels_ring_reuse or layouts_unaligned or small_budget"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:]
+
+
 def test_flash_gemm_panels_not_eligible_falls_back(dev, tmp_path):
     """ldc > n (the gaps between C's rows are not ours to rewrite) and tiny budgets go to the tile
     cache; gemm_path = 2 makes that an error instead of a silent change of path."""
