@@ -17,6 +17,7 @@
 //   device-scope atomics execute at the memory side on MI355X and cost 37 ms per 1e9).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bof_internal.h"
 
@@ -122,6 +123,17 @@ inline size_t scan_tmp_elems(int64_t n) {  // int64 elements needed by exclusive
 constexpr int RS_T = 256, RS_WAVES = RS_T / 64, RS_CHUNKS = 16, RS_SUB = 64 * RS_CHUNKS,
               RS_TILE = RS_WAVES * RS_SUB;
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each with its own
+// L2.  Tile t appends its run of every digit right behind tile t-1's, so when consecutive TILES run
+// on the same XCD at about the same time their short runs (32 records per digit and tile on
+// average at 7 bits) meet in that L2 and leave it as full lines.  tile_of() gives XCD x the
+// contiguous tile range [x*per, (x+1)*per).
+__device__ inline int64_t tile_of(int64_t b, int64_t nblocks, int xcd_order) {
+  if (!xcd_order) return b;
+  const int64_t per = (nblocks + 7) / 8;
+  return (b % 8) * per + b / 8;   // may be >= nblocks for the last XCD: caller skips
+}
+
 struct SortArgs {
   // source: pass 0 reads the CSR arrays, later passes the (key,row,val) records
   const int64_t *col;   // pass 0
@@ -137,6 +149,7 @@ struct SortArgs {
   int64_t nblocks;
   const int64_t *tile_row;  // pass 0: row holding the first record of every tile (nblocks + 1)
   const float *x;           // GEMV mode, pass 0: the record value becomes val * x[row]
+  int xcd_order;            // 1: tiles are dealt to XCDs in contiguous ranges (tile_of)
 };
 
 // row of position p (0-based among the non-zeros): largest r in [lo, hi] with ptr[r] - ptr[0] <= p
@@ -191,18 +204,20 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
   __shared__ uint32_t wsum[RS_WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t mask = (1u << a.wbits) - 1u;
-  const int64_t t0 = (int64_t) blockIdx.x * RS_TILE;
+  const int64_t tile = tile_of(blockIdx.x, a.nblocks, a.xcd_order);
+  if (tile >= a.nblocks) return;
+  const int64_t t0 = tile * RS_TILE;
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
   const int64_t s0 = t0 + (int64_t) w * RS_SUB;  // this wave's quarter
   for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_T) (&run[0][0])[i] = 0;
-  if (threadIdx.x <= mask) gbase[threadIdx.x] = bases[(int64_t) threadIdx.x * a.nblocks + blockIdx.x];
+  if (threadIdx.x <= mask) gbase[threadIdx.x] = bases[(int64_t) threadIdx.x * a.nblocks + tile];
   const int64_t z = FIRST ? a.ptr[0] : 0;
   __syncthreads();
   // phase 0/1: records into registers, digit counts per wave
   uint32_t key[RS_CHUNKS], row[RS_CHUNKS];
   float v[RS_CHUNKS];
   // rows that can own a record of this tile (the upper one may start exactly at the tile end)
-  const int64_t r_lo = FIRST ? a.tile_row[blockIdx.x] : 0, r_hi = FIRST ? a.tile_row[blockIdx.x + 1] : 0;
+  const int64_t r_lo = FIRST ? a.tile_row[tile] : 0, r_hi = FIRST ? a.tile_row[tile + 1] : 0;
 #pragma unroll
   for (int c = 0; c < RS_CHUNKS; c++) {
     const int64_t p = s0 + c * 64 + lane;
@@ -316,7 +331,8 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
 
 template <bool FIRST, bool LAST, bool GEMV = false>
 hipError_t scatter_launch(const SortArgs &a, const int64_t *bases, hipStream_t st) {
-  radix_scatter_kernel<FIRST, LAST, GEMV><<<(unsigned) a.nblocks, RS_T, 0, st>>>(a, bases);
+  const int64_t grid = a.xcd_order ? (a.nblocks + 7) / 8 * 8 : a.nblocks;
+  radix_scatter_kernel<FIRST, LAST, GEMV><<<(unsigned) grid, RS_T, 0, st>>>(a, bases);
   return hipGetLastError();
 }
 
@@ -339,6 +355,11 @@ __global__ __launch_bounds__(256) void offsets_by_search_kernel(const uint32_t *
 }
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+inline int sort_xcd_order() {
+  static const int v = getenv("BOF_SORT_XCD") ? atoi(getenv("BOF_SORT_XCD")) : 1;
+  return v;
+}
 
 struct Layout {
   int passes, wbits;
@@ -478,6 +499,7 @@ hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float
   tile_rows_kernel<<<(unsigned) ((L.nblocks + 1 + 255) / 256), 256, 0, st>>>(ptr, m, nnz, L.nblocks, tile_row);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   SortArgs a{};
+  a.xcd_order = sort_xcd_order();
   a.tile_row = tile_row; a.x = x;
   a.col = col; a.ptr = ptr; a.m = m; a.nnz = nnz; a.nblocks = L.nblocks; a.wbits = L.wbits;
   const char *sorted = nullptr;
@@ -530,6 +552,7 @@ hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const in
   tile_rows_kernel<<<(unsigned) ((L.nblocks + 1 + 255) / 256), 256, 0, st>>>(ptr, m, nnz, L.nblocks, tile_row);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   SortArgs a{};
+  a.xcd_order = sort_xcd_order();
   a.tile_row = tile_row;
   a.col = col; a.ptr = ptr; a.m = m; a.nnz = nnz; a.nblocks = L.nblocks; a.wbits = L.wbits;
   a.col_tr = col_tr;
