@@ -122,6 +122,7 @@ inline size_t scan_tmp_elems(int64_t n) {  // int64 elements needed by exclusive
 // run by run, so every global store instruction covers consecutive addresses.
 constexpr int RS_T = 256, RS_WAVES = RS_T / 64, RS_CHUNKS = 16, RS_SUB = 64 * RS_CHUNKS,
               RS_TILE = RS_WAVES * RS_SUB;
+constexpr int RS_MAXBITS = 10, RS_MAXD = 1 << RS_MAXBITS;  // digits of up to 10 bits
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each with its own
 // L2.  Tile t appends its run of every digit right behind tile t-1's, so when consecutive TILES run
@@ -177,18 +178,18 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const int64_t *__restric
 
 template <bool FIRST>
 __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *__restrict__ hist) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  __shared__ uint32_t h[RS_MAXD];
+  const uint32_t mask = (1u << a.wbits) - 1u;
+  for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) h[d] = 0;
   __syncthreads();
   const int64_t t0 = (int64_t) blockIdx.x * RS_TILE;
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
-  const uint32_t mask = (1u << a.wbits) - 1u;
   for (int64_t p = t0 + threadIdx.x; p < t1; p += RS_T) {
     const uint32_t key = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
     atomicAdd(&h[(key >> a.shift) & mask], 1u);
   }
   __syncthreads();
-  if (threadIdx.x <= mask) hist[(int64_t) threadIdx.x * a.nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
+  for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) hist[(int64_t) d * a.nblocks + blockIdx.x] = h[d];  // digit-major
 }
 
 // GEMV mode (the partition passes of A^T x): records are (column, product) only -- no row
@@ -198,9 +199,9 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
                                                              const int64_t *__restrict__ bases) {
   __shared__ uint32_t skey[RS_TILE], srow[(GEMV && !FIRST) ? 64 : RS_TILE];
   __shared__ float sval[RS_TILE];
-  __shared__ uint32_t run[RS_WAVES][256];  // counts, then running local positions
-  __shared__ uint32_t lstart[256];         // local start of every digit's run
-  __shared__ int64_t gbase[256];           // global start of this tile's run of every digit
+  __shared__ uint32_t run[RS_WAVES][RS_MAXD];  // counts, then running local positions
+  __shared__ uint32_t lstart[RS_MAXD];         // local start of every digit's run
+  __shared__ int64_t gbase[RS_MAXD];           // global start of this tile's run of every digit
   __shared__ uint32_t wsum[RS_WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t mask = (1u << a.wbits) - 1u;
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
   const int64_t t0 = tile * RS_TILE;
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
   const int64_t s0 = t0 + (int64_t) w * RS_SUB;  // this wave's quarter
-  for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_T) (&run[0][0])[i] = 0;
-  if (threadIdx.x <= mask) gbase[threadIdx.x] = bases[(int64_t) threadIdx.x * a.nblocks + tile];
+  for (int i = threadIdx.x; i < (RS_WAVES << a.wbits); i += RS_T) run[i >> a.wbits][i & mask] = 0;
+  for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) gbase[d] = bases[(int64_t) d * a.nblocks + tile];
   const int64_t z = FIRST ? a.ptr[0] : 0;
   __syncthreads();
   // phase 0/1: records into registers, digit counts per wave
@@ -243,9 +244,19 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
       skey[i] = (uint32_t) rel;
     }
     __syncthreads();
-    for (int ri = w; ri < (int) nr; ri += RS_WAVES) {
-      const int b = (int) skey[ri], e = (int) skey[ri + 1];
-      for (int q = b + lane; q < e; q += 64) srow[q] = (uint32_t) (r_lo + ri);
+    if (nr * 16 > cnt) {
+      // short rows (fewer than 16 records on average: the 10-per-row matrices of csrgemv): one
+      // row per LANE -- a wave per row would walk ~100 rows one after the other, each for a
+      // handful of positions (that serial walk was 40 % of the first pass at 10 records per row)
+      for (int ri = threadIdx.x; ri < (int) nr; ri += RS_T) {
+        const int b = (int) skey[ri], e = (int) skey[ri + 1];
+        for (int q = b; q < e; q++) srow[q] = (uint32_t) (r_lo + ri);
+      }
+    } else {
+      for (int ri = w; ri < (int) nr; ri += RS_WAVES) {
+        const int b = (int) skey[ri], e = (int) skey[ri + 1];
+        for (int q = b + lane; q < e; q += 64) srow[q] = (uint32_t) (r_lo + ri);
+      }
     }
     __syncthreads();
   }
@@ -267,13 +278,19 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
   for (int c = 0; c < RS_CHUNKS; c++)
     if (s0 + c * 64 + lane < t1) atomicAdd(&run[w][(key[c] >> a.shift) & mask], 1u);
   __syncthreads();
-  // local layout: digit-major, wave-minor (= input order inside a digit)
+  // local layout: digit-major, wave-minor (= input order inside a digit).  Thread t owns the
+  // dpt consecutive digits [t*dpt, (t+1)*dpt) (dpt = 1, 2 or 4), so the scan over threads is the
+  // scan over digits.
   {
-    const int d = threadIdx.x;
-    uint32_t cw[RS_WAVES], tot = 0;
+    const int dpt = (int) ((mask + 1 + RS_T - 1) / RS_T);
+    uint32_t tot = 0;
+    for (int j = 0; j < dpt; j++) {
+      const uint32_t d = threadIdx.x * dpt + j;
+      if (d <= mask)
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; i++) { cw[i] = run[i][d]; tot += cw[i]; }
-    uint32_t inc = tot;  // exclusive scan of tot over the 256 digits
+        for (int i = 0; i < RS_WAVES; i++) tot += run[i][d];
+    }
+    uint32_t inc = tot;  // inclusive scan of tot over the 256 threads
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = __shfl_up(inc, o);
       if (lane >= o) inc += t;
@@ -282,9 +299,14 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
     __syncthreads();
     uint32_t start = inc - tot;
     for (int i = 0; i < w; i++) start += wsum[i];
-    lstart[d] = start;
+    for (int j = 0; j < dpt; j++) {
+      const uint32_t d = threadIdx.x * dpt + j;
+      if (d <= mask) {
+        lstart[d] = start;
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; i++) { run[i][d] = start; start += cw[i]; }
+        for (int i = 0; i < RS_WAVES; i++) { const uint32_t cw = run[i][d]; run[i][d] = start; start += cw; }
+      }
+    }
   }
   __syncthreads();
   // phase 2: stable placement into the LDS image
@@ -356,6 +378,13 @@ __global__ __launch_bounds__(256) void offsets_by_search_kernel(const uint32_t *
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+// digit width of the transposition sort: 8 bits (the measured default) or up to 10
+// (BOF_SORT_BITS; fewer passes, shorter runs per tile and digit)
+inline int sort_digit_bits() {
+  static const int v = getenv("BOF_SORT_BITS") ? atoi(getenv("BOF_SORT_BITS")) : 8;
+  return v < 4 ? 4 : (v > RS_MAXBITS ? RS_MAXBITS : v);
+}
+
 inline int sort_xcd_order() {
   static const int v = getenv("BOF_SORT_XCD") ? atoi(getenv("BOF_SORT_XCD")) : 1;
   return v;
@@ -371,7 +400,8 @@ Layout make_layout(int64_t n, int64_t nnz) {
   Layout L{};
   int bits = 1;
   while (bits < 32 && ((int64_t) 1 << bits) < n) bits++;
-  L.passes = (bits + 7) / 8;
+  const int per = sort_digit_bits();
+  L.passes = (bits + per - 1) / per;
   L.wbits = (bits + L.passes - 1) / L.passes;
   L.nblocks = (nnz + RS_TILE - 1) / RS_TILE;
   const size_t nh = ((size_t) 1 << L.wbits) * (size_t) (L.nblocks > 0 ? L.nblocks : 1);
@@ -407,7 +437,16 @@ __global__ __launch_bounds__(256) void gemv_t_accumulate_kernel(const uint32_t *
   for (int i = threadIdx.x; i < GT_W; i += 256) ys[i] = 0.f;
   __syncthreads();
   const int64_t b = blockIdx.x, e = bin_off[b + 1];
-  for (int64_t i = bin_off[b] + threadIdx.x; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+  int64_t i = bin_off[b] + threadIdx.x;
+  for (; i + 3 * 256 < e; i += 4 * 256) {  // four record loads in flight per lane before the LDS adds
+    uint32_t kk[4];
+    float pp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { kk[u] = key[i + u * 256]; pp[u] = prod[i + u * 256]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) atomicAdd(&ys[kk[u] & (GT_W - 1)], pp[u]);
+  }
+  for (; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
   __syncthreads();
   const int64_t c0 = b * GT_W;
   for (int i = threadIdx.x; i < GT_W && c0 + i < n; i += 256) y[c0 + i] = ys[i];
