@@ -122,7 +122,11 @@ inline size_t scan_tmp_elems(int64_t n) {  // int64 elements needed by exclusive
 // run by run, so every global store instruction covers consecutive addresses.
 constexpr int RS_T = 256, RS_WAVES = RS_T / 64, RS_CHUNKS = 16, RS_SUB = 64 * RS_CHUNKS,
               RS_TILE = RS_WAVES * RS_SUB;
-constexpr int RS_MAXBITS = 10, RS_MAXD = 1 << RS_MAXBITS;  // digits of up to 10 bits
+// Digits of at most 8 bits.  10-bit digits (two passes instead of three at 1M columns) were built
+// and measured: 41.3 ms against 28.5 ms for the cfg3 matrix -- a 4096-record tile then holds 4
+// records per digit, the scatter's runs shrink to 16 bytes and both passes take 14-17 ms instead of
+// 8-9, and the 1024-entry LDS tables halve the occupancy of the record-only (GEMV) passes.
+constexpr int RS_MAXBITS = 8, RS_MAXD = 1 << RS_MAXBITS;
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each with its own
 // L2.  Tile t appends its run of every digit right behind tile t-1's, so when consecutive TILES run
@@ -378,8 +382,8 @@ __global__ __launch_bounds__(256) void offsets_by_search_kernel(const uint32_t *
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
-// digit width of the transposition sort: 8 bits (the measured default) or up to 10
-// (BOF_SORT_BITS; fewer passes, shorter runs per tile and digit)
+// digit width of the transposition sort: at most RS_MAXBITS (BOF_SORT_BITS narrows it for
+// experiments)
 inline int sort_digit_bits() {
   static const int v = getenv("BOF_SORT_BITS") ? atoi(getenv("BOF_SORT_BITS")) : 8;
   return v < 4 ? 4 : (v > RS_MAXBITS ? RS_MAXBITS : v);
@@ -436,17 +440,34 @@ __global__ __launch_bounds__(256) void gemv_t_accumulate_kernel(const uint32_t *
   __shared__ float ys[GT_W];
   for (int i = threadIdx.x; i < GT_W; i += 256) ys[i] = 0.f;
   __syncthreads();
-  const int64_t b = blockIdx.x, e = bin_off[b + 1];
-  int64_t i = bin_off[b] + threadIdx.x;
-  for (; i + 3 * 256 < e; i += 4 * 256) {  // four record loads in flight per lane before the LDS adds
-    uint32_t kk[4];
-    float pp[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { kk[u] = key[i + u * 256]; pp[u] = prod[i + u * 256]; }
-#pragma unroll
-    for (int u = 0; u < 4; u++) atomicAdd(&ys[kk[u] & (GT_W - 1)], pp[u]);
+  const int64_t b = blockIdx.x, s = bin_off[b], e = bin_off[b + 1];
+  // head up to the first 16-byte boundary, then four consecutive records per lane and load
+  // (dwordx4, two of each array in flight), then the tail
+  const int64_t a0 = (s + 3) & ~(int64_t) 3, a1 = e & ~(int64_t) 3;
+  if (a0 < a1) {
+    for (int64_t i = s + threadIdx.x; i < a0; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(key);
+    const float4 *p4 = reinterpret_cast<const float4 *>(prod);
+    int64_t q = a0 / 4 + threadIdx.x;
+    const int64_t q1 = a1 / 4;
+    for (; q + 256 < q1; q += 512) {
+      const uint4 ka = k4[q], kb = k4[q + 256];
+      const float4 pa = p4[q], pb = p4[q + 256];
+      atomicAdd(&ys[ka.x & (GT_W - 1)], pa.x); atomicAdd(&ys[ka.y & (GT_W - 1)], pa.y);
+      atomicAdd(&ys[ka.z & (GT_W - 1)], pa.z); atomicAdd(&ys[ka.w & (GT_W - 1)], pa.w);
+      atomicAdd(&ys[kb.x & (GT_W - 1)], pb.x); atomicAdd(&ys[kb.y & (GT_W - 1)], pb.y);
+      atomicAdd(&ys[kb.z & (GT_W - 1)], pb.z); atomicAdd(&ys[kb.w & (GT_W - 1)], pb.w);
+    }
+    for (; q < q1; q += 256) {
+      const uint4 ka = k4[q];
+      const float4 pa = p4[q];
+      atomicAdd(&ys[ka.x & (GT_W - 1)], pa.x); atomicAdd(&ys[ka.y & (GT_W - 1)], pa.y);
+      atomicAdd(&ys[ka.z & (GT_W - 1)], pa.z); atomicAdd(&ys[ka.w & (GT_W - 1)], pa.w);
+    }
+    for (int64_t i = a1 + threadIdx.x; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+  } else {
+    for (int64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
   }
-  for (; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
   __syncthreads();
   const int64_t c0 = b * GT_W;
   for (int i = threadIdx.x; i < GT_W && c0 + i < n; i += 256) y[c0 + i] = ys[i];
