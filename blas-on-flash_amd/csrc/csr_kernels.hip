@@ -71,10 +71,8 @@ csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ v
       int mycol = 0;
       float myval = 0.f;
       if (lane < cnt) {
-        // the CSR stream is read once: non-temporal, so that it does not displace B rows from
-        // the L2 / Infinity Cache (B is what gets re-read)
-        mycol = (int) __builtin_nontemporal_load(col + p + lane);
-        myval = __builtin_nontemporal_load(val + p + lane);
+        mycol = (int) col[p + lane];
+        myval = val[p + lane];
       }
       int tI = 0;
       for (; tI + UNROLL <= cnt; tI += UNROLL) {
@@ -111,12 +109,7 @@ csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ v
 #pragma unroll
         for (int e = 0; e < VEC; e++) acc[e] = __builtin_fmaf(alpha, acc[e], beta * old[e]);
       }
-      // written once: non-temporal (native vector type: the builtin does not take HIP's float2/float4)
-      typedef float NV __attribute__((ext_vector_type(VEC)));
-      NV out;
-#pragma unroll
-      for (int e = 0; e < VEC; e++) out[e] = acc[e];
-      __builtin_nontemporal_store(out, reinterpret_cast<NV *>(cp));
+      *reinterpret_cast<V *>(cp) = *reinterpret_cast<V *>(acc);
     }
   }
 }
