@@ -92,10 +92,12 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     write-back all overlap inside the library (flash_gemm_panels.cpp), nothing is staged in Python.
 
     b_once_per_node=True: B is read from storage ONCE per node instead of once per
-    GPU: rank g reads the k-row panel B[k0:k1, :] and one all-gather (RCCL over xGMI) assembles the
-    full matrix on every GPU; A / C slabs are made resident and the level-2 tile DAG runs over them
-    (same tiles, same k-order, so the C file is bit-identical).  Pays when the storage, not PCIe, is
-    the bottleneck (8 x 16 GiB of B reads at cfg4).
+    GPU.  The k-panels of the tile grid are dealt round-robin to the ranks; the owner reads its
+    panels from the file and broadcasts them (RCCL over xGMI, asynchronous, in k order) while the
+    A / C slabs stream in; the tile DAG of each k range is queued behind "its" broadcast only, so
+    MFMA work on panel l overlaps the arrival of panels l+1, ...; same tiles, same k-order as the
+    single call, so the C file is bit-identical.  Pays when the storage, not PCIe, is the
+    bottleneck (8 x 16 GiB of B reads at cfg4: 144 GiB through one device vs 32 GiB).
 
     Returns {bytes_read, bytes_written, rows, b_panel_rows} of this rank.  `one_gpu_debug` runs the
     collective through host memory (gloo) so that two ranks can share one device."""
@@ -121,32 +123,41 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
         return stats
     st = torch.cuda.current_stream(dev).cuda_stream
     rd = wr = 0
-    # --- B: this rank's k-row panel from the file, then all-gather ---------------------------
-    per = (k + world - 1) // world
-    k0, k1 = min(k, rank * per), min(k, (rank + 1) * per)
-    # torch.empty: no fill kernel is queued on torch's stream that could land on top of the data
-    # the library's private copy stream writes; only what the file does not cover is zeroed, and
-    # the transfer itself is ordered behind `st` (bof_file_to_device's stream argument)
-    panel = torch.empty(per * ldb, dtype=torch.float32, device=dev)
-    nbytes = ((k1 - k0 - 1) * ldb + n) * 4 if k1 > k0 else 0   # the last row may end before a full ldb
-    if nbytes < panel.numel() * 4:
-        panel[nbytes // 4:].zero_()
-    if k1 > k0:
-        bofhip.file_to_device(bofhip.FPtr(fd_b, k0 * ldb * 4), nbytes, panel.data_ptr(), o, st)
-        rd += nbytes
+    # --- k-panels of B: the tile grid's own k blocks (tail-merge rule of src/blas/gemm.cpp:69-75),
+    # dealt round-robin to the ranks.  Owner reads its panels from the file; every panel is then
+    # broadcast (RCCL over xGMI, asynchronous, in k order) and consumed by the tile DAG of THAT k
+    # range as soon as it has landed -- the accumulate chains run l = 0, 1, ... exactly as in the
+    # single call, so the C file is bit-identical.
+    nkb = max(1, k // tile) if (k % tile) < 128 and k >= tile else k // tile + (1 if k % tile else 0)
+    nkb = max(nkb, 1)
+    kb = [(l * tile, k if l == nkb - 1 else (l + 1) * tile) for l in range(nkb)]
+    b_elems = (k - 1) * ldb + n
+    b_dev = torch.empty(b_elems, dtype=torch.float32, device=dev)
+
+    def region(l):
+        k0, k1 = kb[l]
+        return k0 * ldb, ((k1 - k0 - 1) * ldb + n)          # element offset, element count
+
+    mine = [l for l in range(nkb) if l % world == rank]
+    for l in mine:
+        off, cnt = region(l)
+        bofhip.file_to_device(bofhip.FPtr(fd_b, off * 4), cnt * 4, b_dev.data_ptr() + off * 4, o, st)
+        rd += cnt * 4
+    works = [None] * nkb
     if world > 1:
-        full = torch.empty(world * per * ldb, dtype=torch.float32, device=dev)
-        if one_gpu_debug:
-            hp, hf = panel.cpu(), torch.empty(world * per * ldb, dtype=torch.float32)
-            dist.all_gather_into_tensor(hf, hp, group=group)
-            full.copy_(hf)
-        else:
-            dist.all_gather_into_tensor(full, panel, group=group)
-        b_dev = full
-    else:
-        b_dev = panel
-    stats = {"bytes_read": 0, "bytes_written": 0, "rows": rows, "b_panel_rows": k1 - k0}
+        for l in range(nkb):
+            off, cnt = region(l)
+            if one_gpu_debug:          # two ranks on one device: the collective goes through host memory
+                h = b_dev[off:off + cnt].cpu() if l % world == rank else torch.empty(cnt, dtype=torch.float32)
+                dist.broadcast(h, src=l % world, group=group)
+                if l % world != rank:
+                    b_dev[off:off + cnt].copy_(h)
+            else:
+                works[l] = dist.broadcast(b_dev[off:off + cnt], src=l % world, group=group, async_op=True)
+    stats = {"bytes_read": 0, "bytes_written": 0, "rows": rows,
+             "b_panel_rows": sum(kb[l][1] - kb[l][0] for l in mine)}
     if rows > 0:
+        # A / C slabs stream in while the broadcasts are in flight
         a_dev = torch.empty(rows * lda, dtype=torch.float32, device=dev)
         a_bytes = ((rows - 1) * lda + k) * 4
         bofhip.file_to_device(bofhip.FPtr(fd_a, r0 * lda * 4), a_bytes, a_dev.data_ptr(), o, st)
@@ -156,12 +167,21 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
         if beta != 0.0 or ldc != n:       # padded rows: keep what lies between the row ends
             bofhip.file_to_device(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o, st)
             rd += c_bytes
-        # (the transfers above are blocking: the slabs are complete before the DAG is queued;
-        #  the write-back below is ordered behind the DAG through its stream argument)
-        bofhip.gemm_resident("R", "N", "N", rows, n, k, alpha, beta, a_dev.data_ptr(), b_dev.data_ptr(),
-                             c_dev.data_ptr(), lda, ldb, ldc, o, st)
+        for l in range(nkb):
+            k0, k1 = kb[l]
+            if works[l] is not None:
+                works[l].wait()           # the CURRENT STREAM waits for panel l; the host does not
+            bofhip.gemm_resident("R", "N", "N", rows, n, k1 - k0, alpha, beta if l == 0 else 1.0,
+                                 a_dev.data_ptr() + k0 * 4, b_dev.data_ptr() + k0 * ldb * 4, c_dev.data_ptr(),
+                                 lda, ldb, ldc, o, st)
+        # the write-back is ordered behind the DAG through its stream argument
         bofhip.device_to_file(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o, st)
         wr += c_bytes
+    else:
+        for w in works:
+            if w is not None:
+                w.wait()
+    torch.cuda.current_stream(dev).synchronize()
     stats["bytes_read"], stats["bytes_written"] = rd, wr
     return stats
 
