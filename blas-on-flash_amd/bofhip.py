@@ -38,6 +38,13 @@ class FPtr(C.Structure):
     _fields_ = [("fd", C.c_int), ("foffset", u64)]
 
 
+class PanelPlan(C.Structure):
+    """bof_panel_plan: which path bof_flash_gemm takes for a budget, and the row-panel layout."""
+    _fields_ = [("eligible", C.c_int32), ("why", C.c_int32), ("streamed", C.c_int32), ("resident", C.c_int32 * 3),
+                ("n_panels", i64 * 3), ("n_slots", i64 * 3), ("slot_bytes", u64 * 3), ("need_bytes", u64),
+                ("groups", i64)]
+
+
 class FlashStats(C.Structure):
     _fields_ = [("bytes_read", u64), ("bytes_written", u64), ("bytes_h2d", u64),
                 ("bytes_d2h", u64), ("tasks", u64), ("tile_hits", u64), ("tile_misses", u64),
@@ -85,6 +92,8 @@ SYMBOLS = [
     ("bof_flash_csrgemv", C.c_int, [chr_, u64, u64, FPtr, FPtr, FPtr, P, P, C.POINTER(Options)]),
     ("bof_file_to_device", C.c_int, [FPtr, u64, P, C.POINTER(Options), P]),
     ("bof_device_to_file", C.c_int, [FPtr, u64, P, C.POINTER(Options), P]),
+    ("bof_flash_gemm_panel_plan", C.c_int, [chr_, chr_, chr_, u64, u64, u64, u64, u64, u64, i64, u64, i64,
+                                            C.POINTER(PanelPlan)]),
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
     ("bof_flash_release", C.c_int, []),
     ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
@@ -264,6 +273,15 @@ def flash_gemm_simulate(ord_, ta, tb, m, n, k, beta, blk, n_slots, lookahead=16,
     check(lib().bof_flash_gemm_simulate(_c(ord_), _c(ta), _c(tb), m, n, k, beta, lda, ldb, ldc, blk,
                                         n_slots, lookahead, C.byref(s)), "bof_flash_gemm_simulate")
     return {f: getattr(s, f) for f, _ in s._fields_}
+
+
+def flash_gemm_panel_plan(ord_, ta, tb, m, n, k, blk, hbm_budget, lda=0, ldb=0, ldc=0, group=1):
+    p = PanelPlan()
+    check(lib().bof_flash_gemm_panel_plan(_c(ord_), _c(ta), _c(tb), m, n, k, lda, ldb, ldc, blk, hbm_budget, group,
+                                          C.byref(p)), "bof_flash_gemm_panel_plan")
+    return {"eligible": bool(p.eligible), "why": p.why, "streamed": p.streamed, "resident": list(p.resident),
+            "n_panels": list(p.n_panels), "n_slots": list(p.n_slots), "slot_bytes": list(p.slot_bytes),
+            "need_bytes": p.need_bytes, "groups": p.groups}
 
 
 def flash_last_stats():

@@ -68,6 +68,9 @@ GemmGeometry gemm_geometry(char ord, char ta, char tb, int64_t m, int64_t n, int
 void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float beta,
                   bof_gemm_task *t);
 
+// row-panel layout of flash::gemm for a budget (plan.cpp; see bof_panel_plan in bof_hip.h)
+bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group);
+
 // ---- fork/join of compute streams (c_api.hip) -----------------------------------
 struct StreamSet {
   int n = 0;

@@ -299,36 +299,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   R.c_read = beta != 0.0f;
   BOF_HIP_TRY(hipGetDevice(&R.dev));
 
-  // ---- panels -----------------------------------------------------------------------------
-  const bof_fptr fp[3] = {fa, fb, fc};
-  for (int x = 0; x < 3; x++) {
-    Mat &M = R.mat[x];
-    M.f = fp[x];
-    M.rdim = g.rdim[x]; M.cdim = g.cdim[x];
-    M.rows = g.size[M.rdim]; M.cols = g.size[M.cdim]; M.ld = g.ld[x];
-    M.blk_r = g.blk[M.rdim]; M.blk_c = g.blk[M.cdim];
-    if (M.ld < M.cols) return 1;                       // malformed: let the tile path report it
-    if (x < 2 && M.cols * 2 < M.ld) return 1;          // a narrow view of a wide matrix: mostly gaps
-    M.panels.resize((size_t) g.nblk[M.rdim]);
-    for (int64_t p = 0; p < g.nblk[M.rdim]; p++) {
-      Panel &P = M.panels[(size_t) p];
-      P.r0 = p * M.blk_r;
-      P.nr = (p == g.nblk[M.rdim] - 1) ? M.rows - P.r0 : M.blk_r;
-      P.bytes = ((uint64_t) (P.nr - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4;
-      M.slot_bytes = std::max<size_t>(M.slot_bytes, (size_t) round_up(P.bytes, 2u << 20));
-    }
-    M.total_bytes = (size_t) (((uint64_t) (M.rows - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4);
-  }
-  if (R.mat[2].ld != R.mat[2].cols) return 1;  // gaps between C's rows belong to someone else
-
-  // ---- who is resident, who streams; does it fit? -----------------------------------------
-  const int dC = g.rdim[2];                    // 0: C paneled along m, 2: along n
-  R.xmat = dC == 0 ? 0 : 1;
-  R.ymat = 1 - R.xmat;
-  const bool x_streams = g.rdim[R.xmat] == dC;
-  const char *genv = getenv("BOF_PANEL_GROUP");
-  const int64_t NpC = g.nblk[dC];
-  const int64_t group = std::max<int64_t>(1, std::min<int64_t>(genv ? atoll(genv) : 1, NpC));
+  // ---- budget and layout (plan.cpp: pure host logic, also behind bof_flash_gemm_panel_plan) ------
   size_t free_b = 0, total_b = 0;
   BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   {
@@ -339,19 +310,35 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   for (int x = 0; x < 3; x++) free_b += R.res->slab_bytes[x];  // what we already hold counts as free
   size_t budget = o.hbm_budget > 0 ? (size_t) o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
-  Mat &X = R.mat[R.xmat], &Y = R.mat[R.ymat], &C = R.mat[2];
-  Y.natural = true;
-  Y.n_slots = (int) Y.panels.size();
-  X.natural = !x_streams;
-  X.n_slots = X.natural ? (int) X.panels.size() : (int) std::min<int64_t>((int64_t) X.panels.size(), 2 * group);
-  C.natural = false;
-  C.n_slots = (int) std::min<int64_t>(NpC, 2 * group + 1);
+  const char *genv = getenv("BOF_PANEL_GROUP");
+  const bof_panel_plan plan = plan_panels(g, budget, genv ? atoll(genv) : 1);
+  if (!plan.eligible) return 1;
+  const int dC = g.rdim[2];                    // 0: C paneled along m, 2: along n
+  R.xmat = dC == 0 ? 0 : 1;
+  R.ymat = 1 - R.xmat;
+  const int64_t NpC = g.nblk[dC];
+  const int64_t group = (NpC + plan.groups - 1) / plan.groups;
+  const bof_fptr fp[3] = {fa, fb, fc};
+  for (int x = 0; x < 3; x++) {
+    Mat &M = R.mat[x];
+    M.f = fp[x];
+    M.rdim = g.rdim[x]; M.cdim = g.cdim[x];
+    M.rows = g.size[M.rdim]; M.cols = g.size[M.cdim]; M.ld = g.ld[x];
+    M.blk_r = g.blk[M.rdim]; M.blk_c = g.blk[M.cdim];
+    M.panels.resize((size_t) plan.n_panels[x]);
+    for (int64_t p = 0; p < plan.n_panels[x]; p++) {
+      Panel &P = M.panels[(size_t) p];
+      P.r0 = p * M.blk_r;
+      P.nr = (p == plan.n_panels[x] - 1) ? M.rows - P.r0 : M.blk_r;
+      P.bytes = ((uint64_t) (P.nr - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4;
+    }
+    M.slot_bytes = (size_t) plan.slot_bytes[x];
+    M.total_bytes = (size_t) (((uint64_t) (M.rows - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4);
+    M.natural = plan.resident[x] != 0;
+    M.n_slots = (int) plan.n_slots[x];
+  }
+  Mat &X = R.mat[R.xmat], &C = R.mat[2];
   auto need_of = [](const Mat &M) { return M.natural ? round_up(M.total_bytes, 2u << 20) : (size_t) M.n_slots * M.slot_bytes; };
-  size_t need = need_of(X) + need_of(Y) + need_of(C);
-  if (need > budget) return 1;
-  // spare budget: a deeper C ring lets compute run ahead of a slow write-back
-  while (C.n_slots < NpC && need + C.slot_bytes <= budget && C.n_slots < 2 * group + 4) { C.n_slots++; need += C.slot_bytes; }
-  if ((int64_t) C.n_slots == NpC && need_of(C) >= round_up(C.total_bytes, 2u << 20)) C.natural = true;
 
   // ---- task list in execution order, panels in first-use order ------------------------------
   std::vector<bof_gemm_task> tasks;

@@ -57,7 +57,67 @@ void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float 
   t->parent = l > 0 ? ((l - 1) * g.nblk[0] + i) * g.nblk[2] + j : -1;
 }
 
+// Row-panel layout (flash_gemm_panels.cpp).  D = the dimension C is paneled along (m for
+// row-major C).  The operand without D ("Y") is needed whole by every group of C panels and is
+// resident; the other one ("X") streams through a ring of 2*group slots when it is paneled along
+// D too, else it is resident as well; C gets a ring of 2*group+1 slots, deepened with spare
+// budget.  Slots are 2 MiB-aligned.
+bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group) {
+  bof_panel_plan P{};
+  P.streamed = -1;
+  auto up = [](uint64_t v) { return (v + (2u << 20) - 1) / (2u << 20) * (2u << 20); };
+  if (g.nblk[0] * g.nblk[1] * g.nblk[2] == 0) { P.why = 1; return P; }
+  uint64_t total[3];
+  for (int x = 0; x < 3; x++) {
+    const int64_t rows = g.size[g.rdim[x]], cols = g.size[g.cdim[x]], ld = g.ld[x];
+    if (ld < cols) { P.why = 2; return P; }
+    if (x < 2 && cols * 2 < ld) { P.why = 3; return P; }
+    P.n_panels[x] = g.nblk[g.rdim[x]];
+    const int64_t last_rows = rows - (P.n_panels[x] - 1) * g.blk[g.rdim[x]];
+    const int64_t max_rows = std::max(last_rows, std::min(rows, g.blk[g.rdim[x]]));
+    P.slot_bytes[x] = up(((uint64_t) (max_rows - 1) * (uint64_t) ld + (uint64_t) cols) * 4);
+    total[x] = up(((uint64_t) (rows - 1) * (uint64_t) ld + (uint64_t) cols) * 4);
+  }
+  if (g.ld[2] != g.size[g.cdim[2]]) { P.why = 4; return P; }
+  const int dC = g.rdim[2];
+  const int xm = dC == 0 ? 0 : 1, ym = 1 - xm;
+  const bool x_streams = g.rdim[xm] == dC;
+  const int64_t NpC = g.nblk[dC];
+  group = std::max<int64_t>(1, std::min(group, NpC));
+  P.groups = (NpC + group - 1) / group;
+  P.resident[ym] = 1;
+  P.n_slots[ym] = P.n_panels[ym];
+  P.resident[xm] = x_streams ? 0 : 1;
+  P.n_slots[xm] = x_streams ? std::min<int64_t>(P.n_panels[xm], 2 * group) : P.n_panels[xm];
+  P.streamed = x_streams && P.n_slots[xm] < P.n_panels[xm] ? xm : -1;
+  P.n_slots[2] = std::min<int64_t>(NpC, 2 * group + 1);
+  auto need_of = [&](int x) { return P.resident[x] ? total[x] : (uint64_t) P.n_slots[x] * P.slot_bytes[x]; };
+  uint64_t need = need_of(0) + need_of(1) + need_of(2);
+  P.need_bytes = need;
+  if (need > budget) { P.why = 5; return P; }
+  // spare budget: a deeper C ring lets compute run ahead of a slow write-back
+  while (P.n_slots[2] < NpC && need + P.slot_bytes[2] <= budget && P.n_slots[2] < 2 * group + 4) {
+    P.n_slots[2]++;
+    need += P.slot_bytes[2];
+  }
+  if (P.n_slots[2] == NpC && need_of(2) >= total[2]) P.resident[2] = 1;
+  P.need_bytes = need_of(0) + need_of(1) + need_of(2);
+  P.eligible = 1;
+  return P;
+}
+
 }  // namespace bof
+
+extern "C" int bof_flash_gemm_panel_plan(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_t k,
+                                         uint64_t lda, uint64_t ldb, uint64_t ldc, int64_t blk,
+                                         uint64_t hbm_budget, int64_t group, bof_panel_plan *out) {
+  if (!out || blk <= 0 || !(ord == 'R' || ord == 'C') || !(ta == 'N' || ta == 'T') || !(tb == 'N' || tb == 'T'))
+    return BOF_EINVAL;
+  const bof::GemmGeometry g = bof::gemm_geometry(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, (int64_t) lda,
+                                                 (int64_t) ldb, (int64_t) ldc, blk);
+  *out = bof::plan_panels(g, hbm_budget, group);
+  return BOF_OK;
+}
 
 extern "C" int64_t bof_gemm_plan(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
                                  float beta, int64_t lda, int64_t ldb, int64_t ldc, int64_t blk,

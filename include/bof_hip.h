@@ -248,6 +248,27 @@ int bof_flash_gemm_simulate(char ord, char trans_a, char trans_b, uint64_t m, ui
                             uint64_t k, float beta, uint64_t lda, uint64_t ldb, uint64_t ldc,
                             int64_t blk, int64_t n_slots, int32_t lookahead,
                             bof_flash_stats *out);
+/* Which path bof_flash_gemm takes for a problem and an HBM budget, and how the row-panel path
+ * would lay the matrices out (pure host code: usable without a GPU).  Panels = `blk` stored
+ * rows x the full stored width of a matrix, kept in HBM in file layout; "resident" matrices keep
+ * all their panels, the others a ring of n_slots. */
+typedef struct {
+  int32_t eligible;     /* 1: row panels; 0: the tile cache takes the call            */
+  int32_t why;          /* 0 ok, 1 empty problem / k = 0, 2 ld < stored width, 3 an operand
+                           is mostly gaps (width < ld / 2), 4 C's rows are not
+                           contiguous in its file (ldc != stored width), 5 budget     */
+  int32_t streamed;     /* the operand whose panels stream through a ring: 0 A, 1 B,
+                           -1 none (both resident)                                    */
+  int32_t resident[3];  /* A, B, C kept whole                                         */
+  int64_t n_panels[3];  /* panels per matrix                                          */
+  int64_t n_slots[3];   /* panel slots held in HBM                                    */
+  uint64_t slot_bytes[3];
+  uint64_t need_bytes;  /* HBM the plan needs                                         */
+  int64_t groups;       /* C panel groups (outer iterations)                          */
+} bof_panel_plan;
+int bof_flash_gemm_panel_plan(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
+                              uint64_t k, uint64_t lda, uint64_t ldb, uint64_t ldc, int64_t blk,
+                              uint64_t hbm_budget, int64_t group, bof_panel_plan *out);
 /* Level-3 calls keep their pinned staging rings and HBM tile slab between calls (the
  * reference keeps its program cache for the life of the process, src/lib_funcs.cpp:9);
  * this frees them. */

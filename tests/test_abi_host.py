@@ -232,3 +232,44 @@ def test_flash_gemm_schedule_under_pressure():
         assert s["bytes_read"] >= 4 * (640 * 600 + 600 * 500 + 640 * 500)
     with pytest.raises(bofhip.BofError):
         bofhip.flash_gemm_simulate("R", "N", "N", 1024, 1024, 1024, 0.0, 256, 3)
+
+
+def test_flash_gemm_panel_plan_paths():
+    """Which path bof_flash_gemm takes (pure host logic, include/bof_hip.h bof_flash_gemm_panel_plan):
+    row panels whenever B, two A panels and three C panels fit the budget and C's rows are contiguous;
+    the tile cache otherwise."""
+    GiB = 1 << 30
+    # cfg2 (32768^3, 4096-tile): B 4 GiB resident, A ring of 2 x 512 MiB, C ring: fits the reference's 8 GiB
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 32768, 32768, 32768, 4096, 8 * GiB)
+    assert p["eligible"] and p["why"] == 0 and p["streamed"] == 0 and p["resident"][:2] == [0, 1]
+    assert p["n_panels"] == [8, 8, 8] and p["n_slots"][0] == 2 and p["n_slots"][1] == 8 and 3 <= p["n_slots"][2] <= 8
+    assert p["slot_bytes"][0] == 512 << 20 and p["need_bytes"] <= 8 * GiB and p["groups"] == 8
+    # a larger budget deepens the C ring only up to its cap
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 32768, 32768, 32768, 4096, 200 * GiB)
+    assert p["eligible"] and p["n_slots"][2] == 6            # the C ring is capped at 2*group + 4 slots
+    # cfg4 size on one GPU: 16 GiB of B cannot live in an 8 GiB budget -> tile cache
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 65536, 65536, 65536, 4096, 8 * GiB)
+    assert not p["eligible"] and p["why"] == 5 and p["need_bytes"] > 16 * GiB
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 65536, 65536, 65536, 4096, 200 * GiB)
+    assert p["eligible"] and p["n_panels"] == [16, 16, 16] and p["slot_bytes"][1] == 1 << 30
+    # a rank's slab of cfg4 (8192 x 65536 x 65536): 2 C panels, both A panels in the ring
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 8192, 65536, 65536, 4096, 200 * GiB)
+    assert p["eligible"] and p["n_panels"] == [2, 16, 2] and p["streamed"] == -1 and p["resident"][2] == 1
+    # A 'T' is stored k x m: paneled along k, so it is resident like B
+    p = bofhip.flash_gemm_panel_plan("R", "T", "N", 32768, 32768, 32768, 4096, 200 * GiB)
+    assert p["eligible"] and p["resident"][:2] == [1, 1] and p["streamed"] == -1
+    # column-major C is paneled along n: B is the streamed operand, A the resident one
+    p = bofhip.flash_gemm_panel_plan("C", "N", "N", 32768, 32768, 32768, 4096, 200 * GiB)
+    assert p["eligible"] and p["streamed"] == 1 and p["resident"][:2] == [1, 0]
+    # gaps between C's rows are not ours to rewrite; a narrow view of a wide operand is mostly gaps
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 600, 600, 600, 256, GiB, ldc=640)
+    assert not p["eligible"] and p["why"] == 4
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 600, 600, 600, 256, GiB, lda=2048)
+    assert not p["eligible"] and p["why"] == 3
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 600, 600, 600, 256, GiB, ldb=599)
+    assert not p["eligible"] and p["why"] == 2
+    # tail-merged last panel: 600 = 256 + 344 rows -> the slot is sized for 344 rows
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 600, 600, 600, 256, GiB)
+    assert p["eligible"] and p["n_panels"] == [2, 2, 2] and p["slot_bytes"][0] == 2 << 20
+    p = bofhip.flash_gemm_panel_plan("R", "N", "N", 600, 600, 600, 256, GiB, group=2)
+    assert p["eligible"] and p["groups"] == 1
