@@ -161,7 +161,12 @@ int64_t bof_csr_blocks(const int64_t *ia, int64_t m, int64_t min_rows,
  * the whole matrices (file layout, leading dims as the caller passes them; 0 =
  * default).  Tasks run in the reference's order; every (i,j) accumulate chain
  * is serialised on one of opts->n_streams compute streams forked from / joined
- * into `stream`.  Asynchronous with respect to the host. */
+ * into `stream`.  Asynchronous with respect to the host.
+ * Scratch: when an operand is stored k-contiguous (A 'N', B 'T' in row-major terms), every
+ * tile is reused by >= 4 tasks and a copy of that operand fits in a QUARTER of the free HBM,
+ * the call first writes a k-major copy of it into library scratch (kept until
+ * bof_flash_release) so that all tile launches take the LDS-DMA kernel; otherwise the
+ * register-staging kernel runs on the operand as it is.  Results are bit-identical either way. */
 int bof_gemm_resident(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
                       int64_t k, float alpha, float beta, const float *a,
                       const float *b, float *c, int64_t lda, int64_t ldb,
