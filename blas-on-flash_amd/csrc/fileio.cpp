@@ -55,7 +55,27 @@ static uint64_t request_bytes() {
 static constexpr unsigned kAioEvents = 1024;
 static constexpr int kIoRetries = 5;                // reference submit_and_reap retries
 
-static inline bool al(uint64_t v) { return (v % kSector) == 0; }
+static inline bool al(uint64_t v, uint64_t a = kSector) { return (v % a) == 0; }
+
+// Alignment O_DIRECT needs on this file: statx(STATX_DIOALIGN) where the kernel and the file
+// system report it (4Kn NVMe namespaces need 4096), else the reference's SECTOR_LEN = 512.
+// The struct is read by offset: the image's headers predate the field (Linux 6.1).
+uint64_t file_dio_align(int fd) {
+  alignas(8) unsigned char stx[256];
+  memset(stx, 0, sizeof(stx));
+  const unsigned kStatxDioAlign = 0x2000u;
+#ifdef SYS_statx
+  if (syscall(SYS_statx, fd, "", 0x1000 /* AT_EMPTY_PATH */, kStatxDioAlign, stx) == 0) {
+    uint32_t mask, mem_align, off_align;
+    memcpy(&mask, stx + 0x00, 4);
+    memcpy(&mem_align, stx + 0x98, 4);
+    memcpy(&off_align, stx + 0x9c, 4);
+    if ((mask & kStatxDioAlign) && off_align >= kSector && (off_align & (off_align - 1)) == 0 && off_align <= 65536)
+      return std::max<uint64_t>(off_align, mem_align <= 4096 ? kSector : mem_align);
+  }
+#endif
+  return kSector;
+}
 
 // requests handed to the kernel (iocbs + pread/pwrite calls), process-wide
 static std::atomic<uint64_t> g_rd_ops{0}, g_wr_ops{0};
@@ -216,8 +236,9 @@ static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_
     n_strides = 1;
   }
   const bool direct = file_is_direct(fd);
-  const bool aligned = al(offset) && al(len) && (n_strides == 1 || al(stride)) &&
-                       al(reinterpret_cast<uintptr_t>(buf));
+  const uint64_t A = direct ? file_dio_align(fd) : kSector;
+  const bool aligned = al(offset, A) && al(len, A) && (n_strides == 1 || al(stride, A)) &&
+                       al(reinterpret_cast<uintptr_t>(buf), A);
   if (direct && !aligned) {
     fd = buffered_twin(fd);
     if (fd < 0) return -EBADF;

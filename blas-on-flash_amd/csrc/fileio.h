@@ -11,6 +11,7 @@ int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uin
 int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
                 const void *buf, bool use_aio);
 bool file_is_direct(int fd);
+uint64_t file_dio_align(int fd);  // O_DIRECT offset/length alignment of this file (>= 512)
 // a buffered descriptor of the same file (fd itself unless it is O_DIRECT; cached; -1 on failure)
 int file_buffered_fd(int fd);
 void file_io_ops(uint64_t *reads, uint64_t *writes);  // requests issued so far (process-wide)

@@ -257,9 +257,10 @@ struct PanelRun {
 // aligned; otherwise every request goes through the buffered twin.  Mixing the two on one file
 // lets a direct write and a buffered write of neighbouring regions meet in one page.
 void pick_descriptor(Mat &M, bool use_odirect, size_t chunk) {
-  bool aligned = (M.f.foffset % 512) == 0 && (chunk % 512) == 0;
+  const uint64_t A = file_is_direct(M.f.fd) ? file_dio_align(M.f.fd) : 512;
+  bool aligned = (M.f.foffset % A) == 0 && (chunk % A) == 0;
   for (const Panel &P : M.panels)
-    aligned = aligned && (P.bytes % 512) == 0 && (((uint64_t) P.r0 * (uint64_t) M.ld * 4) % 512) == 0;
+    aligned = aligned && (P.bytes % A) == 0 && (((uint64_t) P.r0 * (uint64_t) M.ld * 4) % A) == 0;
   M.fd = M.f.fd;
   M.aio = false;
   if (file_is_direct(M.f.fd)) {

@@ -547,11 +547,12 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   build_tiles(g, beta, R.tiles, max_tile);
   R.slot_bytes = round_up(max_tile, 4096);
   for (int x = 0; x < 3; x++) {
-    bool aligned = (R.f[x].foffset % 512) == 0;
+    const uint64_t A = file_is_direct(R.f[x].fd) ? file_dio_align(R.f[x].fd) : 512;
+    bool aligned = (R.f[x].foffset % A) == 0;
     for (const Tile &t : R.tiles)
       if (t.mat == x)
-        aligned = aligned && ((uint64_t) t.off * 4) % 512 == 0 && ((uint64_t) t.ncols * 4) % 512 == 0 &&
-                  (t.nrows <= 1 || ((uint64_t) t.ld * 4) % 512 == 0);
+        aligned = aligned && ((uint64_t) t.off * 4) % A == 0 && ((uint64_t) t.ncols * 4) % A == 0 &&
+                  (t.nrows <= 1 || ((uint64_t) t.ld * 4) % A == 0);
     R.fd_io[x] = R.f[x].fd;
     R.aio_io[x] = false;
     if (file_is_direct(R.f[x].fd)) {
@@ -786,14 +787,15 @@ struct CsrRun {
   }
 
   uint64_t fsize_ja = 0, fsize_a = 0;
+  uint64_t sector = 512;  // the reference widens to SECTOR_LEN = 512; a 4Kn device reports more
   // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
   // end of the file (the last sector of a file is usually partial)
   void seg(int64_t b, int esz, const bof_fptr &f, uint64_t &start, uint64_t &len, uint64_t &delta) const {
     const uint64_t z = (uint64_t) ia[st[b]], nnz = (uint64_t) (ia[st[b] + sz[b]] - ia[st[b]]);
     const uint64_t b0 = f.foffset + z * esz, b1 = b0 + nnz * esz;
     const uint64_t fsize = esz == 8 ? fsize_ja : fsize_a;
-    start = b0 / 512 * 512;
-    uint64_t end = round_up(b1, 512);
+    start = b0 / sector * sector;
+    uint64_t end = round_up(b1, sector);
     if (fsize && end > fsize) end = std::max(b1, std::min(end, fsize));
     len = nnz ? end - start : 0;
     delta = b0 - start;
@@ -1278,6 +1280,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     struct stat sb;
     if (fstat(fja.fd, &sb) == 0) R.fsize_ja = (uint64_t) sb.st_size;
     if (fstat(fa.fd, &sb) == 0) R.fsize_a = (uint64_t) sb.st_size;
+    if (file_is_direct(fja.fd)) R.sector = std::max(R.sector, file_dio_align(fja.fd));
+    if (file_is_direct(fa.fd)) R.sector = std::max(R.sector, file_dio_align(fa.fd));
   }
   size_t max_idx = 0, max_val = 0, max_c = 0;
   for (int64_t b = 0; b < nb; b++) {
@@ -1288,7 +1292,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     }
     if (is_mm) max_c = std::max(max_c, R.c_bytes(b));
   }
-  max_idx = std::max<size_t>(max_idx, 512); max_val = std::max<size_t>(max_val, 512);
+  max_idx = std::max<size_t>(max_idx, R.sector); max_val = std::max<size_t>(max_val, R.sector);
   max_c = std::max<size_t>(max_c, 512);
 
   int64_t *d_ia = nullptr;

@@ -160,6 +160,36 @@ def test_flash_gemm_io_uring_engine_subprocess(dev):
     assert r.returncode == 0, r.stdout[-2500:]
 
 
+@pytest.mark.parametrize("path", [1, 2])
+def test_flash_gemm_unaligned_foffset_small_dims(dev, tmp_path, path):
+    """flash_ptr + a byte offset that is not sector aligned (12-byte headers), dimensions smaller
+    than / not multiples of the tile: every request of every file goes through the buffered twin
+    (one descriptor mode per file per call); both paths, beta != 0, column-major too."""
+    hdr = 12
+    for ord_, ta, tb, (m, n, k) in [("R", "N", "N", (300, 100, 200)), ("C", "T", "N", (129, 257, 64)),
+                                   ("R", "N", "T", (1, 1, 1))]:
+        blk = 128
+        rng = np.random.default_rng(m)
+        sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+        a = rng.uniform(-1, 1, sa).astype(np.float32)
+        b = rng.uniform(-1, 1, sb).astype(np.float32)
+        c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+        ref = orc.flash_gemm(ord_, ta, tb, m, n, k, -0.5, 1.25, a, b, c0.copy(), 0, 0, 0, blk)
+        pad = np.full(hdr // 4, 7.0, np.float32)
+        sub = tmp_path / f"{ord_}{ta}{tb}{path}"
+        sub.mkdir()
+        F = Files(sub, a=np.concatenate([pad, a.ravel()]), b=np.concatenate([pad, b.ravel()]),
+                  c=np.concatenate([pad, c0.ravel(), pad]))
+        try:
+            bofhip.flash_gemm(ord_, ta, tb, m, n, k, -0.5, 1.25, F.fptr("a", hdr), F.fptr("b", hdr), F.fptr("c", hdr),
+                              0, 0, 0, bofhip.default_options(gemm_blk=blk, gemm_path=path, io_chunk_mib=1))
+            got = F.read("c", np.float32, (-1,))
+            assert np.array_equal(got[:3], pad) and np.array_equal(got[-3:], pad)      # neighbours untouched
+            assert np.array_equal(got[3:-3].reshape(sc), ref), (ord_, ta, tb)
+        finally:
+            F.close()
+
+
 def test_flash_gemm_panels_not_eligible_falls_back(dev, tmp_path):
     """ldc > n (the gaps between C's rows are not ours to rewrite) and tiny budgets go to the tile
     cache; gemm_path = 2 makes that an error instead of a silent change of path."""
