@@ -568,8 +568,12 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   size_t budget = R.o.hbm_budget > 0 ? (size_t) R.o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
   int64_t n_slots = (int64_t) (budget / R.slot_bytes);
+  // six slots (two tasks' worth) or, for problems of fewer tiles than that, all of them
+  if (n_slots < std::min<int64_t>(6, (int64_t) R.tiles.size())) {
+    set_error("bof_flash_gemm: HBM budget below 6 tile slots");
+    return BOF_ENOMEM;
+  }
   n_slots = std::min<int64_t>(n_slots, (int64_t) R.tiles.size());
-  if (n_slots < 6) { set_error("bof_flash_gemm: HBM budget below 6 tile slots"); return BOF_ENOMEM; }
   int64_t gi, gj;
   build_order(g, beta, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
   const int T = (int) R.tasks.size();
