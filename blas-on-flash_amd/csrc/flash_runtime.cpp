@@ -790,6 +790,11 @@ struct CsrRun {
     cv.notify_all();
   }
 
+  // the C file is read and written by several threads at once: ONE descriptor mode for every
+  // request of the call (O_DIRECT only if every block's region is aligned, else the buffered
+  // twin), as in flash::gemm -- a direct and a buffered write must never meet in one page
+  int fd_c = -1;
+  bool aio_c = false;
   uint64_t fsize_ja = 0, fsize_a = 0;
   uint64_t sector = 512;  // the reference widens to SECTOR_LEN = 512; a 4Kn device reports more
   // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
@@ -846,10 +851,10 @@ struct CsrRun {
             for (int64_t j = 0; j < k; j++)
               memcpy(c.h_c + (size_t) j * sz[b] * 4, host_c + (size_t) j * m + st[b], (size_t) sz[b] * 4);
         } else if (ord_b == 'R')
-          rc = file_sread(fc.fd, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, use_aio);
+          rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
         else
-          rc = file_sread(fc.fd, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
-                          (uint64_t) sz[b] * 4, c.h_c, use_aio);
+          rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
+                          (uint64_t) sz[b] * 4, c.h_c, aio_c);
         cnt.rd += c_bytes(b);
         if (!rc) e = hipMemcpyAsync(c.d_c, c.h_c, c_bytes(b), hipMemcpyHostToDevice, h2d);
         cnt.h2d += c_bytes(b);
@@ -882,10 +887,10 @@ struct CsrRun {
       } else if (is_mm && !io_error.load()) {
         int rc;
         if (ord_b == 'R')
-          rc = file_swrite(fc.fd, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, use_aio);
+          rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
         else
-          rc = file_swrite(fc.fd, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
-                           (uint64_t) sz[b] * 4, c.h_c, use_aio);
+          rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
+                           (uint64_t) sz[b] * 4, c.h_c, aio_c);
         if (rc) fail_io(rc);
         cnt.wr += c_bytes(b);
       }
@@ -1295,6 +1300,23 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       R.seg(b, 4, fa, s, l, d);  max_val = std::max<size_t>(max_val, l);
     }
     if (is_mm) max_c = std::max(max_c, R.c_bytes(b));
+  }
+  if (is_mm && fc.fd >= 0) {
+    R.fd_c = fc.fd;
+    if (file_is_direct(fc.fd)) {
+      const uint64_t A = file_dio_align(fc.fd);
+      bool aligned = true;
+      for (int64_t b = 0; b < nb && aligned; b++) {
+        if (ord_b == 'R')
+          aligned = (fc.foffset + (uint64_t) R.st[b] * k * 4) % A == 0 && ((uint64_t) R.sz[b] * k * 4) % A == 0;
+        else
+          aligned = (fc.foffset + (uint64_t) R.st[b] * 4) % A == 0 && ((uint64_t) R.sz[b] * 4) % A == 0 &&
+                    ((uint64_t) m * 4) % A == 0;
+      }
+      if (aligned) R.aio_c = R.use_aio;
+      else R.fd_c = file_buffered_fd(fc.fd);
+      if (R.fd_c < 0) { set_error("flash csrmm: cannot open a buffered descriptor of the C file"); return BOF_EIO; }
+    }
   }
   max_idx = std::max<size_t>(max_idx, R.sector); max_val = std::max<size_t>(max_val, R.sector);
   max_c = std::max<size_t>(max_c, 512);

@@ -306,6 +306,33 @@ def test_flash_csrmm(dev, tmp_path, golden, ord_b, k, alpha, beta):
         F.close()
 
 
+@pytest.mark.parametrize("ord_b,k", [("R", 128), ("R", 96), ("C", 128), ("C", 72)])
+def test_flash_csrmm_mixed_alignment_stress(dev, tmp_path, ord_b, k):
+    """Row blocks of 300 rows: some C block regions are sector aligned, most are not, and
+    neighbouring blocks share pages; C is read (beta != 0) and written by a pool of threads.  Every
+    request of the call on the C file must go through one descriptor mode; repeated so that a lost
+    update would show."""
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    rng = np.random.default_rng(k)
+    b = rng.integers(0, 7, (n, k)).astype(np.float32)
+    c0 = rng.integers(0, 5, (m, k)).astype(np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    ref = orc.flash_csrmm(ord_b, m, n, k, 0.5, 2.0, val, ia, ja, b, c0.copy(), 300, 5000, 1024)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=300, n_io_threads=8, pinned_slots=8)
+        for rep in range(12):
+            bofhip.flash_csrmm("N", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), ord_b,
+                               F.fptr("b"), F.fptr("c"), opts)
+            assert np.array_equal(F.read("c", np.float32, c0.shape), ref), rep
+            c0.tofile(F.paths["c"])
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+    finally:
+        F.close()
+
+
 @pytest.mark.parametrize("ord_b", ["R", "C"])
 def test_flash_csrmm_inmem_bc(dev, tmp_path, ord_b):
     """csrmm overload with B and C in host memory (include/flash_blas.h:43-46).
