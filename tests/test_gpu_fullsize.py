@@ -213,3 +213,31 @@ def test_cfg4_rank0_slab_8192x65536x65536_closed_form(dev):
     del a, b, c
     torch.cuda.empty_cache()
     bofhip.lib().bof_flash_release()
+
+
+def test_cfg2_gemm_random_data_vs_float64(dev):
+    """cfg2 size on uniform-random fp32 (integer data cannot expose rounding-order or precision bugs,
+    SURVEY 8d): the 512-task tile DAG at 32768^3, then two full tile-rows of C (rows [0, 4096) and
+    the last 4096 rows: 2 x 4096 x 32768 outputs, each the end of an 8-task accumulate chain) against a
+    float64 product; 1e-4 relative (BASELINE north_star), observed ~2e-6."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    n, blk = 32768, 4096
+    a = torch.empty(n * n, dtype=torch.float32, device=dev)
+    b = torch.empty(n * n, dtype=torch.float32, device=dev)
+    c = torch.empty(n * n, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(ptr(a), 0, n * n, "u", 1, stream())
+    bofhip.gen_dense(ptr(b), 0, n * n, "u", 2, stream())
+    c.fill_(float("nan"))
+    bofhip.gemm_resident("R", "N", "N", n, n, n, 1.0, 0.0, ptr(a), ptr(b), ptr(c), 0, 0, 0,
+                         bofhip.default_options(gemm_blk=blk), stream())
+    torch.cuda.synchronize()
+    for r0 in (0, n - blk):
+        rel = bench.check_tile_row_float64(torch, a[r0 * n:(r0 + blk) * n], b, c[r0 * n:(r0 + blk) * n], n, n)
+        assert rel < 1e-4, (r0, rel)
+    assert not bool(torch.isnan(c).any())
+    del a, b, c
+    torch.cuda.empty_cache()
+    bofhip.lib().bof_flash_release()
