@@ -552,7 +552,7 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
     return out
 
 
-def e2e_csrmm(bofhip, torch, dev, st, workdir, kernel_s, io_threads, reps):
+def e2e_csrmm(bofhip, torch, dev, st, workdir, kernel_s, io_threads, reps, **extra_opts):
     """cfg3 through bof_flash_csrmm: sparse_create(10M, 1M, 1e-4) x dense_create(1M, 128, 's'),
     C = 10M x 128; sha256 of the C file against the hash both reference drivers produced."""
     import hashlib
@@ -593,7 +593,7 @@ def e2e_csrmm(bofhip, torch, dev, st, workdir, kernel_s, io_threads, reps):
             for fd in fds.values():
                 os.close(fd)
             continue
-        opts = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0)
+        opts = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0, **extra_opts)
         runs = []
         for rep in range(reps + (1 if mode == "buffered" else 0)):
             if mode == "odirect":

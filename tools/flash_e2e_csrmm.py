@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--io-threads", type=int, default=8)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--pinned", type=int, default=8, help="row blocks in flight (staging contexts)")
     args = ap.parse_args()
     bofhip.require_device()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     work = tempfile.mkdtemp(prefix="bof_cfg3_", dir=args.dir)
     try:
-        out = bench.e2e_csrmm(bofhip, torch, dev, st, work, None, args.io_threads, args.reps)
+        out = bench.e2e_csrmm(bofhip, torch, dev, st, work, None, args.io_threads, args.reps, pinned_slots=args.pinned)
     finally:
         shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(out), flush=True)
