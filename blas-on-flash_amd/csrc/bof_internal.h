@@ -26,12 +26,6 @@ hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, fl
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
                   float *c, int64_t ldc, hipStream_t st);
-// the same kernels on int32 column indices (level 3 narrows the index segments while staging)
-hipError_t scsrmm_i32(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
-                      const int32_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
-                      float *c, int64_t ldc, hipStream_t st);
-hipError_t scsrgemv_i32(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
-                        const int32_t *col, const float *x, float *y, hipStream_t st);
 hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out,
                          int64_t ld_out, hipStream_t st);
 size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz);

@@ -9,10 +9,7 @@
 // coalescing (one wave-instruction fetches one whole B row segment), many
 // independent row gathers in flight per wave, and streaming the CSR arrays
 // exactly once.  Column indices stay int64 as stored on disk; they are only
-// read, never rewritten.  Every kernel is also instantiated for int32 indices: the
-// level-3 file pipeline narrows the index segments on the host on their way from the
-// file to the pinned staging buffer (A has at most 2^31 columns), which takes a third
-// off the bytes that cross PCIe; the files themselves are never touched.
+// read, never rewritten.
 //
 // Numerics: each output element is the fmaf chain over the row's non-zeros in
 // storage order, then c = beta==0 ? alpha*acc : fmaf(alpha, acc, beta*c):
@@ -49,10 +46,10 @@ template <> __device__ __forceinline__ void vfma<4>(float v, const float4 &b, fl
 // consecutive output columns of a 64*VEC-wide column pass.  The row's (col,val)
 // pairs are loaded 64 at a time with coalesced loads and broadcast by
 // v_readlane; the B-row gathers are issued UNROLL at a time before the fmas.
-template <typename IT, int VEC, int UNROLL>
+template <int VEC, int UNROLL>
 __global__ void __launch_bounds__(64 * CSR_WAVES)
 csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ val,
-                      const IT *__restrict__ col, const int64_t *__restrict__ ptr,
+                      const int64_t *__restrict__ col, const int64_t *__restrict__ ptr,
                       const float *__restrict__ B, int64_t ldb, float beta,
                       float *__restrict__ C, int64_t ldc) {
   typedef typename vecf<VEC>::type V;
@@ -120,10 +117,9 @@ csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ v
 // Generic element-strided B/C (column-major 'C' layout, or unaligned row-major):
 // B(c, j) = B[c*rsb + j*csb], C(i, j) = C[i*rsc + j*csc].  Lanes over rows for
 // column-major so C stores coalesce; one thread owns one (row, column) pair.
-template <typename IT>
 __global__ void __launch_bounds__(256)
 csrmm_strided_kernel(int64_t m, int n, float alpha, const float *__restrict__ val,
-                     const IT *__restrict__ col, const int64_t *__restrict__ ptr,
+                     const int64_t *__restrict__ col, const int64_t *__restrict__ ptr,
                      const float *__restrict__ B, int64_t rsb, int64_t csb, float beta,
                      float *__restrict__ C, int64_t rsc, int64_t csc, int lanes_over_rows) {
   int64_t row;
@@ -139,7 +135,7 @@ csrmm_strided_kernel(int64_t m, int n, float alpha, const float *__restrict__ va
   const int64_t base = ptr[0];
   float acc = 0.f;
   for (int64_t p = ptr[row] - base; p < ptr[row + 1] - base; p++)
-    acc = __builtin_fmaf(val[p], B[(int64_t) col[p] * rsb + (int64_t) j * csb], acc);
+    acc = __builtin_fmaf(val[p], B[col[p] * rsb + (int64_t) j * csb], acc);
   float *cp = C + row * rsc + (int64_t) j * csc;
   *cp = (beta == 0.f) ? alpha * acc : __builtin_fmaf(alpha, acc, beta * (*cp));
 }
@@ -168,10 +164,10 @@ hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t c
   return hipGetLastError();
 }
 
-template <typename IT>
-static hipError_t scsrmm_impl(char ord_b, int64_t m, int64_t n, float alpha, const float *val, const IT *col,
-                              const int64_t *ptr, const float *b, int64_t ldb, float beta, float *c, int64_t ldc,
-                              hipStream_t st) {
+hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
+                  const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
+                  float *c, int64_t ldc, hipStream_t st) {
+  (void) k;
   if (m == 0 || n == 0) return hipSuccess;
   if (ord_b == 'R') {
     const bool al16 = (n % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
@@ -182,33 +178,20 @@ static hipError_t scsrmm_impl(char ord_b, int64_t m, int64_t n, float alpha, con
                      ((reinterpret_cast<uintptr_t>(c) & 7) == 0);
     dim3 grid((unsigned) ((m + CSR_WAVES - 1) / CSR_WAVES)), block(64 * CSR_WAVES);
     if (al16 && n > 128)
-      hipLaunchKernelGGL((csrmm_rowmajor_kernel<IT, 4, 8>), grid, block, 0, st, m, (int) n, alpha, val,
+      hipLaunchKernelGGL((csrmm_rowmajor_kernel<4, 8>), grid, block, 0, st, m, (int) n, alpha, val,
                          col, ptr, b, ldb, beta, c, ldc);
     else if (al8 && n > 64)
-      hipLaunchKernelGGL((csrmm_rowmajor_kernel<IT, 2, 8>), grid, block, 0, st, m, (int) n, alpha, val,
+      hipLaunchKernelGGL((csrmm_rowmajor_kernel<2, 8>), grid, block, 0, st, m, (int) n, alpha, val,
                          col, ptr, b, ldb, beta, c, ldc);
     else
-      hipLaunchKernelGGL((csrmm_rowmajor_kernel<IT, 1, 8>), grid, block, 0, st, m, (int) n, alpha, val,
+      hipLaunchKernelGGL((csrmm_rowmajor_kernel<1, 8>), grid, block, 0, st, m, (int) n, alpha, val,
                          col, ptr, b, ldb, beta, c, ldc);
   } else {
     dim3 grid((unsigned) ((m + 255) / 256), (unsigned) n), block(256);
-    hipLaunchKernelGGL(csrmm_strided_kernel<IT>, grid, block, 0, st, m, (int) n, alpha, val, col, ptr,
+    hipLaunchKernelGGL(csrmm_strided_kernel, grid, block, 0, st, m, (int) n, alpha, val, col, ptr,
                        b, (int64_t) 1, ldb, beta, c, (int64_t) 1, ldc, 1);
   }
   return hipGetLastError();
-}
-
-hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
-                  const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
-                  float *c, int64_t ldc, hipStream_t st) {
-  (void) k;
-  return scsrmm_impl<int64_t>(ord_b, m, n, alpha, val, col, ptr, b, ldb, beta, c, ldc, st);
-}
-hipError_t scsrmm_i32(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
-                      const int32_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
-                      float *c, int64_t ldc, hipStream_t st) {
-  (void) k;
-  return scsrmm_impl<int32_t>(ord_b, m, n, alpha, val, col, ptr, b, ldb, beta, c, ldc, st);
 }
 
 // ---- SpMV --------------------------------------------------------------------
@@ -219,10 +202,9 @@ hipError_t scsrmm_i32(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, 
 // segment of the LDS image sequentially.  A thread-per-row walk of global memory instead
 // touches 64 lines per load instruction and thrashes the 32 KB L1 (11.7 ms -> see DESIGN).
 constexpr int GEMV_CAP = 1024;  // LDS entries per wave (8 KB): 64 rows x 16 nnz on average
-template <typename IT>
 __global__ void __launch_bounds__(256)
 csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__restrict__ ptr,
-                 const IT *__restrict__ col, const float *__restrict__ x,
+                 const int64_t *__restrict__ col, const float *__restrict__ x,
                  float *__restrict__ y) {
   __shared__ float2 sh[4][GEMV_CAP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -238,7 +220,7 @@ csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
   if (staged) {
     int64_t o = lane;
     for (; o + 192 < cnt; o += 256) {  // four coalesced chunks, four gathers in flight
-      const IT c0 = col[p0 + o], c1 = col[p0 + o + 64], c2 = col[p0 + o + 128], c3 = col[p0 + o + 192];
+      const int64_t c0 = col[p0 + o], c1 = col[p0 + o + 64], c2 = col[p0 + o + 128], c3 = col[p0 + o + 192];
       const float v0 = val[p0 + o], v1 = val[p0 + o + 64], v2 = val[p0 + o + 128], v3 = val[p0 + o + 192];
       const float x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
       sh[w][o] = make_float2(v0, x0);
@@ -267,10 +249,9 @@ csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
 // 'T': y[col[p]] += val[p] * x[row]; one thread per row, fp32 atomics (the
 // reference's mutex-guarded vector add, csrgemv_task.h:169-176, becomes
 // memory-side atomic adds; result is order-independent for integer data).
-template <typename IT>
 __global__ void __launch_bounds__(256)
 csrgemv_t_kernel(int64_t m, const float *__restrict__ val, const int64_t *__restrict__ ptr,
-                 const IT *__restrict__ col, const float *__restrict__ x,
+                 const int64_t *__restrict__ col, const float *__restrict__ x,
                  float *__restrict__ y) {
   const int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (row >= m) return;
@@ -280,27 +261,16 @@ csrgemv_t_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
     atomicAdd(y + col[p], val[p] * xv);
 }
 
-template <typename IT>
-static hipError_t scsrgemv_impl(char trans, int64_t m, const float *val, const int64_t *ptr, const IT *col,
-                                const float *x, float *y, hipStream_t st) {
-  if (m == 0) return hipSuccess;
-  dim3 grid((unsigned) ((m + 255) / 256)), block(256);
-  if (trans == 'N')  // same grid: a block = 4 waves x 64 rows
-    hipLaunchKernelGGL(csrgemv_n_kernel<IT>, grid, block, 0, st, m, val, ptr, col, x, y);
-  else
-    hipLaunchKernelGGL(csrgemv_t_kernel<IT>, grid, block, 0, st, m, val, ptr, col, x, y);
-  return hipGetLastError();
-}
-
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
                     const int64_t *col, const float *x, float *y, hipStream_t st) {
   (void) n;
-  return scsrgemv_impl<int64_t>(trans, m, val, ptr, col, x, y, st);
-}
-hipError_t scsrgemv_i32(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
-                        const int32_t *col, const float *x, float *y, hipStream_t st) {
-  (void) n;
-  return scsrgemv_impl<int32_t>(trans, m, val, ptr, col, x, y, st);
+  if (m == 0) return hipSuccess;
+  dim3 grid((unsigned) ((m + 255) / 256)), block(256);
+  if (trans == 'N')  // same grid: a block = 4 waves x 64 rows
+    hipLaunchKernelGGL(csrgemv_n_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+  else
+    hipLaunchKernelGGL(csrgemv_t_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+  return hipGetLastError();
 }
 
 }  // namespace bof

@@ -154,8 +154,6 @@ struct TraceRange {
 // profiles/r2/e2e_stream_aliasing.txt).  High-priority streams get queues of their own, and the
 // D2H blit kernels (0.67 ms per 32 MiB) then go ahead of queued 0.95 ms tile kernels.
 hipError_t copy_stream_create(hipStream_t *s);
-// int64 -> int32 (low halves), `dst` may be the start of the buffer `src` points into
-void narrow_i64_to_i32(const char *src, int32_t *dst, uint64_t count);
 int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
 void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
 

@@ -24,9 +24,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
-#if defined(__SSE2__)
-#include <emmintrin.h>
-#endif
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
@@ -746,26 +743,6 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   return fail;
 }
 
-// int64 column indices -> int32, in place, on their way through the pinned staging buffer (the
-// files are never touched; A has at most 2^31 columns, checked by the entry points).  `src` may
-// sit a few bytes behind `dst` in the same buffer (sector widening) and need not be 8-aligned;
-// element i is written at byte 4i after having been read from byte d0 + 8i >= 4i.
-void narrow_i64_to_i32(const char *src, int32_t *dst, uint64_t count) {
-  uint64_t i = 0;
-#if defined(__SSE2__)
-  for (; i + 4 <= count; i += 4) {
-    const __m128 lo = _mm_loadu_ps(reinterpret_cast<const float *>(src + 8 * i));       // elements i, i+1
-    const __m128 hi = _mm_loadu_ps(reinterpret_cast<const float *>(src + 8 * i + 16));  // elements i+2, i+3
-    _mm_storeu_ps(reinterpret_cast<float *>(dst + i), _mm_shuffle_ps(lo, hi, _MM_SHUFFLE(2, 0, 2, 0)));
-  }
-#endif
-  for (; i < count; i++) {
-    int64_t v;
-    memcpy(&v, src + 8 * i, 8);
-    dst[i] = (int32_t) v;
-  }
-}
-
 // =====================================================================================
 // CSRMM / CSRGEMV: every row block is used exactly once -> a ring of block contexts
 // =====================================================================================
@@ -818,9 +795,6 @@ struct CsrRun {
   // twin), as in flash::gemm -- a direct and a buffered write must never meet in one page
   int fd_c = -1;
   bool aio_c = false;
-  // index segments are narrowed to int32 in the pinned buffer before they cross PCIe
-  // (BOF_CSR_NARROW=0 keeps the int64 stream)
-  bool narrow = false;
   uint64_t fsize_ja = 0, fsize_a = 0;
   uint64_t sector = 512;  // the reference widens to SECTOR_LEN = 512; a 4Kn device reports more
   // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
@@ -865,15 +839,9 @@ struct CsrRun {
       }
       hipError_t e = hipSuccess;
       if (!rc && !res_val) {
-        uint64_t idx_bytes = l0;
-        if (narrow && l0) {
-          const uint64_t nnz_b = (uint64_t) (ia[st[b] + sz[b]] - ia[st[b]]);
-          narrow_i64_to_i32(c.h_idx + d0, reinterpret_cast<int32_t *>(c.h_idx), nnz_b);
-          idx_bytes = nnz_b * 4;
-        }
-        e = hipMemcpyAsync(c.d_idx, c.h_idx, idx_bytes, hipMemcpyHostToDevice, h2d);
+        e = hipMemcpyAsync(c.d_idx, c.h_idx, l0, hipMemcpyHostToDevice, h2d);
         if (e == hipSuccess) e = hipMemcpyAsync(c.d_val, c.h_val, l1, hipMemcpyHostToDevice, h2d);
-        cnt.h2d += idx_bytes + l1;
+        cnt.h2d += l0 + l1;
       }
       if (!rc && e == hipSuccess && is_mm && beta != 0.f) {
         // C block: 'R' contiguous rows, 'C' strided columns of the block (packed [k][r])
@@ -1318,8 +1286,6 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
 
   if (!res) {
-    static const bool narrow_on = !getenv("BOF_CSR_NARROW") || atoi(getenv("BOF_CSR_NARROW")) != 0;
-    R.narrow = narrow_on && n <= (int64_t) INT32_MAX;
     struct stat sb;
     if (fstat(fja.fd, &sb) == 0) R.fsize_ja = (uint64_t) sb.st_size;
     if (fstat(fa.fd, &sb) == 0) R.fsize_a = (uint64_t) sb.st_size;
@@ -1462,8 +1428,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     herr = hipStreamWaitEvent(st, c.ready, 0);
     if (herr != hipSuccess) break;
     const int64_t s = R.st[b], r = R.sz[b];
-    const int64_t *col = nullptr;
-    const int32_t *col32 = nullptr;
+    const int64_t *col;
     const float *val;
     if (res) {
       col = res->col + R.ia[(size_t) s];
@@ -1472,21 +1437,20 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       uint64_t s0, l0, d0, s1, l1, d1;
       R.seg(b, 8, fja, s0, l0, d0);
       R.seg(b, 4, fa, s1, l1, d1);
-      if (R.narrow) col32 = (const int32_t *) c.d_idx;  // narrowed copy starts at the buffer's origin
-      else col = (const int64_t *) (c.d_idx + d0);       // un-shift the sector widening
+      col = (const int64_t *) (c.d_idx + d0);  // un-shift the sector widening
       val = (const float *) (c.d_val + d1);
     }
-    auto mm = [&](float *cdst, int64_t j0, int64_t w) {
-      return col32 ? scsrmm_i32('R', r, w, n, alpha, val, col32, d_ia + s, (const float *) d_b + j0, k, beta, cdst + j0, k, st)
-                   : scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta, cdst + j0, k, st);
-    };
     if (is_mm) {
       if (ord_b == 'C' && beta != 0.f)  // C block arrived packed column-major [k][r]
         herr = transpose_f32((const float *) c.d_c, r, k, r, (float *) c.d_c_rm, k, st);
       for (int64_t j0 = 0; j0 < k && herr == hipSuccess; j0 += R.o.csrmm_cblk) {
         const int64_t w = std::min(k - j0, R.o.csrmm_cblk);
-        // 'C': same row-major kernel on the transposed block (d_b is row-major here)
-        herr = mm(ord_b == 'R' ? (float *) c.d_c : (float *) c.d_c_rm, j0, w);
+        if (ord_b == 'R')
+          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
+                        (float *) c.d_c + j0, k, st);
+        else  // 'C': same row-major kernel on the transposed block (d_b is row-major here)
+          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
+                        (float *) c.d_c_rm + j0, k, st);
       }
       if (ord_b == 'C' && herr == hipSuccess)  // [r][k] -> packed column-major block [k][r]
         herr = transpose_f32((const float *) c.d_c_rm, k, r, k, (float *) c.d_c, r, st);
@@ -1499,10 +1463,10 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       if (herr == hipSuccess) herr = hipEventRecord(c.done, R.d2h);
       R.cnt.d2h += R.c_bytes(b);
     } else {
-      const float *xv = trans == 'N' ? (const float *) d_x : (const float *) d_x + s;
-      float *yv = trans == 'N' ? (float *) d_y + s : (float *) d_y;
-      herr = col32 ? scsrgemv_i32(trans, r, n, val, d_ia + s, col32, xv, yv, st)
-                   : scsrgemv(trans, r, n, val, d_ia + s, col, xv, yv, st);
+      if (trans == 'N')
+        herr = scsrgemv('N', r, n, val, d_ia + s, col, (const float *) d_x, (float *) d_y + s, st);
+      else
+        herr = scsrgemv('T', r, n, val, d_ia + s, col, (const float *) d_x + s, (float *) d_y, st);
       if (herr == hipSuccess) herr = hipEventRecord(c.done, st);
     }
     if (herr != hipSuccess) break;

@@ -15,7 +15,6 @@
 #include "bof_hip.h"
 #include "bof_internal.h"
 #include "fileio.h"
-#include "flash_common.h"
 
 // stand-ins for the device-side half of the library (c_api.hip and the kernels): the code under
 // test here never reaches them
@@ -33,10 +32,6 @@ hipError_t scsrmm(char, int64_t, int64_t, int64_t, float, const float *, const i
                   const float *, int64_t, float, float *, int64_t, hipStream_t) { return hipErrorUnknown; }
 hipError_t scsrgemv(char, int64_t, int64_t, const float *, const int64_t *, const int64_t *, const float *,
                     float *, hipStream_t) { return hipErrorUnknown; }
-hipError_t scsrmm_i32(char, int64_t, int64_t, int64_t, float, const float *, const int32_t *, const int64_t *,
-                      const float *, int64_t, float, float *, int64_t, hipStream_t) { return hipErrorUnknown; }
-hipError_t scsrgemv_i32(char, int64_t, int64_t, const float *, const int64_t *, const int32_t *, const float *,
-                        float *, hipStream_t) { return hipErrorUnknown; }
 hipError_t transpose_f32(const float *, int64_t, int64_t, int64_t, float *, int64_t, hipStream_t) {
   return hipErrorUnknown;
 }
@@ -187,27 +182,7 @@ static void schedules() {
   CHECK(bof_flash_gemm_simulate('R', 'N', 'N', 640, 500, 600, 0.f, 0, 0, 0, 256, 3, 16, &st) != BOF_OK);  // < 6 slots
 }
 
-// CSR index narrowing of the level-3 staging path: in place, source shifted by the sector widening
-static void narrowing() {
-  for (uint64_t count : {0ull, 1ull, 3ull, 4ull, 5ull, 1000ull, 4099ull})
-    for (uint64_t d0 : {0ull, 4ull, 8ull, 12ull, 500ull, 508ull}) {
-      std::vector<char> buf(d0 + count * 8 + 16, (char) 0x5a);
-      std::vector<int64_t> want(count);
-      for (uint64_t i = 0; i < count; i++) {
-        want[i] = (int64_t) ((i * 2654435761ull) % 2147483647ull);
-        memcpy(buf.data() + d0 + 8 * i, &want[i], 8);
-      }
-      bof::narrow_i64_to_i32(buf.data() + d0, reinterpret_cast<int32_t *>(buf.data()), count);
-      for (uint64_t i = 0; i < count; i++) {
-        int32_t got;
-        memcpy(&got, buf.data() + 4 * i, 4);
-        CHECK((int64_t) got == want[i]);
-      }
-    }
-}
-
 int main(int argc, char **argv) {
-  narrowing();
   plans();
   schedules();
   files(argc > 1 ? argv[1] : "/tmp");
