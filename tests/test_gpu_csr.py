@@ -218,3 +218,63 @@ def test_csrgemv_t_partitioned_generator_hash_and_row_range(dev, golden, monkeyp
                             ptr(dy), None, stream())
     torch.cuda.synchronize()
     assert np.array_equal(dy.cpu().numpy(), ref)
+
+
+def test_csr_maximum_column_index(dev, monkeypatch):
+    """Maximum sizes: A with n = 2^31 - 1 columns (the largest the 31-bit column arithmetic of the
+    kernels admits; the entry points reject more) and non-zeros in column 0, 2^30 and n - 1.
+    csrgemv 'N' / 'T' (x resp. y of 8.6 GB) and csrmm with k = 2 (B of 17 GB) on an MI355X;
+    values chosen so that every result is a small integer."""
+    n = 2 ** 31 - 1
+    m = 1000
+    cols = np.array([0, 2 ** 30, n - 1], np.int64)
+    ia = (np.arange(m + 1, dtype=np.int64) * 3)
+    ja = np.tile(cols, m)
+    val = np.tile(np.array([1.0, 2.0, 3.0], np.float32), m) + (np.arange(3 * m) // 3 % 5).astype(np.float32)
+    d_val, d_ja, d_ia = to_dev(val), to_dev(ja), to_dev(ia)
+    # 'N': y[i] = sum_j val[i,j] * x[col j]
+    x = torch.zeros(n, dtype=torch.float32, device=dev)
+    x[0], x[2 ** 30], x[n - 1] = 1.0, 10.0, 100.0
+    y = torch.full((m,), -1.0, dtype=torch.float32, device=dev)
+    bofhip.scsrgemv("N", m, n, ptr(d_val), ptr(d_ia), ptr(d_ja), ptr(x), ptr(y), stream())
+    torch.cuda.synchronize()
+    v = val.reshape(m, 3)
+    assert np.array_equal(y.cpu().numpy(), v[:, 0] * 1 + v[:, 1] * 10 + v[:, 2] * 100)
+    # the whole-matrix level-2 call ('N' row blocks; 'T' through the column-bin partition)
+    bofhip.csrgemv_resident("N", m, n, ptr(d_val), ia.ctypes.data, ptr(d_ia), ptr(d_ja), ptr(x), ptr(y),
+                            bofhip.default_options(), stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), v[:, 0] * 1 + v[:, 1] * 10 + v[:, 2] * 100)
+    del x
+    xt = torch.ones(m, dtype=torch.float32, device=dev)
+    yt = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
+    def check_t():
+        torch.cuda.synchronize()
+        for c, j in ((0, 0), (2 ** 30, 1), (n - 1, 2)):
+            assert float(yt[c]) == float(v[:, j].sum())
+        assert float(yt.double().sum()) == float(v.astype(np.float64).sum())     # nothing landed anywhere else
+    bofhip.scsrgemv("T", m, n, ptr(d_val), ptr(d_ia), ptr(d_ja), ptr(xt), ptr(yt.zero_()), stream())   # atomic form
+    check_t()
+    monkeypatch.setenv("BOF_GEMV_T_PARTITION_MIN_NNZ", "1")     # the column-bin partition: 262144 bins, 3 digit passes
+    yt.fill_(7.0)
+    bofhip.csrgemv_resident("T", m, n, ptr(d_val), ia.ctypes.data, ptr(d_ia), ptr(d_ja), ptr(xt), ptr(yt),
+                            bofhip.default_options(), stream())
+    check_t()
+    del yt, xt
+    torch.cuda.empty_cache()
+    # csrmm k = 2: B is 2^31 - 1 rows of two floats
+    b = torch.zeros(n * 2, dtype=torch.float32, device=dev)
+    B = b.view(n, 2)
+    B[0] = torch.tensor([1.0, 2.0], device=dev)
+    B[2 ** 30] = torch.tensor([10.0, 20.0], device=dev)
+    B[n - 1] = torch.tensor([100.0, 200.0], device=dev)
+    c = torch.full((m, 2), -1.0, dtype=torch.float32, device=dev)
+    bofhip.scsrmm("R", m, 2, n, 1.0, ptr(d_val), ptr(d_ja), ptr(d_ia), ptr(b), 2, 0.0, ptr(c), 2, stream())
+    torch.cuda.synchronize()
+    want = np.stack([v[:, 0] * 1 + v[:, 1] * 10 + v[:, 2] * 100, v[:, 0] * 2 + v[:, 1] * 20 + v[:, 2] * 200], 1)
+    assert np.array_equal(c.cpu().numpy(), want)
+    # one column more is refused, not wrapped
+    with pytest.raises(bofhip.BofError):
+        bofhip.scsrmm("R", m, 2, n + 1, 1.0, ptr(d_val), ptr(d_ja), ptr(d_ia), ptr(b), 2, 0.0, ptr(c), 2, stream())
+    del b, c
+    torch.cuda.empty_cache()
