@@ -50,177 +50,6 @@
 
 namespace bof {
 
-static std::recursive_mutex g_call_mu[64];
-std::recursive_mutex &device_call_mutex() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void) hipGetLastError(); dev = 0; }
-  return g_call_mu[dev & 63];
-}
-
-hipError_t copy_stream_create(hipStream_t *s) {
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
-    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
-  }
-  (void) hipGetLastError();
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-}
-
-// ---- cache of pinned host blocks -------------------------------------------------------------------
-namespace {
-struct PinnedCache {
-  std::mutex mu;
-  std::multimap<size_t, void *> free_;          // size -> block
-  std::unordered_map<void *, size_t> live;      // handed out
-  size_t cached_bytes = 0;
-} g_pin;
-constexpr size_t kPinnedCacheCap = 4ull << 30;
-}  // namespace
-
-int pinned_alloc(void **p, size_t bytes) {
-  if (bytes == 0) bytes = 1;
-  {
-    std::lock_guard<std::mutex> lk(g_pin.mu);
-    auto it = g_pin.free_.lower_bound(bytes);
-    if (it != g_pin.free_.end() && it->first <= std::max(2 * bytes, bytes + (4u << 20))) {
-      *p = it->second;
-      g_pin.live[*p] = it->first;
-      g_pin.cached_bytes -= it->first;
-      g_pin.free_.erase(it);
-      return BOF_OK;
-    }
-  }
-  const size_t rounded = (bytes + 4095) / 4096 * 4096;
-  hipError_t e = hipHostMalloc(p, rounded, hipHostMallocDefault);
-  if (e != hipSuccess) {  // the cache may be what is in the way
-    pinned_cache_release();
-    e = hipHostMalloc(p, rounded, hipHostMallocDefault);
-  }
-  if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (pinned staging block)");
-  std::lock_guard<std::mutex> lk(g_pin.mu);
-  g_pin.live[*p] = rounded;
-  return BOF_OK;
-}
-void pinned_free(void *p) {
-  if (!p) return;
-  size_t sz = 0;
-  {
-    std::lock_guard<std::mutex> lk(g_pin.mu);
-    auto it = g_pin.live.find(p);
-    if (it == g_pin.live.end()) return;
-    sz = it->second;
-    g_pin.live.erase(it);
-    if (g_pin.cached_bytes + sz <= kPinnedCacheCap) {
-      g_pin.free_.emplace(sz, p);
-      g_pin.cached_bytes += sz;
-      return;
-    }
-  }
-  (void) hipHostFree(p);
-}
-void pinned_cache_release() {
-  std::vector<void *> blocks;
-  {
-    std::lock_guard<std::mutex> lk(g_pin.mu);
-    for (auto &kv : g_pin.free_) blocks.push_back(kv.second);
-    g_pin.free_.clear();
-    g_pin.cached_bytes = 0;
-  }
-  for (void *b : blocks) (void) hipHostFree(b);
-}
-
-// ---- roctx ranges -------------------------------------------------------------------------------
-namespace {
-typedef int (*roctx_push_fn)(const char *);
-typedef int (*roctx_pop_fn)(void);
-roctx_push_fn g_roctx_push = nullptr;
-roctx_pop_fn g_roctx_pop = nullptr;
-std::once_flag g_roctx_once;
-void roctx_resolve() {
-  for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
-    void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
-    if (!h) continue;
-    g_roctx_push = (roctx_push_fn) dlsym(h, "roctxRangePushA");
-    g_roctx_pop = (roctx_pop_fn) dlsym(h, "roctxRangePop");
-    if (g_roctx_push && g_roctx_pop) return;
-    g_roctx_push = nullptr; g_roctx_pop = nullptr;
-  }
-}
-}  // namespace
-void trace_push(const char *name) {
-  std::call_once(g_roctx_once, roctx_resolve);
-  if (g_roctx_push) (void) g_roctx_push(name);
-}
-void trace_pop() {
-  if (g_roctx_pop) (void) g_roctx_pop();
-}
-
-// ---- NUMA placement of the I/O threads -------------------------------------------------------
-namespace {
-struct NodeCpus { int node = -2; cpu_set_t set; };   // -2 not looked up yet, -1 unknown
-std::mutex g_numa_mu;
-NodeCpus g_numa[64];
-
-bool parse_cpulist(const char *txt, cpu_set_t *set) {
-  CPU_ZERO(set);
-  int n = 0;
-  const char *p = txt;
-  while (*p) {
-    char *end = nullptr;
-    long a = strtol(p, &end, 10);
-    if (end == p) break;
-    long b = a;
-    p = end;
-    if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
-    for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int) c, set); n++; }
-    while (*p == ',' || *p == ' ' || *p == '\n') p++;
-  }
-  return n > 0;
-}
-bool read_small(const std::string &path, char *buf, size_t cap) {
-  FILE *f = fopen(path.c_str(), "r");
-  if (!f) return false;
-  const size_t n = fread(buf, 1, cap - 1, f);
-  fclose(f);
-  buf[n] = 0;
-  return n > 0;
-}
-}  // namespace
-
-int bind_thread_near_device(int dev) {
-  static const bool enabled = !getenv("BOF_NUMA_BIND") || atoi(getenv("BOF_NUMA_BIND")) != 0;
-  if (!enabled || dev < 0 || dev >= 64) return -1;
-  NodeCpus nc;
-  {
-    std::lock_guard<std::mutex> lk(g_numa_mu);
-    NodeCpus &c = g_numa[dev];
-    if (c.node == -2) {
-      c.node = -1;
-      char bus[64] = {0}, buf[4096];
-      if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), dev) == hipSuccess) {
-        for (char *q = bus; *q; q++) *q = (char) tolower(*q);
-        if (read_small(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", buf, sizeof(buf))) {
-          const int node = atoi(buf);
-          if (node >= 0 &&
-              read_small("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", buf, sizeof(buf)) &&
-              parse_cpulist(buf, &c.set))
-            c.node = node;
-        }
-      } else {
-        (void) hipGetLastError();
-      }
-    }
-    nc = c;
-  }
-  if (nc.node < 0) return -1;
-  // The node's CPU list is requested as it is, NOT intersected with the creating thread's own
-  // mask: the caller may have been narrowed to one core by an OpenMP runtime (a BLAS call made
-  // earlier in the process is enough), and the I/O threads must not inherit that.  The kernel
-  // applies the cpuset of the container itself and refuses only an empty result.
-  if (sched_setaffinity(0, sizeof(nc.set), &nc.set) == 0) return nc.node;
-  return -1;
-}
-
 static bof_flash_stats g_last_stats;
 static std::mutex g_stats_mu;
 
