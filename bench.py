@@ -502,8 +502,9 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
 
     flops = 2.0 * n ** 3
     tiles = 3 * (n // blk) ** 2
+    which = {32768: "BASELINE configs[1]", 65536: "north_star's 64k target, configs[3] on one GPU"}.get(n, "debug size")
     out = {"workload": f"flash _gemm fp32 {n}x{n}x{n}, {blk}-tile, A/B/C as {nbytes / 2**30:.0f} GiB files "
-                       f"(BASELINE configs[1]); wall clock around bof_flash_gemm incl. write-back",
+                       f"({which}); wall clock around bof_flash_gemm incl. write-back",
            "file_system": _fs_of(workdir), "create_files_s": round(create_s, 1), "io_threads": io_threads}
     for mode in modes:
         fds = []
@@ -797,7 +798,7 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
     return out
 
 
-def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s):
+def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm64_kernel_s=None):
     import shutil
     import tempfile
     base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
@@ -821,6 +822,16 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s):
         else:
             out["gemm"] = {"skipped": "not enough free disk for three matrix files"}
         bofhip.lib().bof_flash_release()
+        # north_star's 64k x 64k x 64k out-of-core GEMM at N = 1 (3 x 16 GiB files, 4096 tile tasks,
+        # 563 TFLOP): one O_DIRECT call and one page-cache call, whole C file verified
+        if args.e2e_size == 32768 and not args.no_e2e_64k:
+            free = shutil.disk_usage(workdir).free
+            if free > 3 * 65536 * 65536 * 4 + (4 << 30):
+                out["gemm_65536"] = e2e_gemm(bofhip, torch, dev, st, workdir, 65536, args.blk, gemm64_kernel_s,
+                                             args.io_threads, 1)
+            else:
+                out["gemm_65536"] = {"skipped": f"needs 48 GiB of scratch disk, {free / 2**30:.0f} GiB free"}
+            bofhip.lib().bof_flash_release()
         if args.no_csr or args.e2e_size != 32768:
             pass
         elif free > 19e9:
@@ -856,6 +867,7 @@ def main():
     ap.add_argument("--e2e-dir", default="", help="directory for the matrix files (default $BOF_BENCH_DIR, $TMPDIR, /tmp)")
     ap.add_argument("--e2e-size", type=int, default=32768, help="edge of the file-resident GEMM")
     ap.add_argument("--e2e-reps", type=int, default=2)
+    ap.add_argument("--no-e2e-64k", action="store_true", help="skip the 65536^3 file-resident leg (48 GiB of files)")
     ap.add_argument("--io-threads", type=int, default=8)
     args = ap.parse_args()
 
@@ -1067,8 +1079,9 @@ def main():
                 pass
             torch.cuda.empty_cache()
             csr_ms = (out.get("secondary") or {}).get("csrmm", {}).get("ms")
+            g64_ms = (out.get("secondary") or {}).get("gemm_65536", {}).get("ms_per_step")
             out["e2e"] = e2e_block(bofhip, torch, dev, st, args, dt / args.steps if not args.size else None,
-                                   csr_ms * 1e-3 if csr_ms else None)
+                                   csr_ms * 1e-3 if csr_ms else None, g64_ms * 1e-3 if g64_ms else None)
         if sharded is not None:
             sec = {"scaling": "strong (the BASELINE matrices row-sharded over the ranks; max over ranks)",
                    "ok": sharded["ok"]}
