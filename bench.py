@@ -492,10 +492,9 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
     def reset_c():
         fd, d = _open(pc, True)
         try:
-            z = torch.zeros(1 << 24, dtype=torch.float32, device=dev)
+            t.zero_()
             o = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if d else 0)
-            for off in range(0, nbytes, z.numel() * 4):
-                bofhip.device_to_file(bofhip.FPtr(fd, off), min(z.numel() * 4, nbytes - off), z.data_ptr(), o, st)
+            bofhip.device_to_file(bofhip.FPtr(fd, 0), nbytes, t.data_ptr(), o, st)
         finally:
             bofhip.lib().bof_file_forget(fd)
             os.close(fd)
@@ -522,7 +521,8 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
                                       **extra_opts)
         runs = []
         verified = True
-        for rep in range(reps + (1 if mode == "buffered" else 0)):
+        total = reps + (1 if mode == "buffered" else 0)
+        for rep in range(total):
             if mode == "odirect":
                 _drop_cache((pa, pb, pc))
             t0 = time.perf_counter()
@@ -530,11 +530,11 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
                               bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
             dt = time.perf_counter() - t0
             runs.append({"seconds": dt, "stats": bofhip.flash_last_stats()})
-            if rep == 0:
-                verified = verified and verify()
-                if reps > 1 or mode == "buffered":
-                    reset_c()        # later runs must produce C again, not find it
-        verified = verified and verify()
+            last = rep == total - 1
+            if rep == 0 or last:
+                verified = verified and verify()      # every element of the C file
+            if not last:
+                reset_c()            # later runs must produce C again, not find it
         for fd in fds:
             bofhip.lib().bof_file_forget(fd)
             os.close(fd)
