@@ -797,8 +797,80 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
     bofhip.lib().bof_flash_release()
     return out
 
+CFG5_Y_SHA256 = {"N": "1c0a44dbb962be0a2d7027f5f298ff94ab5b2ee66c8fe467c0408b286b1881e4",
+                 "T": "486766062199bef476611a2675893df3266338c91bfc30db4640ef5dbc2cbf40"}
 
-def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm64_kernel_s=None):
+
+def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps):
+    """BASELINE configs[4] size on one GPU through bof_flash_csrgemv: sparse_create(50M, 50M, 2e-7) as
+    files (2 GB values, 4 GB int64 indices, 400 MB offsets), x = i % 10 and y in HOST memory as in the
+    reference (include/flash_blas.h:55-57); 'N' and 'T'; sha256(y) = the reference's known answers."""
+    import hashlib
+    import numpy as np
+    m = n = 50_000_000
+    npr = 10
+    nnz = m * npr
+    p = {x: os.path.join(workdir, x) for x in ("G.csr", "G.col", "G.off")}
+    wopts = bofhip.default_options(n_io_threads=io_threads)
+    t0 = time.perf_counter()
+    val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    for r0 in range(0, m, 5_000_000):
+        bofhip.gen_sparse_rows(r0, 5_000_000, n, npr, val.data_ptr() + 4 * r0 * npr, col.data_ptr() + 8 * r0 * npr,
+                               off.data_ptr() + 8 * r0, st)
+    for t, name in ((val, "G.csr"), (col, "G.col"), (off, "G.off")):
+        _write_device_tensor(bofhip, t, p[name], True, wopts, st)
+    del val, col, off
+    torch.cuda.empty_cache()
+    out = {"workload": "flash _csrgemv 50M x 50M CSR (5e8 nnz: 6.4 GB of files), x and y in host memory "
+                       "(BASELINE configs[4] size on one GPU); wall clock around bof_flash_csrgemv",
+           "create_files_s": round(time.perf_counter() - t0, 1), "io_threads": io_threads}
+    x = (np.arange(n) % 10).astype(np.float32)
+    y = np.zeros(n, np.float32)
+    alg = nnz * 12 + (m + 1) * 8 + 8 * n
+    for mode in ("odirect", "buffered"):
+        fds, ok_direct = {}, True
+        for name in p:
+            fds[name], d = _open(p[name], mode == "odirect")
+            ok_direct = ok_direct and d
+        if mode == "odirect" and not ok_direct:
+            out[mode] = {"skipped": "file system refuses O_DIRECT"}
+            for fd in fds.values():
+                os.close(fd)
+            continue
+        opts = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0)
+        leg = {}
+        for tr in "NT":
+            secs = []
+            for rep in range(reps + (1 if mode == "buffered" and tr == "N" else 0)):
+                if mode == "odirect":
+                    _drop_cache(p.values())
+                y.fill(-1.0)
+                t0 = time.perf_counter()
+                bofhip.flash_csrgemv(tr, m, n, bofhip.FPtr(fds["G.csr"], 0), bofhip.FPtr(fds["G.off"], 0),
+                                     bofhip.FPtr(fds["G.col"], 0), x.ctypes.data, y.ctypes.data, opts)
+                secs.append(time.perf_counter() - t0)
+            if mode == "buffered" and tr == "N":
+                leg["first_run_cold_cache_s"] = round(secs.pop(0), 3)
+            best = min(secs)
+            stats = bofhip.flash_last_stats()
+            leg[tr] = {"seconds_all": [round(v, 3) for v in secs], "seconds": round(best, 3),
+                       "gflops": round(2.0 * nnz / best / 1e9, 2), "read_GBps": round(stats["bytes_read"] / best / 1e9, 2),
+                       "algorithmic_GBps": round(alg / best / 1e9, 2),
+                       "overlap_kernel_over_e2e": round(kernel_ms[tr] * 1e-3 / best, 3) if kernel_ms and tr in kernel_ms else None,
+                       "sha256_y_matches_reference": bool(hashlib.sha256(y.tobytes()).hexdigest() == CFG5_Y_SHA256[tr])}
+        for fd in fds.values():
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+        out[mode] = leg
+    for f in p.values():
+        os.remove(f)
+    return out
+
+
+
+def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm64_kernel_s=None, gemv_kernel_ms=None):
     import shutil
     import tempfile
     base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
@@ -839,6 +911,12 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
         else:
             out["csrmm"] = {"skipped": "not enough free disk for the cfg3 files (17.7 GB)"}
         bofhip.lib().bof_flash_release()
+        if not (args.no_csr or args.e2e_size != 32768):
+            if shutil.disk_usage(workdir).free > 8e9:
+                out["csrgemv"] = e2e_csrgemv(bofhip, torch, dev, st, workdir, gemv_kernel_ms, args.io_threads, args.e2e_reps)
+            else:
+                out["csrgemv"] = {"skipped": "not enough free disk for the cfg5-size files (6.4 GB)"}
+            bofhip.lib().bof_flash_release()
     except Exception as e:  # the headline line must still be printed
         out["error"] = f"{type(e).__name__}: {str(e)[:300]}"
     finally:
@@ -1079,9 +1157,12 @@ def main():
                 pass
             torch.cuda.empty_cache()
             csr_ms = (out.get("secondary") or {}).get("csrmm", {}).get("ms")
-            g64_ms = (out.get("secondary") or {}).get("gemm_65536", {}).get("ms_per_step")
+            sec = out.get("secondary") or {}
+            g64_ms = sec.get("gemm_65536", {}).get("ms_per_step")
+            gv_ms = {tr: sec.get("csrgemv_" + tr, {}).get("ms") for tr in "NT"}
             out["e2e"] = e2e_block(bofhip, torch, dev, st, args, dt / args.steps if not args.size else None,
-                                   csr_ms * 1e-3 if csr_ms else None, g64_ms * 1e-3 if g64_ms else None)
+                                   csr_ms * 1e-3 if csr_ms else None, g64_ms * 1e-3 if g64_ms else None,
+                                   gv_ms if all(gv_ms.values()) else None)
         if sharded is not None:
             sec = {"scaling": "strong (the BASELINE matrices row-sharded over the ranks; max over ranks)",
                    "ok": sharded["ok"]}
