@@ -127,6 +127,9 @@ constexpr int RS_T = 256, RS_WAVES = RS_T / 64, RS_CHUNKS = 16, RS_SUB = 64 * RS
 // records per digit, the scatter's runs shrink to 16 bytes and both passes take 14-17 ms instead of
 // 8-9, and the 1024-entry LDS tables halve the occupancy of the record-only (GEMV) passes.
 constexpr int RS_MAXBITS = 8, RS_MAXD = 1 << RS_MAXBITS;
+#ifndef RS_OCC
+#define RS_OCC 4
+#endif
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each with its own
 // L2.  Tile t appends its run of every digit right behind tile t-1's, so when consecutive TILES run
@@ -188,10 +191,18 @@ __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *
   __syncthreads();
   const int64_t t0 = (int64_t) blockIdx.x * RS_TILE;
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
-  for (int64_t p = t0 + threadIdx.x; p < t1; p += RS_T) {
-    const uint32_t key = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
-    atomicAdd(&h[(key >> a.shift) & mask], 1u);
+  // all 16 loads of a lane in flight before the first LDS add (a load-add-load-add loop was
+  // latency-bound: 1.28 ms per 1e9 keys, 3.1 TB/s)
+  uint32_t key[RS_TILE / RS_T];
+#pragma unroll
+  for (int c = 0; c < RS_TILE / RS_T; c++) {
+    const int64_t p = t0 + c * RS_T + threadIdx.x;
+    key[c] = 0;
+    if (p < t1) key[c] = FIRST ? (uint32_t) a.col[p] : a.key_in[p];
   }
+#pragma unroll
+  for (int c = 0; c < RS_TILE / RS_T; c++)
+    if (t0 + c * RS_T + threadIdx.x < t1) atomicAdd(&h[(key[c] >> a.shift) & mask], 1u);
   __syncthreads();
   for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) hist[(int64_t) d * a.nblocks + blockIdx.x] = h[d];  // digit-major
 }
@@ -199,14 +210,17 @@ __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *
 // GEMV mode (the partition passes of A^T x): records are (column, product) only -- no row
 // payload is carried or staged.
 template <bool FIRST, bool LAST, bool GEMV>
-__global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
+__global__ __launch_bounds__(RS_T, RS_OCC) void radix_scatter_kernel(SortArgs a,
                                                              const int64_t *__restrict__ bases) {
-  __shared__ uint32_t skey[RS_TILE], srow[(GEMV && !FIRST) ? 64 : RS_TILE];
-  __shared__ float sval[RS_TILE];
+  // 40 KB of LDS per workgroup = four workgroups per CU (a separate 16 KB image per record
+  // field allowed two).  skey: the row offsets while the row ids are painted (first pass), then
+  // the key image.  spay: the painted row ids (first pass), then the payload image -- the row ids
+  // and, once those have been written out, the values (GEMV records carry no row: values only).
+  __shared__ uint32_t skey[RS_TILE], spay[RS_TILE];
   __shared__ uint32_t run[RS_WAVES][RS_MAXD];  // counts, then running local positions
-  __shared__ uint32_t lstart[RS_MAXD];         // local start of every digit's run
-  __shared__ int64_t gbase[RS_MAXD];           // global start of this tile's run of every digit
+  __shared__ int64_t gbase[RS_MAXD];           // global start of this tile's run of a digit MINUS its local start
   __shared__ uint32_t wsum[RS_WAVES];
+  uint32_t *const srow = spay;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t mask = (1u << a.wbits) - 1u;
   const int64_t tile = tile_of(blockIdx.x, a.nblocks, a.xcd_order);
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
     for (int j = 0; j < dpt; j++) {
       const uint32_t d = threadIdx.x * dpt + j;
       if (d <= mask) {
-        lstart[d] = start;
+        gbase[d] -= (int64_t) start;  // position i of the image goes to gbase[d] + i
 #pragma unroll
         for (int i = 0; i < RS_WAVES; i++) { const uint32_t cw = run[i][d]; run[i][d] = start; start += cw; }
       }
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
   __syncthreads();
   // phase 2: stable placement into the LDS image
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint32_t pos[RS_CHUNKS];
 #pragma unroll
   for (int c = 0; c < RS_CHUNKS; c++) {
     const bool ok = s0 + c * 64 + lane < t1;
@@ -325,32 +340,43 @@ __global__ __launch_bounds__(RS_T) void radix_scatter_kernel(SortArgs a,
       peers &= ((d >> b) & 1u) ? vote : ~vote;
     }
     const int rank = __popcll(peers & lt);
-    uint32_t pos = 0;
-    if (ok) pos = run[w][d] + rank;
+    pos[c] = 0;
+    if (ok) pos[c] = run[w][d] + rank;
     __builtin_amdgcn_wave_barrier();
     if (ok && rank == 0) run[w][d] += __popcll(peers);
     __builtin_amdgcn_wave_barrier();
     if (ok) {
-      skey[pos] = key[c];
-      if (!GEMV) srow[pos] = row[c];
-      sval[pos] = v[c];
+      skey[pos[c]] = key[c];
+      spay[pos[c]] = GEMV ? __float_as_uint(v[c]) : row[c];
     }
   }
   __syncthreads();
   // phase 3: run-by-run write-out, consecutive threads -> consecutive addresses
   const int cnt = (int) (t1 - t0);
-  for (int i = threadIdx.x; i < cnt; i += RS_T) {
-    const uint32_t k = skey[i];
-    const uint32_t d = (k >> a.shift) & mask;
-    const int64_t g = gbase[d] + (int64_t) (i - lstart[d]);
-    if (LAST) {
-      a.col_tr[g] = (int64_t) srow[i];
-      a.val_out[g] = sval[i];
-      a.key_out[g] = k;  // sorted keys: the offsets are derived from them
-    } else {
-      a.key_out[g] = k;
-      if (!GEMV) a.row_out[g] = srow[i];
-      a.val_out[g] = sval[i];
+  int64_t g[RS_CHUNKS];
+#pragma unroll
+  for (int j = 0; j < RS_CHUNKS; j++) {
+    const int i = threadIdx.x + j * RS_T;
+    g[j] = 0;
+    if (i < cnt) {
+      const uint32_t k = skey[i];
+      g[j] = gbase[(k >> a.shift) & mask] + i;
+      a.key_out[g[j]] = k;  // last pass: the sorted keys, from which the offsets are derived
+      if (GEMV) a.val_out[g[j]] = __uint_as_float(spay[i]);
+      else if (LAST) a.col_tr[g[j]] = (int64_t) spay[i];
+      else a.row_out[g[j]] = spay[i];
+    }
+  }
+  if (!GEMV) {  // the values take the place of the row ids
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RS_CHUNKS; c++)
+      if (s0 + c * 64 + lane < t1) spay[pos[c]] = __float_as_uint(v[c]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_CHUNKS; j++) {
+      const int i = threadIdx.x + j * RS_T;
+      if (i < cnt) a.val_out[g[j]] = __uint_as_float(spay[i]);
     }
   }
 }
@@ -433,6 +459,18 @@ Layout make_layout(int64_t n, int64_t nnz) {
 // `global_atomic_add_f32` per non-zero (memory-side, ~20 G/s on scattered columns).
 constexpr int GT_LOGW = 13, GT_W = 1 << GT_LOGW;
 
+// LDS float add as a compare-and-swap loop.  `ds_add_f32` runs at 0.8 lane-operations per ns and
+// CU on gfx950 whatever the addresses (203 G/s chip-wide; `ds_add_u32` 10.6, this loop 5.5 on
+// random addresses: tools/exp/lds_atomic_bench.hip) and was the whole cost of the per-bin sums.
+__device__ inline void lds_add_f32(float *p, float v) {
+  uint32_t *q = reinterpret_cast<uint32_t *>(p);
+  uint32_t old = *q, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(q, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}
+
 __global__ __launch_bounds__(256) void gemv_t_accumulate_kernel(const uint32_t *__restrict__ key,
                                                                 const float *__restrict__ prod,
                                                                 const int64_t *__restrict__ bin_off,
@@ -445,7 +483,7 @@ __global__ __launch_bounds__(256) void gemv_t_accumulate_kernel(const uint32_t *
   // (dwordx4, two of each array in flight), then the tail
   const int64_t a0 = (s + 3) & ~(int64_t) 3, a1 = e & ~(int64_t) 3;
   if (a0 < a1) {
-    for (int64_t i = s + threadIdx.x; i < a0; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+    for (int64_t i = s + threadIdx.x; i < a0; i += 256) lds_add_f32(&ys[key[i] & (GT_W - 1)], prod[i]);
     const uint4 *k4 = reinterpret_cast<const uint4 *>(key);
     const float4 *p4 = reinterpret_cast<const float4 *>(prod);
     int64_t q = a0 / 4 + threadIdx.x;
@@ -453,20 +491,20 @@ __global__ __launch_bounds__(256) void gemv_t_accumulate_kernel(const uint32_t *
     for (; q + 256 < q1; q += 512) {
       const uint4 ka = k4[q], kb = k4[q + 256];
       const float4 pa = p4[q], pb = p4[q + 256];
-      atomicAdd(&ys[ka.x & (GT_W - 1)], pa.x); atomicAdd(&ys[ka.y & (GT_W - 1)], pa.y);
-      atomicAdd(&ys[ka.z & (GT_W - 1)], pa.z); atomicAdd(&ys[ka.w & (GT_W - 1)], pa.w);
-      atomicAdd(&ys[kb.x & (GT_W - 1)], pb.x); atomicAdd(&ys[kb.y & (GT_W - 1)], pb.y);
-      atomicAdd(&ys[kb.z & (GT_W - 1)], pb.z); atomicAdd(&ys[kb.w & (GT_W - 1)], pb.w);
+      lds_add_f32(&ys[ka.x & (GT_W - 1)], pa.x); lds_add_f32(&ys[ka.y & (GT_W - 1)], pa.y);
+      lds_add_f32(&ys[ka.z & (GT_W - 1)], pa.z); lds_add_f32(&ys[ka.w & (GT_W - 1)], pa.w);
+      lds_add_f32(&ys[kb.x & (GT_W - 1)], pb.x); lds_add_f32(&ys[kb.y & (GT_W - 1)], pb.y);
+      lds_add_f32(&ys[kb.z & (GT_W - 1)], pb.z); lds_add_f32(&ys[kb.w & (GT_W - 1)], pb.w);
     }
     for (; q < q1; q += 256) {
       const uint4 ka = k4[q];
       const float4 pa = p4[q];
-      atomicAdd(&ys[ka.x & (GT_W - 1)], pa.x); atomicAdd(&ys[ka.y & (GT_W - 1)], pa.y);
-      atomicAdd(&ys[ka.z & (GT_W - 1)], pa.z); atomicAdd(&ys[ka.w & (GT_W - 1)], pa.w);
+      lds_add_f32(&ys[ka.x & (GT_W - 1)], pa.x); lds_add_f32(&ys[ka.y & (GT_W - 1)], pa.y);
+      lds_add_f32(&ys[ka.z & (GT_W - 1)], pa.z); lds_add_f32(&ys[ka.w & (GT_W - 1)], pa.w);
     }
-    for (int64_t i = a1 + threadIdx.x; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+    for (int64_t i = a1 + threadIdx.x; i < e; i += 256) lds_add_f32(&ys[key[i] & (GT_W - 1)], prod[i]);
   } else {
-    for (int64_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&ys[key[i] & (GT_W - 1)], prod[i]);
+    for (int64_t i = s + threadIdx.x; i < e; i += 256) lds_add_f32(&ys[key[i] & (GT_W - 1)], prod[i]);
   }
   __syncthreads();
   const int64_t c0 = b * GT_W;
