@@ -189,7 +189,12 @@ __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *
   const uint32_t mask = (1u << a.wbits) - 1u;
   for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) h[d] = 0;
   __syncthreads();
-  const int64_t t0 = (int64_t) blockIdx.x * RS_TILE;
+  // same dealing of tiles to XCDs as the scatter: the counters of neighbouring tiles are
+  // neighbouring dwords of the digit-major table, and only meet as full lines inside one L2
+  // (written from all 8 XCDs the 125 MB table cost 1.3 GB of partial-line writes per pass)
+  const int64_t tile = tile_of(blockIdx.x, a.nblocks, a.xcd_order);
+  if (tile >= a.nblocks) return;
+  const int64_t t0 = tile * RS_TILE;
   const int64_t t1 = t0 + RS_TILE < a.nnz ? t0 + RS_TILE : a.nnz;
   // all 16 loads of a lane in flight before the first LDS add (a load-add-load-add loop was
   // latency-bound: 1.28 ms per 1e9 keys, 3.1 TB/s)
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(RS_T) void radix_hist_kernel(SortArgs a, uint32_t *
   for (int c = 0; c < RS_TILE / RS_T; c++)
     if (t0 + c * RS_T + threadIdx.x < t1) atomicAdd(&h[(key[c] >> a.shift) & mask], 1u);
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) hist[(int64_t) d * a.nblocks + blockIdx.x] = h[d];  // digit-major
+  for (uint32_t d = threadIdx.x; d <= mask; d += RS_T) hist[(int64_t) d * a.nblocks + tile] = h[d];  // digit-major
 }
 
 // GEMV mode (the partition passes of A^T x): records are (column, product) only -- no row
@@ -615,8 +620,9 @@ hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float
     a.key_out = (uint32_t *) dst;
     a.val_out = (float *) (dst + rec);
     sorted = dst;
-    if (first) radix_hist_kernel<true><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
-    else radix_hist_kernel<false><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
+    const unsigned hgrid = (unsigned) (a.xcd_order ? (L.nblocks + 7) / 8 * 8 : L.nblocks);
+    if (first) radix_hist_kernel<true><<<hgrid, RS_T, 0, st>>>(a, hist);
+    else radix_hist_kernel<false><<<hgrid, RS_T, 0, st>>>(a, hist);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     e = exclusive_scan<uint32_t>(hist, bases, ((int64_t) 1 << L.wbits) * L.nblocks, scan_tmp, st);
     if (e != hipSuccess) return e;
@@ -673,8 +679,9 @@ hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const in
       a.row_out = (uint32_t *) (dst + rec);
       a.val_out = (float *) (dst + 2 * rec);
     }
-    if (first) radix_hist_kernel<true><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
-    else radix_hist_kernel<false><<<(unsigned) L.nblocks, RS_T, 0, st>>>(a, hist);
+    const unsigned hgrid = (unsigned) (a.xcd_order ? (L.nblocks + 7) / 8 * 8 : L.nblocks);
+    if (first) radix_hist_kernel<true><<<hgrid, RS_T, 0, st>>>(a, hist);
+    else radix_hist_kernel<false><<<hgrid, RS_T, 0, st>>>(a, hist);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     e = exclusive_scan<uint32_t>(hist, bases, ((int64_t) 1 << L.wbits) * L.nblocks, scan_tmp, st);
     if (e != hipSuccess) return e;
