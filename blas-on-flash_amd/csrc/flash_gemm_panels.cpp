@@ -14,8 +14,15 @@
 //   * C panels are written back as they complete, while the next panels compute.
 //
 // Schedule (same tasks, same k-order per accumulate chain as src/blas/gemm.cpp:83-129, so
-// the result is bit-identical to the tile path): C panels are processed in groups of
-// `group` (default 1); inside a group tasks go l-major.  Let D be the dimension along which
+// the result is bit-identical to the tile path): the first `group` C panels are processed
+// together, l-major, the others one by one (l-major too).  The first group is the ramp: while the
+// resident operand streams in, panel l of it unlocks `group` x (tiles per C panel) tile tasks,
+// and `group` is chosen so that those take as long as the panel's read (65536^3 from O_DIRECT
+// files: a 1 GiB B panel takes 55 ms to read, the 16 tasks of one C panel 15 ms -- with one C
+// panel per group the first panel's time was all I/O: 4.9 s, with a ramp of 4 panels 4.4 s).
+// Later panels have everything resident but their own X panel, and finish -- and are written
+// back -- one at a time, which keeps the tail after the last kernel to one panel.
+// Let D be the dimension along which
 // C is paneled (m for row-major C, n for column-major).  The operand that does not contain D
 // ("Y": B for row-major) is needed whole by every group and stays resident; the other one
 // ("X": A) is resident too when it is paneled along k, else its panels stream through a small
@@ -36,6 +43,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -311,14 +319,36 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   for (int x = 0; x < 3; x++) free_b += R.res->slab_bytes[x];  // what we already hold counts as free
   size_t budget = o.hbm_budget > 0 ? (size_t) o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
-  const char *genv = getenv("BOF_PANEL_GROUP");
-  const bof_panel_plan plan = plan_panels(g, budget, genv ? atoll(genv) : 1);
-  if (!plan.eligible) return 1;
   const int dC = g.rdim[2];                    // 0: C paneled along m, 2: along n
   R.xmat = dC == 0 ? 0 : 1;
   R.ymat = 1 - R.xmat;
   const int64_t NpC = g.nblk[dC];
-  const int64_t group = (NpC + plan.groups - 1) / plan.groups;
+  const int64_t Nq = dC == 0 ? Nn : Nm;        // C tiles per panel
+  bof_panel_plan plan = plan_panels(g, budget, 1);
+  if (!plan.eligible) return 1;
+  {
+    // size of the ramp group (see the header): read time of one panel of the resident operand
+    // over the time of the tile tasks one C panel contributes per such panel.  The rates are
+    // assumptions (a datacenter NVMe under O_DIRECT; page cache + PCIe otherwise; the fp32 MFMA
+    // tile rate) -- BOF_PANEL_GROUP overrides.
+    const char *genv = getenv("BOF_PANEL_GROUP");
+    int64_t want = genv ? atoll(genv) : 0;
+    if (want <= 0) {
+      const double t_io = (double) plan.slot_bytes[R.ymat] / (o.use_odirect ? 16e9 : 40e9);
+      const double t_task = std::max(2.0 * (double) g.blk[0] * (double) g.blk[1] * (double) g.blk[2] / 140e12, 15e-6);
+      want = (int64_t) std::ceil(t_io / (t_task * (double) Nq));
+      // at most half of the C panels: a ramp group's panels all complete -- and start their
+      // write-back -- together at its end, and on a device-bound problem (cfg2 from O_DIRECT
+      // files: 0.70 s with 2-4 of 8 panels, 0.74-0.80 with 5, 0.76 with 1) that burst must not
+      // wait for most of the reads
+      want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 8), NpC / 2));
+    }
+    for (int64_t G = std::min(want, NpC); G > 1; G--) {
+      const bof_panel_plan p2 = plan_panels(g, budget, G);
+      if (p2.eligible) { plan = p2; break; }
+    }
+  }
+  const int64_t group = plan.first_group;
   const bof_fptr fp[3] = {fa, fb, fc};
   for (int x = 0; x < 3; x++) {
     Mat &M = R.mat[x];
@@ -347,11 +377,14 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   R.group_of.assign((size_t) NpC, 0);
   std::vector<std::vector<char>> seen(3);
   for (int x = 0; x < 3; x++) seen[x].assign(R.mat[x].panels.size(), 0);
-  const int64_t Nq = dC == 0 ? Nn : Nm;        // C tiles per panel
   int n_groups = 0;
   std::vector<size_t> group_end;               // task index one past each group
-  for (int64_t G0 = 0; G0 < NpC; G0 += group, n_groups++) {
-    const int64_t G1 = std::min(NpC, G0 + group);
+  std::vector<int64_t> gb;                     // first C panel of each group, then NpC
+  gb.push_back(0);
+  for (int64_t pc = group; pc < NpC; pc++) gb.push_back(pc);
+  gb.push_back(NpC);
+  for (size_t gx = 0; gx + 1 < gb.size(); gx++, n_groups++) {
+    const int64_t G0 = gb[gx], G1 = gb[gx + 1];
     for (int64_t l = 0; l < Nk; l++)
       for (int64_t pc = G0; pc < G1; pc++) {
         R.group_of[(size_t) pc] = n_groups;
@@ -490,7 +523,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     // flusher and let the streamed operand's panels of this group go
     for (int s = 0; s < R.ss->n && herr == hipSuccess; s++) herr = hipEventRecord(R.group_ev[(size_t) gi][(size_t) s], R.ss->s[s]);
     if (herr != hipSuccess) break;
-    const int64_t G0 = (int64_t) gi * group, G1 = std::min(NpC, G0 + group);
+    const int64_t G0 = gb[(size_t) gi], G1 = gb[(size_t) gi + 1];
     {
       std::lock_guard<std::mutex> lk(R.mu);
       if (!X.natural)

@@ -84,7 +84,8 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
   const bool x_streams = g.rdim[xm] == dC;
   const int64_t NpC = g.nblk[dC];
   group = std::max<int64_t>(1, std::min(group, NpC));
-  P.groups = (NpC + group - 1) / group;
+  P.first_group = group;
+  P.groups = 1 + (NpC - group);   // the ramp group, then one C panel at a time
   P.resident[ym] = 1;
   P.n_slots[ym] = P.n_panels[ym];
   P.resident[xm] = x_streams ? 0 : 1;

@@ -256,7 +256,9 @@ int bof_flash_gemm_simulate(char ord, char trans_a, char trans_b, uint64_t m, ui
 /* Which path bof_flash_gemm takes for a problem and an HBM budget, and how the row-panel path
  * would lay the matrices out (pure host code: usable without a GPU).  Panels = `blk` stored
  * rows x the full stored width of a matrix, kept in HBM in file layout; "resident" matrices keep
- * all their panels, the others a ring of n_slots. */
+ * all their panels, the others a ring of n_slots.  `group` = C panels of the first group (the
+ * ramp that runs while the resident operand streams in; later panels go one at a time);
+ * bof_flash_gemm picks it from the panel sizes (BOF_PANEL_GROUP overrides), here it is given. */
 typedef struct {
   int32_t eligible;     /* 1: row panels; 0: the tile cache takes the call            */
   int32_t why;          /* 0 ok, 1 empty problem / k = 0, 2 ld < stored width, 3 an operand
@@ -269,7 +271,8 @@ typedef struct {
   int64_t n_slots[3];   /* panel slots held in HBM                                    */
   uint64_t slot_bytes[3];
   uint64_t need_bytes;  /* HBM the plan needs                                         */
-  int64_t groups;       /* C panel groups (outer iterations)                          */
+  int64_t groups;       /* outer iterations: the first group, then one C panel each   */
+  int64_t first_group;  /* C panels of the first group (`group` clamped to the count) */
 } bof_panel_plan;
 int bof_flash_gemm_panel_plan(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
                               uint64_t k, uint64_t lda, uint64_t ldb, uint64_t ldc, int64_t blk,
