@@ -801,7 +801,7 @@ CFG5_Y_SHA256 = {"N": "1c0a44dbb962be0a2d7027f5f298ff94ab5b2ee66c8fe467c0408b286
                  "T": "486766062199bef476611a2675893df3266338c91bfc30db4640ef5dbc2cbf40"}
 
 
-def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps):
+def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps, modes=("odirect", "buffered"), **extra_opts):
     """BASELINE configs[4] size on one GPU through bof_flash_csrgemv: sparse_create(50M, 50M, 2e-7) as
     files (2 GB values, 4 GB int64 indices, 400 MB offsets), x = i % 10 and y in HOST memory as in the
     reference (include/flash_blas.h:55-57); 'N' and 'T'; sha256(y) = the reference's known answers."""
@@ -829,7 +829,7 @@ def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps):
     x = (np.arange(n) % 10).astype(np.float32)
     y = np.zeros(n, np.float32)
     alg = nnz * 12 + (m + 1) * 8 + 8 * n
-    for mode in ("odirect", "buffered"):
+    for mode in modes:
         fds, ok_direct = {}, True
         for name in p:
             fds[name], d = _open(p[name], mode == "odirect")
@@ -839,7 +839,7 @@ def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps):
             for fd in fds.values():
                 os.close(fd)
             continue
-        opts = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0)
+        opts = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if mode == "odirect" else 0, **extra_opts)
         leg = {}
         for tr in "NT":
             secs = []
