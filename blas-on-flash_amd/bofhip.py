@@ -70,6 +70,7 @@ SYMBOLS = [
     ("bof_stream_sync", C.c_int, [P]),
     ("bof_mem_info", C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("bof_sgemm", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64, P]),
+    ("bof_skmeans_task", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64, P, P, P, P]),
     ("bof_scsrmm", C.c_int, [chr_, i64, i64, i64, f32, P, P, P, P, i64, f32, P, i64, P]),
     ("bof_scsrgemv", C.c_int, [chr_, i64, i64, P, P, P, P, P, P]),
     ("bof_scsrcsc", C.c_int, [i64, i64, i64, P, P, P, P, P, P, P]),
@@ -79,11 +80,15 @@ SYMBOLS = [
     ("bof_csr_blocks", i64, [P, i64, i64, i64, i64, P, P, i64]),
     ("bof_gemm_resident", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P, i64, i64,
                                     i64, C.POINTER(Options), P]),
+    ("bof_kmeans_resident", C.c_int, [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P, i64, i64,
+                                      i64, P, P, P, C.POINTER(Options), P]),
     ("bof_csrmm_resident", C.c_int, [chr_, i64, i64, i64, f32, f32, P, P, P, P, chr_, P, P,
                                      C.POINTER(Options), P]),
     ("bof_csrgemv_resident", C.c_int, [chr_, i64, i64, P, P, P, P, P, P, C.POINTER(Options), P]),
     ("bof_flash_gemm", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr,
                                  u64, u64, u64, C.POINTER(Options)]),
+    ("bof_flash_kmeans", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr,
+                                   u64, u64, u64, P, P, P, C.POINTER(Options)]),
     ("bof_flash_csrmm", C.c_int, [chr_, u64, u64, u64, f32, f32, FPtr, FPtr, FPtr, chr_, FPtr,
                                   FPtr, C.POINTER(Options)]),
     ("bof_flash_csrcsc", C.c_int, [u64, u64, FPtr, FPtr, FPtr, FPtr, FPtr, FPtr, C.POINTER(Options)]),
@@ -170,6 +175,12 @@ def sgemm(ord_, ta, tb, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc
                           c_ptr, ldc, stream), "bof_sgemm")
 
 
+def skmeans_task(ord_, ta, tb, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc, c_l2sq, p_l2sq, ones,
+                 stream=0):
+    check(lib().bof_skmeans_task(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta,
+                                 c_ptr, ldc, c_l2sq, p_l2sq, ones, stream), "bof_skmeans_task")
+
+
 def scsrmm(ord_b, m, n, k, alpha, val, col, ptr, b, ldb, beta, c, ldc, stream=0):
     check(lib().bof_scsrmm(_c(ord_b), m, n, k, alpha, val, col, ptr, b, ldb, beta, c, ldc, stream),
           "bof_scsrmm")
@@ -216,6 +227,13 @@ def gemm_resident(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda=0, ldb=0, ldc
           "bof_gemm_resident")
 
 
+def kmeans_resident(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, c_l2sq, p_l2sq, ones,
+                    opts=None, stream=0):
+    check(lib().bof_kmeans_resident(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, a, b, c, lda, ldb, ldc,
+                                    c_l2sq, p_l2sq, ones, C.byref(opts) if opts is not None else None, stream),
+          "bof_kmeans_resident")
+
+
 def csrmm_resident(trans_a, m, n, k, alpha, beta, val, ia_host, ia_dev, ja, ord_b, b, c, opts=None,
                    stream=0):
     check(lib().bof_csrmm_resident(_c(trans_a), m, n, k, alpha, beta, val, ia_host, ia_dev, ja,
@@ -233,6 +251,13 @@ def csrgemv_resident(trans_a, m, n, val, ia_host, ia_dev, ja, x, y, opts=None, s
 def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda=0, ldb=0, ldc=0, opts=None):
     check(lib().bof_flash_gemm(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, fa, fb, fc, lda, ldb,
                                ldc, C.byref(opts) if opts is not None else None), "bof_flash_gemm")
+
+
+def flash_kmeans(ord_, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, c_l2sq, p_l2sq, ones, opts=None):
+    """c_l2sq / p_l2sq / ones: host addresses (numpy .ctypes.data)."""
+    check(lib().bof_flash_kmeans(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc,
+                                 c_l2sq, p_l2sq, ones, C.byref(opts) if opts is not None else None),
+          "bof_flash_kmeans")
 
 
 def flash_csrmm(trans_a, m, n, k, alpha, beta, fa, fia, fja, ord_b, fb, fc, opts=None):

@@ -23,6 +23,24 @@ int hip_fail(hipError_t e, const char *what);  // records message, returns BOF_E
 hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                  const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                  int64_t ldc, hipStream_t st);
+// sgemm + the two rank-1 updates of KMeansTask::execute fused into the store (u by C row, v by C column)
+hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                         const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+                         int64_t ldc, const float *u1, const float *v1, const float *u2, const float *v2,
+                         hipStream_t st);
+// the norm vectors of flash::kmeans in HBM (null pointer to the struct: plain gemm)
+struct KmeansVecs {
+  const float *c_l2sq, *p_l2sq, *ones;
+};
+// One tile task of the gemm / kmeans tilers: row0 / col0 = the tile's first row / column of C
+// (kmeans.cpp:115-118 offsets c_l2sq and p_l2sq by them; `ones` is passed un-offset).
+inline hipError_t tile_sgemm(char ord, char ta, char tb, int64_t M, int64_t N, int64_t K, float alpha,
+                             const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+                             int64_t ldc, const KmeansVecs *kv, int64_t row0, int64_t col0, hipStream_t st) {
+  if (!kv) return sgemm(ord, ta, tb, M, N, K, alpha, a, lda, b, ldb, beta, c, ldc, st);
+  return sgemm_rank1x2(ord, ta, tb, M, N, K, alpha, a, lda, b, ldb, beta, c, ldc, kv->c_l2sq + row0, kv->ones,
+                       kv->ones, kv->p_l2sq + col0, st);
+}
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
                   float *c, int64_t ldc, hipStream_t st);

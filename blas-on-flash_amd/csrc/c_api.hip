@@ -189,6 +189,19 @@ int bof_sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float
   return BOF_OK;
 }
 
+int bof_skmeans_task(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                     const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+                     int64_t ldc, const float *c_l2sq, const float *p_l2sq, const float *ones, void *stream) {
+  if (!flag_ok(ord, 'R', 'C') || !flag_ok(ta, 'N', 'T') || !flag_ok(tb, 'N', 'T') || m < 0 ||
+      n < 0 || k < 0 || m > INT32_MAX || n > INT32_MAX || k > INT32_MAX || !c_l2sq || !p_l2sq || !ones) {
+    set_error("bof_skmeans_task: bad argument");
+    return BOF_EINVAL;
+  }
+  BOF_HIP_TRY(sgemm_rank1x2(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, c_l2sq, ones, ones, p_l2sq,
+                            (hipStream_t) stream));
+  return BOF_OK;
+}
+
 int bof_scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
                float *c, int64_t ldc, void *stream) {
@@ -231,12 +244,14 @@ int bof_scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64
 }
 
 // ---- level 2 ------------------------------------------------------------------
-int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
-                      float beta, const float *a, const float *b, float *c, int64_t lda,
-                      int64_t ldb, int64_t ldc, const bof_options *opts, void *stream) {
+// the tile DAG of flash::gemm (kv == nullptr) / flash::kmeans over resident matrices
+static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                              float beta, const float *a, const float *b, float *c, int64_t lda,
+                              int64_t ldb, int64_t ldc, const bof_options *opts, void *stream,
+                              const KmeansVecs *kv) {
   if (!flag_ok(ord, 'R', 'C') || !flag_ok(ta, 'N', 'T') || !flag_ok(tb, 'N', 'T') || m < 0 ||
       n < 0 || k < 0) {
-    set_error("bof_gemm_resident: bad argument");
+    set_error(kv ? "bof_kmeans_resident: bad argument" : "bof_gemm_resident: bad argument");
     return BOF_EINVAL;
   }
   const bof_options o = resolved(opts);
@@ -290,7 +305,8 @@ int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   rc = ss->fork(parent);
   if (rc) return rc;
   if (g.nblk[1] == 0) {  // k == 0: C = beta*C through a single degenerate pass
-    BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, 0, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], ss->s[0]));
+    // (kmeans: the reference's tiler creates no task at all, src/blas/kmeans.cpp:88-90 -- C stays)
+    if (!kv) BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, 0, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], ss->s[0]));
     return ss->join(parent);
   }
   bof_gemm_task t;
@@ -300,10 +316,29 @@ int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
         gemm_task_at(g, l, i, j, beta, &t);
         // chain (i,j) is pinned to one stream: FIFO order gives (l-1,i,j) -> (l,i,j)
         hipStream_t st = ss->s[(i * g.nblk[2] + j) % ss->n];
-        BOF_HIP_TRY(sgemm(ord, ta, tb, t.M, t.N, t.K, alpha, a + t.off[0], t.ld_file[0],
-                          b + t.off[1], t.ld_file[1], t.beta, c + t.off[2], t.ld_file[2], st));
+        BOF_HIP_TRY(tile_sgemm(ord, ta, tb, t.M, t.N, t.K, alpha, a + t.off[0], t.ld_file[0],
+                               b + t.off[1], t.ld_file[1], t.beta, c + t.off[2], t.ld_file[2], kv,
+                               i * g.blk[0], j * g.blk[2], st));
       }
   return ss->join(parent);
+}
+
+int bof_gemm_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                      float beta, const float *a, const float *b, float *c, int64_t lda,
+                      int64_t ldb, int64_t ldc, const bof_options *opts, void *stream) {
+  return gemm_resident_impl(ord, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, opts, stream, nullptr);
+}
+
+int bof_kmeans_resident(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                        float beta, const float *a, const float *b, float *c, int64_t lda,
+                        int64_t ldb, int64_t ldc, const float *c_l2sq, const float *p_l2sq,
+                        const float *ones, const bof_options *opts, void *stream) {
+  if (!c_l2sq || !p_l2sq || !ones) {
+    set_error("bof_kmeans_resident: bad argument");
+    return BOF_EINVAL;
+  }
+  const KmeansVecs kv{c_l2sq, p_l2sq, ones};
+  return gemm_resident_impl(ord, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, opts, stream, &kv);
 }
 
 int bof_csrmm_resident(char trans_a, int64_t m, int64_t n, int64_t k, float alpha, float beta,

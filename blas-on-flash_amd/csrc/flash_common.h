@@ -162,7 +162,7 @@ void publish_stats(const Counters &c, double seconds);    // what bof_flash_last
 // cache of flash_runtime.cpp must take it.
 int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
                       bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
-                      const bof_options &o);
+                      const bof_options &o, const KmeansVecs *kv = nullptr);
 void panel_resources_release();
 
 }  // namespace bof

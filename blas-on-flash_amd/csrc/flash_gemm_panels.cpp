@@ -296,7 +296,7 @@ void panel_resources_release() {
 
 int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
                       bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
-                      const bof_options &o) {
+                      const bof_options &o, const KmeansVecs *kv) {
   PanelRun R;
   R.t_begin = std::chrono::steady_clock::now();
   R.o = o;
@@ -514,7 +514,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       const float *pa = (const float *) R.mat[0].panel_ptr(pn[0]) + idx[R.mat[0].cdim] * R.mat[0].blk_c;
       const float *pb = (const float *) R.mat[1].panel_ptr(pn[1]) + idx[R.mat[1].cdim] * R.mat[1].blk_c;
       float *pcp = (float *) C.panel_ptr(pn[2]) + idx[C.cdim] * C.blk_c;
-      herr = sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, pa, R.mat[0].ld, pb, R.mat[1].ld, tk.beta, pcp, C.ld, st);
+      herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, pa, R.mat[0].ld, pb, R.mat[1].ld, tk.beta, pcp, C.ld,
+                        kv, tk.i * g.blk[0], tk.j * g.blk[2], st);
       if (herr != hipSuccess) break;
       R.cnt.tasks++;
     }

@@ -341,7 +341,7 @@ static bool trace_on() {
 
 static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                            float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
-                           int64_t ldb, int64_t ldc, const bof_options *opts) {
+                           int64_t ldb, int64_t ldc, const bof_options *opts, const KmeansVecs *kv = nullptr) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
@@ -361,7 +361,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
 
   // ---- large working budgets: whole row panels in file layout, big sequential requests ----
   if (R.o.gemm_path != 1) {
-    rc = flash_gemm_panels(ord, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, R.o);
+    rc = flash_gemm_panels(ord, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, R.o, kv);
     if (rc <= 0) return rc;
     if (R.o.gemm_path == 2) {
       set_error("bof_flash_gemm: gemm_path = 2 (panels) but the call is not eligible: C rows must be "
@@ -520,8 +520,9 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
     DevSlot &sa = R.slots[R.tiles[ids[0]].slot], &sb = R.slots[R.tiles[ids[1]].slot],
             &sc = R.slots[R.tiles[ids[2]].slot];
     // packed tiles: leading dim = stored column count (reference gemm.cpp:117-120)
-    herr = sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
-                 (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], st);
+    herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
+                      (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], kv,
+                      tk.i * g.blk[0], tk.j * g.blk[2], st);
     if (herr != hipSuccess) break;
     R.cnt.tasks++;
     DevSlot *used[3] = {&sa, &sb, &sc};
@@ -1462,6 +1463,43 @@ int bof_flash_gemm(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_t 
   }
   return flash_gemm_impl(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, b, c,
                          (int64_t) lda, (int64_t) ldb, (int64_t) ldc, opts);
+}
+
+// flash::kmeans (reference src/blas/kmeans.cpp:27-198): the gemm tiler with KMeansTask tasks.
+// The norm vectors live in host memory as in the reference; they are uploaded once and every
+// tile task adds its slices in its store.
+int bof_flash_kmeans(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_t k, float alpha,
+                     float beta, bof_fptr a, bof_fptr b, bof_fptr c, uint64_t lda, uint64_t ldb,
+                     uint64_t ldc, const float *c_l2sq, const float *p_l2sq, const float *ones,
+                     const bof_options *opts) {
+  if (!(ord == 'R' || ord == 'C') || !(ta == 'N' || ta == 'T') || !(tb == 'N' || tb == 'T') ||
+      a.fd < 0 || b.fd < 0 || c.fd < 0 || !c_l2sq || !p_l2sq || !ones) {
+    set_error("bof_flash_kmeans: bad argument");
+    return BOF_EINVAL;
+  }
+  if (m == 0 || n == 0 || k == 0) return BOF_OK;   // no task is created (kmeans.cpp:88-90)
+  int rc = device_ready();
+  if (rc) return rc;
+  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
+  const bof_options o = resolved(opts);
+  const GemmGeometry g = gemm_geometry(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, (int64_t) lda,
+                                       (int64_t) ldb, (int64_t) ldc, o.gemm_blk);
+  // `ones` is indexed by tile-local row and column (kmeans_task.h:74-81 passes it un-offset)
+  int64_t n_ones = 0;
+  for (int d = 0; d < 3; d += 2) {
+    const int64_t last = g.size[d] - (g.nblk[d] - 1) * g.blk[d];
+    n_ones = std::max(n_ones, std::max(last, std::min(g.size[d], g.blk[d])));
+  }
+  float *dv = nullptr;
+  BOF_HIP_TRY(hipMalloc((void **) &dv, (size_t) (m + n + (uint64_t) n_ones) * sizeof(float)));
+  Cleanup guard;
+  guard.add([&] { (void) hipFree(dv); });
+  BOF_HIP_TRY(hipMemcpy(dv, c_l2sq, (size_t) m * sizeof(float), hipMemcpyHostToDevice));
+  BOF_HIP_TRY(hipMemcpy(dv + m, p_l2sq, (size_t) n * sizeof(float), hipMemcpyHostToDevice));
+  BOF_HIP_TRY(hipMemcpy(dv + m + n, ones, (size_t) n_ones * sizeof(float), hipMemcpyHostToDevice));
+  const KmeansVecs kv{dv, dv + m, dv + m + n};
+  return flash_gemm_impl(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, b, c,
+                         (int64_t) lda, (int64_t) ldb, (int64_t) ldc, opts, &kv);
 }
 
 int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha, float beta,

@@ -28,6 +28,33 @@ constexpr int BK = 32;
 constexpr int XLD = BK + 4;  // XMAJOR LDS row stride (floats): conflict-free b128 reads
 enum { XMAJOR = 0, KMAJOR = 1 };
 
+// ---- epilogue policies -------------------------------------------------------
+// NoEpi: plain sgemm (what every GemmTask runs).  Rank1x2: the two K = 1 products that
+// KMeansTask::execute adds to its tile after the main product (reference
+// include/tasks/kmeans_task.h:73-81), fused into the store: each is rounded as the
+// k-ordered chain above rounds a K = 1 sgemm with alpha = beta = 1,
+//   c = c + round(u1[row]*v1[col]);  c = c + round(u2[row]*v2[col])
+// (row, col: element of the row-major C this launch produces), so the fused tile equals the
+// three-call sequence bit for bit while C crosses HBM once instead of five times.
+struct NoEpi {
+  static constexpr bool active = false;
+};
+struct Rank1x2 {
+  static constexpr bool active = true;
+  const float *u1, *v1, *u2, *v2;
+  __host__ __device__ Rank1x2 shifted(int64_t dr, int64_t dc) const { return Rank1x2{u1 + dr, v1 + dc, u2 + dr, v2 + dc}; }
+};
+inline NoEpi epi_shift(const NoEpi &e, int64_t, int64_t) { return e; }
+inline Rank1x2 epi_shift(const Rank1x2 &e, int64_t dr, int64_t dc) { return e.shifted(dr, dc); }
+template <class EP>
+__device__ __forceinline__ float epi_apply(const EP &ep, float t, int row, int col) {
+  if constexpr (EP::active) {
+    t = __fadd_rn(t, __fmul_rn(ep.u1[row], ep.v1[col]));
+    t = __fadd_rn(t, __fmul_rn(ep.u2[row], ep.v2[col]));
+  }
+  return t;
+}
+
 // ---- global -> registers ---------------------------------------------------
 // One K-slab of one operand of extent BX is BX*8 float4; thread t owns float4
 // #(t + NTHR*p), p = 0..NP-1, kept in registers across the MFMA phase.
@@ -115,11 +142,11 @@ __device__ __forceinline__ f32x4 s2op(const float *__restrict__ s, int x, int q,
 //        whole launch is co-resident (no tail round); one barrier per slab: while slab
 //        kt is multiplied out of buffer kt&1, slab kt+1 (fetched one slab earlier) is
 //        written to the other buffer and slab kt+2's global loads are in flight.
-template <int BM, int BN, int WM, int WN, bool DBUF, int AMODE, int BMODE, bool GUARD>
+template <int BM, int BN, int WM, int WN, bool DBUF, int AMODE, int BMODE, bool GUARD, class EP = NoEpi>
 __global__ void __launch_bounds__(64 * WM * WN, 3)
 sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                   int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
-                  float alpha, float beta, int tiles_m, int tiles_n) {
+                  float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -235,8 +262,9 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
         const int dr = mt * 32 + (r & 3) + 8 * (r >> 2), dc = nt * 32;
         float *dst = ctile + ((int64_t) dr * ldc + dc);
         if (!GUARD || (m0 + lrow + dr < M && n0 + lcol + dc < N))
-          dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                        : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+          dst[lane_off] = epi_apply(ep, (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]),
+                                    m0 + lrow + dr, n0 + lcol + dc);
       }
     }
 }
@@ -244,9 +272,10 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
 // Epilogue shared by the one-wave-per-SIMD 256 x 256 kernels: the wave's 128 x 128 tile (4 x 4
 // accumulators of 32 x 32; lane (i, h) holds rows 8q + 4h' ... of column i, the MFMA output
 // layout) goes out as c = beta == 0 ? alpha*acc : fmaf(alpha, acc, beta*c).
+template <class EP>
 __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64_t ldc, int m0, int n0, int wm,
                                                     int wn, int h, int i, const f32x16 (&acc)[4][4], float alpha,
-                                                    float beta) {
+                                                    float beta, const EP &ep) {
   float *ctile = C + (int64_t) m0 * ldc + n0;
   const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
 #pragma unroll
@@ -262,8 +291,9 @@ __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+        dst[lane_off] = epi_apply(ep, (beta == 0.f) ? alpha * acc[mt][nt][r]
+                                                    : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]),
+                                  m0 + wm * 128 + 4 * h + mt * 32 + (r & 3) + 8 * (r >> 2), n0 + wn * 128 + i + nt * 32);
       }
     }
 }
@@ -386,11 +416,11 @@ __device__ __forceinline__ void slab_1w2(const Bases1w bs, const float *__restri
   }
 }
 
-template <int AMODE, int BMODE, bool KTAIL = false>
+template <int AMODE, int BMODE, bool KTAIL = false, class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                          int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
-                         float alpha, float beta, int tiles_m, int tiles_n) {
+                         float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
   constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
   constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
   constexpr int LDS_BUF = LDS_A + LDS_B;
@@ -489,7 +519,7 @@ sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *
     slab_1w2<AMODE, BMODE, false, false>(bs, Ao, lda, Bo, ldb, 0, a_goff, b_goff, ra, rb, acc);
   }
 
-  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta);
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta, ep);
 }
 
 
@@ -587,10 +617,11 @@ __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const 
   }
 }
 
+template <class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                           int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
-                          float alpha, float beta, int tiles_m, int tiles_n) {
+                          float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
   constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;   // floats
   __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF];
   const int nwg = tiles_m * tiles_n;
@@ -666,7 +697,7 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead fragment reads of the last slab
 
-  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta);
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta, ep);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -782,11 +813,11 @@ __device__ __forceinline__ void slab_1w3(const uint32_t (&a_rd)[2], const uint32
   }
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                          int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
-                         float alpha, float beta, int tiles_m, int tiles_n) {
+                         float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
   constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
   constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
   constexpr int LDS_BUF = LDS_A + LDS_B;
@@ -895,25 +926,25 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // look-ahead loads/reads of the last slabs
 
-  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta);
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta, ep);
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, class EP>
 static hipError_t launch_guarded(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                                  int64_t ldc, int M, int N, int K, float alpha, float beta,
-                                 hipStream_t st) {
+                                 hipStream_t st, EP ep) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
-  hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, true>),
+  hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, true, EP>),
                      dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha,
-                     beta, tiles_m, tiles_n);
+                     beta, tiles_m, tiles_n, ep);
   return hipGetLastError();
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, class EP>
 static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int64_t ldb,
                                float *C, int64_t ldc, int M, int N, int K, float alpha,
-                               float beta, hipStream_t st) {
+                               float beta, hipStream_t st, EP ep) {
   const bool vec_ld = (lda % 4 == 0) && (ldb % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -935,52 +966,54 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   if (vec_ld && k_ok && (int64_t) (Mi / 256) * (Ni / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
     const int tiles_m = Mi / 256, tiles_n = Ni / 256;
     if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
-      hipLaunchKernelGGL(sgemm_tile256_dma2_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
-                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+      hipLaunchKernelGGL(sgemm_tile256_dma2_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
+                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else if (K % (2 * BK) == 0)
-      hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
-                         A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+      hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE, EP>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
+                         A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else if (K % BK == 0)
-      hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, false>), dim3(tiles_m * tiles_n), dim3(256),
-                         0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+      hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, false, EP>), dim3(tiles_m * tiles_n), dim3(256),
+                         0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else
-      hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, true>), dim3(tiles_m * tiles_n), dim3(256),
-                         0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n);
+      hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, true, EP>), dim3(tiles_m * tiles_n), dim3(256),
+                         0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (N > Ni) {  // right strip: rows [0, Mi), columns [Ni, N)
       const float *Bs = (BMODE == XMAJOR) ? B + (int64_t) Ni * ldb : B + Ni;
-      e = launch_guarded<AMODE, BMODE>(A, lda, Bs, ldb, C + Ni, ldc, Mi, N - Ni, K, alpha, beta, st);
+      e = launch_guarded<AMODE, BMODE>(A, lda, Bs, ldb, C + Ni, ldc, Mi, N - Ni, K, alpha, beta, st,
+                                       epi_shift(ep, 0, Ni));
       if (e != hipSuccess) return e;
     }
     if (M > Mi) {  // bottom strip: rows [Mi, M), all columns
       const float *As = (AMODE == XMAJOR) ? A + (int64_t) Mi * lda : A + Mi;
       e = launch_guarded<AMODE, BMODE>(As, lda, B, ldb, C + (int64_t) Mi * ldc, ldc, M - Mi, N, K, alpha,
-                                       beta, st);
+                                       beta, st, epi_shift(ep, Mi, 0));
     }
     return e;
   }
   const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
   dim3 grid(tiles_m * tiles_n), block(256);
   if (vec_ok && M % 128 == 0 && N % 128 == 0)
-    hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, false>), grid, block,
-                       0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+    hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, false, EP>), grid, block,
+                       0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n, ep);
   else
-    hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, true>), grid, block,
-                       0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n);
+    hipLaunchKernelGGL((sgemm_tile_kernel<128, 128, 2, 2, false, AMODE, BMODE, true, EP>), grid, block,
+                       0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, tiles_m, tiles_n, ep);
   return hipGetLastError();
 }
 
 // Row-major core: C[M x N] = alpha*op(A)*op(B) + beta*C.
+template <class EP>
 static hipError_t sgemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float *A,
                            int64_t lda, const float *B, int64_t ldb, float beta, float *C,
-                           int64_t ldc, hipStream_t st) {
+                           int64_t ldc, hipStream_t st, EP ep) {
   // A: 'N' stored [M][K] -> XMAJOR; 'T' stored [K][M] -> KMAJOR
   // B: 'N' stored [K][N] -> KMAJOR; 'T' stored [N][K] -> XMAJOR
-  if (!ta && !tb) return launch_modes<XMAJOR, KMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st);
-  if (!ta && tb)  return launch_modes<XMAJOR, XMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st);
-  if (ta && !tb)  return launch_modes<KMAJOR, KMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st);
-  return launch_modes<KMAJOR, XMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st);
+  if (!ta && !tb) return launch_modes<XMAJOR, KMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
+  if (!ta && tb)  return launch_modes<XMAJOR, XMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
+  if (ta && !tb)  return launch_modes<KMAJOR, KMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
+  return launch_modes<KMAJOR, XMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
 }
 
 // cblas_sgemm argument meaning.  Column-major: C^T = op(B)^T * op(A)^T.
@@ -990,9 +1023,26 @@ hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, fl
   if (m == 0 || n == 0) return hipSuccess;
   if (ord == 'C')
     return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta,
-                    c, ldc, st);
+                    c, ldc, st, NoEpi{});
   return sgemm_rm(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c,
-                  ldc, st);
+                  ldc, st, NoEpi{});
+}
+
+// KMeansTask::execute on one tile (reference include/tasks/kmeans_task.h:53-82):
+//   C = alpha*op(A)*op(B) + beta*C;  C[r][c] += u1[r]*v1[c];  C[r][c] += u2[r]*v2[c]
+// with r along m and c along n whatever the storage order (the reference passes
+// u1 = c_l2sq, v1 = ones, u2 = ones, v2 = p_l2sq).  Column-major runs as the row-major product
+// of the swapped operands, where the roles of the row and column vectors swap with them.
+hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                         const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
+                         int64_t ldc, const float *u1, const float *v1, const float *u2, const float *v2,
+                         hipStream_t st) {
+  if (m == 0 || n == 0) return hipSuccess;
+  if (ord == 'C')
+    return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta,
+                    c, ldc, st, Rank1x2{v1, u1, v2, u2});
+  return sgemm_rm(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c,
+                  ldc, st, Rank1x2{u1, v1, u2, v2});
 }
 
 }  // namespace bof

@@ -21,6 +21,9 @@
  *            blas-on-flash_amd/include/flash_blas.h bind to
  *              include/flash_blas.h:14-18, 37-40, 55-57
  *            -> bof_flash_gemm / bof_flash_csrmm / bof_flash_csrgemv.
+ *   next rows: bof_*_csrcsc, csrmm 'T', column-major B/C, and flash::kmeans as
+ *            a fused GEMM epilogue (include/tasks/kmeans_task.h:53-82) at all three levels
+ *            -> bof_skmeans_task / bof_kmeans_resident / bof_flash_kmeans.
  *
  * Conventions: all integers 64-bit (reference builds with -DMKL_ILP64,
  * include/bof_types.h:11-28); CSR index and offset arrays are int64 exactly as
@@ -102,6 +105,20 @@ int bof_mem_info(size_t *free_bytes, size_t *total_bytes);
 int bof_sgemm(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
               int64_t k, float alpha, const float *a, int64_t lda, const float *b,
               int64_t ldb, float beta, float *c, int64_t ldc, void *stream);
+/* KMeansTask::execute (include/tasks/kmeans_task.h:53-82) on one tile, as ONE kernel: the
+ * sgemm above, then the task's two K = 1 products added in the store,
+ *   C[r][c] += c_l2sq[r] * ones[c];   C[r][c] += ones[r] * p_l2sq[c]
+ * (r along m, c along n, for both storage orders), each rounded as the task's
+ * cblas_sgemm(.., K = 1, alpha = 1, beta = 1) rounds it: c = c + round(u*v).  The fused tile
+ * equals the three-call sequence bit for bit; C crosses HBM once instead of five times.
+ * c_l2sq: >= m, p_l2sq: >= n, ones: >= max(m, n) floats, all DEVICE pointers.
+ * Row-major note: the reference hands its K = 1 products lda = a_nrows for an a_nrows x 1
+ * row-major operand (kmeans_task.h:74-75), i.e. it reads c_l2sq[r * a_nrows] -- out of bounds;
+ * its driver only ever uses 'C' (drivers/kmeans.cpp:37-39).  Here 'R' has the meaning above. */
+int bof_skmeans_task(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
+                     int64_t k, float alpha, const float *a, int64_t lda, const float *b,
+                     int64_t ldb, float beta, float *c, int64_t ldc, const float *c_l2sq,
+                     const float *p_l2sq, const float *ones, void *stream);
 
 /* C[m x n] = alpha * A[m x k] * B[k x n] + beta * C with A in 0-based CSR:
  * mkl_scsrmm('N', m, n, k, alpha, "GXXC"|"GXXF", val, col, ptr, ptr+1, b, ldb,
@@ -171,6 +188,18 @@ int bof_gemm_resident(char ord, char trans_a, char trans_b, int64_t m, int64_t n
                       int64_t k, float alpha, float beta, const float *a,
                       const float *b, float *c, int64_t lda, int64_t ldb,
                       int64_t ldc, const bof_options *opts, void *stream);
+/* flash::kmeans (src/blas/kmeans.cpp:27-198) over resident matrices: the gemm
+ * tiler with one bof_skmeans_task per tile.  Tile (l, i, j) gets c_l2sq + i*blk_m and
+ * p_l2sq + j*blk_n and the un-offset `ones` (kmeans.cpp:115-118, 128-131); like the
+ * reference, EVERY k-block's task adds the two products, so they are added N_k times when k
+ * spans several blocks (the reference's use has k = the point dimension <= one block).
+ * k == 0 or an empty C: no task, C untouched.  c_l2sq: m, p_l2sq: n, ones: the largest tile
+ * edge (<= min(max(m, n), gemm_blk + 127)) floats, DEVICE pointers. */
+int bof_kmeans_resident(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
+                        int64_t k, float alpha, float beta, const float *a,
+                        const float *b, float *c, int64_t lda, int64_t ldb,
+                        int64_t ldc, const float *c_l2sq, const float *p_l2sq,
+                        const float *ones, const bof_options *opts, void *stream);
 /* flash::csrmm 'N' (src/blas/csrmm.cpp:64-126, 203-266): row blocks by nnz
  * budget x column panels; ia_host is the host copy of the offsets (the
  * reference also reads `ia` to the host first, csrmm.cpp:69-71), ia_dev the
@@ -197,6 +226,14 @@ int bof_flash_gemm(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
                    uint64_t k, float alpha, float beta, bof_fptr a, bof_fptr b,
                    bof_fptr c, uint64_t lda, uint64_t ldb, uint64_t ldc,
                    const bof_options *opts);
+/* flash::kmeans (include/flash_blas.h:20-25): bof_flash_gemm's pipeline with the tasks of
+ * bof_kmeans_resident.  c_l2sq (m), p_l2sq (n) and ones (largest tile edge) are HOST arrays,
+ * as in the reference; blocking. */
+int bof_flash_kmeans(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
+                     uint64_t k, float alpha, float beta, bof_fptr a, bof_fptr b,
+                     bof_fptr c, uint64_t lda, uint64_t ldb, uint64_t ldc,
+                     const float *c_l2sq, const float *p_l2sq, const float *ones,
+                     const bof_options *opts);
 /* include/flash_blas.h:37-40.  A is an m x n CSR.  trans_a 'N': B n x k, C m x k.
  * trans_a 'T': C[n x k] = alpha * A^T * B[m x k] + beta * C; A^T is built in HBM by
  * bof_scsrcsc (the reference goes through csrcsc into temporary files,

@@ -254,6 +254,65 @@ void orc_flash_gemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
   free(tasks);
 }
 
+/* KMeansTask::execute (include/tasks/kmeans_task.h:53-82): the tile product, then two K = 1
+ * products with alpha = beta = 1:
+ *   mkl_gemm(ord, NoTrans, Trans, a_nrows, b_ncols, 1, 1.0, c_l2sq, a_nrows, ones, b_ncols, 1.0, C, ldc)
+ *   mkl_gemm(ord, NoTrans, Trans, a_nrows, b_ncols, 1, 1.0, ones, a_nrows, p_l2sq, b_ncols, 1.0, C, ldc)
+ * i.e. C[r][c] += c_l2sq[r]*ones[c], then C[r][c] += ones[r]*p_l2sq[c].
+ * Column-major ('C', the only order the reference's driver uses, drivers/kmeans.cpp:37-39) is
+ * restated call for call.  Row-major is NOT: there the reference's leading dimensions
+ * (a_nrows for an a_nrows x 1 row-major operand) make cblas read c_l2sq[r * a_nrows], out of
+ * bounds for every r > 0, and its tiler offsets c_l2sq by the COLUMN block (kmeans.cpp:115-118);
+ * for 'R' this oracle states the evident intent -- the same two updates, r along m, c along n
+ * (leading dimensions 1) -- and the product documents the deviation (include/bof_hip.h). */
+void orc_skmeans_task(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                      float alpha, const float *a, int64_t lda, const float *b,
+                      int64_t ldb, float beta, float *c, int64_t ldc,
+                      const float *c_l2sq, const float *p_l2sq, const float *ones) {
+  orc_sgemm(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+  if (ord == 'C') {
+    orc_sgemm('C', 'N', 'T', m, n, 1, 1.0f, c_l2sq, m, ones, n, 1.0f, c, ldc);
+    orc_sgemm('C', 'N', 'T', m, n, 1, 1.0f, ones, m, p_l2sq, n, 1.0f, c, ldc);
+  } else {
+    orc_sgemm('R', 'N', 'T', m, n, 1, 1.0f, c_l2sq, 1, ones, 1, 1.0f, c, ldc);
+    orc_sgemm('R', 'N', 'T', m, n, 1, 1.0f, ones, 1, p_l2sq, 1, 1.0f, c, ldc);
+  }
+}
+
+/* src/blas/kmeans.cpp:27-198: flash::gemm's tiler (same blocks, same tail-merge rule :76-81,
+ * same packed tiles :128-131, beta = 1 for l > 0 :121-122) with KMeansTask tasks.  Tile
+ * (l, i, j) gets c_l2sq + i*blk_m and p_l2sq + j*blk_n (:115-118 for 'C'; see above for 'R')
+ * and the un-offset `ones`; every l runs the whole task, so the two updates are added once
+ * per k-block. */
+void orc_flash_kmeans(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                      float alpha, float beta, const float *a, const float *b,
+                      float *c, int64_t lda, int64_t ldb, int64_t ldc, int64_t blk,
+                      const float *c_l2sq, const float *p_l2sq, const float *ones) {
+  int64_t nblk[3];
+  int64_t nt = orc_gemm_plan(ord, ta, tb, m, n, k, beta, lda, ldb, ldc, blk, NULL, 0, nblk);
+  if (nt <= 0) return;
+  orc_gemm_task *tasks = (orc_gemm_task *) malloc(sizeof(orc_gemm_task) * (size_t) nt);
+  orc_gemm_plan(ord, ta, tb, m, n, k, beta, lda, ldb, ldc, blk, tasks, nt, nblk);
+  const int64_t blk_m = blk < m ? blk : m, blk_n = blk < n ? blk : n;
+  for (int64_t t = 0; t < nt; t++) {
+    orc_gemm_task *T = &tasks[t];
+    float *ta_ = (float *) malloc(sizeof(float) * (size_t) (T->nrows[0] * T->ncols[0]));
+    float *tb_ = (float *) malloc(sizeof(float) * (size_t) (T->nrows[1] * T->ncols[1]));
+    float *tc_ = (float *) malloc(sizeof(float) * (size_t) (T->nrows[2] * T->ncols[2]));
+    gather_tile(ta_, a, T->off[0], T->nrows[0], T->ncols[0], T->ld_file[0]);
+    gather_tile(tb_, b, T->off[1], T->nrows[1], T->ncols[1], T->ld_file[1]);
+    if (T->beta != 0.0f)
+      gather_tile(tc_, c, T->off[2], T->nrows[2], T->ncols[2], T->ld_file[2]);
+    orc_skmeans_task(ord, ta, tb, T->M, T->N, T->K, alpha, ta_, T->ncols[0], tb_, T->ncols[1],
+                     T->beta, tc_, T->ncols[2], c_l2sq + T->i * blk_m, p_l2sq + T->j * blk_n, ones);
+    for (int64_t r = 0; r < T->nrows[2]; r++)
+      memcpy(c + T->off[2] + r * T->ld_file[2], tc_ + r * T->ncols[2],
+             sizeof(float) * (size_t) T->ncols[2]);
+    free(ta_); free(tb_); free(tc_);
+  }
+  free(tasks);
+}
+
 /* mkl_scsrmm('N', m, n, k, alpha, "GXXC"|"GXXF", val, col, pntrb, pntre, B, ldb,
  * beta, C, ldc): include/tasks/csrmm_task.h:226-228 (row-major, 0-based) and
  * :310-312 (column-major; the reference converts to 1-based first, we keep

@@ -85,6 +85,17 @@ void orc_flash_gemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
                     float alpha, float beta, const float *a, const float *b,
                     float *c, int64_t lda, int64_t ldb, int64_t ldc,
                     int64_t blk);
+/* KMeansTask::execute (include/tasks/kmeans_task.h:53-82) and flash::kmeans
+ * (src/blas/kmeans.cpp:27-198); see the notes in bof_oracle.c about row-major. */
+void orc_skmeans_task(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                      float alpha, const float *a, int64_t lda, const float *b,
+                      int64_t ldb, float beta, float *c, int64_t ldc,
+                      const float *c_l2sq, const float *p_l2sq, const float *ones);
+void orc_flash_kmeans(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                      float alpha, float beta, const float *a, const float *b,
+                      float *c, int64_t lda, int64_t ldb, int64_t ldc, int64_t blk,
+                      const float *c_l2sq, const float *p_l2sq, const float *ones);
+
 /* mkl_scsrmm('N', ..., "GXXC"/"GXXF") semantics (include/tasks/csrmm_task.h:
  * 226-228, 310-312; drivers/in_mem_csrmm.cpp:100-120) with 0-based indices in
  * both layouts: C[m x n] = alpha * A[m x k](CSR) * B[k x n] + beta * C.

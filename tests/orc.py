@@ -49,6 +49,10 @@ def lib():
         L.orc_sgemm.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64]
         L.orc_flash_gemm.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P,
                                      i64, i64, i64, i64]
+        L.orc_skmeans_task.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64,
+                                       P, P, P]
+        L.orc_flash_kmeans.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P,
+                                       i64, i64, i64, i64, P, P, P]
         L.orc_scsrmm.argtypes = [chr_, i64, i64, i64, f32, P, P, P, P, P, i64, f32, P, i64]
         L.orc_flash_csrmm.argtypes = [chr_, i64, i64, i64, f32, f32, P, P, P, P, P, i64, i64, i64]
         L.orc_scsrgemv.argtypes = [chr_, i64, i64, P, P, P, P, P]
@@ -125,6 +129,19 @@ def sgemm(ord_, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
 def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, blk):
     lib().orc_flash_gemm(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, _p(a), _p(b), _p(c),
                          lda, ldb, ldc, blk)
+    return c
+
+
+def skmeans_task(ord_, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, c_l2sq, p_l2sq, ones):
+    """KMeansTask::execute restated; in place on c."""
+    lib().orc_skmeans_task(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, _p(a), lda, _p(b), ldb, beta,
+                           _p(c), ldc, _p(c_l2sq), _p(p_l2sq), _p(ones))
+    return c
+
+
+def flash_kmeans(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, blk, c_l2sq, p_l2sq, ones):
+    lib().orc_flash_kmeans(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, _p(a), _p(b), _p(c),
+                           lda, ldb, ldc, blk, _p(c_l2sq), _p(p_l2sq), _p(ones))
     return c
 
 

@@ -1,0 +1,142 @@
+"""-m gpu parity of flash::kmeans (KMeansTask fused into the GEMM store) at the three
+levels of the C ABI: against the real-MKL fixtures of the task's three cblas_sgemm calls (1e-4) and
+against the oracle's restatement (bit-exact: same k-ordered chains, same two roundings per update)."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bofhip
+import orc
+from gpu_util import ptr, rel_err, stream, to_dev
+from test_gpu_flash import Files, stored_shapes
+from test_oracle import _kmeans_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def run_task(ord_, ta, tb, m, n, k, alpha, beta, a, lda, b, ldb, c, ldc, cl, pl, ones):
+    da, db, dc, dcl, dpl, do = (to_dev(x) for x in (a, b, c, cl, pl, ones))
+    bofhip.skmeans_task(ord_, ta, tb, m, n, k, alpha, ptr(da), lda, ptr(db), ldb, beta, ptr(dc), ldc, ptr(dcl),
+                        ptr(dpl), ptr(do), stream())
+    torch.cuda.synchronize()
+    return dc.cpu().numpy()
+
+
+def test_kmeans_task_vs_mkl_golden(dev):
+    """bof_skmeans_task against KMeansTask::execute's three cblas_sgemm calls made into MKL, and bit for
+    bit against the oracle on the same inputs."""
+    for key, ta, tb, m, n, k, lda, ldb, ldc, alpha, beta, d in _kmeans_cases():
+        got = run_task("C", ta, tb, m, n, k, alpha, beta, d["a"], lda, d["b"], ldb, d["c0"], ldc, d["cl"], d["pl"],
+                       d["ones"])
+        assert rel_err(got, d["c"]) < 1e-4, key
+        ref = orc.skmeans_task("C", ta, tb, m, n, k, alpha, d["a"], lda, d["b"], ldb, beta, d["c0"].copy(), ldc,
+                               d["cl"], d["pl"], d["ones"])
+        assert np.array_equal(got, ref), key
+
+
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+@pytest.mark.parametrize("m,n,k,alpha,beta", [
+    (300, 200, 100, -2.0, 0.0),       # ragged: guarded 128 x 128 kernel
+    (4096, 2304, 64, -2.0, 0.5),      # 256 x 256 kernels + right strip, K = 2 slabs
+    (4352, 2048, 96, 1.5, 0.0),       # K % 64 != 0: register-staging kernel, bottom strip
+    (2304, 4096, 80, -2.0, 1.0),      # K % 32 != 0: guarded last slab
+])
+def test_kmeans_task_vs_oracle_all_layouts(dev, ord_, ta, tb, m, n, k, alpha, beta):
+    """Every kernel shape behind bof_skmeans_task, all 8 layouts, non-constant `ones` (so a swapped
+    factor or index shows), bit-exact against the oracle."""
+    rng = np.random.default_rng(m + n + k)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    cl = rng.uniform(0, 8, m).astype(np.float32)
+    pl = rng.uniform(0, 8, n).astype(np.float32)
+    ones = rng.uniform(0.5, 1.5, max(m, n)).astype(np.float32)
+    got = run_task(ord_, ta, tb, m, n, k, alpha, beta, a, sa[1], b, sb[1], c0, sc[1], cl, pl, ones)
+    ref = orc.skmeans_task(ord_, ta, tb, m, n, k, alpha, a, sa[1], b, sb[1], beta, c0.copy(), sc[1], cl, pl, ones)
+    assert np.array_equal(got, ref.reshape(sc))
+
+
+@pytest.mark.parametrize("ord_,ta,tb", [("C", "T", "N"), ("C", "N", "T"), ("R", "N", "T"), ("R", "T", "N")])
+def test_kmeans_resident_vs_flash_oracle(dev, ord_, ta, tb):
+    """Tile DAG (level 2): tail-merged tiles, k spanning two blocks (the updates are then added twice,
+    as the reference does), per-tile slices of the norm vectors."""
+    m, n, k, blk = 640, 500, 600, 256
+    rng = np.random.default_rng(3)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    cl = rng.uniform(0, 8, m).astype(np.float32)
+    pl = rng.uniform(0, 8, n).astype(np.float32)
+    ones = rng.uniform(0.5, 1.5, 512).astype(np.float32)   # largest tile edge: 640 - 256 = 384
+    ref = orc.flash_kmeans(ord_, ta, tb, m, n, k, -2.0, 0.5, a, b, c0.copy(), 0, 0, 0, blk, cl, pl, ones)
+    da, db, dc, dcl, dpl, do = (to_dev(x) for x in (a, b, c0, cl, pl, ones))
+    bofhip.kmeans_resident(ord_, ta, tb, m, n, k, -2.0, 0.5, ptr(da), ptr(db), ptr(dc), 0, 0, 0, ptr(dcl), ptr(dpl),
+                           ptr(do), bofhip.default_options(gemm_blk=blk, n_streams=3), stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("ord_,ta,tb", [("C", "T", "N"), ("R", "N", "T"), ("C", "N", "N")])
+def test_flash_kmeans_files(dev, tmp_path, ord_, ta, tb, path):
+    """Level 3: A, B, C as files, the norm vectors in host memory, through the tile cache (1) and the
+    row-panel pipeline (2); bit-exact against the oracle's flash::kmeans."""
+    m, n, k, blk = 640, 500, 300, 256
+    rng = np.random.default_rng(17)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    cl = rng.uniform(0, 8, m).astype(np.float32)
+    pl = rng.uniform(0, 8, n).astype(np.float32)
+    ones = np.ones(max(m, n), np.float32)
+    ref = orc.flash_kmeans(ord_, ta, tb, m, n, k, -2.0, 0.0, a, b, c0.copy(), 0, 0, 0, blk, cl, pl, ones)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=2, n_io_threads=3, pinned_slots=4, gemm_path=path,
+                                      io_chunk_mib=1)
+        bofhip.flash_kmeans(ord_, ta, tb, m, n, k, -2.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                            cl.ctypes.data, pl.ctypes.data, ones.ctypes.data, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+    finally:
+        F.close()
+
+
+def test_kmeans_driver_shape_distances(dev):
+    """The reference driver's call (drivers/kmeans.cpp:37-39): dist = -2 centers^T points + |c|^2 + |p|^2,
+    column-major ncenters x npoints -- checked against float64 squared distances, and the nearest centre
+    of every point against the float64 answer."""
+    ncenters, npoints, dim = 256, 20000, 96
+    rng = np.random.default_rng(9)
+    centers = rng.normal(0, 4, (ncenters, dim)).astype(np.float32)      # stored as the driver's file: centre after centre
+    assign = rng.integers(0, ncenters, npoints)
+    points = (centers[assign] + rng.normal(0, 0.2, (npoints, dim))).astype(np.float32)
+    cl = (centers.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    pl = (points.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    ones = np.ones(max(ncenters, npoints), np.float32)
+    dist = np.zeros((npoints, ncenters), np.float32)                    # column-major ncenters x npoints
+    dc, dp, dd, dcl, dpl, do = (to_dev(x) for x in (centers, points, dist, cl, pl, ones))
+    bofhip.kmeans_resident("C", "T", "N", ncenters, npoints, dim, -2.0, 0.0, ptr(dc), ptr(dp), ptr(dd), dim, dim,
+                           ncenters, ptr(dcl), ptr(dpl), ptr(do), bofhip.default_options(), stream())
+    torch.cuda.synchronize()
+    got = dd.cpu().numpy().astype(np.float64)
+    want = ((points.astype(np.float64)[:, None, :] - centers.astype(np.float64)[None, :, :]) ** 2).sum(2)
+    assert np.abs(got - want).max() < 1e-4 * want.max()
+    assert np.array_equal(got.argmin(1), assign) and np.array_equal(want.argmin(1), assign)
+
+
+def test_kmeans_degenerate(dev):
+    """k == 0 / empty C: the reference's tiler creates no task (kmeans.cpp:88-90): C stays as it is."""
+    c = to_dev(np.full((4, 4), 7.0, np.float32))
+    v = to_dev(np.ones(8, np.float32))
+    bofhip.kmeans_resident("C", "T", "N", 4, 4, 0, 1.0, 0.0, ptr(c), ptr(c), ptr(c), 1, 1, 4, ptr(v), ptr(v), ptr(v),
+                           bofhip.default_options(), stream())
+    bofhip.kmeans_resident("C", "T", "N", 0, 4, 4, 1.0, 0.0, ptr(c), ptr(c), ptr(c), 4, 4, 1, ptr(v), ptr(v), ptr(v),
+                           bofhip.default_options(), stream())
+    torch.cuda.synchronize()
+    assert np.all(c.cpu().numpy() == 7.0)

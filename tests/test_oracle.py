@@ -301,3 +301,72 @@ def test_oracle_vs_mkl_big_random_blocks():
             c = np.ascontiguousarray(cl[r:r + 64, q:q + 64]).copy()
             orc.sgemm("R", "N", "N", 64, 64, k, alpha, asub, k, bsub, 64, beta, c, 64)
             assert np.abs(c - ref).max() / np.abs(ref).max() < 1e-4
+
+
+def _kmeans_cases():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mkl_golden_kmeans.npz"))
+    for key in sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_meta")}):
+        ta, tb, m, n, k, lda, ldb, ldc = (int(v) for v in g[key + "_meta"])
+        yield key, chr(ta), chr(tb), m, n, k, lda, ldb, ldc, float(g[key + "_ab"][0]), float(g[key + "_ab"][1]), \
+            {x: g[f"{key}_{x}"] for x in ("a", "b", "c0", "cl", "pl", "ones", "c")}
+
+
+def test_oracle_kmeans_task_vs_mkl_golden():
+    """orc_skmeans_task against the three cblas_sgemm calls of KMeansTask::execute made into real MKL
+    (tests/golden/make_golden_mkl_kmeans.py), column-major as the reference's driver calls it.  With
+    the all-ones vector the two K = 1 updates are exact sums and only the tile product is subject to
+    MKL's summation order; with a non-constant vector in the place of `ones` the test also pins which
+    factor multiplies which."""
+    n_cases = 0
+    for key, ta, tb, m, n, k, lda, ldb, ldc, alpha, beta, d in _kmeans_cases():
+        c = d["c0"].copy()
+        orc.skmeans_task("C", ta, tb, m, n, k, alpha, d["a"], lda, d["b"], ldb, beta, c, ldc, d["cl"], d["pl"],
+                         d["ones"])
+        want = d["c"]
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(c - want).max() <= 1e-4 * scale, key
+        # padding between columns (ldc > m) untouched
+        cm, wm = c.reshape(n, ldc), want.reshape(n, ldc)
+        assert np.array_equal(cm[:, m:], wm[:, m:]), key
+        n_cases += 1
+    assert n_cases == 22
+
+
+def test_oracle_flash_kmeans_tiler():
+    """flash::kmeans restated = the gemm tiler with kmeans tasks: against a whole-matrix evaluation,
+    including the reference's behaviour of adding the two updates once per k-block, for both orders
+    (row-major has the stated intent, see oracle/bof_oracle.c) and a tail-merged last block."""
+    rng = np.random.default_rng(5)
+    m, n, k, blk = 300, 420, 200, 128          # m: 128 + 172 (tail-merged), n: 128 + 128 + 164, k: one merged block of 200
+    for ord_ in "CR":
+        for ta, tb in (("T", "N"), ("N", "T")):
+            sa = (m, k) if (ta == "N") == (ord_ == "R") else (k, m)
+            sb = (k, n) if (tb == "N") == (ord_ == "R") else (n, k)
+            sc = (m, n) if ord_ == "R" else (n, m)
+            a = rng.integers(-3, 4, sa).astype(np.float32)
+            b = rng.integers(-3, 4, sb).astype(np.float32)
+            c0 = rng.integers(-3, 4, sc).astype(np.float32)
+            cl = rng.integers(0, 9, m).astype(np.float32)
+            pl = rng.integers(0, 9, n).astype(np.float32)
+            ones = np.ones(max(m, n), np.float32)
+            nblk = np.zeros(3, np.int64)
+            orc.lib().orc_gemm_plan(ord_.encode(), ta.encode(), tb.encode(), m, n, k, 0.5, sa[1], sb[1], sc[1], blk,
+                                    None, 0, nblk.ctypes.data)
+            c = c0.copy()
+            orc.flash_kmeans(ord_, ta, tb, m, n, k, 2.0, 0.5, a, b, c, sa[1], sb[1], sc[1], blk, cl, pl, ones)
+            al = a if sa == (m, k) else a.T
+            bl = b if sb == (k, n) else b.T
+            want = 2.0 * (al.astype(np.float64) @ bl.astype(np.float64)) + 0.5 * (c0 if ord_ == "R" else c0.T) \
+                + int(nblk[1]) * (cl[:, None] + pl[None, :])
+            got = c if ord_ == "R" else c.T
+            assert np.array_equal(got.astype(np.float64), want), (ord_, ta, tb)   # integer data: exact
+    # k spanning two blocks: the updates are added twice (reference behaviour, kmeans.cpp:88-131)
+    m, n, k, blk = 64, 64, 512, 256
+    b = rng.integers(-2, 3, (n, k)).astype(np.float32)
+    c = np.zeros((n, m), np.float32)
+    cl = rng.integers(0, 9, m).astype(np.float32)
+    pl = rng.integers(0, 9, n).astype(np.float32)
+    a_cm = rng.integers(-2, 3, (m, k)).astype(np.float32)  # memory of a col-major k x m matrix with lda = k
+    orc.flash_kmeans("C", "T", "N", m, n, k, -2.0, 0.0, a_cm, b, c, k, k, m, blk, cl, pl, np.ones(64, np.float32))
+    want = -2.0 * (a_cm.astype(np.float64) @ b.astype(np.float64).T) + 2 * (cl[:, None] + pl[None, :])
+    assert np.array_equal(c.T.astype(np.float64), want)
