@@ -209,6 +209,67 @@ def csr_pmc():
         return {}, None
 
 
+def kmeans_secondary(bofhip, torch, dev, st, streams, blk=4096):
+    """flash::kmeans (SURVEY 8f-4) resident: the reference driver's call shape (drivers/kmeans.cpp:37-39,
+    'C','T','N', alpha = -2, beta = 0) at 1024 centres x 2^20 points x 256 dimensions -- the squared-distance
+    matrix (4 GiB) as ONE kernel per tile, against the same tiles run as KMeansTask's three calls (the tile
+    product, then two K = 1 sgemm passes over C), and checked against float64 on a sample of points."""
+    import numpy as np
+    ncenters, npoints, dim = 1024, 1 << 20, 256
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    centers = torch.randn(ncenters, dim, device=dev, generator=g)
+    points = torch.randn(npoints, dim, device=dev, generator=g)
+    cl = (centers.double() ** 2).sum(1).float()
+    pl = (points.double() ** 2).sum(1).float()
+    ones = torch.ones(max(ncenters, blk + 127), device=dev)
+    dist = torch.empty(npoints, ncenters, device=dev)     # column-major ncenters x npoints
+    opts = bofhip.default_options(n_streams=max(streams, 4), gemm_blk=blk)
+
+    def timed(fn, iters=3):
+        fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def fused():
+        bofhip.kmeans_resident("C", "T", "N", ncenters, npoints, dim, -2.0, 0.0, centers.data_ptr(), points.data_ptr(),
+                               dist.data_ptr(), dim, dim, ncenters, cl.data_ptr(), pl.data_ptr(), ones.data_ptr(), opts, st)
+
+    ones_n = torch.ones(npoints, device=dev)
+
+    def three_calls():  # the reference task's sequence with whole-matrix K = 1 passes (same C traffic per element)
+        bofhip.gemm_resident("C", "T", "N", ncenters, npoints, dim, -2.0, 0.0, centers.data_ptr(), points.data_ptr(),
+                             dist.data_ptr(), dim, dim, ncenters, opts, st)
+        bofhip.sgemm("C", "N", "T", ncenters, npoints, 1, 1.0, cl.data_ptr(), ncenters, ones_n.data_ptr(), npoints, 1.0,
+                     dist.data_ptr(), ncenters, st)
+        bofhip.sgemm("C", "N", "T", ncenters, npoints, 1, 1.0, ones_n.data_ptr(), ncenters, pl.data_ptr(), npoints, 1.0,
+                     dist.data_ptr(), ncenters, st)
+
+    ms3 = timed(three_calls)
+    ref3 = dist[:4096].clone()
+    ms = timed(fused)
+    same = bool(torch.equal(dist[:4096], ref3))
+    sample = slice(0, 2048)
+    want = ((points[sample].double()[:, None, :] - centers.double()[None, :, :]) ** 2).sum(2)
+    err = float((dist[sample].double() - want).abs().max() / want.abs().max())
+    flops = 2.0 * ncenters * npoints * dim
+    alg = 4 * (ncenters * dim + npoints * dim + ncenters * npoints + ncenters + npoints)
+    return {"workload": "flash kmeans distance matrix: 1024 centres x 2^20 points x 256 dims, column-major, resident in HBM",
+            "ms": round(ms, 3), "gflops": round(flops / ms / 1e6, 1),
+            "three_call_sequence_ms": round(ms3, 3), "fused_speedup": round(ms3 / ms, 2),
+            "fused_equals_three_calls_bitwise": same, "max_rel_err_vs_float64_2048_points": err,
+            "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "algorithmic_bytes": alg, "hbm_frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4)}}
+
+
 def csr_secondary(bofhip, torch, dev, st):
     """Secondary lines of the metric: flash _csrmm at BASELINE configs[2] (10M x 1M CSR, 1e9 nnz,
     x 1M x 128 dense) and _csrgemv at the configs[4] size (50M x 50M, 5e8 nnz), HBM-resident,
@@ -1139,6 +1200,10 @@ def main():
                 out["secondary"] = csr_secondary(bofhip, torch, dev, st)
             except Exception as e:  # the headline line must still be printed
                 out["secondary"] = {"error": str(e)[:200]}
+            try:
+                out["secondary"]["kmeans"] = kmeans_secondary(bofhip, torch, dev, st, args.streams)
+            except Exception as e:
+                out["secondary"]["kmeans_error"] = str(e)[:200]
             # north_star's 64k x 64k x 64k at N = 1 (48 GiB resident), and the slab ONE rank of the
             # 8-GPU run owns (BASELINE configs[3]): the same per-GPU workload the N = 8 line reports
             try:

@@ -203,6 +203,17 @@ namespace flash {
                   "flash::gemm");
   }
 
+  // include/flash_blas.h:20-25; src/blas/kmeans.cpp:27-198
+  FBLAS_INT kmeans(CHAR mat_ord, CHAR trans_a, CHAR trans_b, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k,
+                   FPTYPE alpha, FPTYPE beta, flash_ptr<FPTYPE> a, flash_ptr<FPTYPE> b,
+                   flash_ptr<FPTYPE> c, FBLAS_UINT lda_a, FBLAS_UINT lda_b, FBLAS_UINT lda_c,
+                   FPTYPE* c_l2sq, FPTYPE* p_l2sq, FPTYPE* ones) {
+    const bof_options o = current_options();
+    return finish(bof_flash_kmeans(mat_ord, trans_a, trans_b, m, n, k, alpha, beta, as_fptr(a),
+                                   as_fptr(b), as_fptr(c), lda_a, lda_b, lda_c, c_l2sq, p_l2sq, ones, &o),
+                  "flash::kmeans");
+  }
+
   FBLAS_INT csrmm(CHAR trans_a, FBLAS_UINT m, FBLAS_UINT n, FBLAS_UINT k, FPTYPE alpha, FPTYPE beta,
                   flash_ptr<FPTYPE> a, flash_ptr<MKL_INT> ia, flash_ptr<MKL_INT> ja, CHAR ord_b,
                   flash_ptr<FPTYPE> b, flash_ptr<FPTYPE> c) {

@@ -140,3 +140,26 @@ def test_kmeans_degenerate(dev):
                            bofhip.default_options(), stream())
     torch.cuda.synchronize()
     assert np.all(c.cpu().numpy() == 7.0)
+
+
+def test_kmeans_driver_binary(dev, tmp_path):
+    """bin/kmeans_driver with the reference's argv (drivers/kmeans.cpp:198-201): one Lloyd iteration on
+    files through the C++ flash::kmeans; the rewritten centres file against a float64 iteration."""
+    from test_gpu_flash import run_driver
+    ncenters, npoints, dim = 40, 5000, 48
+    rng = np.random.default_rng(21)
+    true = rng.normal(0, 5, (ncenters, dim))
+    assign = rng.integers(0, ncenters, npoints)
+    points = (true[assign] + rng.normal(0, 0.3, (npoints, dim))).astype(np.float32)
+    centers = (true + rng.normal(0, 0.5, (ncenters, dim))).astype(np.float32)
+    pp, cp = str(tmp_path / "points.bin"), str(tmp_path / "centers.bin")
+    points.tofile(pp)
+    centers.tofile(cp)
+    out = run_driver("kmeans_driver", [pp, cp, npoints, dim, ncenters], {"BOF_GEMM_BLK_SIZE": "1024"})
+    assert "flash::kmeans() returned with 0" in out
+    d = ((points.astype(np.float64)[:, None, :] - centers.astype(np.float64)[None, :, :]) ** 2).sum(2)
+    near = d.argmin(1)
+    want = np.stack([points[near == c].astype(np.float64).mean(0) if np.any(near == c) else np.zeros(dim)
+                     for c in range(ncenters)])
+    got = np.fromfile(cp, np.float32).reshape(ncenters, dim)
+    assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())
