@@ -163,3 +163,35 @@ def test_kmeans_driver_binary(dev, tmp_path):
                      for c in range(ncenters)])
     got = np.fromfile(cp, np.float32).reshape(ncenters, dim)
     assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_flash_kmeans_files_large_equals_resident(dev, tmp_path):
+    """512 centres x 262144 points x 128 dims from files (64 tile tasks of 4096 points, a 512 MiB distance
+    file) through the default level-3 path: bit for bit the level-2 result, and squared distances against
+    float64 on a sample."""
+    ncenters, npoints, dim = 512, 262144, 128
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    centers = torch.randn(ncenters, dim, device="cuda", generator=g)
+    points = torch.randn(npoints, dim, device="cuda", generator=g)
+    cl = (centers.double() ** 2).sum(1).float()
+    pl = (points.double() ** 2).sum(1).float()
+    ones = torch.ones(4096 + 128, device="cuda")
+    dist = torch.empty(npoints, ncenters, device="cuda")
+    bofhip.kmeans_resident("C", "T", "N", ncenters, npoints, dim, -2.0, 0.0, ptr(centers), ptr(points), ptr(dist), dim,
+                           dim, ncenters, ptr(cl), ptr(pl), ptr(ones), bofhip.default_options(), stream())
+    torch.cuda.synchronize()
+    want = ((points[:1024].double()[:, None, :] - centers.double()[None, :, :]) ** 2).sum(2)
+    assert float((dist[:1024].double() - want).abs().max() / want.max()) < 1e-5
+    F = Files(tmp_path, a=centers.cpu().numpy(), b=points.cpu().numpy(), c=np.zeros((npoints, ncenters), np.float32))
+    try:
+        cl_h, pl_h, ones_h = cl.cpu().numpy(), pl.cpu().numpy(), ones.cpu().numpy()
+        bofhip.flash_kmeans("C", "T", "N", ncenters, npoints, dim, -2.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), dim,
+                            dim, ncenters, cl_h.ctypes.data, pl_h.ctypes.data, ones_h.ctypes.data,
+                            bofhip.default_options())
+        st = bofhip.flash_last_stats()
+        assert st["tasks"] == 64
+        got = F.read("c", np.float32, (npoints, ncenters))
+        assert np.array_equal(got, dist.cpu().numpy())
+    finally:
+        F.close()
