@@ -963,7 +963,11 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   // produced by one kernel as one k-ordered chain, so the split does not change a single bit.
   const int Mi = M - M % 256, Ni = N - N % 256;
   const bool k_ok = (K % BK == 0) ? (K >= 2 * BK) : (K >= 3 * BK);
-  if (vec_ld && k_ok && (int64_t) (Mi / 256) * (Ni / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
+  // K < 512 (flash::kmeans: K = the point dimension): a 256 x 256 tile then has less MFMA work than
+  // its prologue + 256 KB store cost with one workgroup per CU; the 128 x 128 kernel keeps three
+  // workgroups per CU in flight (1M x 1024 x 256: 5.7-6.0 ms against 6.5-8.4).  BOF_GEMM_SHORT_K overrides.
+  static const int short_k = getenv("BOF_GEMM_SHORT_K") ? atoi(getenv("BOF_GEMM_SHORT_K")) : 512;
+  if (vec_ld && k_ok && K >= short_k && (int64_t) (Mi / 256) * (Ni / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
     const int tiles_m = Mi / 256, tiles_n = Ni / 256;
     if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
       hipLaunchKernelGGL(sgemm_tile256_dma2_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
