@@ -186,6 +186,36 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     return stats
 
 
+def flash_kmeans_point_sharded(ncenters, npoints, dim, fd_centers, fd_points, fd_dist, c_l2sq, p_l2sq, opts=None,
+                               group=None):
+    """Multi-GPU flash::kmeans in the reference driver's call shape (drivers/kmeans.cpp:37-39:
+    'C','T','N', alpha = -2, beta = 0; dist is column-major ncenters x npoints, i.e. one contiguous
+    run of ncenters distances per point).  The distance matrix shards by POINTS -- the dimension its
+    panels run along -- so rank g owns the tile-aligned points [p0, p1): its slice of the points file,
+    of p_l2sq and of the dist file; the centres and c_l2sq are read by every rank (small).  No
+    collective, like the row-sharded gemm.  c_l2sq / p_l2sq: host float32 arrays (numpy).
+    Returns {points, bytes_read, bytes_written} of this rank."""
+    import numpy as np
+    import torch.distributed as dist
+    import bofhip
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    o = opts if opts is not None else bofhip.default_options()
+    tile = int(o.gemm_blk)
+    p0, p1 = row_shard(npoints, world, rank, tile)
+    stats = {"points": p1 - p0, "bytes_read": 0, "bytes_written": 0}
+    if p1 > p0:
+        ones = np.ones(max(min(ncenters, tile + 127), min(p1 - p0, tile + 127)), np.float32)
+        pl = np.ascontiguousarray(p_l2sq[p0:p1], np.float32)
+        cl = np.ascontiguousarray(c_l2sq, np.float32)
+        bofhip.flash_kmeans("C", "T", "N", ncenters, p1 - p0, dim, -2.0, 0.0, bofhip.FPtr(fd_centers, 0),
+                            bofhip.FPtr(fd_points, p0 * dim * 4), bofhip.FPtr(fd_dist, p0 * ncenters * 4), dim, dim,
+                            ncenters, cl.ctypes.data, pl.ctypes.data, ones.ctypes.data, o)
+        st_ = bofhip.flash_last_stats()
+        stats["bytes_read"], stats["bytes_written"] = st_["bytes_read"], st_["bytes_written"]
+    return stats
+
+
 def _world_rank(group=None):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
