@@ -113,14 +113,15 @@ def test_flash_gemm_mixed_alignment_stress(dev, tmp_path, ord_, ta, tb):
         F.close()
 
 
-@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("group", [1, 2, 3])
 @pytest.mark.parametrize("ord_,ta,tb,beta", [("R", "N", "N", 0.0), ("R", "N", "N", 1.5), ("R", "T", "N", 1.5),
                                              ("C", "N", "T", 0.0), ("C", "T", "T", 1.5), ("R", "N", "T", 0.0)])
 def test_flash_gemm_panels_ring_reuse(dev, tmp_path, monkeypatch, ord_, ta, tb, beta, group):
     """Panel pipeline with an HBM budget that holds the resident operand(s) plus the minimum
     rings (2*group panels of the streamed operand, 2*group+1 of C): every ring slot is reused several
     times, so the write-after-read (operand panels) and write-back-before-refill (C panels, read
-    again when beta != 0) orderings are all exercised.  Tail-merged last panels in m and k."""
+    again when beta != 0) orderings are all exercised.  Tail-merged last panels in m and k.
+    `group` = C panels of the first (ramp) group; the later panels go one at a time."""
     monkeypatch.setenv("BOF_PANEL_GROUP", str(group))
     m, k, n, blk = 1100, 900, 1024, 128          # m: 8 panels + merged tail (76), k: 7 + separate... 900 = 7*128+4 -> merged
     rng = np.random.default_rng(7)
