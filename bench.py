@@ -340,6 +340,13 @@ def csr_secondary(bofhip, torch, dev, st):
     out["csrmm_T"] = {"workload": "flash _csrmm trans_a=T: (10M x 1M CSR)^T x 10M x 128, resident in HBM "
                                   "(transposition + 'N' product over A^T)",
                       "ms": round(ms, 3), "gflops": round(2.0 * nnz * k / ms / 1e6, 1)}
+    alg_t = nnz * 12 + (m + 1) * 8 + 4 * m * k + 4 * n * k      # A once, B (m x k) once, C (n x k) written once
+    out["csrmm_T"]["roofline"] = {"bound": "hbm", "achieved": round(alg_t / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(alg_t / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes": alg_t, "gather_bytes": nnz * k * 4,
+                                  "gather_GBps": round(nnz * k * 4 / max(ms - out["csrcsc"]["ms"], 1e-3) / 1e6, 1),
+                                  "note": "transposition (secondary.csrcsc) + the 'N' kernel over A^T, whose B-row gather "
+                                          "(5.12 GB table, beyond the Infinity Cache) is the bound"}
     del val, col, off, b, c, bt
     torch.cuda.empty_cache()
     bofhip.lib().bof_flash_release()      # the 26 GiB sort workspace goes back before cfg5
