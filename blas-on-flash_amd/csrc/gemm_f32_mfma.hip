@@ -46,14 +46,6 @@ struct Rank1x2 {
 };
 inline NoEpi epi_shift(const NoEpi &e, int64_t, int64_t) { return e; }
 inline Rank1x2 epi_shift(const Rank1x2 &e, int64_t dr, int64_t dc) { return e.shifted(dr, dc); }
-template <class EP>
-__device__ __forceinline__ float epi_apply(const EP &ep, float t, int row, int col) {
-  if constexpr (EP::active) {
-    t = __fadd_rn(t, __fmul_rn(ep.u1[row], ep.v1[col]));
-    t = __fadd_rn(t, __fmul_rn(ep.u2[row], ep.v2[col]));
-  }
-  return t;
-}
 
 // ---- global -> registers ---------------------------------------------------
 // One K-slab of one operand of extent BX is BX*8 float4; thread t owns float4
@@ -244,8 +236,31 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
   float *ctile = C + (int64_t) m0 * ldc + n0;
   const int lrow = wm * WTM + 4 * h, lcol = wn * WTN + i;
   const int lane_off = lrow * (int) ldc + lcol;
+  // Rank1x2: this lane's column factors once, the 16 row factors of an accumulator row block once
+  // per mt (fetched per element they doubled the instruction count of the store loop, and the
+  // stores to C keep the compiler from hoisting them)
+  float v1c[NT], v2c[NT];
+  if constexpr (EP::active) {
 #pragma unroll
-  for (int mt = 0; mt < MT; mt++)
+    for (int nt = 0; nt < NT; nt++) {
+      const int col = n0 + lcol + nt * 32;
+      const bool ok = !GUARD || col < N;
+      v1c[nt] = ok ? ep.v1[col] : 0.f;
+      v2c[nt] = ok ? ep.v2[col] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    float u1r[16], u2r[16];
+    if constexpr (EP::active) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + lrow + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const bool ok = !GUARD || row < M;
+        u1r[r] = ok ? ep.u1[row] : 0.f;
+        u2r[r] = ok ? ep.u2[row] : 0.f;
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       f32x16 old;
@@ -261,12 +276,17 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
       for (int r = 0; r < 16; r++) {
         const int dr = mt * 32 + (r & 3) + 8 * (r >> 2), dc = nt * 32;
         float *dst = ctile + ((int64_t) dr * ldc + dc);
-        if (!GUARD || (m0 + lrow + dr < M && n0 + lcol + dc < N))
-          dst[lane_off] = epi_apply(ep, (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                                      : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]),
-                                    m0 + lrow + dr, n0 + lcol + dc);
+        if (!GUARD || (m0 + lrow + dr < M && n0 + lcol + dc < N)) {
+          float t = (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+          if constexpr (EP::active) {
+            t = __fadd_rn(t, __fmul_rn(u1r[r], v1c[nt]));
+            t = __fadd_rn(t, __fmul_rn(u2r[r], v2c[nt]));
+          }
+          dst[lane_off] = t;
+        }
       }
     }
+  }
 }
 
 // Epilogue shared by the one-wave-per-SIMD 256 x 256 kernels: the wave's 128 x 128 tile (4 x 4
@@ -278,8 +298,24 @@ __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64
                                                     float beta, const EP &ep) {
   float *ctile = C + (int64_t) m0 * ldc + n0;
   const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+  float v1c[4], v2c[4];
+  if constexpr (EP::active) {
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++)
+    for (int nt = 0; nt < 4; nt++) {
+      v1c[nt] = ep.v1[n0 + wn * 128 + i + nt * 32];
+      v2c[nt] = ep.v2[n0 + wn * 128 + i + nt * 32];
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++) {
+    float u1r[16], u2r[16];
+    if constexpr (EP::active) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        u1r[r] = ep.u1[m0 + wm * 128 + 4 * h + mt * 32 + (r & 3) + 8 * (r >> 2)];
+        u2r[r] = ep.u2[m0 + wm * 128 + 4 * h + mt * 32 + (r & 3) + 8 * (r >> 2)];
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) {
       f32x16 old;
@@ -291,11 +327,15 @@ __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        dst[lane_off] = epi_apply(ep, (beta == 0.f) ? alpha * acc[mt][nt][r]
-                                                    : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]),
-                                  m0 + wm * 128 + 4 * h + mt * 32 + (r & 3) + 8 * (r >> 2), n0 + wn * 128 + i + nt * 32);
+        float t = (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+        if constexpr (EP::active) {
+          t = __fadd_rn(t, __fmul_rn(u1r[r], v1c[nt]));
+          t = __fadd_rn(t, __fmul_rn(u2r[r], v2c[nt]));
+        }
+        dst[lane_off] = t;
       }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
