@@ -146,6 +146,30 @@ static void files(const char *dir) {
       CHECK(bof::file_sread(f2, 0, 0, 1, big, bb, true) == 0);
       for (uint64_t i = 0; i < big; i += 4099) CHECK(q[i] == (unsigned char) (i * 2654435761u >> 24));
       CHECK(bof_file_set_request_bytes(4 << 20) == BOF_OK);
+      if (!direct) {
+        // the pages are in the page cache now: large buffered writes go through the shared mapping
+        // (fileio.cpp mapped_write), 8 threads at once on disjoint 3 MiB bands
+        const uint64_t before = bof::file_mapped_write_bytes();
+        for (uint64_t i = 0; i < big; i++) q[i] = (unsigned char) (255 - (i * 40503u >> 8));
+        std::vector<std::thread> wt;
+        std::vector<int> wrc(8, -1);
+        const uint64_t band = big / 8;
+        for (int t = 0; t < 8; t++)
+          wt.emplace_back([&, t] { wrc[t] = bof::file_swrite(f2, t * band, 0, 1, band, q + t * band, true); });
+        for (auto &x : wt) x.join();
+        for (int t = 0; t < 8; t++) CHECK(wrc[t] == 0);
+        CHECK(bof::file_mapped_write_bytes() == before + big);
+        std::vector<unsigned char> back(big);
+        CHECK(pread(f2, back.data(), big, 0) == (ssize_t) big);
+        CHECK(memcmp(back.data(), q, big) == 0);
+        // small writes and writes past the mapped size keep taking pwrite
+        CHECK(bof::file_swrite(f2, 4096, 0, 1, 8192, q, true) == 0);
+        CHECK(ftruncate(f2, (off_t) (big + (2u << 20))) == 0);
+        CHECK(bof::file_swrite(f2, big, 0, 1, 2u << 20, q, true) == 0);
+        CHECK(bof::file_mapped_write_bytes() == before + big);
+        CHECK(pread(f2, back.data(), 2u << 20, (off_t) big) == (ssize_t) (2u << 20));
+        CHECK(memcmp(back.data(), q, 2u << 20) == 0);
+      }
       bof::file_forget(f2);
       close(f2);
       unlink(p2.c_str());
