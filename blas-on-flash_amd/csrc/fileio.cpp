@@ -287,6 +287,13 @@ void unmap_for_forget(int fd) {
   std::lock_guard<std::mutex> lk(g_map_mu);
   unmap_locked(fd);
 }
+// every write mapping goes (bof_flash_release: no level-3 call is running then)
+void file_unmap_all() {
+  std::lock_guard<std::mutex> lk(g_map_mu);
+  for (auto &kv : g_map)
+    if (kv.second.base) ::munmap(kv.second.base, kv.second.size);
+  g_map.clear();
+}
 
 static int rw_full(int fd, bool wr, char *buf, uint64_t len, uint64_t off) {
   if (wr && mapped_write(fd, buf, len, off)) { g_wr_ops++; return 0; }

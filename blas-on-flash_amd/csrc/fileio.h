@@ -16,6 +16,7 @@ uint64_t file_dio_align(int fd);  // O_DIRECT offset/length alignment of this fi
 int file_buffered_fd(int fd);
 // bytes that large buffered writes put into cached pages through a shared mapping (fileio.cpp)
 uint64_t file_mapped_write_bytes();
+void file_unmap_all();
 void file_io_ops(uint64_t *reads, uint64_t *writes);  // requests issued so far (process-wide)
 void file_forget(int fd);  // drop the cached buffered twin of fd (call before close)
 // ---- io_uring engine (uring_io.cpp); BOF_IO_ENGINE=uring selects it for aligned O_DIRECT I/O ----

@@ -1672,6 +1672,7 @@ int bof_flash_release(void) {
   }
   uring_release_buffers();
   pinned_cache_release();
+  file_unmap_all();
   return BOF_OK;
 }
 

@@ -316,7 +316,7 @@ int bof_flash_gemm_panel_plan(char ord, char trans_a, char trans_b, uint64_t m, 
                               uint64_t hbm_budget, int64_t group, bof_panel_plan *out);
 /* Level-3 calls keep their pinned staging rings and HBM tile slab between calls (the
  * reference keeps its program cache for the life of the process, src/lib_funcs.cpp:9);
- * this frees them. */
+ * this frees them (and unmaps the write mappings of buffered files). */
 int bof_flash_release(void);
 
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
@@ -331,8 +331,9 @@ int bof_file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides
  * MAX_CHUNK_SIZE, flash_file_handle.cpp:25). */
 int bof_file_set_request_bytes(uint64_t bytes);
 /* Unaligned requests on an O_DIRECT descriptor go through a cached buffered descriptor of
- * the same file; call this before close(fd) so that it is closed too
- * (FlashFileHandle::close does). */
+ * the same file, and large buffered writes into cached pages through a shared mapping of it;
+ * call this before close(fd) so that both are dropped too (FlashFileHandle::close does;
+ * bof_flash_release drops every mapping). */
 int bof_file_forget(int fd);
 
 /* ---- synthetic inputs generated in HBM (bench / tests) ---------------------- */
