@@ -1195,7 +1195,11 @@ def main():
                          "avg_launch_ms": round(avg_launch_ms, 4),
                          "flops_per_launch": flops_per_launch, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, PMC)",
-                         "traffic_source": traffic_src},
+                         "traffic_source": traffic_src,
+                         "hbm_GBps": round(traffic / avg_launch_ms / 1e6, 1) if traffic else None,
+                         # A tile + B tile + C written, + C read by the tasks of k-blocks 1.. (beta = 1 there)
+                         "algorithmic_bytes_per_launch": int(4 * args.blk * args.blk *
+                                                             (3 + (max(k // args.blk, 1) - 1) / max(k // args.blk, 1)))},
             "parity_first_tile_row_rel_err_vs_float64": rel,
         }
         if not args.no_cpu and n_gpus == 1:
