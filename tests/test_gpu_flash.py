@@ -545,7 +545,7 @@ def run_ref_driver(name, args, env_extra):
 
 
 def test_reference_driver_binaries_unchanged(dev, tmp_path, golden):
-    """The reference's OWN drivers/gemm.cpp, csrmm.cpp, csrgemv.cpp -- compiled unchanged against
+    """The reference's OWN drivers/gemm.cpp, csrmm.cpp, csrmm_pmem.cpp, csrgemv.cpp -- compiled unchanged against
     blas-on-flash_amd/include, linked against libflashblas.so + libbof_hip.so (oracle/Makefile) --
     run with the reference's argv on files: the drop-in boundary end to end."""
     import hashlib
@@ -571,6 +571,12 @@ def test_reference_driver_binaries_unchanged(dev, tmp_path, golden):
     assert "csrmm() took" in out
     want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
     assert hashlib.sha256(np.fromfile(p["C2"], np.float32).tobytes()).hexdigest() == want["gen_csrmm_c"]
+    # drivers/csrmm_pmem.cpp: the overload with B and C in host memory, no flash_setup either.
+    # It runs to the end; its own write-back of C opens the file with std::ios::binary alone, which
+    # libstdc++ refuses, so the file keeps its contents -- only completion can be checked here (the
+    # overload's results are checked through the C ABI in test_flash_csrmm_inmem_bc)
+    out = run_ref_driver("ref_csrmm_pmem_driver", [p["csr"], p["col"], p["off"], p["B2"], p["C2"], m, n, k, 1.0, 0.0, "N", "R"], env)
+    assert "Finished csrmm" in out
     # the reference's csrgemv driver never calls flash_setup (it hangs with the reference library,
     # SURVEY App. B-1); here it runs as shipped
     for trans in "NT":
