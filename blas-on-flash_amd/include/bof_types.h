@@ -4,6 +4,7 @@
 // (CMakeLists.txt:104), which is also the on-disk type of CSR index/offset files.
 #pragma once
 
+#include <cassert>
 #include <cfloat>
 #include <cstdint>
 
@@ -20,6 +21,9 @@ typedef double LONGFPTYPE;
 #define MKL_INT long long
 #endif
 static_assert(sizeof(MKL_INT) == 8, "CSR index/offset files are int64");
+
+// mkl_dot / mkl_axpy / mkl_imin of the reference's bof_types.h:23-28, for its application drivers
+#include "bof_host_blas1.h"
 
 // Build-time macro contract of the reference (CMakeLists.txt:38-91): defaults are
 // supplied here so drivers compile without -D flags.  The tile-size macros only

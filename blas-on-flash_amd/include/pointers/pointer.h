@@ -23,6 +23,10 @@ namespace flash {
     BaseFileHandle* fop = nullptr;  // non-owning; map_file creates it, unmap_file deletes it
 
     flash_ptr() = default;
+    // The reference declares this constructor only to reject it ("Bad usage", include/pointers/
+    // pointer.h:22-24 -- an assert that release builds compile out); its kmeans driver still
+    // names it for two pointers it never uses (drivers/kmeans.cpp:26-27).  Here: a null pointer.
+    flash_ptr(T*) {}
     flash_ptr(T* tag, FBLAS_UINT byte_off, BaseFileHandle* handle)
         : ptr(tag), foffset(byte_off), fop(handle) {}
 

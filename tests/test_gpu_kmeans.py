@@ -240,3 +240,27 @@ def test_flash_kmeans_point_sharded_files(dev, tmp_path, nproc):
     assert np.array_equal(got, ref)
     want = ((points.astype(np.float64)[:, None, :] - centers.astype(np.float64)[None, :, :]) ** 2).sum(2)
     assert np.abs(got - want).max() < 1e-5 * want.max()
+
+
+def test_reference_kmeans_driver_unchanged(dev, tmp_path):
+    """The reference's OWN drivers/kmeans.cpp, compiled unchanged against blas-on-flash_amd/include
+    (oracle/Makefile; its cblas_sdot / isamin / saxpy calls on the mapped files resolve to the plain host
+    loops of bof_host_blas1.h) and linked against the product libraries: one Lloyd iteration on files, the
+    distance matrix through flash::kmeans on the GPU.  The rewritten centres against a float64 iteration."""
+    from test_gpu_flash import run_ref_driver
+    ncenters, npoints, dim = 32, 3000, 24
+    rng = np.random.default_rng(33)
+    true = rng.normal(0, 5, (ncenters, dim))
+    assign = rng.integers(0, ncenters, npoints)
+    points = (true[assign] + rng.normal(0, 0.3, (npoints, dim))).astype(np.float32)
+    centers = (true + rng.normal(0, 0.5, (ncenters, dim))).astype(np.float32)
+    pp, cp = str(tmp_path / "points.bin"), str(tmp_path / "centers.bin")
+    points.tofile(pp)
+    centers.tofile(cp)
+    run_ref_driver("ref_kmeans_driver", [pp, cp, npoints, dim, ncenters], {"BOF_GEMM_BLK_SIZE": "1024"})
+    d = ((points.astype(np.float64)[:, None, :] - centers.astype(np.float64)[None, :, :]) ** 2).sum(2)
+    near = d.argmin(1)
+    want = np.stack([points[near == c].astype(np.float64).mean(0) if np.any(near == c) else np.zeros(dim)
+                     for c in range(ncenters)])
+    got = np.fromfile(cp, np.float32).reshape(ncenters, dim)
+    assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())

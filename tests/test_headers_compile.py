@@ -14,16 +14,16 @@ REF = "/root/reference"
 
 def test_own_drivers_build():
     subprocess.run(["make", "-C", os.path.join(PKG, "drivers"), "-s"], check=True)
-    for d in ("gemm_driver", "csrmm_driver", "csrgemv_driver", "csrcsc_driver"):
+    for d in ("gemm_driver", "csrmm_driver", "csrgemv_driver", "csrcsc_driver", "kmeans_driver"):
         assert os.access(os.path.join(PKG, "bin", d), os.X_OK)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
-@pytest.mark.parametrize("drv", ["gemm", "csrmm", "csrgemv", "csrcsc"])
+@pytest.mark.parametrize("drv", ["gemm", "csrmm", "csrgemv", "csrcsc", "csrmm_pmem", "kmeans"])
 def test_reference_driver_compiles_unchanged(tmp_path, drv):
     subprocess.run(["make", "-C", os.path.join(PKG, "drivers"), "-s"], check=True)
     out = str(tmp_path / f"ref_{drv}")
-    cmd = ["g++", "-std=c++14", "-O1", "-w", "-I", os.path.join(PKG, "include"),
+    cmd = ["g++", "-std=c++14", "-O1", "-w", "-fopenmp", "-I", os.path.join(PKG, "include"),
            os.path.join(REF, "drivers", f"{drv}.cpp"), "-o", out,
            "-L", os.path.join(PKG, "lib"), "-lflashblas", "-lbof_hip",
            f"-Wl,-rpath,{os.path.join(PKG, 'lib')}", "-lpthread"]
