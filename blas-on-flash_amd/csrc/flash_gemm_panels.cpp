@@ -30,6 +30,10 @@
 // not contiguous in its file (ldc != stored width: writing whole panels would clobber what
 // lies between the rows), the call is handed to the tile cache of flash_runtime.cpp.
 //
+// HBM: one allocation per panel slot, made in first-use order by an allocator thread while the
+// first panels are already being read (a cold 65536^3 call spent 0.85 s in hipMalloc before its
+// first read otherwise); slots stay with the device's PanelResources between calls.
+//
 // Threads: n_io_threads readers (file -> pinned slot -> H2D), the caller as dispatcher (tile
 // launches on n_streams compute streams), one flusher (HBM -> pinned, chunk by chunk) and
 // writers (pinned -> file).  Everything is ordered by hipEvents and two condition variables;
@@ -75,11 +79,13 @@ struct Mat {
   bool natural = false;         // whole matrix resident at its file offsets
   int n_slots = 0;
   size_t slot_bytes = 0, total_bytes = 0;
-  char *base = nullptr;
-  char *panel_ptr(int p) const {
-    return natural ? base + (size_t) panels[(size_t) p].r0 * (size_t) ld * 4
-                   : base + (size_t) (p % n_slots) * slot_bytes;
-  }
+  // One HBM allocation per panel slot (resident matrices: one per panel), made in first-use order
+  // by a thread of its own while the first panels are already being read: hipMalloc costs 13-36 ms
+  // per GiB and used to sit in front of the first read (0.85 s of a cold 65536^3 call).  A null
+  // entry = not allocated yet; entries are written under PanelRun::mu.
+  std::vector<char *> *slots = nullptr;
+  int slot_of(int p) const { return natural ? p : p % n_slots; }
+  char *panel_ptr(int p) const { return (*slots)[(size_t) slot_of(p)]; }
   uint64_t file_off(int p) const { return f.foffset + (uint64_t) panels[(size_t) p].r0 * (uint64_t) ld * 4; }
 };
 
@@ -88,8 +94,20 @@ struct WriteReq { int wslot; uint64_t file_off, bytes; int panel; bool last; };
 
 struct PanelResources {
   PinnedRing rring, wring;
-  char *slab[3] = {nullptr, nullptr, nullptr};
-  size_t slab_bytes[3] = {0, 0, 0};
+  std::vector<char *> slot[3];            // kept between calls
+  size_t slot_bytes[3] = {0, 0, 0};
+  size_t held_bytes() const {
+    size_t tot = 0;
+    for (int x = 0; x < 3; x++)
+      for (char *p : slot[x])
+        if (p) tot += slot_bytes[x];
+    return tot;
+  }
+  void drop(int x, size_t keep) {         // free the slots of matrix x from index `keep` on
+    for (size_t i = keep; i < slot[x].size(); i++)
+      if (slot[x][i]) (void) hipFree(slot[x][i]);
+    slot[x].resize(keep);
+  }
 };
 std::mutex g_pres_mu;
 PanelResources *g_pres[64];
@@ -114,6 +132,7 @@ struct PanelRun {
   WorkQueue<int> flush_q;
   WorkQueue<WriteReq> write_q;
   std::vector<std::pair<int, int>> order;  // (mat, panel) in order of first use
+  std::vector<std::pair<int, int>> alloc_order;  // (mat, slot) still to be allocated, in order of first use
   size_t next_fetch = 0;
   std::vector<std::vector<hipEvent_t>> group_ev;  // per group: one event per compute stream
   std::vector<int> group_of;                      // C panel -> group
@@ -155,6 +174,7 @@ struct PanelRun {
       Panel &P = M.panels[(size_t) p];
       const int prev = M.natural ? -1 : p - M.n_slots;
       if (prev >= 0 && !M.panels[(size_t) prev].retired) break;
+      if (!M.panel_ptr(p)) break;   // its HBM slot is still being allocated (alloc_main pumps again)
       const int n_chunks = (int) ((P.bytes + chunk - 1) / chunk);
       P.state = 1;
       P.remaining = n_chunks;
@@ -165,6 +185,25 @@ struct PanelRun {
       cnt.misses++;
       next_fetch++;
     }
+  }
+
+  // HBM slots in first-use order; every new slot may unblock the next fetch / the dispatcher
+  void alloc_main() {
+    (void) hipSetDevice(dev);
+    for (const auto &as : alloc_order) {
+      if (io_error.load()) break;
+      TraceRange r("panel slot hipMalloc");
+      char *p = nullptr;
+      const hipError_t e = hipMalloc((void **) &p, mat[as.first].slot_bytes);
+      if (e != hipSuccess) { fail_io(-1000 - (int) e); break; }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        (*mat[as.first].slots)[(size_t) as.second] = p;
+        pump_fetches();
+      }
+      cv.notify_all();
+    }
+    trace("HBM panel slots allocated");
   }
 
   void reader_main() {
@@ -287,8 +326,7 @@ void panel_resources_release() {
     if (!r) continue;
     r->rring.destroy();
     r->wring.destroy();
-    for (int x = 0; x < 3; x++)
-      if (r->slab[x]) (void) hipFree(r->slab[x]);
+    for (int x = 0; x < 3; x++) r->drop(x, 0);
     delete r;
     g_pres[d] = nullptr;
   }
@@ -316,7 +354,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     if (!g_pres[R.dev & 63]) g_pres[R.dev & 63] = new PanelResources();
     R.res = g_pres[R.dev & 63];
   }
-  for (int x = 0; x < 3; x++) free_b += R.res->slab_bytes[x];  // what we already hold counts as free
+  free_b += R.res->held_bytes();  // what we already hold counts as free
   size_t budget = o.hbm_budget > 0 ? (size_t) o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
   const int dC = g.rdim[2];                    // 0: C paneled along m, 2: along n
@@ -369,7 +407,6 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     M.n_slots = (int) plan.n_slots[x];
   }
   Mat &X = R.mat[R.xmat], &C = R.mat[2];
-  auto need_of = [](const Mat &M) { return M.natural ? round_up(M.total_bytes, 2u << 20) : (size_t) M.n_slots * M.slot_bytes; };
 
   // ---- task list in execution order, panels in first-use order ------------------------------
   std::vector<bof_gemm_task> tasks;
@@ -411,18 +448,32 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     if (R.mat[x].fd < 0) { set_error("bof_flash_gemm: cannot open a buffered descriptor of an unaligned matrix file"); return BOF_EIO; }
   }
   for (int x = 0; x < 3; x++) {
+    // slots kept from an earlier call are reused when they have this call's size; the missing ones
+    // are allocated by alloc_main in first-use order while the pipeline already runs
     Mat &M = R.mat[x];
-    const size_t bytes = need_of(M);
-    if (R.res->slab_bytes[x] < bytes) {
-      if (R.res->slab[x]) (void) hipFree(R.res->slab[x]);
-      R.res->slab[x] = nullptr;
-      R.res->slab_bytes[x] = 0;
-      BOF_HIP_TRY(hipMalloc((void **) &R.res->slab[x], bytes));
-      R.res->slab_bytes[x] = bytes;
+    if (R.res->slot_bytes[x] != M.slot_bytes) {
+      R.res->drop(x, 0);
+      R.res->slot_bytes[x] = M.slot_bytes;
     }
-    M.base = R.res->slab[x];
+    const size_t want = (size_t) (M.natural ? (int) M.panels.size() : M.n_slots);
+    if (R.res->slot[x].size() > want) R.res->drop(x, want);
+    R.res->slot[x].resize(want, nullptr);
+    M.slots = &R.res->slot[x];
   }
-  R.trace("plan + HBM panels");
+  {
+    std::vector<std::vector<char>> listed(3);
+    for (int x = 0; x < 3; x++) listed[x].assign(R.res->slot[x].size(), 0);
+    for (const bof_gemm_task &tk : tasks) {
+      const int64_t idx[3] = {tk.i, tk.l, tk.j};
+      for (int x = 0; x < 3; x++) {
+        const int sl = R.mat[x].slot_of((int) idx[R.mat[x].rdim]);
+        if (listed[x][(size_t) sl]) continue;
+        listed[x][(size_t) sl] = 1;
+        if (!(*R.mat[x].slots)[(size_t) sl]) R.alloc_order.emplace_back(x, sl);
+      }
+    }
+  }
+  R.trace("plan");
   Cleanup guard;
   guard.add([&R] {
     for (auto &M : R.mat)
@@ -469,6 +520,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   for (int i = 0; i < n_readers; i++) readers.emplace_back([&R] { R.reader_main(); });
   for (int i = 0; i < n_writers; i++) writers.emplace_back([&R] { R.writer_main(); });
   std::thread flusher([&R] { R.flusher_main(); });
+  std::thread allocator([&R] { R.alloc_main(); });
   {
     std::lock_guard<std::mutex> lk(R.mu);
     R.pump_fetches();
@@ -494,6 +546,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
           if (R.io_error.load()) return true;
           if (R.mat[0].panels[(size_t) pn[0]].state != 2 || R.mat[1].panels[(size_t) pn[1]].state != 2) return false;
           if (R.c_read) return C.panels[(size_t) pn[2]].state == 2;
+          if (!C.panel_ptr(pn[2])) return false;                  // its HBM slot is still being allocated
           return cprev < 0 || C.panels[(size_t) cprev].retired;   // the slot's write-back is on its way
         });
       }
@@ -545,6 +598,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
 
   // ---- drain ------------------------------------------------------------------------------------
   if (herr != hipSuccess || fail) R.fail_io(-EIO);
+  allocator.join();
   R.fetch_q.close();
   for (auto &th : readers) th.join();
   R.flush_q.close();

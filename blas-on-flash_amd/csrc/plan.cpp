@@ -67,7 +67,6 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
   P.streamed = -1;
   auto up = [](uint64_t v) { return (v + (2u << 20) - 1) / (2u << 20) * (2u << 20); };
   if (g.nblk[0] * g.nblk[1] * g.nblk[2] == 0) { P.why = 1; return P; }
-  uint64_t total[3];
   for (int x = 0; x < 3; x++) {
     const int64_t rows = g.size[g.rdim[x]], cols = g.size[g.cdim[x]], ld = g.ld[x];
     if (ld < cols) { P.why = 2; return P; }
@@ -76,7 +75,6 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
     const int64_t last_rows = rows - (P.n_panels[x] - 1) * g.blk[g.rdim[x]];
     const int64_t max_rows = std::max(last_rows, std::min(rows, g.blk[g.rdim[x]]));
     P.slot_bytes[x] = up(((uint64_t) (max_rows - 1) * (uint64_t) ld + (uint64_t) cols) * 4);
-    total[x] = up(((uint64_t) (rows - 1) * (uint64_t) ld + (uint64_t) cols) * 4);
   }
   if (g.ld[2] != g.size[g.cdim[2]]) { P.why = 4; return P; }
   const int dC = g.rdim[2];
@@ -92,7 +90,9 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
   P.n_slots[xm] = x_streams ? std::min<int64_t>(P.n_panels[xm], 2 * group) : P.n_panels[xm];
   P.streamed = x_streams && P.n_slots[xm] < P.n_panels[xm] ? xm : -1;
   P.n_slots[2] = std::min<int64_t>(NpC, 2 * group + 1);
-  auto need_of = [&](int x) { return P.resident[x] ? total[x] : (uint64_t) P.n_slots[x] * P.slot_bytes[x]; };
+  // every panel slot is an HBM allocation of its own (flash_gemm_panels.cpp allocates them in
+  // first-use order while the first panels are read), resident matrices hold one slot per panel
+  auto need_of = [&](int x) { return (uint64_t) P.n_slots[x] * P.slot_bytes[x]; };
   uint64_t need = need_of(0) + need_of(1) + need_of(2);
   P.need_bytes = need;
   if (need > budget) { P.why = 5; return P; }
@@ -101,7 +101,7 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
     P.n_slots[2]++;
     need += P.slot_bytes[2];
   }
-  if (P.n_slots[2] == NpC && need_of(2) >= total[2]) P.resident[2] = 1;
+  if (P.n_slots[2] == NpC) P.resident[2] = 1;
   P.need_bytes = need_of(0) + need_of(1) + need_of(2);
   P.eligible = 1;
   return P;

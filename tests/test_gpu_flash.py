@@ -132,8 +132,14 @@ def test_flash_gemm_panels_ring_reuse(dev, tmp_path, monkeypatch, ord_, ta, tb, 
     ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.75, beta, a, b, c0.copy(), 0, 0, 0, blk)
     F = Files(tmp_path, a=a, b=b, c=c0)
     try:
-        # slots are rounded to 2 MiB: resident operands 4 MiB each at most, rings 2 MiB per panel
-        budget = (2 * 6 + (2 * group + 2 * group + 1) * 2) << 20
+        # the smallest budget the plan accepts: resident operands hold one slot per panel, the streamed
+        # one 2*group slots, C 2*group + 1 (every slot is an allocation of its own, rounded to 2 MiB)
+        big = bofhip.flash_gemm_panel_plan(ord_, ta, tb, m, n, k, blk, 1 << 40, group=group)
+        assert big["eligible"]
+        npc = big["n_panels"][2]
+        slots = [big["n_slots"][0], big["n_slots"][1], min(npc, 2 * group + 1)]
+        budget = sum(slots[x] * big["slot_bytes"][x] for x in range(3))
+        assert not bofhip.flash_gemm_panel_plan(ord_, ta, tb, m, n, k, blk, budget - 1, group=group)["eligible"]
         opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=4, pinned_slots=3, gemm_path=2,
                                       io_chunk_mib=1, hbm_budget=budget)
         bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.75, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
