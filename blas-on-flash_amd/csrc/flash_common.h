@@ -157,6 +157,23 @@ hipError_t copy_stream_create(hipStream_t *s);
 int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
 void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
 
+// BOF_TRACE=1: wall-clock milestones of a level-3 call on stderr (t_begin = the call's start)
+inline bool trace_enabled() {
+  static const bool on = getenv("BOF_TRACE") != nullptr;
+  return on;
+}
+#define BOF_TRACE_T(label)                                                                       \
+  do {                                                                                           \
+    if (::bof::trace_enabled())                                                                  \
+      fprintf(stderr, "[bof trace] %-28s %8.3f ms\n", label,                                     \
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); \
+  } while (0)
+
+// Whole array <-> file with up to n_thr workers over 32 MiB pinned chunks (flash_csr.cpp)
+int stream_file(const bof_fptr &f, uint64_t bytes, char *dptr, bool to_device, hipStream_t st,
+                bool use_aio, int n_thr, Counters &cnt);
+
+
 // flash::gemm through whole row panels kept in HBM in FILE layout (flash_gemm_panels.cpp).
 // Returns BOF_OK / an error, or +1 when the call is not eligible (layout, budget) and the tile
 // cache of flash_runtime.cpp must take it.

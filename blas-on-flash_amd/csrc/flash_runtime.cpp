@@ -1,7 +1,9 @@
-// flash_runtime.cpp -- level 3: flash::gemm / csrmm / csrgemv on FILE-resident
-// matrices (reference src/blas/gemm.cpp:27-202, src/blas/csrmm.cpp:64-126,203-266,
-// src/blas/csrgemv.cpp:14-97 together with the scheduler/cache/io_executor they run
-// on: src/scheduler/{scheduler,cache,io_executor}.cpp).
+// flash_runtime.cpp -- level 3: flash::gemm / kmeans on FILE-resident matrices through the
+// tile cache (reference src/blas/gemm.cpp:27-202, src/blas/kmeans.cpp:27-198 together with the
+// scheduler/cache/io_executor they run on: src/scheduler/{scheduler,cache,io_executor}.cpp),
+// the entry points that choose between it and the row-panel pipeline (flash_gemm_panels.cpp),
+// the schedule dry run, and what the level-3 calls share (stats, release, region transfers).
+// The CSR calls are in flash_csr.cpp.
 //
 // MI355X-first design (not the reference's):
 //   * the "program cache" is HBM: a pool of fixed-size device tile slots; the task
@@ -328,17 +330,6 @@ struct GemmRun {
 
 }  // namespace
 
-static bool trace_on() {
-  static const bool on = getenv("BOF_TRACE") != nullptr;
-  return on;
-}
-#define BOF_TRACE_T(label)                                                                       \
-  do {                                                                                           \
-    if (trace_on())                                                                              \
-      fprintf(stderr, "[bof trace] %-28s %8.3f ms\n", label,                                     \
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); \
-  } while (0)
-
 static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                            float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
                            int64_t ldb, int64_t ldc, const bof_options *opts, const KmeansVecs *kv = nullptr) {
@@ -493,7 +484,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
     }
     const bof_gemm_task &tk = R.tasks[t];
     const int *ids = &R.task_tiles[(size_t) t * 3];
-    if (trace_on() && (t == 0 || tk.l != R.tasks[t - 1].l)) {
+    if (trace_enabled() && (t == 0 || tk.l != R.tasks[t - 1].l)) {
       char lbl[64];
       snprintf(lbl, sizeof(lbl), "task %d (l=%d) next", t, (int) tk.l);
       BOF_TRACE_T(lbl);
@@ -573,880 +564,6 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   return fail;
 }
 
-// =====================================================================================
-// CSRMM / CSRGEMV: every row block is used exactly once -> a ring of block contexts
-// =====================================================================================
-namespace {
-
-struct CsrCtx {
-  char *d_idx = nullptr, *d_val = nullptr, *d_c = nullptr, *d_c_rm = nullptr;
-  char *h_idx = nullptr, *h_val = nullptr, *h_c = nullptr;
-  hipEvent_t ready = nullptr, done = nullptr;
-  int64_t owner = -1;   // block id this context is reserved for (guarded by mu)
-  int state = 0;        // 0 being filled, 1 loaded (H2D enqueued)
-};
-
-// HBM -> pageable host memory through pinned chunks: a plain hipMemcpy into pageable memory runs
-// at ~5 GB/s on this stack (40 ms for the 200 MB result vector of a cfg5-size csrgemv); here up
-// to n_thr threads each pull 8 MiB chunks into a pinned slot and copy them out.
-int device_to_pageable(void *dst, const void *src, uint64_t bytes, int n_thr) {
-  const uint64_t chunk = 8ull << 20;
-  const int64_t nc = (int64_t) ((bytes + chunk - 1) / chunk);
-  if (nc <= 2) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
-  n_thr = (int) std::max<int64_t>(1, std::min<int64_t>(n_thr, nc));
-  std::atomic<int64_t> next{0};
-  std::atomic<int> fail{0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -1;
-  auto worker = [&, dev] {
-    void *pin = nullptr;
-    hipStream_t st = nullptr;
-    if (hipSetDevice(dev) != hipSuccess || copy_stream_create(&st) != hipSuccess) { fail.store(-1); return; }
-    if (pinned_alloc(&pin, chunk) != BOF_OK) { fail.store(-1); (void) hipStreamDestroy(st); return; }
-    for (;;) {
-      const int64_t i = next.fetch_add(1);
-      if (i >= nc || fail.load()) break;
-      const uint64_t o = (uint64_t) i * chunk, len = std::min<uint64_t>(chunk, bytes - o);
-      if (hipMemcpyAsync(pin, (const char *) src + o, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess) { fail.store(-1); break; }
-      memcpy((char *) dst + o, pin, len);
-    }
-    pinned_free(pin);
-    (void) hipStreamDestroy(st);
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < n_thr; t++) th.emplace_back(worker);
-  worker();
-  for (auto &x : th) x.join();
-  return fail.load();
-}
-
-// host arrays that are about to be overwritten whole: no value-initialisation pass
-template <class T>
-struct NoInitAlloc : std::allocator<T> {
-  template <class U> struct rebind { using other = NoInitAlloc<U>; };
-  template <class U> void construct(U *p) noexcept { ::new ((void *) p) U; }
-  template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *) p) U(std::forward<A>(a)...); }
-};
-using HostI64 = std::vector<int64_t, NoInitAlloc<int64_t>>;
-
-struct CsrRun {
-  bof_options o;
-  bool is_mm = true;
-  char ord_b = 'R', trans = 'N';
-  int64_t m = 0, n = 0, k = 0;
-  float alpha = 1.f, beta = 0.f;
-  bof_fptr fa, fja, fb, fc;
-  const float *host_b = nullptr;  // csrmm overload with B and C in host memory
-  float *host_c = nullptr;
-  // A already in HBM (the transposed matrix of csrmm 'T'): 0-based arrays, nothing to read
-  const float *res_val = nullptr;
-  const int64_t *res_col = nullptr;
-  HostI64 ia;
-  std::vector<int64_t> st, sz;
-  std::vector<CsrCtx> ctx;
-  int depth = 3;
-  std::atomic<int64_t> next_blk{0};
-  hipStream_t h2d = nullptr, d2h = nullptr;
-  WorkQueue<int64_t> done_q;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::atomic<int> io_error{0};
-  Counters cnt;
-  int dev = 0;
-  bool use_aio = true;
-
-  void fail_io(int code) {  // see GemmRun::fail_io
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      int none = 0;
-      io_error.compare_exchange_strong(none, code);
-    }
-    cv.notify_all();
-  }
-
-  // the C file is read and written by several threads at once: ONE descriptor mode for every
-  // request of the call (O_DIRECT only if every block's region is aligned, else the buffered
-  // twin), as in flash::gemm -- a direct and a buffered write must never meet in one page
-  int fd_c = -1;
-  bool aio_c = false;
-  uint64_t fsize_ja = 0, fsize_a = 0;
-  uint64_t sector = 512;  // the reference widens to SECTOR_LEN = 512; a 4Kn device reports more
-  // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
-  // end of the file (the last sector of a file is usually partial)
-  void seg(int64_t b, int esz, const bof_fptr &f, uint64_t &start, uint64_t &len, uint64_t &delta) const {
-    const uint64_t z = (uint64_t) ia[st[b]], nnz = (uint64_t) (ia[st[b] + sz[b]] - ia[st[b]]);
-    const uint64_t b0 = f.foffset + z * esz, b1 = b0 + nnz * esz;
-    const uint64_t fsize = esz == 8 ? fsize_ja : fsize_a;
-    start = b0 / sector * sector;
-    uint64_t end = round_up(b1, sector);
-    if (fsize && end > fsize) end = std::max(b1, std::min(end, fsize));
-    len = nnz ? end - start : 0;
-    delta = b0 - start;
-  }
-  size_t c_bytes(int64_t b) const { return (size_t) sz[b] * k * sizeof(float); }
-
-  void reader_main() {
-    (void) hipSetDevice(dev);
-    (void) bind_thread_near_device(dev);
-    const int64_t nb = (int64_t) st.size();
-    for (;;) {
-      const int64_t b = next_blk.fetch_add(1);
-      if (b >= nb) break;
-      CsrCtx &c = ctx[b % depth];
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return c.owner == b || io_error.load(); });
-      }
-      if (io_error.load()) {
-        { std::lock_guard<std::mutex> lk(mu); c.state = 1; }
-        cv.notify_all();
-        continue;
-      }
-      uint64_t s0 = 0, l0 = 0, d0 = 0, s1 = 0, l1 = 0, d1 = 0;
-      int rc = 0;
-      if (!res_val) {
-        seg(b, 8, fja, s0, l0, d0);
-        seg(b, 4, fa, s1, l1, d1);
-        rc = file_sread(fja.fd, s0, 0, 1, l0, c.h_idx, use_aio);
-        if (!rc) rc = file_sread(fa.fd, s1, 0, 1, l1, c.h_val, use_aio);
-        cnt.rd += l0 + l1;
-      }
-      hipError_t e = hipSuccess;
-      if (!rc && !res_val) {
-        e = hipMemcpyAsync(c.d_idx, c.h_idx, l0, hipMemcpyHostToDevice, h2d);
-        if (e == hipSuccess) e = hipMemcpyAsync(c.d_val, c.h_val, l1, hipMemcpyHostToDevice, h2d);
-        cnt.h2d += l0 + l1;
-      }
-      if (!rc && e == hipSuccess && is_mm && beta != 0.f) {
-        // C block: 'R' contiguous rows, 'C' strided columns of the block (packed [k][r])
-        if (host_c) {
-          if (ord_b == 'R') memcpy(c.h_c, host_c + (size_t) st[b] * k, c_bytes(b));
-          else
-            for (int64_t j = 0; j < k; j++)
-              memcpy(c.h_c + (size_t) j * sz[b] * 4, host_c + (size_t) j * m + st[b], (size_t) sz[b] * 4);
-        } else if (ord_b == 'R')
-          rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
-        else
-          rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
-                          (uint64_t) sz[b] * 4, c.h_c, aio_c);
-        cnt.rd += c_bytes(b);
-        if (!rc) e = hipMemcpyAsync(c.d_c, c.h_c, c_bytes(b), hipMemcpyHostToDevice, h2d);
-        cnt.h2d += c_bytes(b);
-      }
-      if (!rc && e == hipSuccess) e = hipEventRecord(c.ready, h2d);
-      // the pinned buffers are reused only after this block retires (owner hand-over),
-      // which is after its kernels, which wait for these copies
-      if (rc) fail_io(rc);
-      if (e != hipSuccess) fail_io(-1000 - (int) e);
-      { std::lock_guard<std::mutex> lk(mu); c.state = 1; }
-      cv.notify_all();
-    }
-  }
-
-  // retires a block: waits for its last GPU op, writes C (csrmm), hands its context to block b + depth
-  // (run by a small pool: blocks in flight always sit in different contexts)
-  void retire_main() {
-    (void) hipSetDevice(dev);
-    (void) bind_thread_near_device(dev);
-    int64_t b;
-    while (done_q.pop(b)) {
-      CsrCtx &c = ctx[b % depth];
-      hipError_t e = hipEventSynchronize(c.done);
-      if (e != hipSuccess) fail_io(-1000 - (int) e);
-      if (is_mm && !io_error.load() && host_c) {
-        if (ord_b == 'R') memcpy(host_c + (size_t) st[b] * k, c.h_c, c_bytes(b));
-        else
-          for (int64_t j = 0; j < k; j++)
-            memcpy(host_c + (size_t) j * m + st[b], c.h_c + (size_t) j * sz[b] * 4, (size_t) sz[b] * 4);
-      } else if (is_mm && !io_error.load()) {
-        int rc;
-        if (ord_b == 'R')
-          rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
-        else
-          rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
-                           (uint64_t) sz[b] * 4, c.h_c, aio_c);
-        if (rc) fail_io(rc);
-        cnt.wr += c_bytes(b);
-      }
-      { std::lock_guard<std::mutex> lk(mu); c.owner = b + depth; c.state = 0; }
-      cv.notify_all();
-    }
-  }
-};
-
-// File -> host array, in 16 MiB pieces taken by up to n_thr threads (one thread reads the page
-// cache at ~5 GB/s and first touches the destination's pages alone: the 400 MB of offsets of the
-// cfg5-size matrix took 85 ms of a 280 ms csrgemv call).
-int read_host(const bof_fptr &f, uint64_t bytes, void *dst, bool use_aio, int n_thr = 8) {
-  const uint64_t piece = 16ull << 20;
-  const int64_t np = (int64_t) ((bytes + piece - 1) / piece);
-  n_thr = (int) std::max<int64_t>(1, std::min<int64_t>(n_thr, np));
-  if (n_thr == 1) return file_sread(f.fd, f.foffset, 0, 1, bytes, dst, use_aio);
-  std::atomic<int64_t> next{0};
-  std::atomic<int> fail{0};
-  auto worker = [&] {
-    for (;;) {
-      const int64_t i = next.fetch_add(1);
-      if (i >= np || fail.load()) break;
-      const uint64_t o = (uint64_t) i * piece, len = std::min<uint64_t>(piece, bytes - o);
-      const int io = file_sread(f.fd, f.foffset + o, 0, 1, len, (char *) dst + o, use_aio);
-      if (io) { int z = 0; fail.compare_exchange_strong(z, io); }
-    }
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < n_thr; t++) th.emplace_back(worker);
-  worker();
-  for (auto &x : th) x.join();
-  return fail.load();
-}
-
-
-// Whole array <-> file with up to n_thr workers; each owns a 2-slot pinned ring and takes
-// 32 MiB chunks off a shared counter.  to_device: file -> pinned -> HBM; else the reverse.
-int stream_file(const bof_fptr &f, uint64_t bytes, char *dptr, bool to_device, hipStream_t st,
-                bool use_aio, int n_thr, Counters &cnt) {
-  if (bytes == 0) return BOF_OK;
-  const size_t chunk = (size_t) std::min<uint64_t>(32ull << 20, round_up(bytes, 4096));
-  const int64_t nchunks = (int64_t) ((bytes + chunk - 1) / chunk);
-  n_thr = (int) std::max<int64_t>(1, std::min<int64_t>(n_thr, nchunks));
-  std::atomic<int64_t> next{0};
-  std::atomic<int> fail{0};
-  int dev = 0;
-  BOF_HIP_TRY(hipGetDevice(&dev));
-  auto worker = [&, dev] {
-    (void) hipSetDevice(dev);
-    PinnedRing ring;
-    if (ring.init(2, chunk)) { fail.store(-1000); return; }
-    for (;;) {
-      const int64_t i = next.fetch_add(1);
-      if (i >= nchunks || fail.load()) break;
-      const uint64_t o = (uint64_t) i * chunk, len = std::min<uint64_t>(chunk, bytes - o);
-      const int sl = ring.acquire();
-      int io = 0;
-      hipError_t e = hipSuccess;
-      if (to_device) {
-        io = file_sread(f.fd, f.foffset + o, 0, 1, len, ring.ptr(sl), use_aio);
-        if (!io) e = hipMemcpyAsync(dptr + o, ring.ptr(sl), len, hipMemcpyHostToDevice, st);
-        if (!io && e == hipSuccess && ring.mark_busy(sl, st)) e = hipErrorUnknown;
-        cnt.rd += len; cnt.h2d += len;
-      } else {
-        e = hipMemcpyAsync(ring.ptr(sl), dptr + o, len, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && ring.mark_busy(sl, st)) e = hipErrorUnknown;
-        if (e == hipSuccess) e = hipEventSynchronize(ring.event(sl));
-        if (e == hipSuccess) io = file_swrite(f.fd, f.foffset + o, 0, 1, len, ring.ptr(sl), use_aio);
-        cnt.d2h += len; cnt.wr += len;
-      }
-      ring.release(sl);
-      if (io) fail.store(io);
-      if (e != hipSuccess) fail.store(-1000 - (int) e);
-    }
-    ring.destroy();
-  };
-  std::vector<std::thread> th;
-  for (int i = 1; i < n_thr; i++) th.emplace_back(worker);
-  worker();
-  for (auto &t : th) t.join();
-  const int fl = fail.load();
-  if (fl) {
-    set_error(std::string(to_device ? "loading" : "storing") + " an array failed: " +
-              (fl > -1000 ? std::string(strerror(-fl)) : "HIP error " + std::to_string(-1000 - fl)));
-    return fl > -1000 ? BOF_EIO : BOF_EHIP;
-  }
-  return BOF_OK;
-}
-
-// A^T of a file-resident CSR matrix, built in HBM scratch (SCR_TR_*), offsets also on the host
-struct ResidentCsr {
-  const float *val = nullptr;
-  const int64_t *col = nullptr, *ia_dev = nullptr;
-  HostI64 ia_host;
-  int64_t nnz = 0;
-};
-
-}  // namespace
-
-// Reads CSR(a, ia, ja) (m x n) whole into HBM and transposes it there (csrcsc_kernels.hip).
-// The reference does this out of core with per-row-block mkl_csrcsc + a column-block merge
-// through temporary files (src/blas/csrcsc.cpp:32-159) because its program cache is 8 GiB of
-// DRAM; with 288 GB of HBM the matrices of the BASELINE family (12 GB) fit whole, so the
-// transposition is one device-side sort.  Callers that can go out of core (flash::csrcsc) check
-// the budget first; here a working set beyond free HBM is refused with BOF_ENOMEM.
-static int flash_transpose_to_hbm(int64_t m, int64_t n, bof_fptr fa, bof_fptr fia, bof_fptr fja,
-                                  const bof_options &o, Counters &cnt, ResidentCsr &out) {
-  const bool use_aio = o.use_odirect != 0;
-  std::vector<int64_t> ia((size_t) m + 1, 0);
-  if (m > 0) {
-    const int io = read_host(fia, (uint64_t) (m + 1) * 8, ia.data(), use_aio);
-    if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
-    cnt.rd += (uint64_t) (m + 1) * 8;
-  }
-  const int64_t z = ia[0], nnz = ia[(size_t) m] - z;
-  if (nnz < 0) { set_error("csrcsc: offsets are not ascending"); return BOF_EINVAL; }
-  out.nnz = nnz;
-  const size_t in_bytes = (size_t) nnz * 12 + (size_t) (m + 1) * 8;
-  const size_t out_bytes = (size_t) nnz * 12 + (size_t) (n + 1) * 8 + csrcsc_workspace_bytes(n, nnz);
-  size_t free_b = 0, total_b = 0;
-  BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if (in_bytes + out_bytes > free_b) {  // scratch that is already allocated only helps
-    set_error("csrcsc: the matrix needs " + std::to_string((in_bytes + out_bytes) >> 20) +
-              " MiB of HBM, " + std::to_string(free_b >> 20) + " MiB are free (out-of-core transposition "
-              "is not implemented)");
-    return BOF_ENOMEM;
-  }
-  void *vt = nullptr, *ct = nullptr, *pt = nullptr;
-  int rc = scratch_get(SCR_TR_VAL, (size_t) std::max<int64_t>(nnz, 1) * 4, &vt);
-  if (!rc) rc = scratch_get(SCR_TR_COL, (size_t) std::max<int64_t>(nnz, 1) * 8, &ct);
-  if (!rc) rc = scratch_get(SCR_TR_PTR, (size_t) (n + 1) * 8, &pt);
-  if (rc) return rc;
-  char *d_val = nullptr, *d_col = nullptr, *d_ia = nullptr;
-  hipStream_t st = nullptr;
-  Cleanup guard;
-  guard.add([&] {
-    (void) hipFree(d_val); (void) hipFree(d_col); (void) hipFree(d_ia);
-    if (st) (void) hipStreamDestroy(st);
-  });
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  BOF_HIP_TRY(hipMalloc((void **) &d_val, (size_t) std::max<int64_t>(nnz, 1) * 4));
-  BOF_HIP_TRY(hipMalloc((void **) &d_col, (size_t) std::max<int64_t>(nnz, 1) * 8));
-  BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
-  BOF_HIP_TRY(hipMemcpyAsync(d_ia, ia.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice, st));
-  cnt.h2d += (uint64_t) (m + 1) * 8;
-  bof_fptr fv = fa, fc = fja;
-  fv.foffset += (uint64_t) z * 4;
-  fc.foffset += (uint64_t) z * 8;
-  rc = stream_file(fv, (uint64_t) nnz * 4, d_val, true, st, use_aio, o.n_io_threads, cnt);
-  if (!rc) rc = stream_file(fc, (uint64_t) nnz * 8, d_col, true, st, use_aio, o.n_io_threads, cnt);
-  if (rc) return rc;
-  void *ws = nullptr;
-  if (m > 0 && nnz > 0) {
-    rc = scratch_get(SCR_CSRCSC, csrcsc_workspace_bytes(n, nnz), &ws);
-    if (rc) return rc;
-  }
-  BOF_HIP_TRY(scsrcsc(m, n, nnz, (const float *) d_val, (const int64_t *) d_ia, (const int64_t *) d_col,
-                      (float *) vt, (int64_t *) pt, (int64_t *) ct, ws, st));
-  out.ia_host.resize((size_t) n + 1);
-  BOF_HIP_TRY(hipMemcpyAsync(out.ia_host.data(), pt, (size_t) (n + 1) * 8, hipMemcpyDeviceToHost, st));
-  BOF_HIP_TRY(hipStreamSynchronize(st));
-  cnt.d2h += (uint64_t) (n + 1) * 8;
-  out.val = (const float *) vt; out.col = (const int64_t *) ct; out.ia_dev = (const int64_t *) pt;
-  return BOF_OK;
-}
-
-// An unnamed temporary file next to `near_fd` (falls back to $TMPDIR, /tmp): the reference's
-// flash_malloc'ed block files (src/blas/csrcsc.cpp:61-66).
-static int temp_file_near(int near_fd) {
-  char link[64], path[4096];
-  snprintf(link, sizeof(link), "/proc/self/fd/%d", near_fd);
-  std::vector<std::string> dirs;
-  const ssize_t len = readlink(link, path, sizeof(path) - 1);
-  if (len > 0) {
-    path[len] = 0;
-    std::string d(path);
-    const size_t slash = d.rfind('/');
-    if (slash != std::string::npos) dirs.push_back(slash ? d.substr(0, slash) : "/");
-  }
-  if (getenv("TMPDIR")) dirs.push_back(getenv("TMPDIR"));
-  dirs.push_back("/tmp");
-  for (const auto &d : dirs) {
-    const int fd = open(d.c_str(), O_TMPFILE | O_RDWR, 0600);
-    if (fd >= 0) return fd;
-  }
-  return -1;
-}
-
-// Out-of-core transposition for matrices whose working set exceeds the HBM budget -- the
-// reference's scheme (src/blas/csrcsc.cpp:32-159) with the GPU doing both halves:
-//   phase A: row blocks sized to the budget are transposed in HBM (bof::scsrcsc) and their
-//            (values, block-local row ids) written to temporary files, offsets kept on the host;
-//   phase B: column blocks sized to the budget gather their runs from every row block's file
-//            segment and are merged in block order (csc_merge_kernel) into the output files.
-static int flash_csrcsc_blocked(int64_t m, int64_t n, const std::vector<int64_t> &ia, bof_fptr fja, bof_fptr fa,
-                                bof_fptr fia_tr, bof_fptr fja_tr, bof_fptr fa_tr, const bof_options &o,
-                                size_t budget, Counters &cnt) {
-  const bool use_aio = o.use_odirect != 0;
-  const int64_t z = ia[0], nnz = ia[(size_t) m] - z;
-  // per-non-zero HBM cost of a block: input 12 B + output 12 B + sort workspace
-  const size_t fixed = (size_t) (n + 1) * 8 * 2 + (1 << 20);
-  const size_t per_nnz = 24 + (csrcsc_workspace_bytes(n, 1 << 24) >> 24) + 1;
-  if (budget <= fixed + per_nnz * 4096) {
-    set_error("csrcsc: HBM budget too small for the out-of-core transposition");
-    return BOF_ENOMEM;
-  }
-  const int64_t blk_nnz = (int64_t) ((budget - fixed) / per_nnz);
-  // ---- row blocks ----------------------------------------------------------------------
-  std::vector<int64_t> rb;  // block boundaries (rows)
-  rb.push_back(0);
-  while (rb.back() < m) {
-    const int64_t r0 = rb.back();
-    int64_t r1 = std::upper_bound(ia.begin() + r0 + 1, ia.begin() + m + 1, ia[(size_t) r0] + blk_nnz) - ia.begin() - 1;
-    if (r1 <= r0) {
-      set_error("csrcsc: one row of the matrix exceeds the HBM budget");
-      return BOF_ENOMEM;
-    }
-    rb.push_back(std::min(r1, m));
-  }
-  const int nb = (int) rb.size() - 1;
-  const int tfd_val = temp_file_near(fa_tr.fd), tfd_col = temp_file_near(fja_tr.fd);
-  hipStream_t st = nullptr;
-  char *d_val = nullptr, *d_col = nullptr, *d_ia = nullptr, *d_vt = nullptr, *d_ct = nullptr, *d_pt = nullptr;
-  char *d_aux = nullptr;
-  Cleanup guard;
-  guard.add([&] {
-    if (tfd_val >= 0) close(tfd_val);
-    if (tfd_col >= 0) close(tfd_col);
-    (void) hipFree(d_val); (void) hipFree(d_col); (void) hipFree(d_ia); (void) hipFree(d_vt); (void) hipFree(d_ct);
-    (void) hipFree(d_pt); (void) hipFree(d_aux);
-    if (st) (void) hipStreamDestroy(st);
-  });
-  if (tfd_val < 0 || tfd_col < 0) { set_error("csrcsc: cannot create temporary files"); return BOF_EIO; }
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  int64_t max_b = 0, max_rows = 0;
-  for (int b = 0; b < nb; b++) {
-    max_b = std::max(max_b, ia[(size_t) rb[b + 1]] - ia[(size_t) rb[b]]);
-    max_rows = std::max(max_rows, rb[b + 1] - rb[b]);
-  }
-  const size_t cap = (size_t) std::max<int64_t>(max_b, 1);
-  BOF_HIP_TRY(hipMalloc((void **) &d_val, cap * 4));
-  BOF_HIP_TRY(hipMalloc((void **) &d_col, cap * 8));
-  BOF_HIP_TRY(hipMalloc((void **) &d_vt, cap * 4));
-  BOF_HIP_TRY(hipMalloc((void **) &d_ct, cap * 8));
-  BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (max_rows + 1) * 8));
-  BOF_HIP_TRY(hipMalloc((void **) &d_pt, (size_t) (n + 1) * 8));
-  void *ws = nullptr;
-  int rc = scratch_get(SCR_CSRCSC, csrcsc_workspace_bytes(n, (int64_t) cap), &ws);
-  if (rc) return rc;
-  std::vector<std::vector<int64_t>> bptr((size_t) nb, std::vector<int64_t>((size_t) n + 1));
-  std::vector<int64_t> ia_tr((size_t) n + 1, 0);
-  for (int b = 0; b < nb; b++) {
-    const int64_t r0 = rb[b], r1 = rb[b + 1], zb = ia[(size_t) r0] - z, nb_nnz = ia[(size_t) r1] - ia[(size_t) r0];
-    BOF_HIP_TRY(hipMemcpyAsync(d_ia, ia.data() + r0, (size_t) (r1 - r0 + 1) * 8, hipMemcpyHostToDevice, st));
-    bof_fptr fv = fa, fc = fja;
-    fv.foffset += (uint64_t) (z + zb) * 4;
-    fc.foffset += (uint64_t) (z + zb) * 8;
-    rc = stream_file(fv, (uint64_t) nb_nnz * 4, d_val, true, st, use_aio, o.n_io_threads, cnt);
-    if (!rc) rc = stream_file(fc, (uint64_t) nb_nnz * 8, d_col, true, st, use_aio, o.n_io_threads, cnt);
-    if (rc) return rc;
-    BOF_HIP_TRY(scsrcsc(r1 - r0, n, nb_nnz, (const float *) d_val, (const int64_t *) d_ia, (const int64_t *) d_col,
-                        (float *) d_vt, (int64_t *) d_pt, (int64_t *) d_ct, ws, st));
-    BOF_HIP_TRY(hipMemcpyAsync(bptr[(size_t) b].data(), d_pt, (size_t) (n + 1) * 8, hipMemcpyDeviceToHost, st));
-    BOF_HIP_TRY(hipStreamSynchronize(st));
-    bof_fptr tv{tfd_val, (uint64_t) zb * 4}, tc{tfd_col, (uint64_t) zb * 8};
-    rc = stream_file(tv, (uint64_t) nb_nnz * 4, d_vt, false, st, false, o.n_io_threads, cnt);
-    if (!rc) rc = stream_file(tc, (uint64_t) nb_nnz * 8, d_ct, false, st, false, o.n_io_threads, cnt);
-    if (rc) return rc;
-    for (int64_t c = 0; c < n; c++) ia_tr[(size_t) c + 1] += bptr[(size_t) b][(size_t) c + 1] - bptr[(size_t) b][(size_t) c];
-    cnt.tasks++;
-  }
-  for (int64_t c = 0; c < n; c++) ia_tr[(size_t) c + 1] += ia_tr[(size_t) c];
-  if (ia_tr[(size_t) n] != nnz) { set_error("csrcsc: block transposes lost entries"); return BOF_EHIP; }
-  // ---- column blocks: gather the runs of every row block, merge, write ----------------------
-  (void) hipFree(d_ia); d_ia = nullptr;
-  (void) hipFree(d_pt); d_pt = nullptr;
-  int64_t c0 = 0;
-  while (c0 < n) {
-    // largest c1 with nnz(c0..c1) <= cap and auxiliary arrays within reason
-    int64_t c1 = std::upper_bound(ia_tr.begin() + c0 + 1, ia_tr.begin() + n + 1, ia_tr[(size_t) c0] + (int64_t) cap) -
-                 ia_tr.begin() - 1;
-    c1 = std::min<int64_t>(std::max(c1, c0 + 1), n);
-    c1 = std::min<int64_t>(c1, c0 + std::max<int64_t>(1, (int64_t) (64 << 20) / (nb + 1)));
-    const int64_t cw = c1 - c0, out_nnz = ia_tr[(size_t) c1] - ia_tr[(size_t) c0];
-    if (out_nnz > (int64_t) cap) { set_error("csrcsc: one column of the matrix exceeds the HBM budget"); return BOF_ENOMEM; }
-    // auxiliary arrays: nb x (cw+1) block offsets (relative to the block's segment), nb bases,
-    // nb first rows, cw+1 output offsets
-    std::vector<int64_t> aux((size_t) nb * (size_t) (cw + 1) + 2 * (size_t) nb + (size_t) (cw + 1));
-    int64_t *h_bp = aux.data(), *h_base = h_bp + (size_t) nb * (size_t) (cw + 1), *h_r0 = h_base + nb,
-            *h_out = h_r0 + nb;
-    int64_t fill = 0;
-    for (int b = 0; b < nb; b++) {
-      const std::vector<int64_t> &bp = bptr[(size_t) b];
-      const int64_t s = bp[(size_t) c0], e = bp[(size_t) c1], zb = ia[(size_t) rb[b]] - z;
-      for (int64_t c = 0; c <= cw; c++) h_bp[(size_t) b * (size_t) (cw + 1) + (size_t) c] = bp[(size_t) (c0 + c)] - s;
-      h_base[b] = fill;
-      h_r0[b] = rb[b];
-      if (e > s) {
-        bof_fptr tv{tfd_val, (uint64_t) (zb + s) * 4}, tc{tfd_col, (uint64_t) (zb + s) * 8};
-        rc = stream_file(tv, (uint64_t) (e - s) * 4, d_val + (size_t) fill * 4, true, st, false, o.n_io_threads, cnt);
-        if (!rc) rc = stream_file(tc, (uint64_t) (e - s) * 8, d_col + (size_t) fill * 8, true, st, false, o.n_io_threads, cnt);
-        if (rc) return rc;
-      }
-      fill += e - s;
-    }
-    for (int64_t c = 0; c <= cw; c++) h_out[c] = ia_tr[(size_t) (c0 + c)] - ia_tr[(size_t) c0];
-    (void) hipFree(d_aux); d_aux = nullptr;
-    BOF_HIP_TRY(hipMalloc((void **) &d_aux, aux.size() * 8));
-    BOF_HIP_TRY(hipMemcpyAsync(d_aux, aux.data(), aux.size() * 8, hipMemcpyHostToDevice, st));
-    const int64_t *g = (const int64_t *) d_aux;
-    BOF_HIP_TRY(csc_merge(nb, cw, g, g + (size_t) nb * (size_t) (cw + 1), g + (size_t) nb * (size_t) (cw + 1) + nb,
-                          g + (size_t) nb * (size_t) (cw + 1) + 2 * (size_t) nb, (const float *) d_val,
-                          (const int64_t *) d_col, (float *) d_vt, (int64_t *) d_ct, st));
-    BOF_HIP_TRY(hipStreamSynchronize(st));
-    bof_fptr ov = fa_tr, oc = fja_tr;
-    ov.foffset += (uint64_t) ia_tr[(size_t) c0] * 4;
-    oc.foffset += (uint64_t) ia_tr[(size_t) c0] * 8;
-    rc = stream_file(ov, (uint64_t) out_nnz * 4, d_vt, false, st, use_aio, o.n_io_threads, cnt);
-    if (!rc) rc = stream_file(oc, (uint64_t) out_nnz * 8, d_ct, false, st, use_aio, o.n_io_threads, cnt);
-    if (rc) return rc;
-    cnt.tasks++;
-    c0 = c1;
-  }
-  const int io = file_swrite(fia_tr.fd, fia_tr.foffset, 0, 1, (uint64_t) (n + 1) * 8, ia_tr.data(), use_aio);
-  if (io) { set_error(std::string("writing ia_tr failed: ") + strerror(-io)); return BOF_EIO; }
-  cnt.wr += (uint64_t) (n + 1) * 8;
-  return BOF_OK;
-}
-
-static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, bof_fptr fa,
-                             bof_fptr fia_tr, bof_fptr fja_tr, bof_fptr fa_tr, const bof_options *opts) {
-  const auto t_begin = std::chrono::steady_clock::now();
-  int rc = device_ready();
-  if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
-  const bof_options o = resolved(opts);
-  Counters cnt;
-  {
-    // does the whole matrix fit?  (input + output + sort workspace against the budget)
-    std::vector<int64_t> ia((size_t) m + 1, 0);
-    if (m > 0) {
-      const int io = read_host(fia, (uint64_t) (m + 1) * 8, ia.data(), o.use_odirect != 0);
-      if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
-    }
-    const int64_t nnz = ia[(size_t) m] - ia[0];
-    size_t free_b = 0, total_b = 0;
-    BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = o.hbm_budget > 0 ? std::min((size_t) o.hbm_budget, (size_t) (free_b * 0.9)) : (size_t) (free_b * 0.9);
-    const size_t need = (size_t) std::max<int64_t>(nnz, 0) * 24 + (size_t) (m + n + 2) * 8 + csrcsc_workspace_bytes(n, std::max<int64_t>(nnz, 0));
-    if (nnz > 0 && need > budget) {
-      cnt.rd += (uint64_t) (m + 1) * 8;
-      rc = flash_csrcsc_blocked(m, n, ia, fja, fa, fia_tr, fja_tr, fa_tr, o, budget, cnt);
-      publish_stats(cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-      return rc;
-    }
-  }
-  ResidentCsr T;
-  rc = flash_transpose_to_hbm(m, n, fa, fia, fja, o, cnt, T);
-  if (rc) return rc;
-  hipStream_t st = nullptr;
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  Cleanup guard;
-  guard.add([&] { (void) hipStreamDestroy(st); });
-  const bool use_aio = o.use_odirect != 0;
-  rc = stream_file(fa_tr, (uint64_t) T.nnz * 4, (char *) T.val, false, st, use_aio, o.n_io_threads, cnt);
-  if (!rc) rc = stream_file(fja_tr, (uint64_t) T.nnz * 8, (char *) T.col, false, st, use_aio, o.n_io_threads, cnt);
-  if (!rc) {
-    const int io = file_swrite(fia_tr.fd, fia_tr.foffset, 0, 1, (uint64_t) (n + 1) * 8, T.ia_host.data(), use_aio);
-    if (io) { set_error(std::string("writing ia_tr failed: ") + strerror(-io)); rc = BOF_EIO; }
-    cnt.wr += (uint64_t) (n + 1) * 8;
-  }
-  cnt.tasks++;
-  publish_stats(cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-  return rc;
-}
-
-// Shared driver of csrmm (is_mm) and csrgemv.  For csrgemv: hb = input vector (host), hc =
-// output vector (host).
-static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t k, float alpha,
-                          float beta, bof_fptr fa, bof_fptr fia, bof_fptr fja, char ord_b,
-                          bof_fptr fb, bof_fptr fc, const float *hb, float *hc,
-                          const bof_options *opts, const ResidentCsr *res = nullptr,
-                          Counters *carry = nullptr) {
-  const auto t_begin = std::chrono::steady_clock::now();
-  int rc = device_ready();
-  if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
-  TraceRange range(is_mm ? "bof_flash_csrmm" : "bof_flash_csrgemv");
-  CsrRun R;
-  if (carry) {  // bytes moved by the transposition that produced `res`
-    R.cnt.rd += carry->rd.load(); R.cnt.h2d += carry->h2d.load(); R.cnt.d2h += carry->d2h.load();
-  }
-  if (res) { R.res_val = res->val; R.res_col = res->col; }
-  R.o = resolved(opts);
-  R.is_mm = is_mm; R.trans = trans; R.ord_b = ord_b;
-  R.m = m; R.n = n; R.k = k; R.alpha = alpha; R.beta = beta;
-  R.fa = fa; R.fja = fja; R.fb = fb; R.fc = fc;
-  if (is_mm && fb.fd < 0) { R.host_b = hb; R.host_c = hc; }
-  R.use_aio = R.o.use_odirect != 0;
-  BOF_HIP_TRY(hipGetDevice(&R.dev));
-  if (m == 0) return BOF_OK;
-
-  // offsets are read to the host first, as the reference does (csrmm.cpp:69-71)
-  if (res) {
-    R.ia = res->ia_host;
-  } else {
-    R.ia.resize((size_t) m + 1);
-    int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia.data(), R.use_aio);
-    if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
-    R.cnt.rd += (uint64_t) (m + 1) * 8;
-  }
-  BOF_TRACE_T("csr: offsets on the host");
-  const int64_t nb = bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, nullptr, nullptr, 0);
-  R.st.resize((size_t) nb); R.sz.resize((size_t) nb);
-  bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
-
-  if (!res) {
-    struct stat sb;
-    if (fstat(fja.fd, &sb) == 0) R.fsize_ja = (uint64_t) sb.st_size;
-    if (fstat(fa.fd, &sb) == 0) R.fsize_a = (uint64_t) sb.st_size;
-    if (file_is_direct(fja.fd)) R.sector = std::max(R.sector, file_dio_align(fja.fd));
-    if (file_is_direct(fa.fd)) R.sector = std::max(R.sector, file_dio_align(fa.fd));
-  }
-  size_t max_idx = 0, max_val = 0, max_c = 0;
-  for (int64_t b = 0; b < nb; b++) {
-    uint64_t s, l, d;
-    if (!res) {
-      R.seg(b, 8, fja, s, l, d); max_idx = std::max<size_t>(max_idx, l);
-      R.seg(b, 4, fa, s, l, d);  max_val = std::max<size_t>(max_val, l);
-    }
-    if (is_mm) max_c = std::max(max_c, R.c_bytes(b));
-  }
-  if (is_mm && fc.fd >= 0) {
-    R.fd_c = fc.fd;
-    if (file_is_direct(fc.fd)) {
-      const uint64_t A = file_dio_align(fc.fd);
-      bool aligned = true;
-      for (int64_t b = 0; b < nb && aligned; b++) {
-        if (ord_b == 'R')
-          aligned = (fc.foffset + (uint64_t) R.st[b] * k * 4) % A == 0 && ((uint64_t) R.sz[b] * k * 4) % A == 0;
-        else
-          aligned = (fc.foffset + (uint64_t) R.st[b] * 4) % A == 0 && ((uint64_t) R.sz[b] * 4) % A == 0 &&
-                    ((uint64_t) m * 4) % A == 0;
-      }
-      if (aligned) R.aio_c = R.use_aio;
-      else R.fd_c = file_buffered_fd(fc.fd);
-      if (R.fd_c < 0) { set_error("flash csrmm: cannot open a buffered descriptor of the C file"); return BOF_EIO; }
-    }
-  }
-  max_idx = std::max<size_t>(max_idx, R.sector); max_val = std::max<size_t>(max_val, R.sector);
-  max_c = std::max<size_t>(max_c, 512);
-
-  int64_t *d_ia = nullptr;
-  char *d_b = nullptr, *d_x = nullptr, *d_y = nullptr;
-  hipEvent_t resident_ev = nullptr;
-  Cleanup guard;
-  guard.add([&] {
-    for (auto &c : R.ctx) {
-      (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c); (void) hipFree(c.d_c_rm);
-      pinned_free(c.h_idx);
-      pinned_free(c.h_val);
-      pinned_free(c.h_c);
-      if (c.ready) (void) hipEventDestroy(c.ready);
-      if (c.done) (void) hipEventDestroy(c.done);
-    }
-    if (resident_ev) (void) hipEventDestroy(resident_ev);
-    if (!res) (void) hipFree(d_ia);
-    (void) hipFree(d_b); (void) hipFree(d_x); (void) hipFree(d_y);
-    if (R.h2d) (void) hipStreamDestroy(R.h2d);
-    if (R.d2h) (void) hipStreamDestroy(R.d2h);
-  });
-  BOF_HIP_TRY(copy_stream_create(&R.h2d));
-  BOF_HIP_TRY(copy_stream_create(&R.d2h));
-  if (res) {
-    d_ia = const_cast<int64_t *>(res->ia_dev);
-  } else {
-    BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
-    BOF_HIP_TRY(hipMemcpyAsync(d_ia, R.ia.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice, R.h2d));
-    R.cnt.h2d += (uint64_t) (m + 1) * 8;
-  }
-  const int64_t xlen = trans == 'N' ? n : m, ylen = trans == 'N' ? m : n;
-  if (is_mm) {
-    // B stays resident for the whole call (one shared read, like the reference's
-    // single "use_full" cache key, csrmm_task.h:175-183)
-    BOF_HIP_TRY(hipMalloc((void **) &d_b, (size_t) n * k * 4));
-    if (R.host_b) {
-      BOF_HIP_TRY(hipMemcpyAsync(d_b, R.host_b, (size_t) n * k * 4, hipMemcpyHostToDevice, R.h2d));
-      R.cnt.h2d += (uint64_t) n * k * 4;
-    } else {
-      rc = stream_file(fb, (uint64_t) n * k * 4, d_b, true, R.h2d, R.use_aio, R.o.n_io_threads, R.cnt);
-      if (rc) return rc;
-    }
-    if (ord_b == 'C') {  // column-major B (n x k, ld = n) -> row-major copy used by the kernel
-      void *tmp = nullptr;
-      rc = scratch_get(SCR_B_RM, (size_t) n * k * 4, &tmp);
-      if (rc) return rc;
-      BOF_HIP_TRY(hipMemcpyAsync(tmp, d_b, (size_t) n * k * 4, hipMemcpyDeviceToDevice, R.h2d));
-      BOF_HIP_TRY(transpose_f32((const float *) tmp, n, k, n, (float *) d_b, k, R.h2d));
-    }
-  } else {
-    BOF_HIP_TRY(hipMalloc((void **) &d_x, (size_t) xlen * 4));
-    BOF_HIP_TRY(hipMalloc((void **) &d_y, (size_t) ylen * 4));
-    BOF_HIP_TRY(hipMemcpyAsync(d_x, hb, (size_t) xlen * 4, hipMemcpyHostToDevice, R.h2d));
-    if (trans == 'T') BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
-    R.cnt.h2d += (uint64_t) xlen * 4;
-  }
-  BOF_HIP_TRY(hipEventCreateWithFlags(&resident_ev, hipEventDisableTiming));
-  BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
-  BOF_TRACE_T("csr: B / x resident (queued)");
-
-  // one context = one row block in flight (index + value segments, C block); the device delivers
-  // its sequential rate only with several large requests queued, so as many blocks are in flight
-  // as there are staging slots, each read by its own thread, and retired (C written back) by a
-  // small pool instead of one thread
-  R.depth = (int) std::min<int64_t>(std::max(2, R.o.pinned_slots), nb);
-  R.ctx.resize((size_t) R.depth);
-  for (int i = 0; i < R.depth; i++) {
-    CsrCtx &c = R.ctx[i];
-    if (!res) {
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_idx, max_idx));
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_val, max_val));
-      rc = pinned_alloc((void **) &c.h_idx, max_idx);
-      if (!rc) rc = pinned_alloc((void **) &c.h_val, max_val);
-      if (rc) return rc;
-    }
-    if (is_mm) {
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_c, max_c));
-      if (ord_b == 'C') BOF_HIP_TRY(hipMalloc((void **) &c.d_c_rm, max_c));
-      rc = pinned_alloc((void **) &c.h_c, max_c);
-      if (rc) return rc;
-    }
-    BOF_HIP_TRY(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
-    BOF_HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
-    c.owner = i;
-  }
-  StreamSet *ss = stream_set(R.o.n_streams);
-  if (!ss) { set_error("flash csr: stream creation failed"); return BOF_EHIP; }
-  for (int i = 0; i < ss->n; i++) BOF_HIP_TRY(hipStreamWaitEvent(ss->s[i], resident_ev, 0));
-
-  BOF_TRACE_T("csr: block contexts ready");
-  std::vector<std::thread> readers;
-  for (int i = 0; i < std::max(1, std::min<int>(R.o.n_io_threads, R.depth)); i++)
-    readers.emplace_back([&R] { R.reader_main(); });
-  std::vector<std::thread> retirers;
-  for (int i = 0; i < std::max(1, std::min(4, R.depth / 2)); i++) retirers.emplace_back([&R] { R.retire_main(); });
-
-  hipError_t herr = hipSuccess;
-  int fail = 0;
-  for (int64_t b = 0; b < nb && !fail; b++) {
-    CsrCtx &c = R.ctx[b % R.depth];
-    {
-      std::unique_lock<std::mutex> lk(R.mu);
-      R.cv.wait(lk, [&] { return (c.owner == b && c.state == 1) || R.io_error.load(); });
-    }
-    if (R.io_error.load()) { fail = BOF_EIO; break; }
-    hipStream_t st = ss->s[b % ss->n];
-    herr = hipStreamWaitEvent(st, c.ready, 0);
-    if (herr != hipSuccess) break;
-    const int64_t s = R.st[b], r = R.sz[b];
-    const int64_t *col;
-    const float *val;
-    if (res) {
-      col = res->col + R.ia[(size_t) s];
-      val = res->val + R.ia[(size_t) s];
-    } else {
-      uint64_t s0, l0, d0, s1, l1, d1;
-      R.seg(b, 8, fja, s0, l0, d0);
-      R.seg(b, 4, fa, s1, l1, d1);
-      col = (const int64_t *) (c.d_idx + d0);  // un-shift the sector widening
-      val = (const float *) (c.d_val + d1);
-    }
-    if (is_mm) {
-      if (ord_b == 'C' && beta != 0.f)  // C block arrived packed column-major [k][r]
-        herr = transpose_f32((const float *) c.d_c, r, k, r, (float *) c.d_c_rm, k, st);
-      for (int64_t j0 = 0; j0 < k && herr == hipSuccess; j0 += R.o.csrmm_cblk) {
-        const int64_t w = std::min(k - j0, R.o.csrmm_cblk);
-        if (ord_b == 'R')
-          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
-                        (float *) c.d_c + j0, k, st);
-        else  // 'C': same row-major kernel on the transposed block (d_b is row-major here)
-          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
-                        (float *) c.d_c_rm + j0, k, st);
-      }
-      if (ord_b == 'C' && herr == hipSuccess)  // [r][k] -> packed column-major block [k][r]
-        herr = transpose_f32((const float *) c.d_c_rm, k, r, k, (float *) c.d_c, r, st);
-      if (herr != hipSuccess) break;
-      // C block -> pinned buffer on the D2H stream, after the kernels
-      herr = hipEventRecord(c.done, st);
-      if (herr == hipSuccess) herr = hipStreamWaitEvent(R.d2h, c.done, 0);
-      if (herr == hipSuccess)
-        herr = hipMemcpyAsync(c.h_c, c.d_c, R.c_bytes(b), hipMemcpyDeviceToHost, R.d2h);
-      if (herr == hipSuccess) herr = hipEventRecord(c.done, R.d2h);
-      R.cnt.d2h += R.c_bytes(b);
-    } else {
-      if (trans == 'N')
-        herr = scsrgemv('N', r, n, val, d_ia + s, col, (const float *) d_x, (float *) d_y + s, st);
-      else
-        herr = scsrgemv('T', r, n, val, d_ia + s, col, (const float *) d_x + s, (float *) d_y, st);
-      if (herr == hipSuccess) herr = hipEventRecord(c.done, st);
-    }
-    if (herr != hipSuccess) break;
-    R.cnt.tasks++;
-    R.done_q.push(b);
-  }
-  BOF_TRACE_T("csr: all blocks dispatched");
-  if (herr != hipSuccess || fail) R.fail_io(-EIO);  // releases readers parked on a context hand-over
-  for (auto &th : readers) th.join();
-  R.done_q.close();
-  for (auto &th : retirers) th.join();
-  (void) hipDeviceSynchronize();
-  BOF_TRACE_T("csr: drained (C written)");
-  if (!is_mm && !fail && herr == hipSuccess) {
-    if (device_to_pageable(hc, d_y, (uint64_t) ylen * 4, R.o.n_io_threads)) herr = hipErrorUnknown;
-    R.cnt.d2h += (uint64_t) ylen * 4;
-    BOF_TRACE_T("csr: y on the host");
-  }
-  if (herr != hipSuccess && !fail) fail = hip_fail(herr, "flash csr dispatch");
-  if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
-    const int e = R.io_error.load();
-    set_error("flash csr: I/O pipeline failed: " +
-              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
-    fail = BOF_EIO;
-  }
-  publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-  return fail;
-}
-
-// csrmm with trans_a = 'T': C[n x k] = alpha * A^T * B[m x k] + beta * C.  A^T is built in HBM
-// and the row-block pipeline of the 'N' case runs over it with nothing left to read for A
-// (the reference writes A^T to temporary files first, src/blas/csrmm.cpp:355-422).
-static int flash_csrmm_trans(uint64_t m, uint64_t n, uint64_t k, float alpha, float beta, bof_fptr a,
-                             bof_fptr ia, bof_fptr ja, char ord_b, bof_fptr b, bof_fptr c,
-                             const float *hb, float *hc, const bof_options *opts) {
-  int rc = device_ready();
-  if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
-  if (n == 0) return BOF_OK;
-  const bof_options o = resolved(opts);
-  Counters cnt;
-  bof_fptr none{-1, 0};
-  {
-    // A^T + the sort workspace must fit beside B and the block contexts; if they do not, A^T goes
-    // to temporary files through the out-of-core transposition and the ordinary file pipeline
-    // of the 'N' case runs on those (what the reference intends, src/blas/csrmm.cpp:355-386)
-    std::vector<int64_t> iav((size_t) m + 1, 0);
-    if (m > 0) {
-      const int io = read_host(ia, (uint64_t) (m + 1) * 8, iav.data(), o.use_odirect != 0);
-      if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
-    }
-    const int64_t nnz = iav[(size_t) m] - iav[0];
-    size_t free_b = 0, total_b = 0;
-    BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = o.hbm_budget > 0 ? std::min((size_t) o.hbm_budget, (size_t) (free_b * 0.9)) : (size_t) (free_b * 0.9);
-    const size_t need = (size_t) std::max<int64_t>(nnz, 0) * 24 + (size_t) (m + n + 2) * 8 +
-                        csrcsc_workspace_bytes((int64_t) n, std::max<int64_t>(nnz, 0)) + (size_t) m * k * 4;
-    if (nnz > 0 && need > budget) {
-      const int anchor = c.fd >= 0 ? c.fd : a.fd;
-      const int t_ia = temp_file_near(anchor), t_ja = temp_file_near(anchor), t_a = temp_file_near(anchor);
-      Cleanup guard;
-      guard.add([&] {
-        for (int fd : {t_ia, t_ja, t_a})
-          if (fd >= 0) { file_forget(fd); close(fd); }
-      });
-      if (t_ia < 0 || t_ja < 0 || t_a < 0) { set_error("csrmm 'T': cannot create temporary files"); return BOF_EIO; }
-      bof_options plain = o;
-      plain.use_odirect = 0;   // the temporaries are buffered descriptors
-      rc = flash_csrcsc_blocked((int64_t) m, (int64_t) n, iav, ja, a, bof_fptr{t_ia, 0}, bof_fptr{t_ja, 0},
-                                bof_fptr{t_a, 0}, plain, budget, cnt);
-      if (rc) return rc;
-      return flash_csr_impl(true, 'N', (int64_t) n, (int64_t) m, (int64_t) k, alpha, beta, bof_fptr{t_a, 0},
-                            bof_fptr{t_ia, 0}, bof_fptr{t_ja, 0}, ord_b, b, c, hb, hc, opts, nullptr, &cnt);
-    }
-  }
-  ResidentCsr T;
-  rc = flash_transpose_to_hbm((int64_t) m, (int64_t) n, a, ia, ja, o, cnt, T);
-  if (rc) return rc;
-  return flash_csr_impl(true, 'N', (int64_t) n, (int64_t) m, (int64_t) k, alpha, beta, none, none, none,
-                        ord_b, b, c, hb, hc, opts, &T, &cnt);
-}
-
 }  // namespace bof
 
 using namespace bof;
@@ -1500,65 +617,6 @@ int bof_flash_kmeans(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_
   const KmeansVecs kv{dv, dv + m, dv + m + n};
   return flash_gemm_impl(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, b, c,
                          (int64_t) lda, (int64_t) ldb, (int64_t) ldc, opts, &kv);
-}
-
-int bof_flash_csrmm(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha, float beta,
-                    bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b, bof_fptr b, bof_fptr c,
-                    const bof_options *opts) {
-  if (trans_a != 'N' && trans_a != 'T') {  // reference csrmm.cpp:446-449
-    set_error("bof_flash_csrmm: unrecognized value for param: trans_a");
-    return BOF_EINVAL;
-  }
-  if (ord_b != 'R' && ord_b != 'C') {      // reference csrmm.cpp:433-436, 442-445
-    set_error("bof_flash_csrmm: unrecognized value for param: ord_b");
-    return BOF_EINVAL;
-  }
-  if (n > (uint64_t) INT32_MAX || (trans_a == 'T' && m > (uint64_t) INT32_MAX) || a.fd < 0 ||
-      ia.fd < 0 || ja.fd < 0 || b.fd < 0 || c.fd < 0) {
-    set_error("bof_flash_csrmm: bad argument");
-    return BOF_EINVAL;
-  }
-  if (k == 0) return BOF_OK;
-  if (trans_a == 'T') return flash_csrmm_trans(m, n, k, alpha, beta, a, ia, ja, ord_b, b, c, nullptr, nullptr, opts);
-  return flash_csr_impl(true, 'N', (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, ia, ja,
-                        ord_b, b, c, nullptr, nullptr, opts);
-}
-
-int bof_flash_csrcsc(uint64_t m, uint64_t n, bof_fptr ia, bof_fptr ja, bof_fptr a, bof_fptr ia_tr,
-                     bof_fptr ja_tr, bof_fptr a_tr, const bof_options *opts) {
-  if (m > (uint64_t) INT32_MAX || n > (uint64_t) INT32_MAX || ia.fd < 0 || ja.fd < 0 || a.fd < 0 ||
-      ia_tr.fd < 0 || ja_tr.fd < 0 || a_tr.fd < 0) {
-    set_error("bof_flash_csrcsc: bad argument (m, n must fit 31 bits)");
-    return BOF_EINVAL;
-  }
-  return flash_csrcsc_impl((int64_t) m, (int64_t) n, ia, ja, a, ia_tr, ja_tr, a_tr, opts);
-}
-
-int bof_flash_csrmm_inmem(char trans_a, uint64_t m, uint64_t n, uint64_t k, float alpha, float beta,
-                          bof_fptr a, bof_fptr ia, bof_fptr ja, char ord_b, const float *b, float *c,
-                          const bof_options *opts) {
-  if ((trans_a != 'N' && trans_a != 'T') || (ord_b != 'R' && ord_b != 'C') || !b || !c || a.fd < 0 ||
-      ia.fd < 0 || ja.fd < 0 || n > (uint64_t) INT32_MAX || (trans_a == 'T' && m > (uint64_t) INT32_MAX)) {
-    set_error("bof_flash_csrmm_inmem: bad argument");
-    return BOF_EINVAL;
-  }
-  if (k == 0) return BOF_OK;
-  bof_fptr none{-1, 0};
-  if (trans_a == 'T') return flash_csrmm_trans(m, n, k, alpha, beta, a, ia, ja, ord_b, none, none, b, c, opts);
-  return flash_csr_impl(true, 'N', (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, ia, ja,
-                        ord_b, none, none, b, c, opts);
-}
-
-int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a, bof_fptr ia, bof_fptr ja,
-                      const float *b, float *c, const bof_options *opts) {
-  if ((trans_a != 'N' && trans_a != 'T') || !b || !c || a.fd < 0 || ia.fd < 0 || ja.fd < 0 ||
-      n > (uint64_t) INT32_MAX) {
-    set_error("bof_flash_csrgemv: bad argument");
-    return BOF_EINVAL;
-  }
-  bof_fptr none{-1, 0};
-  return flash_csr_impl(false, trans_a, (int64_t) m, (int64_t) n, 1, 1.f, 0.f, a, ia, ja, 'R', none,
-                        none, b, c, opts);
 }
 
 int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_t k, float beta,

@@ -11,7 +11,7 @@ def test_plan_fileio_and_schedule_under_asan_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "blas-on-flash_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-I", csrc,
-           os.path.join(csrc, "plan.cpp"), os.path.join(csrc, "fileio.cpp"), os.path.join(csrc, "flash_runtime.cpp"),
+           os.path.join(csrc, "plan.cpp"), os.path.join(csrc, "fileio.cpp"), os.path.join(csrc, "flash_runtime.cpp"), os.path.join(csrc, "flash_csr.cpp"),
            os.path.join(csrc, "flash_gemm_panels.cpp"), os.path.join(csrc, "uring_io.cpp"),
            os.path.join(csrc, "flash_support.cpp"),
            os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64",
