@@ -1,6 +1,6 @@
 // c_api.hip -- extern "C" entry points of libbof_hip.so: library/device helpers,
 // level 1 (per-tile compute) and level 2 (tile DAG over HBM-resident matrices).
-// Level 3 (file-resident matrices) lives in flash_runtime.cpp.
+// Level 3 (file-resident matrices) lives in flash_gemm_panels.cpp, flash_runtime.cpp and flash_csr.cpp.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 

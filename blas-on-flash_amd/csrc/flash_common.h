@@ -1,4 +1,4 @@
-// flash_common.h -- pieces shared by the level-3 pipelines (flash_runtime.cpp: tile cache, CSR
+// flash_common.h -- pieces shared by the level-3 pipelines (flash_runtime.cpp: tile cache; flash_csr.cpp: CSR
 // row-block ring, transposition; flash_gemm_panels.cpp: panel pipeline of flash::gemm).
 #pragma once
 #include <hip/hip_runtime.h>
