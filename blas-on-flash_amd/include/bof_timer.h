@@ -1,18 +1,20 @@
-// bof_timer.h -- wall-clock timer; elapsed() is in milliseconds like the
-// reference's flash::Timer (include/bof_timer.h:8-27).
+// bof_timer.h -- wall-clock stopwatch with the interface of the reference's flash::Timer
+// (include/bof_timer.h:8-27): elapsed() in milliseconds, reset().
 #pragma once
 #include <chrono>
 
 namespace flash {
   class Timer {
-    std::chrono::steady_clock::time_point t0_ = std::chrono::steady_clock::now();
+    using clock = std::chrono::steady_clock;
+    clock::time_point origin_{clock::now()};
 
    public:
-    void reset() { t0_ = std::chrono::steady_clock::now(); }
-    // whole milliseconds since construction / reset()
+    Timer() = default;
+    // whole milliseconds since construction or the last reset()
     float elapsed() const {
-      using namespace std::chrono;
-      return (float) duration_cast<milliseconds>(steady_clock::now() - t0_).count();
+      const auto span = clock::now() - origin_;
+      return static_cast<float>(std::chrono::duration_cast<std::chrono::milliseconds>(span).count());
     }
+    void reset() { origin_ = clock::now(); }
   };
 }  // namespace flash

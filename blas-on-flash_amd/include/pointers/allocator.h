@@ -21,32 +21,43 @@
 
 namespace flash {
   namespace detail {
-    // bytes of address space a mapping of `fh` from `foffset` on occupies (never 0)
-    inline size_t map_span(const FlashFileHandle& fh, FBLAS_UINT foffset) {
-      return fh.file_sz > foffset ? (size_t) (fh.file_sz - foffset) : (size_t) 1;
+    struct FileView {
+      void* address;             // first byte of the view (distinct per file byte, see above)
+      FlashFileHandle* owner;    // heap object; unmap_file deletes it
+    };
+    // address space a view of `fh` starting `skip` bytes into the file occupies (never 0)
+    inline size_t view_bytes(const FlashFileHandle& fh, FBLAS_UINT skip) {
+      return fh.file_sz > skip ? (size_t) (fh.file_sz - skip) : (size_t) 1;
+    }
+    inline FileView open_view(std::string path, Mode how, FBLAS_UINT skip, int extra_flags) {
+      FileView v{nullptr, new FlashFileHandle()};
+      v.owner->open(path, how);
+      const size_t len = view_bytes(*v.owner, skip);
+      v.address = ::mmap(nullptr, len, how == Mode::READ ? PROT_READ : (PROT_READ | PROT_WRITE),
+                         MAP_SHARED | extra_flags, v.owner->file_desc, 0);
+      if (v.address == MAP_FAILED)  // empty or unmappable file: a reservation of addresses is enough
+        v.address = ::mmap(nullptr, len, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (v.address == MAP_FAILED) GLOG_FATAL("map_file(", path, "): no address space: ", std::strerror(errno));
+      return v;
+    }
+    inline void close_view(BaseFileHandle* any, void* address, FBLAS_UINT skip) {
+      FlashFileHandle* owner = dynamic_cast<FlashFileHandle*>(any);
+      if (owner == nullptr) return;  // not produced by map_file
+      if (::munmap(address, view_bytes(*owner, skip)) != 0)
+        GLOG_ERROR("unmap_file: munmap: ", std::strerror(errno));
+      delete owner;
     }
   }  // namespace detail
 
   template<typename T>
   flash_ptr<T> map_file(std::string fname, Mode mode, FBLAS_UINT foffset = 0, int flags = 0) {
     GLOG_INFO("Mapping ", fname, ":", foffset, " to flash_ptr");
-    FlashFileHandle* handle = new FlashFileHandle();
-    handle->open(fname, mode);
-    const size_t span = detail::map_span(*handle, foffset);
-    const int prot = mode == Mode::READ ? PROT_READ : PROT_READ | PROT_WRITE;
-    void* tag = ::mmap(nullptr, span, prot, flags | MAP_SHARED, handle->file_desc, 0);
-    if (tag == MAP_FAILED)  // empty file or an unmappable one: address space is all we need
-      tag = ::mmap(nullptr, span, PROT_NONE, MAP_ANONYMOUS | MAP_NORESERVE | MAP_PRIVATE, -1, 0);
-    if (tag == MAP_FAILED) GLOG_FATAL("map_file(", fname, "): mmap failed: ", std::strerror(errno));
-    return flash_ptr<T>(static_cast<T*>(tag), foffset, handle);
+    const detail::FileView v = detail::open_view(fname, mode, foffset, flags);
+    return flash_ptr<T>(static_cast<T*>(v.address), foffset, v.owner);
   }
 
   template<typename T>
   void unmap_file(flash_ptr<T> fptr) {
-    FlashFileHandle* handle = dynamic_cast<FlashFileHandle*>(fptr.fop);
-    if (handle == nullptr) return;  // not one of ours
-    if (::munmap((void*) fptr.ptr, detail::map_span(*handle, fptr.foffset)) != 0)
-      GLOG_ERROR("unmap_file: munmap failed: ", std::strerror(errno));
-    delete handle;
+    detail::close_view(fptr.fop, (void*) fptr.ptr, fptr.foffset);
   }
 }  // namespace flash
