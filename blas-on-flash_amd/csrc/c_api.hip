@@ -305,7 +305,7 @@ static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, 
   rc = ss->fork(parent);
   if (rc) return rc;
   if (g.nblk[1] == 0) {  // k == 0: C = beta*C through a single degenerate pass
-    // (kmeans: the reference's tiler creates no task at all, src/blas/kmeans.cpp:88-90 -- C stays)
+    // (kmeans: nothing to do, C stays -- the reference's tiler divides by zero for k = 0, kmeans.cpp:52, 76-77)
     if (!kv) BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, 0, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], ss->s[0]));
     return ss->join(parent);
   }

@@ -594,7 +594,7 @@ int bof_flash_kmeans(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_
     set_error("bof_flash_kmeans: bad argument");
     return BOF_EINVAL;
   }
-  if (m == 0 || n == 0 || k == 0) return BOF_OK;   // no task is created (kmeans.cpp:88-90)
+  if (m == 0 || n == 0 || k == 0) return BOF_OK;   // nothing to do (the reference divides by zero: kmeans.cpp:52, 76-77)
   int rc = device_ready();
   if (rc) return rc;
   std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());

@@ -193,7 +193,8 @@ int bof_gemm_resident(char ord, char trans_a, char trans_b, int64_t m, int64_t n
  * p_l2sq + j*blk_n and the un-offset `ones` (kmeans.cpp:115-118, 128-131); like the
  * reference, EVERY k-block's task adds the two products, so they are added N_k times when k
  * spans several blocks (the reference's use has k = the point dimension <= one block).
- * k == 0 or an empty C: no task, C untouched.  c_l2sq: m, p_l2sq: n, ones: the largest tile
+ * A zero dimension: nothing to do, C untouched (the reference's tiler divides by zero there,
+ * kmeans.cpp:52, 76-77).  c_l2sq: m, p_l2sq: n, ones: the largest tile
  * edge (<= min(max(m, n), gemm_blk + 127)) floats, DEVICE pointers. */
 int bof_kmeans_resident(char ord, char trans_a, char trans_b, int64_t m, int64_t n,
                         int64_t k, float alpha, float beta, const float *a,

@@ -131,7 +131,7 @@ def test_kmeans_driver_shape_distances(dev):
 
 
 def test_kmeans_degenerate(dev):
-    """k == 0 / empty C: the reference's tiler creates no task (kmeans.cpp:88-90): C stays as it is."""
+    """k == 0 / empty C: nothing to do, C stays as it is (the reference's tiler divides by zero there)."""
     c = to_dev(np.full((4, 4), 7.0, np.float32))
     v = to_dev(np.ones(8, np.float32))
     bofhip.kmeans_resident("C", "T", "N", 4, 4, 0, 1.0, 0.0, ptr(c), ptr(c), ptr(c), 1, 1, 4, ptr(v), ptr(v), ptr(v),
