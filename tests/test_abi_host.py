@@ -273,3 +273,38 @@ def test_flash_gemm_panel_plan_paths():
     assert p["eligible"] and p["n_panels"] == [2, 2, 2] and p["slot_bytes"][0] == 2 << 20
     p = bofhip.flash_gemm_panel_plan("R", "N", "N", 600, 600, 600, 256, GiB, group=2)
     assert p["eligible"] and p["groups"] == 1
+
+
+def test_panel_plan_invariants_property():
+    """bof_flash_gemm_panel_plan on random problems (pure host code): an eligible plan fits its budget, its
+    slot counts are consistent with the resident / streamed flags, the group arithmetic holds, and a plan
+    that fits a budget also fits a larger one."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.sampled_from("RC"), st.sampled_from("NT"), st.sampled_from("NT"),
+           st.integers(1, 40000), st.integers(1, 40000), st.integers(1, 40000),
+           st.sampled_from([128, 256, 1000, 4096]), st.integers(1, 1 << 36), st.integers(1, 9))
+    def check(ord_, ta, tb, m, n, k, blk, budget, group):
+        p = bofhip.flash_gemm_panel_plan(ord_, ta, tb, m, n, k, blk, budget, group=group)
+        if not p["eligible"]:
+            assert p["why"] in (1, 2, 3, 4, 5)
+            return
+        npan, nsl = p["n_panels"], p["n_slots"]
+        assert p["need_bytes"] <= budget
+        assert p["need_bytes"] == sum(nsl[x] * p["slot_bytes"][x] for x in range(3))
+        for x in range(3):
+            assert 1 <= nsl[x] <= npan[x]
+            if p["resident"][x]:
+                assert nsl[x] == npan[x]
+        assert p["streamed"] in (-1, 0, 1)
+        if p["streamed"] >= 0:
+            assert not p["resident"][p["streamed"]] and nsl[p["streamed"]] < npan[p["streamed"]]
+        assert 1 <= p["first_group"] <= min(group, npan[2])
+        assert p["groups"] == 1 + npan[2] - p["first_group"]
+        assert nsl[2] >= min(npan[2], 2 * p["first_group"] + 1)
+        bigger = bofhip.flash_gemm_panel_plan(ord_, ta, tb, m, n, k, blk, 2 * budget, group=group)
+        assert bigger["eligible"] and bigger["need_bytes"] >= p["need_bytes"]
+
+    check()
