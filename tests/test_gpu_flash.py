@@ -712,3 +712,26 @@ def test_flash_csr_row_sharded_files(dev, tmp_path, golden, nproc):
     assert h("C.bin") == want["gen_csrmm_c"]
     assert h("yN.bin") == want["gen_csrgemv_N"]
     assert h("yT.bin") == want["gen_csrgemv_T"]
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_flash_gemm_buffered_descriptors(dev, tmp_path, path):
+    """Files opened WITHOUT O_DIRECT and just written (so in the page cache): reads are preads, the 1 MiB
+    write-back requests of the panel path take the shared-mapping route of fileio.cpp (pages resident),
+    the tile path's row-sized ones pwrite.  Bit-exact against the oracle either way, beta != 0."""
+    m, k, n, blk = 1024, 768, 1024, 256
+    rng = np.random.default_rng(41)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    ref = orc.flash_gemm("R", "N", "N", m, n, k, 0.5, 1.5, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, direct=False, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=2, n_io_threads=4, pinned_slots=4, gemm_path=path,
+                                      io_chunk_mib=1, use_odirect=0)
+        bofhip.flash_gemm("R", "N", "N", m, n, k, 0.5, 1.5, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        for fd in F.fds.values():
+            bofhip.lib().bof_file_forget(fd)
+        assert np.array_equal(F.read("c", np.float32, (m, n)), ref)
+    finally:
+        F.close()
