@@ -18,6 +18,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <linux/aio_abi.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -223,7 +224,8 @@ bool file_is_direct(int fd) {
 // (profiles/r2/iobench_*.json) -- that lock, not PCIe, bounded cfg3 from page-cache-resident
 // files (the 5.12 GB of C: 0.39 s of a 0.44 s call).  A store into a page that is NOT in the page
 // cache would first fault it in from the device, so the mapping is used only for ranges that
-// mincore() reports resident (a file that was just written or read: the buffered case);
+// mincore() reports resident (a file that was just written or read: the buffered case), in files
+// without holes;
 // anything else takes pwrite.  The mapping is per descriptor, checked against the file's identity
 // on every use (a descriptor number may have been reused) and only used while the file keeps the
 // size it was mapped with; dropped by file_forget.
@@ -234,7 +236,21 @@ struct MapEntry {
   uint64_t size = 0;
   dev_t dev = 0;
   ino_t ino = 0;
+  bool no_holes = false;   // every block of the file is allocated (checked until it is)
 };
+
+// A store into a hole has its block allocated at fault / write-back time, where a full disk means
+// SIGBUS or lost data instead of pwrite's ENOSPC: the mapping is only used for files without
+// holes.  Asked through a private descriptor (lseek moves the file position of the one it is given).
+bool file_has_no_holes(int fd, uint64_t size) {
+  char path[64];
+  snprintf(path, sizeof(path), "/proc/self/fd/%d", fd);
+  const int probe = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (probe < 0) return false;
+  const off_t hole = ::lseek(probe, 0, SEEK_HOLE);
+  ::close(probe);
+  return hole >= 0 && (uint64_t) hole >= size;
+}
 std::mutex g_map_mu;
 std::unordered_map<int, MapEntry> g_map;
 std::atomic<uint64_t> g_mapped_bytes{0};
@@ -262,12 +278,18 @@ bool mapped_write(int fd, const char *buf, uint64_t len, uint64_t off) {
     // same file, other size (it grew under pwrite): other threads may be storing through the
     // mapping right now, so it is left alone and this request takes pwrite
     if (it != g_map.end() && it->second.size != (uint64_t) sb.st_size) return false;
+    if (it != g_map.end() && it->second.base && !it->second.no_holes) {
+      it->second.no_holes = file_has_no_holes(fd, it->second.size);
+      if (!it->second.no_holes) return false;
+    }
     if (it == g_map.end()) {
       MapEntry e;
       e.dev = sb.st_dev; e.ino = sb.st_ino; e.size = (uint64_t) sb.st_size;
       void *p = ::mmap(nullptr, e.size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
       e.base = p == MAP_FAILED ? nullptr : (char *) p;   // nullptr: remembered, not retried (O_WRONLY, no mmap)
+      if (e.base) e.no_holes = file_has_no_holes(fd, e.size);
       it = g_map.emplace(fd, e).first;
+      if (e.base && !e.no_holes) return false;
     }
     base = it->second.base;
   }
