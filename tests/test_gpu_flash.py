@@ -52,12 +52,15 @@ class Files:
             os.close(fd)
 
 
-@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("path", [1, 2, 3])
 @pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
-def test_flash_gemm_layouts_unaligned(dev, tmp_path, ord_, ta, tb, path):
+def test_flash_gemm_layouts_unaligned(dev, tmp_path, monkeypatch, ord_, ta, tb, path):
     """SURVEY 8c trust-matrix shape: 640x600x500 with unaligned leading dims, tile
     256 (separate tail, merged tail), alpha=0.5, beta=2, random C, all 8 layouts; through the
-    tile cache (path 1) and through the row-panel pipeline (path 2)."""
+    tile cache (path 1), through the row-panel pipeline (path 2) and through the row-panel pipeline
+    with the k-major copies of k-contiguous operand panels forced on (3: BOF_PANEL_KMAJOR=2)."""
+    monkeypatch.setenv("BOF_PANEL_KMAJOR", "2" if path == 3 else "0")
+    path = min(path, 2)
     m, k, n, blk = 640, 600, 500, 256
     rng = np.random.default_rng(11)
     sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
