@@ -10,7 +10,8 @@
 //     default 32 MiB) instead of thousands of row requests per tile; every request lands in a
 //     pinned staging slot and crosses PCIe as one linear SDMA copy;
 //   * no packing anywhere: a tile task is `pointer into a panel + leading dimension`, exactly
-//     what the level-2 tile DAG passes to the kernel;
+//     what the level-2 tile DAG passes to the kernel (for a k-contiguous operand: into the
+//     panel's k-major copy, made once per panel on the H2D stream -- Mat::kmajor_copy);
 //   * C panels are written back as they complete, while the next panels compute.
 //
 // Schedule (same tasks, same k-order per accumulate chain as src/blas/gemm.cpp:83-129, so
