@@ -24,7 +24,11 @@ class Options(C.Structure):
     _fields_ = [("gemm_blk", i64), ("max_nnzs", i64), ("csrmm_rblk", i64), ("csrmm_cblk", i64),
                 ("hbm_budget", i64), ("n_io_threads", C.c_int32), ("n_streams", C.c_int32),
                 ("use_odirect", C.c_int32), ("pinned_slots", C.c_int32), ("gemm_path", C.c_int32),
-                ("io_chunk_mib", C.c_int32)]
+                ("io_chunk_mib", C.c_int32),
+                # ABI v3: in-process device list + per-call forms of the environment knobs
+                ("n_devices", C.c_int32), ("devices", C.c_int32 * 16), ("io_engine", C.c_int32),
+                ("io_request_kib", C.c_int32), ("panel_group", C.c_int32), ("panel_streams", C.c_int32),
+                ("panel_writers", C.c_int32), ("panel_kmajor", C.c_int32)]
 
 
 class GemmTask(C.Structure):
@@ -100,6 +104,7 @@ SYMBOLS = [
     ("bof_flash_gemm_panel_plan", C.c_int, [chr_, chr_, chr_, u64, u64, u64, u64, u64, u64, i64, u64, i64,
                                             C.POINTER(PanelPlan)]),
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
+    ("bof_flash_last_device_stats", C.c_int, [C.POINTER(FlashStats), C.c_int]),
     ("bof_flash_release", C.c_int, []),
     ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
                                           C.c_int32, C.POINTER(FlashStats)]),
@@ -157,7 +162,13 @@ def default_options(**kw):
     o = Options()
     lib().bof_default_options(C.byref(o))
     for k, v in kw.items():
-        setattr(o, k, v)
+        if k == "devices":          # devices=[0, 1, ...]: the in-process device list (repeats allowed)
+            v = list(v)
+            o.n_devices = len(v)
+            for i, d in enumerate(v):
+                o.devices[i] = d
+        else:
+            setattr(o, k, v)
     return o
 
 
@@ -313,6 +324,15 @@ def flash_last_stats():
     s = FlashStats()
     check(lib().bof_flash_last_stats(C.byref(s)), "bof_flash_last_stats")
     return {f: getattr(s, f) for f, _ in s._fields_}
+
+
+def flash_last_device_stats():
+    """Per-device counters of the last level-3 call, in device-list order."""
+    arr = (FlashStats * 16)()
+    n = lib().bof_flash_last_device_stats(arr, 16)
+    if n < 0:
+        raise BofError("bof_flash_last_device_stats failed")
+    return [{f: getattr(arr[i], f) for f, _ in FlashStats._fields_} for i in range(min(n, 16))]
 
 
 # ---- generators --------------------------------------------------------------------

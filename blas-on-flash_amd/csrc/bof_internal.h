@@ -68,6 +68,8 @@ int scratch_get(int which, size_t bytes, void **ptr);
 void scratch_release_all();
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
                     const int64_t *col, const float *x, float *y, hipStream_t st);
+// dst = sum of n_src vectors (fixed order; sources may be peer-device memory, dst may alias one of them)
+hipError_t sum_partials(float *dst, const float *const *srcs, int n_src, int64_t len, hipStream_t st);
 hipError_t gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed,
                      hipStream_t st);
 hipError_t gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols, int64_t nnz_per_row,
@@ -87,7 +89,10 @@ void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float 
                   bof_gemm_task *t);
 
 // row-panel layout of flash::gemm for a budget (plan.cpp; see bof_panel_plan in bof_hip.h)
-bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group);
+// full_dC: when g describes ONE DEVICE'S SLAB of a larger problem (size along the C panel dimension D
+// cut down), the stored width of an operand whose columns run along D is still the whole problem's
+// (its panels are shared by all devices); 0 = g is the whole problem.
+bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group, int64_t full_dC = 0);
 
 // ---- fork/join of compute streams (c_api.hip) -----------------------------------
 struct StreamSet {

@@ -38,6 +38,16 @@ bof_options resolved(const bof_options *o) {
   if (o->pinned_slots > 0) r.pinned_slots = o->pinned_slots;
   if (o->gemm_path >= 0 && o->gemm_path <= 2) r.gemm_path = o->gemm_path;
   if (o->io_chunk_mib > 0) r.io_chunk_mib = o->io_chunk_mib > 1024 ? 1024 : o->io_chunk_mib;
+  if (o->n_devices > 0) {
+    r.n_devices = o->n_devices;   // checked by resolve_devices
+    for (int i = 0; i < BOF_MAX_DEVICES; i++) r.devices[i] = o->devices[i];
+  }
+  if (o->io_engine > 0) r.io_engine = o->io_engine;
+  if (o->io_request_kib > 0) r.io_request_kib = o->io_request_kib;
+  if (o->panel_group > 0) r.panel_group = o->panel_group;
+  if (o->panel_streams > 0) r.panel_streams = o->panel_streams;
+  if (o->panel_writers > 0) r.panel_writers = o->panel_writers;
+  if (o->panel_kmajor > 0) r.panel_kmajor = o->panel_kmajor;
   return r;
 }
 
@@ -137,6 +147,14 @@ void bof_default_options(bof_options *o) {
   o->pinned_slots = 8;
   o->gemm_path = 0;
   o->io_chunk_mib = 32;
+  o->n_devices = 0;
+  for (int i = 0; i < BOF_MAX_DEVICES; i++) o->devices[i] = 0;
+  o->io_engine = 0;
+  o->io_request_kib = 0;
+  o->panel_group = 0;
+  o->panel_streams = 0;
+  o->panel_writers = 0;
+  o->panel_kmajor = 0;
 }
 
 int bof_device_count(void) {

@@ -17,6 +17,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
+#include "bof_hip.h"
+
 namespace bof {
 
 constexpr int CSR_WAVES = 4;  // waves per block, one CSR row per wave at a time
@@ -270,6 +274,30 @@ hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const in
     hipLaunchKernelGGL(csrgemv_n_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
   else
     hipLaunchKernelGGL(csrgemv_t_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+  return hipGetLastError();
+}
+
+// dst[i] = srcs[0][i] + srcs[1][i] + ... (fixed order), srcs may live in the HBM of peer devices
+// (peer access: the loads cross xGMI) and dst may be one of them.  The multi-device form of the
+// reference's mutex-guarded vector add (include/tasks/csrgemv_task.h:169-176): device d owns
+// segment d of y and sums that segment of every device's partial.
+struct PartialPtrs { const float *p[BOF_MAX_DEVICES]; };
+__global__ void __launch_bounds__(256)
+sum_partials_kernel(float *dst, PartialPtrs src, int n_src, int64_t len) {
+  const int64_t stride = (int64_t) gridDim.x * 256;
+  for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < len; i += stride) {
+    float acc = src.p[0][i];
+    for (int s = 1; s < n_src; s++) acc += src.p[s][i];
+    dst[i] = acc;
+  }
+}
+hipError_t sum_partials(float *dst, const float *const *srcs, int n_src, int64_t len, hipStream_t st) {
+  if (len <= 0 || n_src <= 0) return hipSuccess;
+  if (n_src > BOF_MAX_DEVICES) return hipErrorInvalidValue;
+  PartialPtrs pp;
+  for (int s = 0; s < BOF_MAX_DEVICES; s++) pp.p[s] = s < n_src ? srcs[s] : nullptr;
+  const unsigned blocks = (unsigned) std::min<int64_t>((len + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks), dim3(256), 0, st, dst, pp, n_src, len);
   return hipGetLastError();
 }
 

@@ -54,6 +54,16 @@ static uint64_t request_bytes() {
   }
   return v;
 }
+// Engine for aligned O_DIRECT requests: 1 kernel AIO, 2 io_uring.  Level-3 calls set it from
+// bof_options.io_engine at their start (0 there = $BOF_IO_ENGINE, read at that call, else AIO).
+static std::atomic<int> g_engine{0};
+void file_set_engine(int engine) {
+  if (engine != 1 && engine != 2) {
+    const char *e = getenv("BOF_IO_ENGINE");
+    engine = e && !strcmp(e, "uring") ? 2 : 1;
+  }
+  g_engine.store(engine, std::memory_order_relaxed);
+}
 static constexpr unsigned kAioEvents = 1024;
 static constexpr int kIoRetries = 5;                // reference submit_and_reap retries
 
@@ -351,7 +361,8 @@ static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_
     if (fd < 0) return -EBADF;
   }
   char *p = static_cast<char *>(buf);
-  static const bool use_uring = getenv("BOF_IO_ENGINE") && !strcmp(getenv("BOF_IO_ENGINE"), "uring");
+  if (g_engine.load(std::memory_order_relaxed) == 0) file_set_engine(0);   // first use outside a level-3 call
+  const bool use_uring = g_engine.load(std::memory_order_relaxed) == 2;
   if (direct && aligned && use_aio && use_uring) {
     std::vector<IoPiece> pieces;
     const uint64_t piece = request_bytes();

@@ -19,6 +19,7 @@ uint64_t file_mapped_write_bytes();
 void file_unmap_all();
 void file_io_ops(uint64_t *reads, uint64_t *writes);  // requests issued so far (process-wide)
 void file_forget(int fd);  // drop the cached buffered twin of fd (call before close)
+void file_set_engine(int engine);   // 1 kernel AIO, 2 io_uring, anything else: $BOF_IO_ENGINE (read now) or AIO
 // ---- io_uring engine (uring_io.cpp); BOF_IO_ENGINE=uring selects it for aligned O_DIRECT I/O ----
 struct IoPiece { int fd; bool wr; void *buf; uint64_t len; uint64_t off; };
 int uring_run(const std::vector<IoPiece> &pieces);   // 0 / -errno; -ENOSYS: no io_uring here

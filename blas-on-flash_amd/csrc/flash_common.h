@@ -57,11 +57,14 @@ class WorkQueue {
 };
 
 // Pinned staging ring.  A slot handed out by acquire() is safe to overwrite: the GPU
-// copy that last referenced it (mark_busy) has completed.
+// copies that last referenced it (mark_busy) have completed.  A slot carries one event per
+// device of the call (`cols`): a chunk every device needs is copied out of ONE slot to all of
+// them, each copy on that device's own H2D stream (events are device-affine).
 class PinnedRing {
   std::vector<void *> slots;
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev;      // cols per slot
   std::vector<char> ev_set;
+  std::vector<int> ev_dev;         // HIP ordinal of event column j
   std::deque<int> free_;
   std::mutex mu;
   std::condition_variable cv;
@@ -69,33 +72,53 @@ class PinnedRing {
  public:
   size_t bytes = 0;
   int count() const { return (int) slots.size(); }
-  int init(int n, size_t nbytes) {
-    if ((int) slots.size() == n && bytes == nbytes) {  // reuse a cached ring as is
+  int cols() const { return (int) ev_dev.size(); }
+  // devs: the ordinal of every event column (default: one column on the current device)
+  int init(int n, size_t nbytes, const std::vector<int> *devs = nullptr) {
+    std::vector<int> want;
+    if (devs) want = *devs;
+    else {
+      int cur = 0;
+      BOF_HIP_TRY(hipGetDevice(&cur));
+      want.push_back(cur);
+    }
+    if ((int) slots.size() == n && bytes == nbytes && want == ev_dev) {  // reuse a cached ring as is
       free_.clear();
       for (int i = 0; i < n; i++) free_.push_back(i);
       return BOF_OK;
     }
     destroy();
     bytes = nbytes;
+    ev_dev = want;
+    int cur = 0;
+    BOF_HIP_TRY(hipGetDevice(&cur));
     for (int i = 0; i < n; i++) {
       void *p = nullptr;
       const int rc = pinned_alloc(&p, nbytes);
       if (rc) return rc;
-      hipEvent_t e;
-      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       file_buffers_add(p, nbytes);   // io_uring fixed buffer (no effect on the AIO engine)
-      slots.push_back(p); ev.push_back(e); ev_set.push_back(0); free_.push_back(i);
+      slots.push_back(p); free_.push_back(i);
+      for (int d : ev_dev) {
+        hipEvent_t e;
+        BOF_HIP_TRY(hipSetDevice(d));
+        const hipError_t he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        (void) hipSetDevice(cur);
+        if (he != hipSuccess) return hip_fail(he, "hipEventCreate (pinned ring)");
+        ev.push_back(e); ev_set.push_back(0);
+      }
     }
     return BOF_OK;
   }
   void destroy() {
-    for (size_t i = 0; i < slots.size(); i++) {
+    for (size_t i = 0; i < ev.size(); i++) {
       if (ev_set[i]) (void) hipEventSynchronize(ev[i]);
-      file_buffers_remove(slots[i]);
-      pinned_free(slots[i]);
       (void) hipEventDestroy(ev[i]);
     }
-    slots.clear(); ev.clear(); ev_set.clear(); free_.clear();
+    for (size_t i = 0; i < slots.size(); i++) {
+      file_buffers_remove(slots[i]);
+      pinned_free(slots[i]);
+    }
+    slots.clear(); ev.clear(); ev_set.clear(); ev_dev.clear(); free_.clear();
   }
   int acquire() {
     int idx;
@@ -105,19 +128,22 @@ class PinnedRing {
       idx = free_.front();
       free_.pop_front();
     }
-    if (ev_set[idx]) { (void) hipEventSynchronize(ev[idx]); ev_set[idx] = 0; }
+    const size_t c = ev_dev.size();
+    for (size_t j = 0; j < c; j++)
+      if (ev_set[(size_t) idx * c + j]) { (void) hipEventSynchronize(ev[(size_t) idx * c + j]); ev_set[(size_t) idx * c + j] = 0; }
     return idx;
   }
   void release(int idx) {
     { std::lock_guard<std::mutex> lk(mu); free_.push_back(idx); }
     cv.notify_one();
   }
-  int mark_busy(int idx, hipStream_t st) {
-    BOF_HIP_TRY(hipEventRecord(ev[idx], st));
-    ev_set[idx] = 1;
+  int mark_busy(int idx, hipStream_t st, int col = 0) {
+    const size_t e = (size_t) idx * ev_dev.size() + (size_t) col;
+    BOF_HIP_TRY(hipEventRecord(ev[e], st));
+    ev_set[e] = 1;
     return BOF_OK;
   }
-  hipEvent_t event(int idx) { return ev[idx]; }
+  hipEvent_t event(int idx, int col = 0) { return ev[(size_t) idx * ev_dev.size() + (size_t) col]; }
   void *ptr(int idx) { return slots[idx]; }
 };
 
@@ -156,6 +182,30 @@ struct TraceRange {
 hipError_t copy_stream_create(hipStream_t *s);
 int device_ready();                                       // BOF_OK or BOF_ENODEV (+ message)
 void publish_stats(const Counters &c, double seconds);    // what bof_flash_last_stats reports
+void publish_device_stats(const std::vector<bof_flash_stats> &per_device);   // bof_flash_last_device_stats
+
+// The devices a level-3 call runs on: opts->devices, else $BOF_DEVICES ("0,1" / "all"), else the
+// calling thread's current device.  Ordinals are checked against hipGetDeviceCount; repeats are kept.
+int resolve_devices(const bof_options &o, std::vector<int> &devs);
+// Holds the per-device call locks of every distinct ordinal in the list (ascending order) for
+// the duration of a level-3 call.
+class DeviceCallLock {
+  std::vector<std::recursive_mutex *> held;
+ public:
+  explicit DeviceCallLock(const std::vector<int> &devs);
+  ~DeviceCallLock();
+};
+// Sets the calling thread's device for a scope and puts the previous one back.
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    (void) hipSetDevice(dev);
+  }
+  ~DeviceScope() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+// environment knob read at every call (never cached): `dflt` when unset or empty
+long env_long(const char *name, long dflt);
 
 // BOF_TRACE=1: wall-clock milestones of a level-3 call on stderr (t_begin = the call's start)
 inline bool trace_enabled() {
@@ -177,9 +227,17 @@ int stream_file(const bof_fptr &f, uint64_t bytes, char *dptr, bool to_device, h
 // flash::gemm through whole row panels kept in HBM in FILE layout (flash_gemm_panels.cpp).
 // Returns BOF_OK / an error, or +1 when the call is not eligible (layout, budget) and the tile
 // cache of flash_runtime.cpp must take it.
+// `devs`: the devices the C panels are dealt to (contiguous ranges); kh: flash::kmeans' host vectors.
+struct KmeansHost {
+  const float *c_l2sq, *p_l2sq, *ones;
+  int64_t m, n, n_ones;
+};
 int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
                       bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
-                      const bof_options &o, const KmeansVecs *kv = nullptr);
+                      const bof_options &o, const std::vector<int> &devs, const KmeansHost *kh = nullptr);
+// the three norm vectors of flash::kmeans on the current device (one allocation: free kv->c_l2sq)
+int kmeans_upload(const KmeansHost &kh, KmeansVecs *kv);
 void panel_resources_release();
+void panel_resources_release_device(int dev);   // the cached panel slots of one ordinal (its call lock is held)
 
 }  // namespace bof

@@ -102,6 +102,7 @@ struct CsrRun {
   bool is_mm = true;
   char ord_b = 'R', trans = 'N';
   int64_t m = 0, n = 0, k = 0;
+  int64_t c_ld = 0;   // rows of the WHOLE column-major C (= m unless this call is one device's row shard)
   float alpha = 1.f, beta = 0.f;
   bof_fptr fa, fja, fb, fc;
   const float *host_b = nullptr;  // csrmm overload with B and C in host memory
@@ -109,7 +110,8 @@ struct CsrRun {
   // A already in HBM (the transposed matrix of csrmm 'T'): 0-based arrays, nothing to read
   const float *res_val = nullptr;
   const int64_t *res_col = nullptr;
-  HostI64 ia;
+  const int64_t *ia = nullptr;   // host offsets of the rows of this call (m + 1 entries, absolute)
+  HostI64 ia_store;              // ... when this call read them itself
   std::vector<int64_t> st, sz;
   std::vector<CsrCtx> ctx;
   int depth = 3;
@@ -191,11 +193,11 @@ struct CsrRun {
           if (ord_b == 'R') memcpy(c.h_c, host_c + (size_t) st[b] * k, c_bytes(b));
           else
             for (int64_t j = 0; j < k; j++)
-              memcpy(c.h_c + (size_t) j * sz[b] * 4, host_c + (size_t) j * m + st[b], (size_t) sz[b] * 4);
+              memcpy(c.h_c + (size_t) j * sz[b] * 4, host_c + (size_t) j * c_ld + st[b], (size_t) sz[b] * 4);
         } else if (ord_b == 'R')
           rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
         else
-          rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
+          rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) c_ld * 4, (uint64_t) k,
                           (uint64_t) sz[b] * 4, c.h_c, aio_c);
         cnt.rd += c_bytes(b);
         if (!rc) e = hipMemcpyAsync(c.d_c, c.h_c, c_bytes(b), hipMemcpyHostToDevice, h2d);
@@ -225,13 +227,13 @@ struct CsrRun {
         if (ord_b == 'R') memcpy(host_c + (size_t) st[b] * k, c.h_c, c_bytes(b));
         else
           for (int64_t j = 0; j < k; j++)
-            memcpy(host_c + (size_t) j * m + st[b], c.h_c + (size_t) j * sz[b] * 4, (size_t) sz[b] * 4);
+            memcpy(host_c + (size_t) j * c_ld + st[b], c.h_c + (size_t) j * sz[b] * 4, (size_t) sz[b] * 4);
       } else if (is_mm && !io_error.load()) {
         int rc;
         if (ord_b == 'R')
           rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
         else
-          rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) m * 4, (uint64_t) k,
+          rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) c_ld * 4, (uint64_t) k,
                            (uint64_t) sz[b] * 4, c.h_c, aio_c);
         if (rc) fail_io(rc);
         cnt.wr += c_bytes(b);
@@ -572,8 +574,15 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = device_ready();
   if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
-  const bof_options o = resolved(opts);
+  bof_options o = resolved(opts);
+  std::vector<int> devs;
+  rc = resolve_devices(o, devs);
+  if (rc) return rc;
+  devs.resize(1);   // the transposition is one device's sort: the first device of the list
+  DeviceCallLock call_lock(devs);
+  DeviceScope on_dev(devs[0]);
+  o.n_devices = 1; o.devices[0] = devs[0];
+  file_set_engine(o.io_engine);
   Counters cnt;
   {
     // does the whole matrix fit?  (input + output + sort workspace against the budget)
@@ -614,26 +623,36 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
   return rc;
 }
 
-// Shared driver of csrmm (is_mm) and csrgemv.  For csrgemv: hb = input vector (host), hc =
-// output vector (host).
-static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t k, float alpha,
-                          float beta, bof_fptr fa, bof_fptr fia, bof_fptr fja, char ord_b,
-                          bof_fptr fb, bof_fptr fc, const float *hb, float *hc,
-                          const bof_options *opts, const ResidentCsr *res = nullptr,
-                          Counters *carry = nullptr) {
+// What a multi-device call hands each device's pipeline (all null / absent in a single-device call).
+struct CsrExtra {
+  const int64_t *ia = nullptr;     // the offsets of this device's rows, already on the host
+  char *shared_op = nullptr;       // B (csrmm) / x (csrgemv 'N') already on its way into THIS device's HBM ...
+  hipEvent_t shared_ready = nullptr;  // ... complete when this event (of this device) has fired
+  float *partial_y = nullptr;      // csrgemv 'T': zeroed full-length vector in this device's HBM that takes
+                                   // the partial sums and STAYS there (the caller reduces the partials)
+  int64_t c_ld = 0;                // column-major C: rows of the whole matrix (0: this call's m)
+  Counters *out = nullptr;         // counters are added here instead of being published
+};
+
+// One device's pipeline of csrmm (is_mm) / csrgemv on the CURRENT device (the caller holds the call lock).
+// For csrgemv: hb = input vector (host), hc = output vector (host).
+static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_t k, float alpha,
+                            float beta, bof_fptr fa, bof_fptr fia, bof_fptr fja, char ord_b,
+                            bof_fptr fb, bof_fptr fc, const float *hb, float *hc,
+                            const bof_options &ro, const ResidentCsr *res = nullptr,
+                            Counters *carry = nullptr, const CsrExtra *ex = nullptr) {
   const auto t_begin = std::chrono::steady_clock::now();
-  int rc = device_ready();
-  if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
+  int rc = BOF_OK;
   TraceRange range(is_mm ? "bof_flash_csrmm" : "bof_flash_csrgemv");
   CsrRun R;
   if (carry) {  // bytes moved by the transposition that produced `res`
     R.cnt.rd += carry->rd.load(); R.cnt.h2d += carry->h2d.load(); R.cnt.d2h += carry->d2h.load();
   }
   if (res) { R.res_val = res->val; R.res_col = res->col; }
-  R.o = resolved(opts);
+  R.o = ro;
   R.is_mm = is_mm; R.trans = trans; R.ord_b = ord_b;
   R.m = m; R.n = n; R.k = k; R.alpha = alpha; R.beta = beta;
+  R.c_ld = ex && ex->c_ld > 0 ? ex->c_ld : m;
   R.fa = fa; R.fja = fja; R.fb = fb; R.fc = fc;
   if (is_mm && fb.fd < 0) { R.host_b = hb; R.host_c = hc; }
   R.use_aio = R.o.use_odirect != 0;
@@ -642,17 +661,20 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
 
   // offsets are read to the host first, as the reference does (csrmm.cpp:69-71)
   if (res) {
-    R.ia = res->ia_host;
+    R.ia = res->ia_host.data();
+  } else if (ex && ex->ia) {
+    R.ia = ex->ia;
   } else {
-    R.ia.resize((size_t) m + 1);
-    int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia.data(), R.use_aio);
+    R.ia_store.resize((size_t) m + 1);
+    int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia_store.data(), R.use_aio);
     if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
     R.cnt.rd += (uint64_t) (m + 1) * 8;
+    R.ia = R.ia_store.data();
   }
   BOF_TRACE_T("csr: offsets on the host");
-  const int64_t nb = bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, nullptr, nullptr, 0);
+  const int64_t nb = bof_csr_blocks(R.ia, m, 128, R.o.csrmm_rblk, R.o.max_nnzs, nullptr, nullptr, 0);
   R.st.resize((size_t) nb); R.sz.resize((size_t) nb);
-  bof_csr_blocks(R.ia.data(), m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
+  bof_csr_blocks(R.ia, m, 128, R.o.csrmm_rblk, R.o.max_nnzs, R.st.data(), R.sz.data(), nb);
 
   if (!res) {
     struct stat sb;
@@ -680,7 +702,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
           aligned = (fc.foffset + (uint64_t) R.st[b] * k * 4) % A == 0 && ((uint64_t) R.sz[b] * k * 4) % A == 0;
         else
           aligned = (fc.foffset + (uint64_t) R.st[b] * 4) % A == 0 && ((uint64_t) R.sz[b] * 4) % A == 0 &&
-                    ((uint64_t) m * 4) % A == 0;
+                    ((uint64_t) R.c_ld * 4) % A == 0;
       }
       if (aligned) R.aio_c = R.use_aio;
       else R.fd_c = file_buffered_fd(fc.fd);
@@ -692,6 +714,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
 
   int64_t *d_ia = nullptr;
   char *d_b = nullptr, *d_x = nullptr, *d_y = nullptr;
+  char *own_b = nullptr, *own_x = nullptr, *own_y = nullptr;   // what this call allocated (and frees)
   hipEvent_t resident_ev = nullptr;
   Cleanup guard;
   guard.add([&] {
@@ -705,7 +728,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     }
     if (resident_ev) (void) hipEventDestroy(resident_ev);
     if (!res) (void) hipFree(d_ia);
-    (void) hipFree(d_b); (void) hipFree(d_x); (void) hipFree(d_y);
+    (void) hipFree(own_b); (void) hipFree(own_x); (void) hipFree(own_y);
     if (R.h2d) (void) hipStreamDestroy(R.h2d);
     if (R.d2h) (void) hipStreamDestroy(R.d2h);
   });
@@ -715,16 +738,21 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     d_ia = const_cast<int64_t *>(res->ia_dev);
   } else {
     BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
-    BOF_HIP_TRY(hipMemcpyAsync(d_ia, R.ia.data(), (size_t) (m + 1) * 8, hipMemcpyHostToDevice, R.h2d));
+    BOF_HIP_TRY(hipMemcpyAsync(d_ia, R.ia, (size_t) (m + 1) * 8, hipMemcpyHostToDevice, R.h2d));
     R.cnt.h2d += (uint64_t) (m + 1) * 8;
   }
   const int64_t xlen = trans == 'N' ? n : m, ylen = trans == 'N' ? m : n;
+  const bool ext_op = ex && ex->shared_op;        // B / x comes from the multi-device caller
+  const bool ext_y = ex && ex->partial_y;         // the partial result stays in the caller's vector
   if (is_mm) {
-    BOF_HIP_TRY(hipMalloc((void **) &d_b, (size_t) n * k * 4));
+    if (!ext_op) BOF_HIP_TRY(hipMalloc((void **) &d_b, (size_t) n * k * 4));
   } else {
-    BOF_HIP_TRY(hipMalloc((void **) &d_x, (size_t) xlen * 4));
-    BOF_HIP_TRY(hipMalloc((void **) &d_y, (size_t) ylen * 4));
+    if (!ext_op) BOF_HIP_TRY(hipMalloc((void **) &d_x, (size_t) xlen * 4));
+    if (!ext_y) BOF_HIP_TRY(hipMalloc((void **) &d_y, (size_t) ylen * 4));
   }
+  own_b = d_b; own_x = d_x; own_y = d_y;
+  if (ext_op) (is_mm ? d_b : d_x) = ex->shared_op;
+  if (ext_y) d_y = (char *) ex->partial_y;
   BOF_HIP_TRY(hipEventCreateWithFlags(&resident_ev, hipEventDisableTiming));
   // B (csrmm) / x (csrgemv) go to HBM on a thread of their own while the block contexts are set up
   // and the first row blocks are already being read; the compute streams wait for `resident_ev`
@@ -732,6 +760,12 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   // the first block read).
   auto upload_resident = [&]() -> int {
     (void) hipSetDevice(R.dev);
+    if (ext_op) {   // on its way already (multi-device call): order this device's streams behind it
+      BOF_HIP_TRY(hipStreamWaitEvent(R.h2d, ex->shared_ready, 0));
+      if (!is_mm && trans == 'T' && !ext_y) BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
+      BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
+      return BOF_OK;
+    }
     if (is_mm) {
       // B stays resident for the whole call (one shared read, like the reference's
       // single "use_full" cache key, csrmm_task.h:175-183)
@@ -751,7 +785,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       }
     } else {
       BOF_HIP_TRY(hipMemcpyAsync(d_x, hb, (size_t) xlen * 4, hipMemcpyHostToDevice, R.h2d));
-      if (trans == 'T') BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
+      if (trans == 'T' && !ext_y) BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
       R.cnt.h2d += (uint64_t) xlen * 4;
     }
     BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
@@ -872,7 +906,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   for (auto &th : retirers) th.join();
   (void) hipDeviceSynchronize();
   BOF_TRACE_T("csr: drained (C written)");
-  if (!is_mm && !fail && herr == hipSuccess) {
+  if (!is_mm && !ext_y && !fail && herr == hipSuccess) {
     if (device_to_pageable(hc, d_y, (uint64_t) ylen * 4, R.o.n_io_threads)) herr = hipErrorUnknown;
     R.cnt.d2h += (uint64_t) ylen * 4;
     BOF_TRACE_T("csr: y on the host");
@@ -884,8 +918,298 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
               (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
     fail = BOF_EIO;
   }
-  publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  if (ex && ex->out) {
+    Counters &o = *ex->out;
+    o.rd += R.cnt.rd.load(); o.wr += R.cnt.wr.load(); o.h2d += R.cnt.h2d.load(); o.d2h += R.cnt.d2h.load();
+    o.tasks += R.cnt.tasks.load();
+  } else {
+    publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  }
   return fail;
+}
+
+// One source (a file region, or a host array when f is null) -> the same bytes in the HBM of several
+// devices: every chunk is read ONCE into a pinned slot and copied from there to each device on that
+// device's stream, i.e. over that device's own PCIe link.
+static int fan_out(const bof_fptr *f, const char *host, uint64_t bytes, const std::vector<int> &devs,
+                   const std::vector<char *> &dst, const std::vector<hipStream_t> &st, bool use_aio, int n_thr,
+                   Counters &cnt) {
+  if (bytes == 0) return BOF_OK;
+  const size_t chunk = (size_t) std::min<uint64_t>(32ull << 20, round_up(bytes, 4096));
+  const int64_t nchunks = (int64_t) ((bytes + chunk - 1) / chunk);
+  n_thr = (int) std::max<int64_t>(1, std::min<int64_t>(n_thr, nchunks));
+  std::atomic<int64_t> next{0};
+  std::atomic<int> fail{0};
+  auto worker = [&] {
+    (void) hipSetDevice(devs[0]);
+    (void) bind_thread_near_device(devs[0]);
+    PinnedRing ring;
+    if (ring.init(2, chunk, &devs)) { fail.store(-1000); return; }
+    for (;;) {
+      const int64_t i = next.fetch_add(1);
+      if (i >= nchunks || fail.load()) break;
+      const uint64_t o = (uint64_t) i * chunk, len = std::min<uint64_t>(chunk, bytes - o);
+      const int sl = ring.acquire();
+      int io = 0;
+      if (f) {
+        io = file_sread(f->fd, f->foffset + o, 0, 1, len, ring.ptr(sl), use_aio);
+        cnt.rd += len;
+      } else {
+        memcpy(ring.ptr(sl), host + o, len);
+      }
+      hipError_t e = hipSuccess;
+      for (size_t d = 0; d < devs.size() && !io && e == hipSuccess; d++) {
+        e = hipSetDevice(devs[d]);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst[d] + o, ring.ptr(sl), len, hipMemcpyHostToDevice, st[d]);
+        if (e == hipSuccess && ring.mark_busy(sl, st[d], (int) d)) e = hipErrorUnknown;
+        cnt.h2d += len;
+      }
+      ring.release(sl);
+      if (io) fail.store(io);
+      if (e != hipSuccess) fail.store(-1000 - (int) e);
+    }
+    ring.destroy();
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < n_thr; i++) th.emplace_back(worker);
+  worker();
+  for (auto &t : th) t.join();
+  const int fl = fail.load();
+  if (fl) {
+    set_error("bringing the shared operand into the devices' HBM failed: " +
+              (fl > -1000 ? std::string(strerror(-fl)) : "HIP error " + std::to_string(-1000 - fl)));
+    return fl > -1000 ? BOF_EIO : BOF_EHIP;
+  }
+  return BOF_OK;
+}
+
+// flash::csrmm 'N' / flash::csrgemv on files: the device list, the call locks, then either the
+// single-device pipeline or -- several devices in this process -- the row blocks dealt to the
+// devices in contiguous, nnz-balanced ranges, each device running that pipeline on its
+// rows.  What every device needs (B; x of csrgemv 'N') is read / staged ONCE and copied to all of
+// them (fan_out); C rows and y slices are disjoint.  csrgemv 'T' leaves a full-length partial on
+// every device: device d sums segment d of all partials straight out of its peers' HBM
+// (reduce-scatter shape over xGMI; the reference's mutex-guarded vector add,
+// include/tasks/csrgemv_task.h:169-176) and sends that segment to the host itself, so the
+// result leaves over D PCIe links and no all-gather is needed.
+static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t k, float alpha,
+                          float beta, bof_fptr fa, bof_fptr fia, bof_fptr fja, char ord_b,
+                          bof_fptr fb, bof_fptr fc, const float *hb, float *hc,
+                          const bof_options *opts, const ResidentCsr *res = nullptr,
+                          Counters *carry = nullptr) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = device_ready();
+  if (rc) return rc;
+  const bof_options o = resolved(opts);
+  std::vector<int> devs;
+  rc = resolve_devices(o, devs);
+  if (rc) return rc;
+  if (res) devs.resize(1);   // a matrix that already sits in one device's HBM (csrmm 'T') is used there
+  DeviceCallLock call_lock(devs);
+  if (o.io_request_kib > 0) (void) bof_file_set_request_bytes((uint64_t) o.io_request_kib << 10);
+  file_set_engine(o.io_engine);
+  if (devs.size() == 1 || m == 0) {
+    DeviceScope ds(devs[0]);
+    return flash_csr_device(is_mm, trans, m, n, k, alpha, beta, fa, fia, fja, ord_b, fb, fc, hb, hc, o, res, carry);
+  }
+
+  // ---- offsets on the host, the reference's row blocks, contiguous block ranges per device -------
+  const bool use_aio = o.use_odirect != 0;
+  Counters total;
+  HostI64 ia((size_t) m + 1);
+  {
+    const int io = read_host(fia, (uint64_t) (m + 1) * 8, ia.data(), use_aio);
+    if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
+    total.rd += (uint64_t) (m + 1) * 8;
+  }
+  const int64_t nb = bof_csr_blocks(ia.data(), m, 128, o.csrmm_rblk, o.max_nnzs, nullptr, nullptr, 0);
+  std::vector<int64_t> bst((size_t) nb), bsz((size_t) nb);
+  bof_csr_blocks(ia.data(), m, 128, o.csrmm_rblk, o.max_nnzs, bst.data(), bsz.data(), nb);
+  const int D = (int) std::min<int64_t>((int64_t) devs.size(), nb);
+  std::vector<int> used(devs.begin(), devs.begin() + D);
+  std::vector<int64_t> cut((size_t) D + 1, 0);   // block index where each device's range starts
+  cut[(size_t) D] = nb;
+  {
+    const int64_t z = ia[0], nnz = ia[(size_t) m] - z;
+    for (int d = 1; d < D; d++) {
+      const int64_t target = z + nnz / D * d + nnz % D * d / D;
+      int64_t b = std::lower_bound(bst.begin(), bst.end(), target,
+                                   [&](int64_t row, int64_t t) { return ia[(size_t) row] < t; }) - bst.begin();
+      b = std::max(b, cut[(size_t) d - 1] + 1);          // at least one block each ...
+      cut[(size_t) d] = std::min<int64_t>(b, nb - (D - d));   // ... for the later devices too
+    }
+  }
+  struct Shard {
+    int dev = 0;
+    int64_t row0 = 0, rows = 0;
+    char *op = nullptr;          // B / x of this device
+    float *partial = nullptr;    // csrgemv 'T'
+    hipStream_t st = nullptr;
+    hipEvent_t ready = nullptr;
+    Counters cnt;
+    int rc = 0;
+    std::string err;
+    double seconds = 0;
+  };
+  std::vector<Shard> sh((size_t) D);
+  const bool share_op = is_mm || trans == 'N';           // csrgemv 'T' uses a private slice of x per device
+  const uint64_t op_bytes = is_mm ? (uint64_t) n * k * 4 : (uint64_t) n * 4;
+  Cleanup guard;
+  guard.add([&] {
+    for (Shard &S : sh) {
+      DeviceScope ds(S.dev);
+      (void) hipFree(S.op);
+      (void) hipFree(S.partial);
+      if (S.ready) (void) hipEventDestroy(S.ready);
+      if (S.st) (void) hipStreamDestroy(S.st);
+    }
+  });
+  for (int d = 0; d < D; d++) {
+    Shard &S = sh[(size_t) d];
+    S.dev = used[(size_t) d];
+    S.row0 = bst[(size_t) cut[(size_t) d]];
+    S.rows = (cut[(size_t) d + 1] == nb ? m : bst[(size_t) cut[(size_t) d + 1]]) - S.row0;
+    DeviceScope ds(S.dev);
+    BOF_HIP_TRY(copy_stream_create(&S.st));
+    BOF_HIP_TRY(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+    if (share_op) BOF_HIP_TRY(hipMalloc((void **) &S.op, std::max<uint64_t>(op_bytes, 4)));
+    if (!is_mm && trans == 'T') {
+      BOF_HIP_TRY(hipMalloc((void **) &S.partial, (size_t) std::max<int64_t>(n, 1) * 4));
+      BOF_HIP_TRY(hipMemsetAsync(S.partial, 0, (size_t) n * 4, S.st));
+      BOF_HIP_TRY(hipStreamSynchronize(S.st));   // zero before the device's first kernel adds into it
+    }
+  }
+
+  // ---- the shared operand goes to every device while the pipelines start ------------------------------
+  int feed_rc = BOF_OK;
+  std::string feed_err;
+  std::thread feeder([&] {
+    if (!share_op) return;
+    std::vector<char *> dst;
+    std::vector<hipStream_t> sts;
+    for (Shard &S : sh) { dst.push_back(S.op); sts.push_back(S.st); }
+    const bool from_file = is_mm && fb.fd >= 0;
+    feed_rc = fan_out(from_file ? &fb : nullptr, (const char *) hb, op_bytes, used, dst, sts, use_aio, o.n_io_threads, total);
+    for (Shard &S : sh) {
+      DeviceScope ds(S.dev);
+      hipError_t e = hipSuccess;
+      if (!feed_rc && is_mm && ord_b == 'C') {  // column-major B (n x k, ld = n) -> the row-major image the kernel reads
+        void *tmp = nullptr;
+        if (scratch_get(SCR_B_RM, (size_t) op_bytes, &tmp)) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipMemcpyAsync(tmp, S.op, (size_t) op_bytes, hipMemcpyDeviceToDevice, S.st);
+        if (e == hipSuccess) e = transpose_f32((const float *) tmp, n, k, n, (float *) S.op, k, S.st);
+      }
+      if (e == hipSuccess) e = hipEventRecord(S.ready, S.st);   // recorded even after a failed feed: nobody may wait forever
+      if (e != hipSuccess && !feed_rc) feed_rc = hip_fail(e, "shared operand");
+    }
+    if (feed_rc) feed_err = bof_last_error();
+  });
+
+  // ---- one pipeline per device on its rows ------------------------------------------------------------
+  auto run_shard = [&](Shard &S) {
+    DeviceScope ds(S.dev);
+    CsrExtra ex;
+    ex.ia = ia.data() + S.row0;
+    ex.out = &S.cnt;
+    if (share_op) { ex.shared_op = S.op; ex.shared_ready = S.ready; }
+    bof_fptr c_f = fc;
+    const float *b_h = hb;
+    float *c_h = hc;
+    if (is_mm) {
+      ex.c_ld = m;
+      const uint64_t c_off = ord_b == 'R' ? (uint64_t) S.row0 * (uint64_t) k : (uint64_t) S.row0;
+      if (fc.fd >= 0) c_f.foffset += c_off * 4;
+      if (c_h) c_h += c_off;
+    } else if (trans == 'N') {
+      c_h += S.row0;               // y rows of this device
+    } else {
+      b_h += S.row0;               // x rows of this device; the partial stays in HBM
+      ex.partial_y = S.partial;
+    }
+    S.rc = flash_csr_device(is_mm, trans, S.rows, n, k, alpha, beta, fa, fia, fja, ord_b, fb, c_f, b_h, c_h, o, nullptr,
+                            nullptr, &ex);
+    if (S.rc) S.err = bof_last_error();
+    S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  };
+  {
+    std::vector<std::thread> th;
+    for (int d = 1; d < D; d++) th.emplace_back([&, d] { run_shard(sh[(size_t) d]); });
+    run_shard(sh[0]);
+    for (auto &t : th) t.join();
+  }
+  feeder.join();
+  if (feed_rc) { rc = feed_rc; set_error(feed_err); }
+  for (Shard &S : sh)
+    if (S.rc && !rc) { rc = S.rc; set_error(S.err); }
+
+  // ---- csrgemv 'T': reduce-scatter of the partials between the devices, every segment home over its own link ----
+  if (!rc && !is_mm && trans == 'T' && n > 0) {
+    // peer access between every pair of distinct devices (xGMI); without it the partials cross through a staging copy
+    bool peers = true;
+    for (int a = 0; a < D && peers; a++)
+      for (int b = 0; b < D && peers; b++) {
+        if (sh[(size_t) a].dev == sh[(size_t) b].dev) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, sh[(size_t) a].dev, sh[(size_t) b].dev) != hipSuccess || !can) { peers = false; break; }
+        DeviceScope ds(sh[(size_t) a].dev);
+        const hipError_t e = hipDeviceEnablePeerAccess(sh[(size_t) b].dev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
+        (void) hipGetLastError();
+      }
+    for (Shard &S : sh) {   // every partial complete before anybody reads it
+      DeviceScope ds(S.dev);
+      (void) hipDeviceSynchronize();
+    }
+    std::vector<int> seg_rc((size_t) D, 0);
+    auto reduce_segment = [&](int d) {
+      Shard &S = sh[(size_t) d];
+      DeviceScope ds(S.dev);
+      const int64_t s0 = n / D * d + std::min<int64_t>(d, n % D), len = n / D + (d < n % D ? 1 : 0);
+      if (len == 0) return;
+      hipError_t e = hipSuccess;
+      float *tmp = nullptr;
+      if (peers) {
+        const float *srcs[BOF_MAX_DEVICES];
+        for (int e2 = 0; e2 < D; e2++) srcs[e2] = sh[(size_t) e2].partial + s0;
+        e = sum_partials(S.partial + s0, srcs, D, len, S.st);
+      } else {
+        e = hipMalloc((void **) &tmp, (size_t) len * 4);
+        for (int e2 = 0; e2 < D && e == hipSuccess; e2++) {
+          if (e2 == d) continue;
+          e = hipMemcpyPeerAsync(tmp, S.dev, sh[(size_t) e2].partial + s0, sh[(size_t) e2].dev, (size_t) len * 4, S.st);
+          const float *two[2] = {S.partial + s0, tmp};
+          if (e == hipSuccess) e = sum_partials(S.partial + s0, two, 2, len, S.st);
+        }
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(S.st);
+      if (e == hipSuccess && device_to_pageable(hc + s0, S.partial + s0, (uint64_t) len * 4, std::max(1, o.n_io_threads / D)))
+        e = hipErrorUnknown;
+      (void) hipFree(tmp);
+      S.cnt.d2h += (uint64_t) len * 4;
+      if (e != hipSuccess) seg_rc[(size_t) d] = hip_fail(e, "csrgemv 'T': reducing the partial sums");
+    };
+    // NOTE on summation order: segment sums run e = 0 .. D-1, a fixed order; the partials themselves
+    // are sums of fp32 atomics (as in the single-device call), exact on integer data
+    std::vector<std::thread> th;
+    for (int d = 1; d < D; d++) th.emplace_back([&, d] { reduce_segment(d); });
+    reduce_segment(0);
+    for (auto &t : th) t.join();
+    for (int d = 0; d < D; d++)
+      if (seg_rc[(size_t) d] && !rc) { rc = seg_rc[(size_t) d]; set_error("csrgemv 'T': reducing the partial sums across the devices failed"); }
+  }
+
+  std::vector<bof_flash_stats> per;
+  for (Shard &S : sh) {
+    total.rd += S.cnt.rd.load(); total.wr += S.cnt.wr.load(); total.h2d += S.cnt.h2d.load(); total.d2h += S.cnt.d2h.load();
+    total.tasks += S.cnt.tasks.load();
+    bof_flash_stats ps{};
+    ps.bytes_read = S.cnt.rd; ps.bytes_written = S.cnt.wr; ps.bytes_h2d = S.cnt.h2d; ps.bytes_d2h = S.cnt.d2h;
+    ps.tasks = S.cnt.tasks; ps.seconds = S.seconds;
+    per.push_back(ps);
+  }
+  publish_stats(total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  publish_device_stats(per);
+  return rc;
 }
 
 // csrmm with trans_a = 'T': C[n x k] = alpha * A^T * B[m x k] + beta * C.  A^T is built in HBM
@@ -896,9 +1220,17 @@ static int flash_csrmm_trans(uint64_t m, uint64_t n, uint64_t k, float alpha, fl
                              const float *hb, float *hc, const bof_options *opts) {
   int rc = device_ready();
   if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   if (n == 0) return BOF_OK;
-  const bof_options o = resolved(opts);
+  bof_options o = resolved(opts);
+  std::vector<int> devs;
+  rc = resolve_devices(o, devs);
+  if (rc) return rc;
+  devs.resize(1);   // A^T is built in ONE device's HBM and used there: the first device of the list
+  DeviceCallLock call_lock(devs);
+  DeviceScope on_dev(devs[0]);
+  o.n_devices = 1; o.devices[0] = devs[0];
+  opts = &o;
+  file_set_engine(o.io_engine);
   Counters cnt;
   bof_fptr none{-1, 0};
   {

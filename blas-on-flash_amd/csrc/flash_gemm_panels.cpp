@@ -35,10 +35,22 @@
 // first panels are already being read (a cold 65536^3 call spent 0.85 s in hipMalloc before its
 // first read otherwise); slots stay with the device's PanelResources between calls.
 //
-// Threads: n_io_threads readers (file -> pinned slot -> H2D), the caller as dispatcher (tile
-// launches on n_streams compute streams), one flusher (HBM -> pinned, chunk by chunk) and
-// writers (pinned -> file).  Everything is ordered by hipEvents and two condition variables;
-// nothing polls.
+// Threads: n_io_threads readers (file -> pinned slot -> H2D), one dispatcher per device (tile
+// launches on its compute streams; the caller itself for the first device), one flusher per device
+// (HBM -> pinned, chunk by chunk) and writers (pinned -> file).  Everything is ordered by hipEvents
+// and one condition variable; nothing polls.
+//
+// Several devices in ONE process (bof_options.devices / $BOF_DEVICES; the reference runs its
+// N_COMPUTE_THR workers behind flash::gemm inside one process, src/scheduler/scheduler.cpp:9-16):
+// the C panels are dealt to the devices in contiguous ranges (output row blocks), and
+// every device runs the schedule above on ITS slab -- same tiles, same k-order per chain, so the
+// C file is bit-identical to the single-device call.  A panel only one device needs (its C
+// panels, the A panels of its rows) is private to it; a panel every device needs (B for
+// row-major; A too when it is paneled along k) is SHARED: it is read from the file ONCE into a
+// pinned slot and copied from there to every device on that device's own H2D stream, i.e. over
+// its own PCIe link -- storage sees A, B and C once whatever the number of devices.  Readers,
+// the read ring and the writers serve all devices; panel slots, copy streams, write ring,
+// flusher and dispatcher are per device.
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE
 #endif
@@ -50,6 +62,8 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -71,11 +85,14 @@ struct Panel {
 };
 
 struct Mat {
-  bof_fptr f{-1, 0};
+  bof_fptr f{-1, 0};            // element 0 of what THIS device uses of the matrix
   int fd = -1;                  // descriptor every request of this call uses (O_DIRECT or twin)
   bool aio = false;
   int rdim = 0, cdim = 0;
   int64_t rows = 0, cols = 0, ld = 0, blk_r = 0, blk_c = 0;
+  bool shared = false;          // every device needs every panel: read once, copied to all of them
+  int64_t col_base = 0;         // shared operand whose columns run along the C panel dimension:
+                                // first stored column of this device's slab
   std::vector<Panel> panels;
   bool natural = false;         // whole matrix resident at its file offsets
   int n_slots = 0;
@@ -83,7 +100,7 @@ struct Mat {
   // One HBM allocation per panel slot (resident matrices: one per panel), made in first-use order
   // by a thread of its own while the first panels are already being read: hipMalloc costs 13-36 ms
   // per GiB and used to sit in front of the first read (0.85 s of a cold 65536^3 call).  A null
-  // entry = not allocated yet; entries are written under PanelRun::mu.
+  // entry = not allocated yet; entries are written under PanelHub::mu.
   std::vector<char *> *slots = nullptr;
   int slot_of(int p) const { return natural ? p : p % n_slots; }
   char *panel_ptr(int p) const { return (*slots)[(size_t) slot_of(p)]; }
@@ -95,14 +112,18 @@ struct Mat {
   size_t tslot_bytes = 0;
   std::vector<char *> *tslots = nullptr;
   char *tpanel_ptr(int p) const { return (*tslots)[(size_t) slot_of(p)]; }
+  bool slot_ready(int p) const { return panel_ptr(p) && (!kmajor_copy || tpanel_ptr(p)); }
   uint64_t file_off(int p) const { return f.foffset + (uint64_t) panels[(size_t) p].r0 * (uint64_t) ld * 4; }
 };
 
-struct ChunkReq { int mat, panel; uint64_t off, bytes; };
-struct WriteReq { int wslot; uint64_t file_off, bytes; int panel; bool last; };
+struct ChunkReq { int di, mat, panel; uint64_t off, bytes; };   // di < 0: a shared panel (every device)
+struct WriteReq { int di, wslot; uint64_t file_off, bytes; int panel; bool last; };
 
+// Per device (and per repetition of one ordinal in the device list): the HBM panel slots and the
+// write ring, kept between calls.
 struct PanelResources {
-  PinnedRing rring, wring;
+  int dev = 0;
+  PinnedRing wring;
   std::vector<char *> slot[3];            // kept between calls
   size_t slot_bytes[3] = {0, 0, 0};
   std::vector<char *> tslot[2];           // k-major copies of operand panels (A, B)
@@ -127,9 +148,16 @@ struct PanelResources {
       if (tslot[x][i]) (void) hipFree(tslot[x][i]);
     tslot[x].resize(keep);
   }
+  void drop_all() {
+    DeviceScope ds(dev);
+    wring.destroy();
+    for (int x = 0; x < 3; x++) drop(x, 0);
+    for (int x = 0; x < 2; x++) drop_t(x, 0);
+  }
 };
 std::mutex g_pres_mu;
-PanelResources *g_pres[64];
+std::map<std::pair<int, int>, PanelResources *> g_pres;   // (ordinal, repetition) -> resources
+PinnedRing *g_rring = nullptr;                            // the read ring serves every device of a call
 
 int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel read / flush / write
   static const int lvl = getenv("BOF_TRACE") ? std::max(1, atoi(getenv("BOF_TRACE"))) : 0;
@@ -137,38 +165,73 @@ int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel re
 }
 bool trace_on() { return trace_level() >= 1; }
 
+struct PanelHub;
+
+// One device's share of the call: the single-device schedule over its slab of C.
 struct PanelRun {
+  PanelHub *hub = nullptr;
+  int di = 0, dev = 0;          // position in the hub's device list, HIP ordinal
   bof_options o;
-  GemmGeometry g;
+  GemmGeometry g;               // the slab's geometry (size along the C panel dimension cut down)
+  char ord = 'R', ta = 'N', tb = 'N';
+  float alpha = 1.f, beta = 0.f;
   Mat mat[3];
   int xmat = 0, ymat = 1;       // streamed-or-resident operand / always-resident operand
+  int dC = 0;
+  int64_t NpC = 0, Nq = 0;
+  int64_t row_base = 0, col_base = 0;   // first row / column of the slab in the whole C (kmeans vectors)
   bool c_read = false;
   size_t chunk = 32u << 20;
   PanelResources *res = nullptr;
   hipStream_t h2d = nullptr, d2h = nullptr;
   StreamSet *ss = nullptr;
-  WorkQueue<ChunkReq> fetch_q;
   WorkQueue<int> flush_q;
-  WorkQueue<WriteReq> write_q;
-  std::vector<std::pair<int, int>> order;  // (mat, panel) in order of first use
+  std::vector<std::pair<int, int>> order;        // (mat, panel) in order of first use
   std::vector<std::pair<int, int>> alloc_order;  // (mat, slot) still to be allocated, in order of first use
   size_t next_fetch = 0;
+  std::vector<bof_gemm_task> tasks;               // execution order
+  std::vector<size_t> group_end;                  // task index one past each group
+  std::vector<int64_t> gb;                        // first C panel of each group, then NpC
+  int n_groups = 0;
   std::vector<std::vector<hipEvent_t>> group_ev;  // per group: one event per compute stream
   std::vector<int> group_of;                      // C panel -> group
+  KmeansVecs kv{nullptr, nullptr, nullptr};
+  bool has_kv = false;
+  Counters cnt;                                   // this device's share of the counters
+  hipError_t herr = hipSuccess;
+  int fail = 0;
+  double seconds = 0;
+
+  int plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t full_dC, const bof_fptr fp[3], const GemmGeometry &gfull,
+           int64_t p_first);
+  int prepare();
+  void alloc_main();
+  void flusher_main();
+  void dispatch();
+  void trace(const char *label) const;
+  void trace2(const char *what, int x, int p) const {
+    if (trace_level() >= 2) {
+      char lbl[64];
+      snprintf(lbl, sizeof(lbl), "d%d %s %c%d", di, what, "ABC"[x], p);
+      trace(lbl);
+    }
+  }
+};
+
+// What the devices of one call share: the fetch / write queues with their thread pools, the read
+// ring, the error flag and the one mutex + condition variable everything is ordered by.
+struct PanelHub {
+  std::vector<std::unique_ptr<PanelRun>> runs;
+  PinnedRing *rring = nullptr;
+  WorkQueue<ChunkReq> fetch_q;
+  WorkQueue<WriteReq> write_q;
+  std::vector<char> issued[2];   // shared operand panels whose read has been queued
   std::mutex mu;
   std::condition_variable cv;
   std::atomic<int> io_error{0};
   Counters cnt;
-  int dev = 0;
   std::chrono::steady_clock::time_point t_begin;
 
-  void trace2(const char *what, int x, int p) const {
-    if (trace_level() >= 2) {
-      char lbl[64];
-      snprintf(lbl, sizeof(lbl), "%s %c%d", what, "ABC"[x], p);
-      trace(lbl);
-    }
-  }
   void trace(const char *label) const {
     if (trace_on())
       fprintf(stderr, "[bof trace] %-34s %8.3f ms\n", label,
@@ -183,157 +246,217 @@ struct PanelRun {
     cv.notify_all();
   }
 
-  // Push the chunk requests of every panel, in first-use order, whose HBM slot is free: the
-  // whole-matrix images always are, a ring slot once its previous occupant has retired.
-  // Strictly in order, so the readers always work on what is needed soonest.  Caller holds mu.
-  void pump_fetches() {
-    while (next_fetch < order.size()) {
-      const int x = order[next_fetch].first, p = order[next_fetch].second;
-      Mat &M = mat[x];
-      Panel &P = M.panels[(size_t) p];
-      const int prev = M.natural ? -1 : p - M.n_slots;
-      if (prev >= 0 && !M.panels[(size_t) prev].retired) break;
-      if (!M.panel_ptr(p) || (M.kmajor_copy && !M.tpanel_ptr(p))) break;   // slot still being allocated (alloc_main pumps again)
-      const int n_chunks = (int) ((P.bytes + chunk - 1) / chunk);
-      P.state = 1;
-      P.remaining = n_chunks;
-      for (int c = 0; c < n_chunks; c++) {
-        const uint64_t off = (uint64_t) c * chunk;
-        fetch_q.push(ChunkReq{x, p, off, std::min<uint64_t>(chunk, P.bytes - off)});
+  // One step of a device's fetch list: queue the chunk requests of its next panel, in first-use
+  // order, if the HBM slot is free -- the whole-matrix images always are, a ring slot once its
+  // previous occupant has retired.  Strictly in order per device, so the readers always work on
+  // what that device needs soonest.  A shared panel is queued once, by whichever device gets to
+  // it first, when EVERY device has its slot allocated.  Caller holds mu.
+  bool pump_step(PanelRun &R) {
+    if (R.next_fetch >= R.order.size()) return false;
+    const int x = R.order[R.next_fetch].first, p = R.order[R.next_fetch].second;
+    Mat &M = R.mat[x];
+    Panel &P = M.panels[(size_t) p];
+    const int n_chunks = (int) ((P.bytes + R.chunk - 1) / R.chunk);
+    if (M.shared) {
+      if (!issued[x][(size_t) p]) {
+        for (auto &Q : runs)
+          if (!Q->mat[x].slot_ready(p)) return false;     // a slot is still being allocated (alloc_main pumps again)
+        issued[x][(size_t) p] = 1;
+        for (auto &Q : runs) {
+          Panel &PQ = Q->mat[x].panels[(size_t) p];
+          PQ.state = 1;
+          PQ.remaining = n_chunks;
+        }
+        for (int c = 0; c < n_chunks; c++) {
+          const uint64_t off = (uint64_t) c * R.chunk;
+          fetch_q.push(ChunkReq{-1, x, p, off, std::min<uint64_t>(R.chunk, P.bytes - off)});
+        }
+        cnt.misses++;
       }
-      cnt.misses++;
-      next_fetch++;
+      R.next_fetch++;
+      return true;
+    }
+    const int prev = M.natural ? -1 : p - M.n_slots;
+    if (prev >= 0 && !M.panels[(size_t) prev].retired) return false;
+    if (!M.slot_ready(p)) return false;
+    P.state = 1;
+    P.remaining = n_chunks;
+    for (int c = 0; c < n_chunks; c++) {
+      const uint64_t off = (uint64_t) c * R.chunk;
+      fetch_q.push(ChunkReq{R.di, x, p, off, std::min<uint64_t>(R.chunk, P.bytes - off)});
+    }
+    cnt.misses++;
+    R.next_fetch++;
+    return true;
+  }
+  void pump_fetches() {   // round robin over the devices, one panel each, until nobody can go on
+    for (bool progress = true; progress;) {
+      progress = false;
+      for (auto &R : runs) progress = pump_step(*R) || progress;
     }
   }
 
-  // HBM slots in first-use order; every new slot may unblock the next fetch / the dispatcher
-  void alloc_main() {
-    (void) hipSetDevice(dev);
-    for (const auto &as : alloc_order) {
-      if (io_error.load()) break;
-      TraceRange r("panel slot hipMalloc");
-      char *p = nullptr, *tp = nullptr;
-      Mat &M = mat[as.first];
-      hipError_t e = hipSuccess;
-      if (!(*M.slots)[(size_t) as.second]) e = hipMalloc((void **) &p, M.slot_bytes);
-      if (e == hipSuccess && M.kmajor_copy && !(*M.tslots)[(size_t) as.second]) e = hipMalloc((void **) &tp, M.tslot_bytes);
-      if (e != hipSuccess) { fail_io(-1000 - (int) e); break; }
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (tp) (*M.tslots)[(size_t) as.second] = tp;   // before the raw slot: a usable raw slot implies its copy's
-        if (p) (*M.slots)[(size_t) as.second] = p;
-        pump_fetches();
-      }
-      cv.notify_all();
-    }
-    trace("HBM panel slots allocated");
-  }
+  void reader_main(int home);
+  void writer_main(int home);
+};
 
-  void reader_main() {
-    (void) hipSetDevice(dev);
-    (void) bind_thread_near_device(dev);
-    ChunkReq rq;
-    while (fetch_q.pop(rq)) {
-      Mat &M = mat[rq.mat];
-      Panel &P = M.panels[(size_t) rq.panel];
-      const int ps = res->rring.acquire();
-      int rc = 0;
-      if (!io_error.load()) {
-        TraceRange r("panel chunk read");
-        rc = file_sread(M.fd, M.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, res->rring.ptr(ps), M.aio);
-      }
-      if (rc) fail_io(rc);
-      hipError_t e = hipSuccess;
+void PanelRun::trace(const char *label) const {
+  if (!trace_on()) return;
+  char lbl[96];
+  snprintf(lbl, sizeof(lbl), "d%d %s", di, label);
+  hub->trace(lbl);
+}
+
+// HBM slots in first-use order; every new slot may unblock the next fetch / the dispatcher
+void PanelRun::alloc_main() {
+  (void) hipSetDevice(dev);
+  for (const auto &as : alloc_order) {
+    if (hub->io_error.load()) break;
+    TraceRange r("panel slot hipMalloc");
+    char *p = nullptr, *tp = nullptr;
+    Mat &M = mat[as.first];
+    hipError_t e = hipSuccess;
+    if (!(*M.slots)[(size_t) as.second]) e = hipMalloc((void **) &p, M.slot_bytes);
+    if (e == hipSuccess && M.kmajor_copy && !(*M.tslots)[(size_t) as.second]) e = hipMalloc((void **) &tp, M.tslot_bytes);
+    if (e != hipSuccess) { (void) hipGetLastError(); hub->fail_io(e == hipErrorOutOfMemory ? -ENOMEM : -1000 - (int) e); break; }
+    {
+      std::lock_guard<std::mutex> lk(hub->mu);
+      if (tp) (*M.tslots)[(size_t) as.second] = tp;   // before the raw slot: a usable raw slot implies its copy's
+      if (p) (*M.slots)[(size_t) as.second] = p;
+      hub->pump_fetches();
+    }
+    hub->cv.notify_all();
+  }
+  trace("HBM panel slots allocated");
+}
+
+// file -> pinned slot -> HBM of the device(s) that need the chunk
+void PanelHub::reader_main(int home) {
+  PanelRun &H = *runs[(size_t) home % runs.size()];
+  (void) hipSetDevice(H.dev);
+  (void) bind_thread_near_device(H.dev);
+  ChunkReq rq;
+  while (fetch_q.pop(rq)) {
+    PanelRun &R0 = *runs[(size_t) std::max(rq.di, 0)];
+    Mat &M0 = R0.mat[rq.mat];
+    const int ps = rring->acquire();
+    int rc = 0;
+    if (!io_error.load()) {
+      TraceRange r("panel chunk read");
+      rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, rring->ptr(ps), M0.aio);
+    }
+    if (rc) fail_io(rc);
+    cnt.rd += rq.bytes;
+    if (rq.di >= 0) R0.cnt.rd += rq.bytes;
+    const size_t d0 = rq.di < 0 ? 0 : (size_t) rq.di, d1 = rq.di < 0 ? runs.size() : (size_t) rq.di + 1;
+    hipError_t e = hipSuccess;
+    for (size_t d = d0; d < d1 && e == hipSuccess; d++) {
+      PanelRun &R = *runs[d];
+      Mat &M = R.mat[rq.mat];
+      e = hipSetDevice(R.dev);
       const int prev = M.natural ? -1 : rq.panel - M.n_slots;
       if (prev >= 0)  // WAR: the slot's previous occupant (its events were recorded before it retired)
         for (hipEvent_t w : M.panels[(size_t) prev].retire_ev)
-          if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
+          if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, w, 0);
       if (e == hipSuccess && !rc)
-        e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, res->rring.ptr(ps), rq.bytes, hipMemcpyHostToDevice, h2d);
-      if (e == hipSuccess) (void) res->rring.mark_busy(ps, h2d);
-      res->rring.release(ps);
-      cnt.rd += rq.bytes;
+        e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, rring->ptr(ps), rq.bytes, hipMemcpyHostToDevice, R.h2d);
+      if (e == hipSuccess) (void) rring->mark_busy(ps, R.h2d, R.di);
       cnt.h2d += rq.bytes;
-      {
-        // the copy above is enqueued before this decrement, so whoever brings the count to
-        // zero records `ready` behind every copy of the panel
-        std::lock_guard<std::mutex> lk(mu);
+      R.cnt.h2d += rq.bytes;
+    }
+    rring->release(ps);
+    {
+      // the copies above are enqueued before these decrements, so whoever brings a panel's count
+      // to zero records `ready` behind every copy of the panel on that device
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t d = d0; d < d1; d++) {
+        PanelRun &R = *runs[d];
+        Mat &M = R.mat[rq.mat];
+        Panel &P = M.panels[(size_t) rq.panel];
         if (--P.remaining == 0) {
+          if (e == hipSuccess) e = hipSetDevice(R.dev);
           if (e == hipSuccess && M.kmajor_copy)
             e = transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
-                              P.nr, h2d);
-          if (e == hipSuccess) e = hipEventRecord(P.ready, h2d);
+                              P.nr, R.h2d);
+          if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           P.state = 2;
-          trace2("read + H2D queued:", rq.mat, rq.panel);
+          R.trace2("read + H2D queued:", rq.mat, rq.panel);
         }
       }
-      if (e != hipSuccess) fail_io(-1000 - (int) e);
-      cv.notify_all();
     }
+    if (e != hipSuccess) fail_io(-1000 - (int) e);
+    cv.notify_all();
   }
+}
 
-  // HBM -> pinned ring, chunk by chunk, for every finished C panel; then the panel's slot is
-  // free for a later one.
-  void flusher_main() {
-    (void) hipSetDevice(dev);
-    (void) bind_thread_near_device(dev);
-    int pc;
-    while (flush_q.pop(pc)) {
-      Mat &C = mat[2];
-      Panel &P = C.panels[(size_t) pc];
-      hipError_t e = hipSuccess;
-      for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
-        if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
-      for (uint64_t off = 0; off < P.bytes && e == hipSuccess && !io_error.load(); off += chunk) {
-        const uint64_t len = std::min<uint64_t>(chunk, P.bytes - off);
-        const int ws = res->wring.acquire();
-        e = hipMemcpyAsync(res->wring.ptr(ws), C.panel_ptr(pc) + off, len, hipMemcpyDeviceToHost, d2h);
-        if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
-        if (e != hipSuccess) { res->wring.release(ws); break; }
-        cnt.d2h += len;
-        write_q.push(WriteReq{ws, C.file_off(pc) + off, len, pc, off + len >= P.bytes});
-      }
-      if (e == hipSuccess) e = hipEventRecord(P.d2h_done, d2h);
-      if (e != hipSuccess) fail_io(-1000 - (int) e);
-      trace2("D2H queued:", 2, pc);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        P.retire_ev.assign(1, P.d2h_done);
-        P.retired = true;
-        pump_fetches();
-      }
-      cv.notify_all();
+// HBM -> pinned ring, chunk by chunk, for every finished C panel; then the panel's slot is
+// free for a later one.
+void PanelRun::flusher_main() {
+  (void) hipSetDevice(dev);
+  (void) bind_thread_near_device(dev);
+  int pc;
+  while (flush_q.pop(pc)) {
+    Mat &C = mat[2];
+    Panel &P = C.panels[(size_t) pc];
+    hipError_t e = hipSuccess;
+    for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
+      if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
+    for (uint64_t off = 0; off < P.bytes && e == hipSuccess && !hub->io_error.load(); off += chunk) {
+      const uint64_t len = std::min<uint64_t>(chunk, P.bytes - off);
+      const int ws = res->wring.acquire();
+      e = hipMemcpyAsync(res->wring.ptr(ws), C.panel_ptr(pc) + off, len, hipMemcpyDeviceToHost, d2h);
+      if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
+      if (e != hipSuccess) { res->wring.release(ws); break; }
+      cnt.d2h += len;
+      hub->cnt.d2h += len;
+      hub->write_q.push(WriteReq{di, ws, C.file_off(pc) + off, len, pc, off + len >= P.bytes});
     }
+    if (e == hipSuccess) e = hipEventRecord(P.d2h_done, d2h);
+    if (e != hipSuccess) hub->fail_io(-1000 - (int) e);
+    trace2("D2H queued:", 2, pc);
+    {
+      std::lock_guard<std::mutex> lk(hub->mu);
+      P.retire_ev.assign(1, P.d2h_done);
+      P.retired = true;
+      hub->pump_fetches();
+    }
+    hub->cv.notify_all();
   }
+}
 
-  void writer_main() {
-    (void) hipSetDevice(dev);
-    (void) bind_thread_near_device(dev);
-    WriteReq rq;
-    while (write_q.pop(rq)) {
-      hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
-      if (e != hipSuccess) fail_io(-1000 - (int) e);
-      int rc = 0;
-      if (!io_error.load()) {
-        TraceRange r("panel chunk write");
-        rc = file_swrite(mat[2].fd, rq.file_off, 0, 1, rq.bytes, res->wring.ptr(rq.wslot), mat[2].aio);
-      }
-      if (rc) fail_io(rc);
-      cnt.wr += rq.bytes;
-      res->wring.release(rq.wslot);
-      if (rq.last) trace2("last chunk written:", 2, rq.panel);
+void PanelHub::writer_main(int home) {
+  PanelRun &H = *runs[(size_t) home % runs.size()];
+  (void) hipSetDevice(H.dev);
+  (void) bind_thread_near_device(H.dev);
+  WriteReq rq;
+  while (write_q.pop(rq)) {
+    PanelRun &R = *runs[(size_t) rq.di];
+    hipError_t e = hipEventSynchronize(R.res->wring.event(rq.wslot));
+    if (e != hipSuccess) fail_io(-1000 - (int) e);
+    int rc = 0;
+    if (!io_error.load()) {
+      TraceRange r("panel chunk write");
+      rc = file_swrite(R.mat[2].fd, rq.file_off, 0, 1, rq.bytes, R.res->wring.ptr(rq.wslot), R.mat[2].aio);
     }
+    if (rc) fail_io(rc);
+    cnt.wr += rq.bytes;
+    R.cnt.wr += rq.bytes;
+    R.res->wring.release(rq.wslot);
+    if (rq.last) R.trace2("last chunk written:", 2, rq.panel);
   }
-};
+}
 
 // One descriptor mode per file per call: O_DIRECT only if EVERY request of the call is sector
 // aligned; otherwise every request goes through the buffered twin.  Mixing the two on one file
 // lets a direct write and a buffered write of neighbouring regions meet in one page.
-void pick_descriptor(Mat &M, bool use_odirect, size_t chunk) {
+bool requests_aligned(const Mat &M, size_t chunk) {
   const uint64_t A = file_is_direct(M.f.fd) ? file_dio_align(M.f.fd) : 512;
   bool aligned = (M.f.foffset % A) == 0 && (chunk % A) == 0;
   for (const Panel &P : M.panels)
     aligned = aligned && (P.bytes % A) == 0 && (((uint64_t) P.r0 * (uint64_t) M.ld * 4) % A) == 0;
+  return aligned;
+}
+void pick_descriptor(Mat &M, bool aligned, bool use_odirect) {
   M.fd = M.f.fd;
   M.aio = false;
   if (file_is_direct(M.f.fd)) {
@@ -343,63 +466,37 @@ void pick_descriptor(Mat &M, bool use_odirect, size_t chunk) {
   }
 }
 
-}  // namespace
-
-void panel_resources_release() {
-  std::lock_guard<std::mutex> lk(g_pres_mu);
-  for (int d = 0; d < 64; d++) {
-    PanelResources *r = g_pres[d];
-    if (!r) continue;
-    r->rring.destroy();
-    r->wring.destroy();
-    for (int x = 0; x < 3; x++) r->drop(x, 0);
-    for (int x = 0; x < 2; x++) r->drop_t(x, 0);
-    delete r;
-    g_pres[d] = nullptr;
-  }
-}
-
-int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
-                      bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
-                      const bof_options &o, const KmeansVecs *kv) {
-  PanelRun R;
-  R.t_begin = std::chrono::steady_clock::now();
-  R.o = o;
-  R.g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
-  const GemmGeometry &g = R.g;
-  const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
-  if (Nm * Nn == 0 || Nk == 0) return 1;
-  R.chunk = (size_t) std::max(1, o.io_chunk_mib) << 20;
-  R.c_read = beta != 0.0f;
-  BOF_HIP_TRY(hipGetDevice(&R.dev));
-
-  // ---- budget and layout (plan.cpp: pure host logic, also behind bof_flash_gemm_panel_plan) ------
+// ---- plan of one device's slab ------------------------------------------------------------------
+// gfull: the whole problem; p_first: first C panel of the slab (this->NpC panels); budget from the
+// device's free HBM (divided by the number of times the ordinal appears in the device list).
+// Returns BOF_OK, +1 (not eligible: the tile cache must take the call) or an error.
+int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t full_dC, const bof_fptr fp[3],
+                   const GemmGeometry &gfull, int64_t p_first) {
+  (void) all_devs;
+  const int64_t Nk = g.nblk[1];
+  chunk = (size_t) std::max(1, o.io_chunk_mib) << 20;
+  c_read = beta != 0.0f;
   size_t free_b = 0, total_b = 0;
   BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  {
-    std::lock_guard<std::mutex> lk(g_pres_mu);
-    if (!g_pres[R.dev & 63]) g_pres[R.dev & 63] = new PanelResources();
-    R.res = g_pres[R.dev & 63];
-  }
-  free_b += R.res->held_bytes();  // what we already hold counts as free
+  free_b += res->held_bytes();  // what we already hold counts as free
+  free_b /= (size_t) std::max(1, reps_of_dev);
   size_t budget = o.hbm_budget > 0 ? (size_t) o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
-  const int dC = g.rdim[2];                    // 0: C paneled along m, 2: along n
-  R.xmat = dC == 0 ? 0 : 1;
-  R.ymat = 1 - R.xmat;
-  const int64_t NpC = g.nblk[dC];
-  const int64_t Nq = dC == 0 ? Nn : Nm;        // C tiles per panel
-  bof_panel_plan plan = plan_panels(g, budget, 1);
-  if (!plan.eligible) return 1;
+  dC = g.rdim[2];                              // 0: C paneled along m, 2: along n
+  xmat = dC == 0 ? 0 : 1;
+  ymat = 1 - xmat;
+  NpC = g.nblk[dC];
+  Nq = dC == 0 ? g.nblk[2] : g.nblk[0];        // C tiles per panel
+  bof_panel_plan pl = plan_panels(g, budget, 1, full_dC);
+  if (!pl.eligible) return 1;
   {
     // size of the ramp group (see the header): read time of one panel of the resident operand
     // over the time of the tile tasks one C panel contributes per such panel.  The rates are
     // assumptions (a datacenter NVMe under O_DIRECT; page cache + PCIe otherwise; the fp32 MFMA
-    // tile rate) -- BOF_PANEL_GROUP overrides.
-    const char *genv = getenv("BOF_PANEL_GROUP");
-    int64_t want = genv ? atoll(genv) : 0;
+    // tile rate) -- bof_options.panel_group / BOF_PANEL_GROUP override.
+    int64_t want = o.panel_group > 0 ? o.panel_group : env_long("BOF_PANEL_GROUP", 0);
     if (want <= 0) {
-      const double t_io = (double) plan.slot_bytes[R.ymat] / (o.use_odirect ? 16e9 : 40e9);
+      const double t_io = (double) pl.slot_bytes[ymat] / (o.use_odirect ? 16e9 : 40e9);
       const double t_task = std::max(2.0 * (double) g.blk[0] * (double) g.blk[1] * (double) g.blk[2] / 140e12, 15e-6);
       want = (int64_t) std::ceil(t_io / (t_task * (double) Nq));
       // at most half of the C panels: a ramp group's panels all complete -- and start their
@@ -409,41 +506,49 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 8), NpC / 2));
     }
     for (int64_t G = std::min(want, NpC); G > 1; G--) {
-      const bof_panel_plan p2 = plan_panels(g, budget, G);
-      if (p2.eligible) { plan = p2; break; }
+      const bof_panel_plan p2 = plan_panels(g, budget, G, full_dC);
+      if (p2.eligible) { pl = p2; break; }
     }
   }
-  const int64_t group = plan.first_group;
-  const bof_fptr fp[3] = {fa, fb, fc};
+  const int64_t group = pl.first_group;
+  const int64_t slab0 = p_first * gfull.blk[dC];     // first element of the slab along dC
+  row_base = dC == 0 ? slab0 : 0;
+  col_base = dC == 2 ? slab0 : 0;
   for (int x = 0; x < 3; x++) {
-    Mat &M = R.mat[x];
+    Mat &M = mat[x];
     M.f = fp[x];
     M.rdim = g.rdim[x]; M.cdim = g.cdim[x];
-    M.rows = g.size[M.rdim]; M.cols = g.size[M.cdim]; M.ld = g.ld[x];
+    M.ld = g.ld[x];
     M.blk_r = g.blk[M.rdim]; M.blk_c = g.blk[M.cdim];
-    M.panels.resize((size_t) plan.n_panels[x]);
-    for (int64_t p = 0; p < plan.n_panels[x]; p++) {
+    M.rows = g.size[M.rdim]; M.cols = g.size[M.cdim];
+    // a matrix that does not contain the C panel dimension (Y) or contains it along its stored
+    // columns (X paneled along k) is needed by every device panel by panel
+    M.shared = x < 2 && M.rdim != dC;
+    if (x == 2 || M.rdim == dC) {
+      M.f.foffset += (uint64_t) slab0 * (uint64_t) M.ld * 4;      // this device's stored rows
+    } else if (M.cdim == dC) {
+      M.cols = gfull.size[dC];                                    // whole panels; the slab is a column range
+      M.blk_c = gfull.blk[dC];
+      M.col_base = slab0;
+    }
+    M.panels.resize((size_t) pl.n_panels[x]);
+    for (int64_t p = 0; p < pl.n_panels[x]; p++) {
       Panel &P = M.panels[(size_t) p];
       P.r0 = p * M.blk_r;
-      P.nr = (p == plan.n_panels[x] - 1) ? M.rows - P.r0 : M.blk_r;
+      P.nr = (p == pl.n_panels[x] - 1) ? M.rows - P.r0 : M.blk_r;
       P.bytes = ((uint64_t) (P.nr - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4;
     }
-    M.slot_bytes = (size_t) plan.slot_bytes[x];
+    M.slot_bytes = (size_t) pl.slot_bytes[x];
     M.total_bytes = (size_t) (((uint64_t) (M.rows - 1) * (uint64_t) M.ld + (uint64_t) M.cols) * 4);
-    M.natural = plan.resident[x] != 0;
-    M.n_slots = (int) plan.n_slots[x];
+    M.natural = pl.resident[x] != 0;
+    M.n_slots = (int) pl.n_slots[x];
   }
-  Mat &X = R.mat[R.xmat], &C = R.mat[2];
 
   // ---- task list in execution order, panels in first-use order ------------------------------
-  std::vector<bof_gemm_task> tasks;
-  tasks.reserve((size_t) (Nm * Nk * Nn));
-  R.group_of.assign((size_t) NpC, 0);
+  tasks.reserve((size_t) (g.nblk[0] * Nk * g.nblk[2]));
+  group_of.assign((size_t) NpC, 0);
   std::vector<std::vector<char>> seen(3);
-  for (int x = 0; x < 3; x++) seen[x].assign(R.mat[x].panels.size(), 0);
-  int n_groups = 0;
-  std::vector<size_t> group_end;               // task index one past each group
-  std::vector<int64_t> gb;                     // first C panel of each group, then NpC
+  for (int x = 0; x < 3; x++) seen[x].assign(mat[x].panels.size(), 0);
   gb.push_back(0);
   for (int64_t pc = group; pc < NpC; pc++) gb.push_back(pc);
   gb.push_back(NpC);
@@ -451,7 +556,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     const int64_t G0 = gb[gx], G1 = gb[gx + 1];
     for (int64_t l = 0; l < Nk; l++)
       for (int64_t pc = G0; pc < G1; pc++) {
-        R.group_of[(size_t) pc] = n_groups;
+        group_of[(size_t) pc] = n_groups;
         for (int64_t q = 0; q < Nq; q++) {
           const int64_t i = dC == 0 ? pc : q, j = dC == 0 ? q : pc;
           bof_gemm_task t;
@@ -459,45 +564,39 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
           tasks.push_back(t);
           const int64_t idx[3] = {i, l, j};
           for (int x = 0; x < 3; x++) {
-            const int p = (int) idx[R.mat[x].rdim];
+            const int p = (int) idx[mat[x].rdim];
             if (seen[x][(size_t) p]) continue;
             seen[x][(size_t) p] = 1;
-            if (x < 2 || R.c_read) R.order.emplace_back(x, p);
+            if (x < 2 || c_read) order.emplace_back(x, p);
           }
         }
       }
     group_end.push_back(tasks.size());
   }
 
-  // ---- descriptors, HBM, rings, streams, events -----------------------------------------------
+  // ---- HBM slots: kept from an earlier call when they have this call's size; the missing ones
+  // are allocated by alloc_main in first-use order while the pipeline already runs
   for (int x = 0; x < 3; x++) {
-    pick_descriptor(R.mat[x], o.use_odirect != 0, R.chunk);
-    if (R.mat[x].fd < 0) { set_error("bof_flash_gemm: cannot open a buffered descriptor of an unaligned matrix file"); return BOF_EIO; }
-  }
-  for (int x = 0; x < 3; x++) {
-    // slots kept from an earlier call are reused when they have this call's size; the missing ones
-    // are allocated by alloc_main in first-use order while the pipeline already runs
-    Mat &M = R.mat[x];
-    if (R.res->slot_bytes[x] != M.slot_bytes) {
-      R.res->drop(x, 0);
-      R.res->slot_bytes[x] = M.slot_bytes;
+    Mat &M = mat[x];
+    if (res->slot_bytes[x] != M.slot_bytes) {
+      res->drop(x, 0);
+      res->slot_bytes[x] = M.slot_bytes;
     }
     const size_t want = (size_t) (M.natural ? (int) M.panels.size() : M.n_slots);
-    if (R.res->slot[x].size() > want) R.res->drop(x, want);
-    R.res->slot[x].resize(want, nullptr);
-    M.slots = &R.res->slot[x];
+    if (res->slot[x].size() > want) res->drop(x, want);
+    res->slot[x].resize(want, nullptr);
+    M.slots = &res->slot[x];
   }
   {
     // k-major copies (see Mat::kmajor_copy): for an operand stored k-contiguous whose panels'
     // row counts keep the copy's leading dimension a multiple of 4 (vector loads), whose tiles
-    // are each used by >= 4 tasks, and whose copies still fit the budget.  BOF_PANEL_KMAJOR=0
-    // turns them off, =2 drops the reuse condition (tests).
-    const char *kenv = getenv("BOF_PANEL_KMAJOR");
-    const int kmode = kenv ? atoi(kenv) : 1;
+    // are each used by >= 4 tasks, and whose copies still fit the budget.  bof_options.panel_kmajor
+    // (1 off, 2 on, 3 on without the reuse condition: tests) / BOF_PANEL_KMAJOR (0, 1, 2).
+    const int kmode = o.panel_kmajor > 0 ? o.panel_kmajor - 1 : (int) env_long("BOF_PANEL_KMAJOR", 1);
     size_t extra = 0;
     for (int x = 0; x < 2; x++) {
-      Mat &M = R.mat[x];
-      const int64_t reuse = x == R.xmat ? Nq : NpC;
+      Mat &M = mat[x];
+      const int64_t reuse = x == xmat ? Nq : NpC;
       bool ok = kmode > 0 && M.cdim == 1 && M.cols % 4 == 0 && (kmode > 1 || reuse >= 4);
       int64_t max_nr = 0;
       for (const Panel &P : M.panels) {
@@ -505,93 +604,73 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
         max_nr = std::max(max_nr, P.nr);
       }
       M.tslot_bytes = round_up((size_t) max_nr * (size_t) M.cols * 4, 2u << 20);
-      const size_t cnt = (size_t) (M.natural ? (int) M.panels.size() : M.n_slots);
-      if (ok && plan.need_bytes + extra + cnt * M.tslot_bytes > budget) ok = false;
+      const size_t n = (size_t) (M.natural ? (int) M.panels.size() : M.n_slots);
+      if (ok && pl.need_bytes + extra + n * M.tslot_bytes > budget) ok = false;
       M.kmajor_copy = ok;
-      if (!ok || R.res->tslot_bytes[x] != M.tslot_bytes) {
-        R.res->drop_t(x, 0);
-        R.res->tslot_bytes[x] = ok ? M.tslot_bytes : 0;
+      if (!ok || res->tslot_bytes[x] != M.tslot_bytes) {
+        res->drop_t(x, 0);
+        res->tslot_bytes[x] = ok ? M.tslot_bytes : 0;
       }
       if (ok) {
-        extra += cnt * M.tslot_bytes;
-        if (R.res->tslot[x].size() > cnt) R.res->drop_t(x, cnt);
-        R.res->tslot[x].resize(cnt, nullptr);
+        extra += n * M.tslot_bytes;
+        if (res->tslot[x].size() > n) res->drop_t(x, n);
+        res->tslot[x].resize(n, nullptr);
       }
-      M.tslots = &R.res->tslot[x];
+      M.tslots = &res->tslot[x];
     }
   }
   {
     std::vector<std::vector<char>> listed(3);
-    for (int x = 0; x < 3; x++) listed[x].assign(R.res->slot[x].size(), 0);
+    for (int x = 0; x < 3; x++) listed[x].assign(res->slot[x].size(), 0);
     for (const bof_gemm_task &tk : tasks) {
       const int64_t idx[3] = {tk.i, tk.l, tk.j};
       for (int x = 0; x < 3; x++) {
-        const int sl = R.mat[x].slot_of((int) idx[R.mat[x].rdim]);
+        const int sl = mat[x].slot_of((int) idx[mat[x].rdim]);
         if (listed[x][(size_t) sl]) continue;
         listed[x][(size_t) sl] = 1;
-        if (!(*R.mat[x].slots)[(size_t) sl] || (R.mat[x].kmajor_copy && !(*R.mat[x].tslots)[(size_t) sl]))
-          R.alloc_order.emplace_back(x, sl);
+        if (!(*mat[x].slots)[(size_t) sl] || (mat[x].kmajor_copy && !(*mat[x].tslots)[(size_t) sl]))
+          alloc_order.emplace_back(x, sl);
       }
     }
   }
-  R.trace("plan");
-  Cleanup guard;
-  guard.add([&R] {
-    for (auto &M : R.mat)
-      for (auto &P : M.panels) {
-        if (P.ready) (void) hipEventDestroy(P.ready);
-        if (P.d2h_done) (void) hipEventDestroy(P.d2h_done);
-      }
-    for (auto &v : R.group_ev)
-      for (hipEvent_t e : v) (void) hipEventDestroy(e);
-    if (R.h2d) (void) hipStreamDestroy(R.h2d);
-    if (R.d2h) (void) hipStreamDestroy(R.d2h);
-  });
+  return BOF_OK;
+}
+
+// events, streams, the write ring (the device is current)
+int PanelRun::prepare() {
   for (int x = 0; x < 3; x++)
-    for (auto &P : R.mat[x].panels) {
+    for (auto &P : mat[x].panels) {
       BOF_HIP_TRY(hipEventCreateWithFlags(&P.ready, hipEventDisableTiming));
       if (x == 2) BOF_HIP_TRY(hipEventCreateWithFlags(&P.d2h_done, hipEventDisableTiming));
     }
   // A 4096^2 tile launch is 256 workgroups = the whole chip, so more than two compute streams only
   // interleave whole-chip kernels of different chains and starve the copy queues: measured on
   // cfg2 files (page cache) 0.70 s with 4 streams, 0.58 s with 2, 0.59 s with 1
-  // (profiles/r2/e2e_sweep_*.txt).  BOF_PANEL_STREAMS overrides.
-  const char *senv = getenv("BOF_PANEL_STREAMS");
-  R.ss = stream_set(senv && atoi(senv) > 0 ? std::min(atoi(senv), 16) : std::min(o.n_streams, 2));
-  if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
-  R.group_ev.assign((size_t) n_groups, std::vector<hipEvent_t>());
-  for (auto &v : R.group_ev)
-    for (int s = 0; s < R.ss->n; s++) {
+  // (profiles/r2/e2e_sweep_*.txt).  bof_options.panel_streams / BOF_PANEL_STREAMS override.
+  const long senv = o.panel_streams > 0 ? o.panel_streams : env_long("BOF_PANEL_STREAMS", 0);
+  ss = stream_set(senv > 0 ? (int) std::min<long>(senv, 16) : std::min(o.n_streams, 2));
+  if (!ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
+  group_ev.assign((size_t) n_groups, std::vector<hipEvent_t>());
+  for (auto &v : group_ev)
+    for (int s = 0; s < ss->n; s++) {
       hipEvent_t e;
       BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       v.push_back(e);
     }
-  int rc = R.res->rring.init(std::max(2, o.pinned_slots), R.chunk);
+  const int rc = res->wring.init(std::max(2, o.pinned_slots), chunk);
   if (rc) return rc;
-  rc = R.res->wring.init(std::max(2, o.pinned_slots), R.chunk);
-  if (rc) return rc;
-  BOF_HIP_TRY(copy_stream_create(&R.h2d));
-  BOF_HIP_TRY(copy_stream_create(&R.d2h));
-  R.trace("rings/streams ready");
+  BOF_HIP_TRY(copy_stream_create(&h2d));
+  BOF_HIP_TRY(copy_stream_create(&d2h));
+  return BOF_OK;
+}
 
-  std::vector<std::thread> readers, writers;
-  const int n_readers = std::max(1, o.n_io_threads);
-  const char *wenv = getenv("BOF_PANEL_WRITERS");
-  const int n_writers = wenv && atoi(wenv) > 0 ? atoi(wenv) : std::max(2, std::min(8, o.n_io_threads / 2));
-  for (int i = 0; i < n_readers; i++) readers.emplace_back([&R] { R.reader_main(); });
-  for (int i = 0; i < n_writers; i++) writers.emplace_back([&R] { R.writer_main(); });
-  std::thread flusher([&R] { R.flusher_main(); });
-  std::thread allocator([&R] { R.alloc_main(); });
-  {
-    std::lock_guard<std::mutex> lk(R.mu);
-    R.pump_fetches();
-  }
-
-  // ---- dispatch ---------------------------------------------------------------------------------
-  hipError_t herr = hipSuccess;
-  int fail = 0;
+// the device's tile launches, in schedule order
+void PanelRun::dispatch() {
+  (void) hipSetDevice(dev);
+  PanelHub &H = *hub;
+  Mat &X = mat[xmat], &C = mat[2];
   // per (matrix, stream): the panel whose events that stream has already been told to wait for
-  std::vector<int> waited((size_t) 3 * (size_t) R.ss->n, -1);
+  std::vector<int> waited((size_t) 3 * (size_t) ss->n, -1);
   size_t t = 0;
   for (int gi = 0; gi < n_groups && !fail && herr == hipSuccess; gi++) {
     TraceRange grange("panel group dispatch");
@@ -599,27 +678,27 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       const bof_gemm_task &tk = tasks[t];
       const int64_t idx[3] = {tk.i, tk.l, tk.j};
       int pn[3];
-      for (int x = 0; x < 3; x++) pn[x] = (int) idx[R.mat[x].rdim];
+      for (int x = 0; x < 3; x++) pn[x] = (int) idx[mat[x].rdim];
       const int cprev = C.natural ? -1 : pn[2] - C.n_slots;
       {
-        std::unique_lock<std::mutex> lk(R.mu);
-        R.cv.wait(lk, [&] {
-          if (R.io_error.load()) return true;
-          if (R.mat[0].panels[(size_t) pn[0]].state != 2 || R.mat[1].panels[(size_t) pn[1]].state != 2) return false;
-          if (R.c_read) return C.panels[(size_t) pn[2]].state == 2;
+        std::unique_lock<std::mutex> lk(H.mu);
+        H.cv.wait(lk, [&] {
+          if (H.io_error.load()) return true;
+          if (mat[0].panels[(size_t) pn[0]].state != 2 || mat[1].panels[(size_t) pn[1]].state != 2) return false;
+          if (c_read) return C.panels[(size_t) pn[2]].state == 2;
           if (!C.panel_ptr(pn[2])) return false;                  // its HBM slot is still being allocated
           return cprev < 0 || C.panels[(size_t) cprev].retired;   // the slot's write-back is on its way
         });
       }
-      if (R.io_error.load()) { fail = BOF_EIO; break; }
+      if (H.io_error.load()) { fail = BOF_EIO; break; }
       const int64_t q = dC == 0 ? tk.j : tk.i;
-      const int sidx = (int) (((int64_t) pn[2] * Nq + q) % R.ss->n);   // chain -> stream: FIFO = parent dependency
-      hipStream_t st = R.ss->s[sidx];
+      const int sidx = (int) (((int64_t) pn[2] * Nq + q) % ss->n);   // chain -> stream: FIFO = parent dependency
+      hipStream_t st = ss->s[sidx];
       for (int x = 0; x < 3 && herr == hipSuccess; x++) {
-        int &w = waited[(size_t) x * (size_t) R.ss->n + (size_t) sidx];
+        int &w = waited[(size_t) x * (size_t) ss->n + (size_t) sidx];
         if (w == pn[x]) continue;
         w = pn[x];
-        if (x < 2 || R.c_read) herr = hipStreamWaitEvent(st, R.mat[x].panels[(size_t) pn[x]].ready, 0);
+        if (x < 2 || c_read) herr = hipStreamWaitEvent(st, mat[x].panels[(size_t) pn[x]].ready, 0);
         else if (cprev >= 0)
           for (hipEvent_t e : C.panels[(size_t) cprev].retire_ev)
             if (herr == hipSuccess) herr = hipStreamWaitEvent(st, e, 0);
@@ -631,8 +710,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       int64_t ldo[2];
       char flag[2] = {ta, tb};
       for (int x = 0; x < 2; x++) {
-        const Mat &M = R.mat[x];
-        const int64_t k0 = idx[M.cdim] * M.blk_c;
+        const Mat &M = mat[x];
+        const int64_t k0 = M.col_base + idx[M.cdim] * M.blk_c;   // first stored column of the tile
         if (M.kmajor_copy) {
           const int64_t nr = M.panels[(size_t) pn[x]].nr;
           po[x] = (const float *) M.tpanel_ptr(pn[x]) + k0 * nr;
@@ -645,54 +724,240 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       }
       float *pcp = (float *) C.panel_ptr(pn[2]) + idx[C.cdim] * C.blk_c;
       herr = tile_sgemm(ord, flag[0], flag[1], tk.M, tk.N, tk.K, alpha, po[0], ldo[0], po[1], ldo[1], tk.beta, pcp, C.ld,
-                        kv, tk.i * g.blk[0], tk.j * g.blk[2], st);
+                        has_kv ? &kv : nullptr, row_base + tk.i * g.blk[0], col_base + tk.j * g.blk[2], st);
       if (herr != hipSuccess) break;
-      R.cnt.tasks++;
+      cnt.tasks++;
+      H.cnt.tasks++;
     }
     if (fail || herr != hipSuccess) break;
     // group finished on the host side: mark where every stream stands, hand its C panels to the
     // flusher and let the streamed operand's panels of this group go
-    for (int s = 0; s < R.ss->n && herr == hipSuccess; s++) herr = hipEventRecord(R.group_ev[(size_t) gi][(size_t) s], R.ss->s[s]);
+    for (int s = 0; s < ss->n && herr == hipSuccess; s++) herr = hipEventRecord(group_ev[(size_t) gi][(size_t) s], ss->s[s]);
     if (herr != hipSuccess) break;
     const int64_t G0 = gb[(size_t) gi], G1 = gb[(size_t) gi + 1];
     {
-      std::lock_guard<std::mutex> lk(R.mu);
+      std::lock_guard<std::mutex> lk(H.mu);
       if (!X.natural)
         for (int64_t pc = G0; pc < G1; pc++) {
           Panel &P = X.panels[(size_t) pc];
-          P.retire_ev = R.group_ev[(size_t) gi];
+          P.retire_ev = group_ev[(size_t) gi];
           P.retired = true;
         }
-      R.pump_fetches();
+      H.pump_fetches();
     }
-    for (int64_t pc = G0; pc < G1; pc++) R.flush_q.push((int) pc);
+    for (int64_t pc = G0; pc < G1; pc++) flush_q.push((int) pc);
     if (trace_on()) {
       char lbl[64];
       snprintf(lbl, sizeof(lbl), "group %d dispatched", gi);
-      R.trace(lbl);
+      trace(lbl);
     }
   }
+  if (herr != hipSuccess || fail) H.fail_io(-EIO);
+  seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - H.t_begin).count();
+}
+
+}  // namespace
+
+void panel_resources_release() {
+  std::lock_guard<std::mutex> lk(g_pres_mu);
+  for (auto &kv : g_pres) {
+    kv.second->drop_all();
+    delete kv.second;
+  }
+  g_pres.clear();
+  if (g_rring) {
+    g_rring->destroy();
+    delete g_rring;
+    g_rring = nullptr;
+  }
+}
+
+void panel_resources_release_device(int dev) {
+  std::lock_guard<std::mutex> lk(g_pres_mu);
+  for (auto it = g_pres.begin(); it != g_pres.end();) {
+    if (it->first.first == dev) {
+      it->second->drop_all();
+      delete it->second;
+      it = g_pres.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+int kmeans_upload(const KmeansHost &kh, KmeansVecs *kv) {
+  float *dv = nullptr;
+  BOF_HIP_TRY(hipMalloc((void **) &dv, (size_t) (kh.m + kh.n + kh.n_ones) * sizeof(float)));
+  hipError_t e = hipMemcpy(dv, kh.c_l2sq, (size_t) kh.m * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv + kh.m, kh.p_l2sq, (size_t) kh.n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv + kh.m + kh.n, kh.ones, (size_t) kh.n_ones * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void) hipFree(dv); return hip_fail(e, "flash::kmeans: uploading the norm vectors"); }
+  *kv = KmeansVecs{dv, dv + kh.m, dv + kh.m + kh.n};
+  return BOF_OK;
+}
+
+int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta,
+                      bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda, int64_t ldb, int64_t ldc,
+                      const bof_options &o, const std::vector<int> &devs, const KmeansHost *kh) {
+  PanelHub H;
+  H.t_begin = std::chrono::steady_clock::now();
+  const GemmGeometry gfull = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
+  if (gfull.nblk[0] * gfull.nblk[2] == 0 || gfull.nblk[1] == 0) return 1;
+  int caller_dev = 0;
+  BOF_HIP_TRY(hipGetDevice(&caller_dev));
+  DeviceScope restore(caller_dev);
+  const int dC = gfull.rdim[2];
+  const int64_t NpC = gfull.nblk[dC];
+  const bof_fptr fp[3] = {fa, fb, fc};
+
+  // ---- C panels dealt to the devices in contiguous ranges; plan of every slab ----------------------
+  const int n_use = (int) std::min<int64_t>((int64_t) devs.size(), NpC);
+  std::vector<int> used(devs.begin(), devs.begin() + n_use);
+  Cleanup guard;
+  guard.add([&H] {
+    for (auto &Rp : H.runs) {
+      PanelRun &R = *Rp;
+      DeviceScope ds(R.dev);
+      for (auto &M : R.mat)
+        for (auto &P : M.panels) {
+          if (P.ready) (void) hipEventDestroy(P.ready);
+          if (P.d2h_done) (void) hipEventDestroy(P.d2h_done);
+        }
+      for (auto &v : R.group_ev)
+        for (hipEvent_t e : v) (void) hipEventDestroy(e);
+      if (R.h2d) (void) hipStreamDestroy(R.h2d);
+      if (R.d2h) (void) hipStreamDestroy(R.d2h);
+      if (R.has_kv) (void) hipFree(const_cast<float *>(R.kv.c_l2sq));
+    }
+  });
+  int64_t p_next = 0;
+  for (int d = 0; d < n_use; d++) {
+    const int64_t cnt = NpC / n_use + (d < NpC % n_use ? 1 : 0), p0 = p_next;
+    p_next += cnt;
+    std::unique_ptr<PanelRun> Rp(new PanelRun());
+    PanelRun &R = *Rp;
+    R.hub = &H; R.di = d; R.dev = used[(size_t) d]; R.o = o;
+    R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
+    // the slab as a problem of its own: rows [p0 * blk, (p0 + cnt) * blk) of the C panel dimension
+    // (the last slab runs to the end: a tail-merged last panel stays merged), explicit leading dims
+    const int64_t e0 = p0 * gfull.blk[dC];
+    const int64_t e1 = p0 + cnt == NpC ? gfull.size[dC] : (p0 + cnt) * gfull.blk[dC];
+    const int64_t md = dC == 0 ? e1 - e0 : m, nd = dC == 2 ? e1 - e0 : n;
+    R.g = gemm_geometry(ord, ta, tb, md, nd, k, gfull.ld[0], gfull.ld[1], gfull.ld[2], o.gemm_blk);
+    if (R.g.nblk[dC] != cnt || (cnt > 1 && R.g.blk[dC] != gfull.blk[dC])) {
+      set_error("bof_flash_gemm: internal error: a device slab does not tile like the whole problem");
+      return BOF_EINVAL;
+    }
+    int rep = 0, reps = 0;
+    for (int e = 0; e < n_use; e++)
+      if (used[(size_t) e] == R.dev) { if (e < d) rep++; reps++; }
+    BOF_HIP_TRY(hipSetDevice(R.dev));
+    {
+      std::lock_guard<std::mutex> lk(g_pres_mu);
+      PanelResources *&pr = g_pres[std::make_pair(R.dev, rep)];
+      if (!pr) { pr = new PanelResources(); pr->dev = R.dev; }
+      R.res = pr;
+    }
+    const int rc = R.plan(used, reps, n_use > 1 ? gfull.size[dC] : 0, fp, gfull, p0);
+    if (rc) return rc;   // +1: some slab is not eligible -> the whole call goes to the tile cache
+    H.runs.push_back(std::move(Rp));
+  }
+
+  // ---- descriptors: one mode per FILE per call, over every device's requests -----------------------
+  for (int x = 0; x < 3; x++) {
+    bool aligned = true;
+    for (auto &R : H.runs) aligned = aligned && requests_aligned(R->mat[x], R->chunk);
+    for (auto &R : H.runs) {
+      pick_descriptor(R->mat[x], aligned, o.use_odirect != 0);
+      if (R->mat[x].fd < 0) { set_error("bof_flash_gemm: cannot open a buffered descriptor of an unaligned matrix file"); return BOF_EIO; }
+    }
+  }
+  for (int x = 0; x < 2; x++) H.issued[x].assign(H.runs[0]->mat[x].panels.size(), 0);
+  H.trace("plan");
+
+  // ---- per-device events, streams, write rings; the shared read ring --------------------------------
+  for (auto &R : H.runs) {
+    BOF_HIP_TRY(hipSetDevice(R->dev));
+    int rc = R->prepare();
+    if (rc) return rc;
+    if (kh) {
+      rc = kmeans_upload(*kh, &R->kv);
+      if (rc) return rc;
+      R->has_kv = true;
+    }
+  }
+  BOF_HIP_TRY(hipSetDevice(caller_dev));
+  {
+    std::lock_guard<std::mutex> lk(g_pres_mu);
+    if (!g_rring) g_rring = new PinnedRing();
+    H.rring = g_rring;
+  }
+  // a chunk copied to D devices stays in its slot until the slowest copy is done: two more slots per extra device
+  int rc = H.rring->init(std::max(2, o.pinned_slots) + 2 * ((int) H.runs.size() - 1), H.runs[0]->chunk, &used);
+  if (rc) return rc;
+  H.trace("rings/streams ready");
+
+  const int nd = (int) H.runs.size();
+  std::vector<std::thread> readers, writers, flushers, allocators, dispatchers;
+  const int n_readers = std::max(1, o.n_io_threads) + (nd - 1);
+  const long wenv = o.panel_writers > 0 ? o.panel_writers : env_long("BOF_PANEL_WRITERS", 0);
+  const int n_writers = (wenv > 0 ? (int) wenv : std::max(2, std::min(8, o.n_io_threads / 2))) + (nd - 1);
+  for (int i = 0; i < n_readers; i++) readers.emplace_back([&H, i] { H.reader_main(i); });
+  for (int i = 0; i < n_writers; i++) writers.emplace_back([&H, i] { H.writer_main(i); });
+  for (auto &R : H.runs) {
+    PanelRun *r = R.get();
+    flushers.emplace_back([r] { r->flusher_main(); });
+    allocators.emplace_back([r] { r->alloc_main(); });
+  }
+  {
+    std::lock_guard<std::mutex> lk(H.mu);
+    H.pump_fetches();
+  }
+
+  // ---- dispatch: the caller drives the first device, a thread each of the others ---------------------
+  for (int d = 1; d < nd; d++) {
+    PanelRun *r = H.runs[(size_t) d].get();
+    dispatchers.emplace_back([r] { r->dispatch(); });
+  }
+  H.runs[0]->dispatch();
+  for (auto &th : dispatchers) th.join();
 
   // ---- drain ------------------------------------------------------------------------------------
-  if (herr != hipSuccess || fail) R.fail_io(-EIO);
-  allocator.join();
-  R.fetch_q.close();
+  for (auto &th : allocators) th.join();
+  H.fetch_q.close();
   for (auto &th : readers) th.join();
-  R.flush_q.close();
-  flusher.join();
-  R.write_q.close();
+  for (auto &R : H.runs) R->flush_q.close();
+  for (auto &th : flushers) th.join();
+  H.write_q.close();
   for (auto &th : writers) th.join();
-  (void) hipDeviceSynchronize();
-  R.trace("drained (writes done)");
-  if (herr != hipSuccess && !fail) fail = hip_fail(herr, "bof_flash_gemm (panels) dispatch");
-  if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
-    const int e = R.io_error.load();
+  for (auto &R : H.runs) {
+    (void) hipSetDevice(R->dev);
+    (void) hipDeviceSynchronize();
+  }
+  (void) hipSetDevice(caller_dev);
+  H.trace("drained (writes done)");
+  int fail = 0;
+  for (auto &R : H.runs) {
+    if (R->herr != hipSuccess && !fail) fail = hip_fail(R->herr, "bof_flash_gemm (panels) dispatch");
+    if (R->fail && !fail) fail = R->fail;
+  }
+  if (H.io_error.load() && (!fail || fail == BOF_EIO)) {
+    const int e = H.io_error.load();
     set_error("bof_flash_gemm: I/O pipeline failed: " +
               (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
-    fail = BOF_EIO;
+    fail = e == -ENOMEM ? BOF_ENOMEM : BOF_EIO;
   }
-  R.cnt.hits = 3 * R.cnt.tasks.load() - std::min<uint64_t>(R.cnt.misses.load(), 3 * R.cnt.tasks.load());
-  publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - R.t_begin).count());
+  H.cnt.hits = 3 * H.cnt.tasks.load() - std::min<uint64_t>(H.cnt.misses.load(), 3 * H.cnt.tasks.load());
+  publish_stats(H.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - H.t_begin).count());
+  std::vector<bof_flash_stats> per((size_t) nd);
+  for (int d = 0; d < nd; d++) {
+    const PanelRun &R = *H.runs[(size_t) d];
+    bof_flash_stats s{};
+    s.bytes_read = R.cnt.rd; s.bytes_written = R.cnt.wr; s.bytes_h2d = R.cnt.h2d; s.bytes_d2h = R.cnt.d2h;
+    s.tasks = R.cnt.tasks; s.seconds = R.seconds;
+    per[(size_t) d] = s;
+  }
+  publish_device_stats(per);
   return fail;
 }
 

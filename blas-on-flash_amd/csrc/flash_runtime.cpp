@@ -65,6 +65,12 @@ int device_ready() {
   return BOF_OK;
 }
 
+static std::vector<bof_flash_stats> g_last_dev_stats;
+void publish_device_stats(const std::vector<bof_flash_stats> &per_device) {
+  std::lock_guard<std::mutex> lk(g_stats_mu);
+  g_last_dev_stats = per_device;
+}
+
 void publish_stats(const Counters &c, double seconds) {
   std::lock_guard<std::mutex> lk(g_stats_mu);
   g_last_stats.bytes_read = c.rd; g_last_stats.bytes_written = c.wr;
@@ -74,6 +80,7 @@ void publish_stats(const Counters &c, double seconds) {
   uint64_t r = 0, w = 0;
   file_io_ops(&r, &w);
   g_last_stats.read_ops = r - c.ops0[0]; g_last_stats.write_ops = w - c.ops0[1];
+  g_last_dev_stats.assign(1, g_last_stats);   // a multi-device call replaces this right after
 }
 
 // =====================================================================================
@@ -330,16 +337,15 @@ struct GemmRun {
 
 }  // namespace
 
-static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
-                           float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
-                           int64_t ldb, int64_t ldc, const bof_options *opts, const KmeansVecs *kv = nullptr) {
+// The tile-cache pipeline on the CURRENT device (the caller holds the device's call lock).
+// out: the call's counters (the caller publishes them).
+static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                                float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
+                                int64_t ldb, int64_t ldc, const bof_options &o, const KmeansHost *kh, Counters *out) {
   const auto t_begin = std::chrono::steady_clock::now();
-  int rc = device_ready();
-  if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
-  TraceRange range("bof_flash_gemm");
+  int rc;
   GemmRun R;
-  R.o = resolved(opts);
+  R.o = o;
   R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
   R.f[0] = fa; R.f[1] = fb; R.f[2] = fc;
   R.use_aio = R.o.use_odirect != 0;
@@ -348,18 +354,14 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   const GemmGeometry &g = R.g;
   const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
   if (Nm * Nn == 0) return BOF_OK;
-  if (Nk == 0) { set_error("bof_flash_gemm: k == 0 is not supported on the file path"); return BOF_EINVAL; }
-
-  // ---- large working budgets: whole row panels in file layout, big sequential requests ----
-  if (R.o.gemm_path != 1) {
-    rc = flash_gemm_panels(ord, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, R.o, kv);
-    if (rc <= 0) return rc;
-    if (R.o.gemm_path == 2) {
-      set_error("bof_flash_gemm: gemm_path = 2 (panels) but the call is not eligible: C rows must be "
-                "contiguous in the file (ldc = stored width) and B, two A panels and three C panels must "
-                "fit hbm_budget");
-      return BOF_ENOMEM;
-    }
+  KmeansVecs kvd{nullptr, nullptr, nullptr};
+  const KmeansVecs *kv = nullptr;
+  Cleanup kv_guard;
+  if (kh) {
+    rc = kmeans_upload(*kh, &kvd);
+    if (rc) return rc;
+    kv = &kvd;
+    kv_guard.add([&kvd] { (void) hipFree(const_cast<float *>(kvd.c_l2sq)); });
   }
 
   // ---- tiles ------------------------------------------------------------------------
@@ -383,8 +385,15 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   }
 
   // ---- HBM budget -> slot count -> C super-block (gi x gj chains per pass) --------------
+  // the panel path's cached slots (up to ~80 % of HBM after a large call) are of no use to this
+  // call: give them back before the budget is taken from what is free
+  panel_resources_release_device(R.dev);
   size_t free_b = 0, total_b = 0;
   BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  {
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    if (g_res[R.dev & 63]) free_b += g_res[R.dev & 63]->slab_bytes;   // our own slab is re-used / re-sized below
+  }
   size_t budget = R.o.hbm_budget > 0 ? (size_t) R.o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
   int64_t n_slots = (int64_t) (budget / R.slot_bytes);
@@ -560,8 +569,124 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   }
   // the pinned rings and the device slab stay cached for the next call (bof_flash_release)
   BOF_TRACE_T("resources released");
-  publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  if (out) {
+    out->rd += R.cnt.rd.load(); out->wr += R.cnt.wr.load(); out->h2d += R.cnt.h2d.load(); out->d2h += R.cnt.d2h.load();
+    out->tasks += R.cnt.tasks.load(); out->hits += R.cnt.hits.load(); out->misses += R.cnt.misses.load();
+  }
   return fail;
+}
+
+static bof_flash_stats stats_of(const Counters &c, double seconds) {
+  bof_flash_stats s{};
+  s.bytes_read = c.rd; s.bytes_written = c.wr; s.bytes_h2d = c.h2d; s.bytes_d2h = c.d2h;
+  s.tasks = c.tasks; s.tile_hits = c.hits; s.tile_misses = c.misses; s.seconds = seconds;
+  return s;
+}
+
+// flash::gemm / flash::kmeans on files: the device list, the per-device call locks, then the row-panel
+// pipeline (all devices in one hub) or -- small budgets, C rows with gaps -- the tile cache, where
+// every device runs the single-device pipeline on its slab of C (no operand is shared there: it is
+// the budget-limited path).
+static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
+                           float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
+                           int64_t ldb, int64_t ldc, const bof_options *opts, const KmeansHost *kh = nullptr) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = device_ready();
+  if (rc) return rc;
+  const bof_options o = resolved(opts);
+  std::vector<int> devs;
+  rc = resolve_devices(o, devs);
+  if (rc) return rc;
+  DeviceCallLock call_lock(devs);
+  TraceRange range("bof_flash_gemm");
+  if (o.io_request_kib > 0) (void) bof_file_set_request_bytes((uint64_t) o.io_request_kib << 10);
+  file_set_engine(o.io_engine);
+  const GemmGeometry g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
+  if (g.nblk[0] * g.nblk[2] == 0) return BOF_OK;
+  if (g.nblk[1] == 0) { set_error("bof_flash_gemm: k == 0 is not supported on the file path"); return BOF_EINVAL; }
+
+  // ---- large working budgets: whole row panels in file layout, big sequential requests ----
+  if (o.gemm_path != 1) {
+    rc = flash_gemm_panels(ord, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, o, devs, kh);
+    if (rc <= 0) return rc;
+    if (o.gemm_path == 2) {
+      set_error("bof_flash_gemm: gemm_path = 2 (panels) but the call is not eligible: C rows must be "
+                "contiguous in the file (ldc = stored width) and B, two A panels and three C panels must "
+                "fit hbm_budget");
+      return BOF_ENOMEM;
+    }
+  }
+
+  // ---- tile cache ---------------------------------------------------------------------------
+  const int dC = g.rdim[2];
+  const int64_t NpC = g.nblk[dC];
+  const int n_use = (int) std::min<int64_t>((int64_t) devs.size(), NpC);
+  struct Slab {
+    int dev;
+    int64_t m, n;
+    bof_fptr f[3];
+    KmeansHost kh;
+    Counters cnt;
+    int rc = 0;
+    std::string err;
+    double seconds = 0;
+  };
+  std::vector<std::unique_ptr<Slab>> slabs;
+  int64_t p_next = 0;
+  for (int d = 0; d < n_use; d++) {
+    const int64_t cnt = NpC / n_use + (d < NpC % n_use ? 1 : 0), p0 = p_next;
+    p_next += cnt;
+    const int64_t e0 = p0 * g.blk[dC], e1 = p0 + cnt == NpC ? g.size[dC] : (p0 + cnt) * g.blk[dC];
+    std::unique_ptr<Slab> S(new Slab());
+    S->dev = devs[(size_t) d];
+    S->m = dC == 0 ? e1 - e0 : m;
+    S->n = dC == 2 ? e1 - e0 : n;
+    S->f[0] = fa; S->f[1] = fb; S->f[2] = fc;
+    S->f[2].foffset += (uint64_t) e0 * (uint64_t) g.ld[2] * 4;
+    const int xm = dC == 0 ? 0 : 1;   // the operand that carries the C panel dimension
+    S->f[xm].foffset += g.rdim[xm] == dC ? (uint64_t) e0 * (uint64_t) g.ld[xm] * 4 : (uint64_t) e0 * 4;
+    if (kh) {
+      S->kh = *kh;
+      S->kh.m = S->m; S->kh.n = S->n;
+      if (dC == 0) S->kh.c_l2sq += e0; else S->kh.p_l2sq += e0;
+    }
+    slabs.push_back(std::move(S));
+  }
+  auto run_slab = [&](Slab &S) {
+    DeviceScope ds(S.dev);
+    S.rc = flash_gemm_tilecache(ord, ta, tb, S.m, S.n, k, alpha, beta, S.f[0], S.f[1], S.f[2], g.ld[0], g.ld[1],
+                                g.ld[2], o, kh ? &S.kh : nullptr, &S.cnt);
+    if (S.rc) S.err = bof_last_error();
+    S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  };
+  if (slabs.size() == 1) {
+    run_slab(*slabs[0]);
+  } else {
+    // one thread per distinct ordinal: slabs that share a device (an ordinal listed twice) run one after
+    // the other -- they share that device's tile slab and rings
+    std::vector<int> ords;
+    for (auto &S : slabs)
+      if (std::find(ords.begin(), ords.end(), S->dev) == ords.end()) ords.push_back(S->dev);
+    std::vector<std::thread> th;
+    for (int od : ords)
+      th.emplace_back([&, od] {
+        for (auto &S : slabs)
+          if (S->dev == od) run_slab(*S);
+      });
+    for (auto &t : th) t.join();
+  }
+  Counters total;
+  std::vector<bof_flash_stats> per;
+  for (auto &S : slabs) {
+    total.rd += S->cnt.rd.load(); total.wr += S->cnt.wr.load(); total.h2d += S->cnt.h2d.load(); total.d2h += S->cnt.d2h.load();
+    total.tasks += S->cnt.tasks.load(); total.hits += S->cnt.hits.load(); total.misses += S->cnt.misses.load();
+    per.push_back(stats_of(S->cnt, S->seconds));
+    if (S->rc && !rc) { rc = S->rc; set_error(S->err); }
+  }
+  total.ops0[0] = slabs[0]->cnt.ops0[0]; total.ops0[1] = slabs[0]->cnt.ops0[1];
+  publish_stats(total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  if (per.size() > 1) publish_device_stats(per);
+  return rc;
 }
 
 }  // namespace bof
@@ -595,9 +720,6 @@ int bof_flash_kmeans(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_
     return BOF_EINVAL;
   }
   if (m == 0 || n == 0 || k == 0) return BOF_OK;   // nothing to do (the reference divides by zero: kmeans.cpp:52, 76-77)
-  int rc = device_ready();
-  if (rc) return rc;
-  std::lock_guard<std::recursive_mutex> call_lock(device_call_mutex());
   const bof_options o = resolved(opts);
   const GemmGeometry g = gemm_geometry(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, (int64_t) lda,
                                        (int64_t) ldb, (int64_t) ldc, o.gemm_blk);
@@ -607,16 +729,10 @@ int bof_flash_kmeans(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_
     const int64_t last = g.size[d] - (g.nblk[d] - 1) * g.blk[d];
     n_ones = std::max(n_ones, std::max(last, std::min(g.size[d], g.blk[d])));
   }
-  float *dv = nullptr;
-  BOF_HIP_TRY(hipMalloc((void **) &dv, (size_t) (m + n + (uint64_t) n_ones) * sizeof(float)));
-  Cleanup guard;
-  guard.add([&] { (void) hipFree(dv); });
-  BOF_HIP_TRY(hipMemcpy(dv, c_l2sq, (size_t) m * sizeof(float), hipMemcpyHostToDevice));
-  BOF_HIP_TRY(hipMemcpy(dv + m, p_l2sq, (size_t) n * sizeof(float), hipMemcpyHostToDevice));
-  BOF_HIP_TRY(hipMemcpy(dv + m + n, ones, (size_t) n_ones * sizeof(float), hipMemcpyHostToDevice));
-  const KmeansVecs kv{dv, dv + m, dv + m + n};
+  // every device of the call gets its own copy of the three vectors (flash_gemm_panels / the tile cache)
+  const KmeansHost kh{c_l2sq, p_l2sq, ones, (int64_t) m, (int64_t) n, n_ones};
   return flash_gemm_impl(ord, ta, tb, (int64_t) m, (int64_t) n, (int64_t) k, alpha, beta, a, b, c,
-                         (int64_t) lda, (int64_t) ldb, (int64_t) ldc, opts, &kv);
+                         (int64_t) lda, (int64_t) ldb, (int64_t) ldc, opts, &kh);
 }
 
 int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, uint64_t k, float beta,
@@ -732,6 +848,13 @@ int bof_flash_release(void) {
   pinned_cache_release();
   file_unmap_all();
   return BOF_OK;
+}
+
+int bof_flash_last_device_stats(bof_flash_stats *out, int cap) {
+  std::lock_guard<std::mutex> lk(g_stats_mu);
+  const int n = (int) g_last_dev_stats.size();
+  for (int i = 0; out && i < std::min(n, cap); i++) out[i] = g_last_dev_stats[(size_t) i];
+  return n;
 }
 
 int bof_flash_last_stats(bof_flash_stats *out) {

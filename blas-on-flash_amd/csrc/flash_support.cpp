@@ -32,6 +32,63 @@ std::recursive_mutex &device_call_mutex() {
   return g_call_mu[dev & 63];
 }
 
+long env_long(const char *name, long dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atol(v) : dflt;
+}
+
+int resolve_devices(const bof_options &o, std::vector<int> &devs) {
+  devs.clear();
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void) hipGetLastError();
+    set_error("no HIP device: the flash path has no CPU fallback");
+    return BOF_ENODEV;
+  }
+  if (o.n_devices > 0) {
+    if (o.n_devices > BOF_MAX_DEVICES) { set_error("bof_options.n_devices exceeds BOF_MAX_DEVICES"); return BOF_EINVAL; }
+    for (int i = 0; i < o.n_devices; i++) devs.push_back(o.devices[i]);
+  } else if (const char *e = getenv("BOF_DEVICES")) {
+    if (!strcmp(e, "all")) {
+      for (int d = 0; d < std::min(count, BOF_MAX_DEVICES); d++) devs.push_back(d);
+    } else {
+      for (const char *p = e; *p;) {
+        char *end = nullptr;
+        const long d = strtol(p, &end, 10);
+        if (end == p) break;
+        devs.push_back((int) d);
+        p = end;
+        while (*p == ',' || *p == ' ') p++;
+      }
+    }
+    if (devs.size() > BOF_MAX_DEVICES) { set_error("BOF_DEVICES names more than BOF_MAX_DEVICES devices"); return BOF_EINVAL; }
+  }
+  if (devs.empty()) {
+    int cur = 0;
+    BOF_HIP_TRY(hipGetDevice(&cur));
+    devs.push_back(cur);
+  }
+  for (int d : devs)
+    if (d < 0 || d >= count || d >= 64) {
+      set_error("device list: ordinal " + std::to_string(d) + " is not one of the " + std::to_string(count) + " visible devices");
+      return BOF_EINVAL;
+    }
+  return BOF_OK;
+}
+
+DeviceCallLock::DeviceCallLock(const std::vector<int> &devs) {
+  std::vector<int> u(devs);
+  std::sort(u.begin(), u.end());
+  u.erase(std::unique(u.begin(), u.end()), u.end());
+  for (int d : u) {
+    g_call_mu[d & 63].lock();
+    held.push_back(&g_call_mu[d & 63]);
+  }
+}
+DeviceCallLock::~DeviceCallLock() {
+  for (auto it = held.rbegin(); it != held.rend(); ++it) (*it)->unlock();
+}
+
 hipError_t copy_stream_create(hipStream_t *s) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
@@ -66,10 +123,10 @@ int pinned_alloc(void **p, size_t bytes) {
     }
   }
   const size_t rounded = (bytes + 4095) / 4096 * 4096;
-  hipError_t e = hipHostMalloc(p, rounded, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(p, rounded, hipHostMallocPortable);
   if (e != hipSuccess) {  // the cache may be what is in the way
     pinned_cache_release();
-    e = hipHostMalloc(p, rounded, hipHostMallocDefault);
+    e = hipHostMalloc(p, rounded, hipHostMallocPortable);
   }
   if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (pinned staging block)");
   std::lock_guard<std::mutex> lk(g_pin.mu);
@@ -132,6 +189,14 @@ void trace_pop() {
 
 // ---- NUMA placement of the I/O threads -------------------------------------------------------
 namespace {
+struct InitialMask {
+  cpu_set_t set;
+  bool ok = false;
+  InitialMask() {   // static initialisation: runs on the thread that loads the library
+    CPU_ZERO(&set);
+    ok = sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0;
+  }
+} g_initial_mask;
 struct NodeCpus { int node = -2; cpu_set_t set; };   // -2 not looked up yet, -1 unknown
 std::mutex g_numa_mu;
 NodeCpus g_numa[64];
@@ -188,11 +253,16 @@ int bind_thread_near_device(int dev) {
     nc = c;
   }
   if (nc.node < 0) return -1;
-  // The node's CPU list is requested as it is, NOT intersected with the creating thread's own
-  // mask: the caller may have been narrowed to one core by an OpenMP runtime (a BLAS call made
-  // earlier in the process is enough), and the I/O threads must not inherit that.  The kernel
-  // applies the cpuset of the container itself and refuses only an empty result.
-  if (sched_setaffinity(0, sizeof(nc.set), &nc.set) == 0) return nc.node;
+  // The node's CPU list is intersected with the mask the PROCESS had when the library was loaded
+  // (taskset / numactl / a launcher's per-rank pinning must hold for the I/O threads too), not with
+  // the creating thread's current mask: that one may have been narrowed to a single core by an
+  // OpenMP runtime (a BLAS call made earlier in the process is enough).  An intersection that is
+  // empty or a single core falls back to the bare node list; the kernel applies the container's
+  // cpuset itself and refuses only an empty result.
+  cpu_set_t want;
+  CPU_AND(&want, &nc.set, &g_initial_mask.set);
+  if (!g_initial_mask.ok || CPU_COUNT(&want) <= 1) want = nc.set;
+  if (sched_setaffinity(0, sizeof(want), &want) == 0) return nc.node;
   return -1;
 }
 

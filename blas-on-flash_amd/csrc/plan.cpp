@@ -62,13 +62,15 @@ void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float 
 // resident; the other one ("X") streams through a ring of 2*group slots when it is paneled along
 // D too, else it is resident as well; C gets a ring of 2*group+1 slots, deepened with spare
 // budget.  Slots are 2 MiB-aligned.
-bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group) {
+bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group, int64_t full_dC) {
   bof_panel_plan P{};
   P.streamed = -1;
   auto up = [](uint64_t v) { return (v + (2u << 20) - 1) / (2u << 20) * (2u << 20); };
   if (g.nblk[0] * g.nblk[1] * g.nblk[2] == 0) { P.why = 1; return P; }
+  const int dC = g.rdim[2];
   for (int x = 0; x < 3; x++) {
-    const int64_t rows = g.size[g.rdim[x]], cols = g.size[g.cdim[x]], ld = g.ld[x];
+    const int64_t rows = g.size[g.rdim[x]], ld = g.ld[x];
+    const int64_t cols = (full_dC > 0 && x < 2 && g.cdim[x] == dC) ? full_dC : g.size[g.cdim[x]];
     if (ld < cols) { P.why = 2; return P; }
     if (x < 2 && cols * 2 < ld) { P.why = 3; return P; }
     P.n_panels[x] = g.nblk[g.rdim[x]];
@@ -77,7 +79,6 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
     P.slot_bytes[x] = up(((uint64_t) (max_rows - 1) * (uint64_t) ld + (uint64_t) cols) * 4);
   }
   if (g.ld[2] != g.size[g.cdim[2]]) { P.why = 4; return P; }
-  const int dC = g.rdim[2];
   const int xm = dC == 0 ? 0 : 1, ym = 1 - xm;
   const bool x_streams = g.rdim[xm] == dC;
   const int64_t NpC = g.nblk[dC];

@@ -21,6 +21,8 @@ namespace flash {
   std::string mnt_dir = "./";
   std::function<void(void)> dummy_std_func = [](void) {};
 
+  static std::vector<int> g_devices;   // set by flash_setup
+
   static long env_long(const char* name, long dflt) {
     const char* v = ::getenv(name);
     return (v && *v) ? ::atol(v) : dflt;
@@ -53,15 +55,39 @@ namespace flash {
     o.use_odirect = sched.use_odirect ? 1 : 0;
     o.gemm_path = (int32_t) env_long("BOF_GEMM_PATH", 0);       // 0 choose, 1 tile cache, 2 panels
     o.io_chunk_mib = (int32_t) env_long("BOF_IO_CHUNK_MIB", 0);
+    o.n_devices = (int32_t) g_devices.size();
+    for (size_t i = 0; i < g_devices.size(); i++) o.devices[i] = g_devices[i];
     return o;
   }
 
+  // The devices every kernel call of this process shards over (the reference's N_COMPUTE_THR workers
+  // live inside the process too, src/lib_funcs.cpp:9): $BOF_DEVICES ("0,1,2", "all"; an ordinal may
+  // repeat) if set; else ONE device when a launcher assigned one ($BOF_DEVICE, or $LOCAL_RANK under
+  // torchrun-style one-process-per-GPU runs); else every visible device.
   void flash_setup(std::string mntdir) {
     mnt_dir = mntdir;
-    const long dev = env_long("BOF_DEVICE", env_long("LOCAL_RANK", 0));
-    if (bof_device_count() <= 0)
-      GLOG_FATAL("no HIP device visible: this build has no CPU compute path");
-    if (bof_set_device((int) dev) != BOF_OK) GLOG_FATAL("bof_set_device failed: ", bof_last_error());
+    const int count = bof_device_count();
+    if (count <= 0) GLOG_FATAL("no HIP device visible: this build has no CPU compute path");
+    g_devices.clear();
+    const char* list = ::getenv("BOF_DEVICES");
+    if (list && *list && ::strcmp(list, "all") != 0) {
+      for (const char* p = list; *p;) {
+        char* end = nullptr;
+        const long d = ::strtol(p, &end, 10);
+        if (end == p) break;
+        g_devices.push_back((int) d);
+        p = end;
+        while (*p == ',' || *p == ' ') p++;
+      }
+    } else if (!(list && *list) && (::getenv("BOF_DEVICE") || ::getenv("LOCAL_RANK"))) {
+      g_devices.push_back((int) env_long("BOF_DEVICE", env_long("LOCAL_RANK", 0)));
+    } else {
+      for (int d = 0; d < count && d < BOF_MAX_DEVICES; d++) g_devices.push_back(d);
+    }
+    if (g_devices.empty() || g_devices.size() > BOF_MAX_DEVICES) GLOG_FATAL("bad device list in BOF_DEVICES");
+    for (int d : g_devices)
+      if (d < 0 || d >= count) GLOG_FATAL("device ", d, " is not one of the ", count, " visible HIP devices");
+    if (bof_set_device(g_devices[0]) != BOF_OK) GLOG_FATAL("bof_set_device failed: ", bof_last_error());
   }
   void flash_destroy() { bof_flash_release(); }
   unsigned long next_flash_malloc_serial() {

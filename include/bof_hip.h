@@ -54,7 +54,7 @@ extern "C" {
 #define BOF_ENODEV (-4) /* no HIP device */
 #define BOF_ENOMEM (-5)
 
-#define BOF_ABI_VERSION 2
+#define BOF_ABI_VERSION 3
 
 /* ---- library ---------------------------------------------------------------- */
 int bof_abi_version(void);
@@ -80,7 +80,31 @@ typedef struct {
                             read/written as large contiguous requests (needs B,
                             two A panels and three C panels inside hbm_budget)    */
   int32_t io_chunk_mib;  /* size of one panel read/write request  default 32      */
+  /* ---- ABI v3 ---------------------------------------------------------------- */
+  /* Level-3 calls shard over these HIP devices INSIDE the calling process, by output row
+   * block: C row panels (gemm / kmeans) or nnz-balanced row blocks (csrmm /
+   * csrgemv) are dealt to the devices in contiguous ranges; an operand every device needs
+   * (B, x) is read from its file ONCE into a pinned slot and copied from there to every
+   * device over that device's own PCIe link; csrgemv 'T' partials are summed device to
+   * device (peer access) before they leave for the host.  The reference runs its
+   * N_COMPUTE_THR workers inside one process behind flash::gemm in the same way
+   * (src/scheduler/scheduler.cpp:9-16, src/lib_funcs.cpp:9).
+   * n_devices = 0: $BOF_DEVICES ("0,1,2" or "all") if set, else only the calling thread's
+   * current device.  An ordinal may repeat: one GPU then plays several devices (how the
+   * sharded path is exercised on a 1-GPU box). */
+  int32_t n_devices;
+  int32_t devices[16];
+  /* per-call forms of what used to be process-wide environment knobs; 0 = the default,
+   * which is the environment variable named, read at every call, else the built-in value */
+  int32_t io_engine;      /* 1 kernel AIO, 2 io_uring      ($BOF_IO_ENGINE=uring)           */
+  int32_t io_request_kib; /* O_DIRECT request size         ($BOF_IO_REQUEST_KIB, 4096)      */
+  int32_t panel_group;    /* C panels of the ramp group    ($BOF_PANEL_GROUP, computed)     */
+  int32_t panel_streams;  /* compute streams, panel path   ($BOF_PANEL_STREAMS, min(n_streams, 2)) */
+  int32_t panel_writers;  /* writer threads, panel path    ($BOF_PANEL_WRITERS, n_io_threads / 2)  */
+  int32_t panel_kmajor;   /* k-major panel copies: 1 off, 2 on, 3 on even for tiles reused
+                             fewer than 4 times            ($BOF_PANEL_KMAJOR + 1, 2)       */
 } bof_options;
+#define BOF_MAX_DEVICES 16
 void bof_default_options(bof_options *o);
 
 /* ---- device memory / streams (thin wrappers for non-torch hosts) ------------ */
@@ -284,6 +308,11 @@ typedef struct {
                                          (iocbs + pread/pwrite calls)  */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
+/* The same counters per device of the last level-3 call, in the order of the device list
+ * (bytes_read = what was read for this device alone; an operand read once for all devices is
+ * only in the call's totals).  Returns the number of devices the call ran on (1 for a
+ * single-device call) or a negative error; fills out[0 .. min(count, cap)). */
+int bof_flash_last_device_stats(bof_flash_stats *out, int cap);
 /* Dry run of bof_flash_gemm's schedule (task order, HBM tile-slot replacement, write-back)
  * for a budget of n_slots tile slots and a prefetch lookahead in tasks: fills the byte and
  * hit/miss counters the real call would report, without touching files or the GPU. */

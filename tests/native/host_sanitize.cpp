@@ -42,7 +42,9 @@ hipError_t csc_merge(int, int64_t, const int64_t *, const int64_t *, const int64
                      const int64_t *, float *, int64_t *, hipStream_t) { return hipErrorUnknown; }
 hipError_t scsrcsc(int64_t, int64_t, int64_t, const float *, const int64_t *, const int64_t *, float *,
                    int64_t *, int64_t *, void *, hipStream_t) { return hipErrorUnknown; }
+hipError_t sum_partials(float *, const float *const *, int, int64_t, hipStream_t) { return hipErrorUnknown; }
 }  // namespace bof
+extern "C" const char *bof_last_error(void) { return ""; }
 
 #define CHECK(c)                                                        \
   do {                                                                  \

@@ -1,0 +1,286 @@
+"""-m gpu: the IN-PROCESS multi-device level 3 (bof_options.devices / $BOF_DEVICES): C row panels
+(gemm / kmeans) or nnz-balanced row blocks (csrmm / csrgemv) dealt to the devices of the list, every
+operand all devices need read from its file once and fanned out (reference: N workers inside one
+process behind flash::gemm, src/scheduler/scheduler.cpp:9-16; the mutex-guarded vector add of
+csrgemv 'T', include/tasks/csrgemv_task.h:169-176, becomes a device-to-device segment sum).
+
+The device list names device 0 several times, so a 1-GPU box runs every code path of the sharded
+call: per-device pipelines, shared-panel fan-out, per-device write-back, the partial-sum reduce.
+The bar: files / vectors bit-equal to the single-device call and to the oracle, and the byte
+counters show every matrix read ONCE whatever the number of devices."""
+import hashlib
+import itertools
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bofhip
+import orc
+from test_gpu_flash import Files, stored_shapes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "blas-on-flash_amd", "bin")
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_flash_gemm_devices_all_layouts(dev, tmp_path, ord_, ta, tb, path, ndev):
+    """640 x 600 x 500, tile 128 (5 / 4 C panels + tails), unaligned leading dims, beta != 0, all 8
+    layouts; tile cache (1), row panels (2), row panels with k-major copies forced (3).  The C panels
+    are dealt 3+2 / 2+2+1 (row-major: 5 panels) or 2+2 / 2+1+1 (column-major: 4)."""
+    m, k, n, blk = 640, 600, 500, 128
+    rng = np.random.default_rng(5)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=3, pinned_slots=4,
+                                      gemm_path=min(path, 2), io_chunk_mib=1, panel_kmajor=3 if path == 3 else 1,
+                                      devices=[0] * ndev)
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+        st = bofhip.flash_last_stats()
+        per = bofhip.flash_last_device_stats()
+        assert len(per) == ndev
+        assert st["tasks"] == 5 * 5 * 4 and sum(p["tasks"] for p in per) == st["tasks"]
+        assert st["bytes_written"] == 4 * c0.size and sum(p["bytes_written"] for p in per) == st["bytes_written"]
+        if path >= 2:
+            # the panel path reads A, B and C exactly once in total: the shared operand is NOT re-read per device
+            assert st["bytes_read"] == 4 * (a.size + b.size + c0.size)
+            shared = b.size if ord_ == "R" else a.size        # the operand without the C panel dimension
+            shared += (a.size if ord_ == "R" and ta == "T" else 0) + (b.size if ord_ == "C" and tb == "T" else 0)
+            assert st["bytes_h2d"] == st["bytes_read"] + 4 * shared * (ndev - 1)   # ... but copied to every device
+        else:
+            assert st["bytes_read"] >= 4 * (a.size + b.size + c0.size)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_,ta,tb,beta", [("R", "N", "N", 0.0), ("R", "T", "N", 1.5), ("C", "N", "T", 0.0),
+                                             ("C", "T", "T", 1.5)])
+def test_flash_gemm_devices_ring_reuse(dev, tmp_path, ord_, ta, tb, beta):
+    """Two devices, each with the smallest budget its slab's plan accepts: streamed-operand and C
+    ring slots are reused on both devices while the shared operand's panels arrive once for both."""
+    m, k, n, blk = 2200, 900, 1024, 128
+    if ord_ == "C":
+        m, n = n, m
+    rng = np.random.default_rng(8)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.75, beta, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        # budget of one slab (half of the C panel dimension) with group 2: resident operands one slot per
+        # panel, rings of 4 and 5 slots; a little slack for the shared operand's full width
+        half_m, half_n = (m // 2 // blk * blk + blk, n) if ord_ == "R" else (m, n // 2 // blk * blk + blk)
+        plan = bofhip.flash_gemm_panel_plan(ord_, ta, tb, half_m, half_n, k, blk, 1 << 40, group=2)
+        budget = int(plan["need_bytes"] * 1.6)
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=2, n_io_threads=4, pinned_slots=4, gemm_path=2,
+                                      io_chunk_mib=1, hbm_budget=budget, panel_group=2, panel_kmajor=1,
+                                      devices=[0, 0])
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.75, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+        st = bofhip.flash_last_stats()
+        assert st["bytes_read"] == 4 * (a.size + b.size + (c0.size if beta else 0))
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_,ta,tb", [("C", "T", "N"), ("R", "N", "T")])
+@pytest.mark.parametrize("path", [1, 2])
+def test_flash_kmeans_devices(dev, tmp_path, ord_, ta, tb, path):
+    """flash::kmeans over two devices: every device gets its own copy of the norm vectors and adds the
+    slices of ITS tiles (row / column offsets of the slab)."""
+    m, n, k, blk = 640, 500, 300, 128
+    rng = np.random.default_rng(17)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    cl = rng.uniform(0, 8, m).astype(np.float32)
+    pl = rng.uniform(0, 8, n).astype(np.float32)
+    ones = np.ones(max(m, n), np.float32)
+    ref = orc.flash_kmeans(ord_, ta, tb, m, n, k, -2.0, 0.0, a, b, c0.copy(), 0, 0, 0, blk, cl, pl, ones)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=2, n_io_threads=3, pinned_slots=4, gemm_path=path,
+                                      io_chunk_mib=1, devices=[0, 0])
+        bofhip.flash_kmeans(ord_, ta, tb, m, n, k, -2.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                            cl.ctypes.data, pl.ctypes.data, ones.ctypes.data, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+@pytest.mark.parametrize("ord_b,k,alpha,beta", [("R", 128, 1.0, 0.0), ("R", 1030, 0.5, 2.0), ("C", 128, 1.0, 0.0),
+                                               ("C", 1030, 0.5, 2.0)])
+def test_flash_csrmm_devices(dev, tmp_path, ord_b, k, alpha, beta, ndev):
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    b = orc.dense_fill(n, k, "s")
+    rng = np.random.default_rng(k)
+    c0 = rng.integers(0, 5, (m, k)).astype(np.float32) if beta else np.zeros((m, k), np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    ref = orc.flash_csrmm(ord_b, m, n, k, alpha, beta, val, ia, ja, b, c0.copy(), 1000, 5000, 1024)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000, n_io_threads=2, devices=[0] * ndev)
+        bofhip.flash_csrmm("N", m, n, k, alpha, beta, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
+                           ord_b, F.fptr("b"), F.fptr("c"), opts)
+        assert np.array_equal(F.read("c", np.float32, c0.shape), ref)
+        st = bofhip.flash_last_stats()
+        per = bofhip.flash_last_device_stats()
+        assert len(per) == ndev and all(p["tasks"] > 0 for p in per)
+        assert st["bytes_written"] == 4 * c0.size
+        # B is read once; its bytes cross PCIe once per device
+        assert st["bytes_h2d"] >= 4 * b.size * ndev
+        csr = 12 * ja.size + 8 * ia.size
+        slack = 2 * 1024 * sum(p["tasks"] for p in per)     # sector widening of the segments
+        assert 4 * b.size + csr + (4 * c0.size if beta else 0) <= st["bytes_read"] <= \
+            4 * b.size + csr + (4 * c0.size if beta else 0) + slack
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_b", ["R", "C"])
+def test_flash_csrmm_inmem_devices(dev, tmp_path, ord_b):
+    m, n, k = 4096, 2048, 136
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    rng = np.random.default_rng(1)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    ref = orc.flash_csrmm(ord_b, m, n, k, 0.5, 2.0, val, ia, ja, b, c0.copy(), 1000, 5000, 1024)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia)
+    try:
+        c = c0.copy()
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000, devices=[0, 0, 0])
+        bofhip.flash_csrmm_inmem("N", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"),
+                                 ord_b, b.ctypes.data, c.ctypes.data, opts)
+        assert np.array_equal(c, ref)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+@pytest.mark.parametrize("trans", ["N", "T"])
+def test_flash_csrgemv_devices(dev, tmp_path, golden, trans, ndev):
+    """'N': disjoint y slices; 'T': full-length partials per device, summed segment by segment on the
+    devices (sum_partials_kernel) -- the generator's integer data makes the result exact, so the
+    reference's hash must come out."""
+    m, n = 4096, 2048
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    x = (np.arange(n if trans == "N" else m) % 10).astype(np.float32)
+    y = np.full(m if trans == "N" else n, 3.0, np.float32)
+    F = Files(tmp_path, val=val, ja=ja, ia=ia)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000, devices=[0] * ndev)
+        bofhip.flash_csrgemv(trans, m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), x.ctypes.data,
+                             y.ctypes.data, opts)
+        want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
+        assert hashlib.sha256(y.tobytes()).hexdigest() == want["gen_csrgemv_" + trans]
+        assert len(bofhip.flash_last_device_stats()) == ndev
+    finally:
+        F.close()
+
+
+def test_flash_csr_devices_ragged_random(dev, tmp_path):
+    """Random values, ragged rows with a run of empty rows, more devices than some shards have blocks for."""
+    rng = np.random.default_rng(9)
+    m, n, k = 3000, 777, 96
+    counts = rng.integers(0, 12, m)
+    counts[100:400] = 0
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    ref = orc.flash_csrmm("R", m, n, k, 0.5, 2.0, val, ia, ja, b, c0.copy(), 200, 300, 64)
+    F = Files(tmp_path, direct=False, val=val, ja=ja, ia=ia, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(max_nnzs=300, csrmm_rblk=200, csrmm_cblk=64, use_odirect=0, devices=[0, 0, 0, 0])
+        bofhip.flash_csrmm("N", m, n, k, 0.5, 2.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), "R",
+                           F.fptr("b"), F.fptr("c"), opts)
+        assert np.array_equal(F.read("c", np.float32, (m, k)), ref)
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        y = np.zeros(m, np.float32)
+        bofhip.flash_csrgemv("N", m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), x.ctypes.data, y.ctypes.data, opts)
+        assert np.array_equal(y, orc.flash_csrgemv("N", m, n, val, ia, ja, x, np.zeros(m, np.float32), 200, 300))
+        xt = rng.uniform(-1, 1, m).astype(np.float32)
+        yt = np.zeros(n, np.float32)
+        bofhip.flash_csrgemv("T", m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), xt.ctypes.data, yt.ctypes.data, opts)
+        rt = orc.flash_csrgemv("T", m, n, val, ia, ja, xt, np.zeros(n, np.float32), 200, 300)
+        assert np.abs(yt - rt).max() / np.abs(rt).max() < 1e-4   # atomics + segment sums: order-dependent rounding
+    finally:
+        F.close()
+
+
+def test_devices_bad_list(dev, tmp_path):
+    a = np.zeros((256, 256), np.float32)
+    F = Files(tmp_path, a=a, b=a, c=a)
+    try:
+        with pytest.raises(bofhip.BofError, match="not one of"):
+            bofhip.flash_gemm("R", "N", "N", 256, 256, 256, 1.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              bofhip.default_options(gemm_blk=128, devices=[0, 63]))
+    finally:
+        F.close()
+
+
+def _run(binary, args, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([binary] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_reference_drivers_shard_over_bof_devices(dev, tmp_path, golden):
+    """The UNCHANGED reference driver sources (oracle/_ref/ref_*_driver: drivers/gemm.cpp, csrmm.cpp,
+    csrgemv.cpp compiled against our headers) with BOF_DEVICES=0,0: flash_setup hands the list to every
+    kernel call, the outputs equal the single-device ones."""
+    if not os.path.exists(os.path.join(REF, "ref_gemm_driver")):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    m, k, n, blk = 640, 600, 500, 128
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    ref = orc.flash_gemm("R", "N", "N", m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk)
+    pa, pb, pc = (str(tmp_path / x) for x in ("A", "B", "C"))
+    a.tofile(pa); b.tofile(pb); c0.tofile(pc)
+    env = {"BOF_DEVICES": "0,0", "BOF_GEMM_BLK_SIZE": str(blk), "BOF_TRACE": "1"}
+    out = _run(os.path.join(REF, "ref_gemm_driver"), [pa, pb, pc, m, k, n, 0.5, 2.0, "N", "N", "R", k, n, n], env)
+    assert "gemm() took" in out
+    assert np.array_equal(np.fromfile(pc, np.float32).reshape(m, n), ref)
+
+    mm, nn, kk = 4096, 2048, 128
+    val, ja, ia = orc.sparse_create(mm, nn, 0.01)
+    bm = orc.dense_fill(nn, kk, "s")
+    cref = orc.flash_csrmm("R", mm, nn, kk, 1.0, 0.0, val, ia, ja, bm, np.zeros((mm, kk), np.float32), 1000, 5000, 1024)
+    paths = {x: str(tmp_path / x) for x in ("val", "ja", "ia", "bm", "cm")}
+    val.tofile(paths["val"]); ja.tofile(paths["ja"]); ia.tofile(paths["ia"]); bm.tofile(paths["bm"])
+    np.zeros((mm, kk), np.float32).tofile(paths["cm"])
+    env = {"BOF_DEVICES": "0,0,0", "BOF_MAX_NNZS": "5000", "BOF_CSRMM_RBLK_SIZE": "1000"}
+    _run(os.path.join(REF, "ref_csrmm_driver"), [paths["val"], paths["ja"], paths["ia"], paths["bm"], paths["cm"],
+                                                 mm, nn, kk, 1.0, 0.0, "N", "R"], env)
+    assert np.array_equal(np.fromfile(paths["cm"], np.float32).reshape(mm, kk), cref)
+    want = {t.split()[1]: t.split()[2] for t in golden["meta"] if t.startswith("exact")}
+    for trans in "NT":
+        x = (np.arange(nn if trans == "N" else mm) % 10).astype(np.float32)
+        px, py = str(tmp_path / f"x{trans}"), str(tmp_path / f"y{trans}")
+        x.tofile(px)
+        np.zeros(mm if trans == "N" else nn, np.float32).tofile(py)
+        _run(os.path.join(REF, "ref_csrgemv_driver"), [paths["val"], paths["ja"], paths["ia"], px, py, mm, nn, trans], env)
+        assert hashlib.sha256(np.fromfile(py, np.float32).tobytes()).hexdigest() == want["gen_csrgemv_" + trans]
