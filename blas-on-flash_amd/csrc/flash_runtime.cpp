@@ -618,6 +618,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   }
 
   // ---- tile cache ---------------------------------------------------------------------------
+  rc = BOF_OK;
   const int dC = g.rdim[2];
   const int64_t NpC = g.nblk[dC];
   const int n_use = (int) std::min<int64_t>((int64_t) devs.size(), NpC);
