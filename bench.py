@@ -40,87 +40,25 @@ def _best_of(fn, reps):
     return best
 
 
-def cpu_baseline(bofhip, dev, st, with_csr=True):
+def cpu_baseline(with_csr=True):
     """The reference's CPU arithmetic timed on this box's host cores (path B):
-    the reference computes with Intel MKL (cblas_sgemm, mkl_scsrmm, mkl_cspblas_scsrgemv); the
-    image carries MKL inside PyTorch's CPU ops, so the whole-matrix calls of drivers/in_mem_gemm.cpp:63-70
-    / in_mem_csrmm.cpp:116-121 are timed as torch.mm / torch.sparse.mm on CSR, all cores, one warm-up,
-    best of N, wall clock around the call only.  Bounded samples of the workload (sizes in `sample`).
-    The oracle's own OpenMP loop nest is reported too, clearly labelled: it is a checker, not a BLAS."""
-    import numpy as np
-    import torch
-    cores = torch.get_num_threads()
-    out = {"unit": "GFLOP/s", "cores": cores, "kind": "port",
-           "what": "MKL sgemm through torch.mm (torch " + torch.__version__ + ", BLAS_INFO=mkl, "
-                   + ("mkl available" if torch.backends.mkl.is_available() else "mkl NOT available")
-                   + "): the routine the reference calls, not the reference binary"}
-    g = torch.Generator().manual_seed(0)
-    a = torch.rand((16384, 16384), generator=g) * 2 - 1
-    b = torch.rand((16384, 16384), generator=g) * 2 - 1
-    a4, b4 = a[:4096, :4096].contiguous(), b[:4096, :4096].contiguous()
-    torch.mm(a4, b4)                                               # warm-up (MKL's first call is several x slower)
-    t4 = _best_of(lambda: torch.mm(a4, b4), 3)
-    torch.mm(a[:8192, :8192].contiguous(), b[:8192, :8192].contiguous())
-    t16 = _best_of(lambda: torch.mm(a, b), 2)
-    out["value"] = round(2.0 * 16384 ** 3 / t16 / 1e9, 1)
-    out["sample"] = (f"sgemm 16384^3 fp32 (1/8 of a step), best of 2 after warm-up: {t16:.2f} s; "
-                     f"4096^3 (BASELINE configs[0], one tile task), best of 3: {t4 * 1e3:.0f} ms")
-    out["sgemm_4096_gflops"] = round(2.0 * 4096 ** 3 / t4 / 1e9, 1)
-    del a, b
+    tools/cpu_baseline.py in a CHILD process that never touches the GPU (its OpenMP runtime and thread
+    pinning stay out of this process) -- Intel MKL's cblas_sgemm / mkl_scsrmm / mkl_cspblas_scsrgemv
+    through dlopen when an MKL runtime is on the box, else the same operations through torch's
+    MKL-linked CPU ops; one thread per physical core, pinned; best of 3 and the spread; bounded
+    samples (sizes in `sample`).  kind "port": the routine the reference calls, not its binary."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py")] + ([] if with_csr else ["--no-csr"])
     try:
-        import orc
-        L = orc.lib()
-        an, bn = a4.numpy(), b4.numpy()
-        cn = np.empty((4096, 4096), np.float32)
-        L.orc_sgemm_mt(512, 512, 512, an.ctypes.data, bn.ctypes.data, cn.ctypes.data, L.orc_max_threads())
-        t0 = time.perf_counter()
-        L.orc_sgemm_mt(4096, 4096, 4096, an.ctypes.data, bn.ctypes.data, cn.ctypes.data, L.orc_max_threads())
-        out["oracle_loop_nest_gflops_NOT_A_BLAS"] = round(2.0 * 4096 ** 3 / (time.perf_counter() - t0) / 1e9, 1)
-    except Exception as e:  # pragma: no cover
-        out["oracle_note"] = str(e)[:80]
-    if not with_csr:
-        return out
-    # ---- CSRMM: 1/10 of BASELINE configs[2]: the first 1M rows of the 10M x 1M matrix x 1M x 128 ----
-    try:
-        m, n, k, npr = 1_000_000, 1_000_000, 128, 100
-        val = torch.empty(m * npr, dtype=torch.float32, device=dev)
-        col = torch.empty(m * npr, dtype=torch.int64, device=dev)
-        off = torch.empty(m + 1, dtype=torch.int64, device=dev)
-        bofhip.gen_sparse_rows(0, m, n, npr, val.data_ptr(), col.data_ptr(), off.data_ptr(), st)
-        bd = torch.empty(n * k, dtype=torch.float32, device=dev)
-        bofhip.gen_dense(bd.data_ptr(), 0, n * k, "s", 0, st)
-        torch.cuda.synchronize()
-        A = torch.sparse_csr_tensor(off.cpu(), col.cpu(), val.cpu(), size=(m, n))
-        B = bd.cpu().view(n, k)
-        del val, col, off, bd
-        C = torch.sparse.mm(A, B)                                  # warm-up
-        t = _best_of(lambda: torch.sparse.mm(A, B), 3)
-        out["csrmm"] = {"value": round(2.0 * m * npr * k / t / 1e9, 2), "unit": "GFLOP/s", "cores": cores,
-                        "sample": f"rows [0, 1M) of the cfg3 matrix (1e8 nnz) x 1M x 128 via torch.sparse.mm on CSR "
-                                  f"(MKL sparse BLAS), best of 3: {t:.3f} s",
-                        "checksum_first_row": [float(v) for v in C[0, :4]]}   # [1950, 2446, 1692, 2188]: App. A-3
-        del A, B, C
-        # ---- CSRGEMV: 1/10 of the cfg5-size matrix: rows [0, 5M) of 50M x 50M, 10 nnz/row ----------
-        m, n, npr = 5_000_000, 50_000_000, 10
-        val = torch.empty(m * npr, dtype=torch.float32, device=dev)
-        col = torch.empty(m * npr, dtype=torch.int64, device=dev)
-        off = torch.empty(m + 1, dtype=torch.int64, device=dev)
-        bofhip.gen_sparse_rows(0, m, n, npr, val.data_ptr(), col.data_ptr(), off.data_ptr(), st)
-        torch.cuda.synchronize()
-        A = torch.sparse_csr_tensor(off.cpu(), col.cpu(), val.cpu(), size=(m, n))
-        del val, col, off
-        x = (torch.arange(n) % 10).float()
-        y = torch.mv(A, x)
-        t = _best_of(lambda: torch.mv(A, x), 3)
-        out["csrgemv_N"] = {"value": round(2.0 * m * npr / t / 1e9, 2), "unit": "GFLOP/s", "cores": cores,
-                            "sample": f"rows [0, 5M) of the 50M x 50M matrix (5e7 nnz) x vector via torch.mv on CSR, "
-                                      f"best of 3: {t * 1e3:.1f} ms",
-                            "checksum_y0_6": [float(v) for v in y[:6]]}     # [230, 274, 243, 172, 222, 348]
-        del A, x, y
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"unit": "GFLOP/s", "cores": 0, "kind": "port", "value": None, "sample": "",
+                "error": (r.stderr or r.stdout)[-300:]}
     except Exception as e:  # the headline must still be printed
-        out["csr_error"] = f"{type(e).__name__}: {str(e)[:160]}"
-    torch.cuda.empty_cache()
-    return out
+        return {"unit": "GFLOP/s", "cores": 0, "kind": "port", "value": None, "sample": "",
+                "error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def pmc_traffic():
@@ -315,6 +253,10 @@ def csr_secondary(bofhip, torch, dev, st):
                                  # what the kernel actually moves: one 512-byte B row per non-zero
                                  "gather_bytes": nnz * k * 4, "gather_GBps": round(nnz * k * 4 / ms / 1e6, 1),
                                  "gather_frac_of_hbm_peak": round(nnz * k * 4 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                 # MI355X_MICROARCH.md: random 512-byte rows run at 8.6 TB/s out of the Infinity
+                                 # Cache (MALL) and 5.7 TB/s out of HBM; B is 512 MB, 256 MB of it fit the MALL
+                                 "gather_frac_of_ceiling": round(nnz * k * 4 / ms / 1e6 / 8600.0, 4),
+                                 "gather_ceiling_GBps": 8600.0,
                                  "traffic": pmc.get("csrmm"), "traffic_source": pmc_src,
                                  "traffic_over_algorithmic": round(pmc["csrmm"] / alg, 1) if "csrmm" in pmc else None,
                                  "note": "bytes roofline 3 %: every non-zero fetches a B row from Infinity Cache/HBM "
@@ -501,6 +443,132 @@ def _drop_cache(paths):
             os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
         finally:
             os.close(fd)
+
+
+def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
+    """What this box's scratch disk, page cache and PCIe link deliver RIGHT NOW (about five seconds):
+    the ceilings the `roofline_e2e` fractions of this same run are taken against.  Measured with the
+    library's own file primitives into pinned buffers (bof_file_sread / bof_file_swrite, 32 MiB per call
+    cut into the default 4 MiB requests, `io_threads` threads), like tools/iobench.py's full sweep."""
+    import threading
+    L = bofhip.lib()
+    size = int(gib * 2**30)
+    slot = 32 << 20
+    path = os.path.join(workdir, "ceilings.bin")
+    out = {}
+    t = torch.empty(size // 4, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(t.data_ptr(), 0, t.numel(), "u", 7, st)
+    _write_device_tensor(bofhip, t, path, True, bofhip.default_options(n_io_threads=io_threads), st)
+    hbuf = []
+    for _ in range(2 * io_threads):
+        p = ctypes.c_void_p()
+        bofhip.check(L.bof_host_alloc(ctypes.byref(p), slot), "host_alloc")
+        hbuf.append(p.value)
+    nchunks = size // slot
+
+    def run(nthr, fn):
+        th = [threading.Thread(target=fn, args=(i, nthr)) for i in range(nthr)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return size / (time.perf_counter() - t0) / 1e9
+    try:
+        fd, direct = _open(path, True)
+        if direct:
+            def rd(i, nthr, fd_=fd, base=0):
+                for cidx in range(i, nchunks, nthr):
+                    L.bof_file_sread(fd_, cidx * slot, 0, 1, slot, hbuf[base + i], 1)
+
+            def wr(i, nthr, fd_=fd, base=0):
+                for cidx in range(i, nchunks, nthr):
+                    L.bof_file_swrite(fd_, cidx * slot, 0, 1, slot, hbuf[base + i], 1)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            out["disk_read_GBps"] = round(run(io_threads, rd), 2)
+            out["disk_write_GBps"] = round(run(io_threads, wr), 2)
+            # both directions at once (the pipeline's steady state): readers on one file, writers on another
+            path2 = path + ".2"
+            _write_device_tensor(bofhip, t, path2, True, bofhip.default_options(n_io_threads=io_threads), st)
+            fd2, _ = _open(path2, True)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            both = {}
+            ta = threading.Thread(target=lambda: both.__setitem__("r", run(io_threads, rd)))
+            tb = threading.Thread(target=lambda: both.__setitem__(
+                "w", run(max(2, io_threads // 2), lambda i, n: wr(i, n, fd2, io_threads))))
+            ta.start(); tb.start(); ta.join(); tb.join()
+            out["disk_read_GBps_while_writing"] = round(both["r"], 2)
+            out["disk_write_GBps_while_reading"] = round(both["w"], 2)
+            L.bof_file_forget(fd2)
+            os.close(fd2)
+            os.remove(path2)
+        else:
+            out["disk_note"] = "the scratch file system refuses O_DIRECT"
+        L.bof_file_forget(fd)
+        os.close(fd)
+        fd, _ = _open(path, False)
+
+        def prd(i, nthr):
+            for cidx in range(i, nchunks, nthr):
+                L.bof_file_sread(fd, cidx * slot, 0, 1, slot, hbuf[i], 0)
+        run(io_threads, prd)                       # fills the page cache
+        out["page_cache_read_GBps"] = round(run(io_threads, prd), 2)
+        os.close(fd)
+        # PCIe, pinned <-> HBM, 32 MiB linear copies on two streams
+        s1, s2 = ctypes.c_void_p(), ctypes.c_void_p()
+        L.bof_stream_create(ctypes.byref(s1))
+        L.bof_stream_create(ctypes.byref(s2))
+        d0, reps = t.data_ptr(), 24
+
+        def timed(fn):
+            fn()
+            L.bof_stream_sync(s1); L.bof_stream_sync(s2)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            L.bof_stream_sync(s1); L.bof_stream_sync(s2)
+            return reps * slot / (time.perf_counter() - t0) / 1e9
+        out["pcie_h2d_GBps"] = round(timed(lambda: L.bof_memcpy_h2d(d0, hbuf[0], slot, s1)), 2)
+        out["pcie_d2h_GBps"] = round(timed(lambda: L.bof_memcpy_d2h(hbuf[1], d0 + slot, slot, s2)), 2)
+
+        def bidir():
+            L.bof_memcpy_h2d(d0, hbuf[0], slot, s1)
+            L.bof_memcpy_d2h(hbuf[1], d0 + slot, slot, s2)
+        out["pcie_each_way_when_both_GBps"] = round(timed(bidir), 2)
+        L.bof_stream_destroy(s1); L.bof_stream_destroy(s2)
+    finally:
+        for h in hbuf:
+            L.bof_host_free(h)
+        if os.path.exists(path):
+            os.remove(path)
+        del t
+        torch.cuda.empty_cache()
+    return out
+
+
+def roofline_e2e(leg, ceil, flops, kernel_s, mode):
+    """Lower bound on the wall time of one out-of-core call from the ceilings measured in THIS run, and the
+    fraction of it the call achieved: t_bound = max over the stages that all run concurrently in the
+    pipeline -- kernel time at the measured kernel rate, bytes over PCIe each way, bytes read / written at
+    the disk's (odirect) or the page cache's (buffered) rate; frac = t_bound / seconds."""
+    st = leg["stats"]
+    terms = {"mfma" if flops > 1e13 else "hbm": kernel_s or 0.0}
+    if ceil.get("pcie_h2d_GBps"):
+        terms["pcie_h2d"] = st["bytes_h2d"] / (ceil["pcie_h2d_GBps"] * 1e9)
+        terms["pcie_d2h"] = st["bytes_d2h"] / (ceil["pcie_d2h_GBps"] * 1e9)
+    if mode == "odirect" and ceil.get("disk_read_GBps"):
+        terms["disk_read"] = st["bytes_read"] / (ceil["disk_read_GBps"] * 1e9)
+        terms["disk_write"] = st["bytes_written"] / (ceil["disk_write_GBps"] * 1e9)
+        # reads and writes share the device: the sum of both at their concurrent rates is a bound too
+        if ceil.get("disk_read_GBps_while_writing"):
+            terms["disk_read+write"] = max(st["bytes_read"] / (ceil["disk_read_GBps_while_writing"] * 1e9),
+                                           st["bytes_written"] / (ceil["disk_write_GBps_while_reading"] * 1e9))
+    elif mode == "buffered" and ceil.get("page_cache_read_GBps"):
+        terms["page_cache_read"] = st["bytes_read"] / (ceil["page_cache_read_GBps"] * 1e9)
+    bound = max(terms, key=terms.get)
+    t_bound = terms[bound]
+    return {"seconds": leg["seconds"], "gflops": leg["gflops"], "bound": bound, "t_bound_s": round(t_bound, 4),
+            "frac": round(t_bound / leg["seconds"], 3), "terms_s": {k: round(v, 4) for k, v in terms.items()}}
 
 
 def _leg_summary(runs, flops, kernel_s, compulsory_rd, compulsory_wr, units):
@@ -720,7 +788,8 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
     import numpy as np
     import torch.distributed as dist
     out = {"what": f"{m_local * world}x{k}x{n} fp32 flash _gemm on files, row-block sharded over {world} ranks "
-                   f"(each: {m_local} C rows; B streamed by every rank; no collective), wall clock between barriers"}
+                   f"(each: {m_local} C rows; B read from storage once per node: panel l by rank l % {world}, passed on "
+                   f"through node-shared memory; no data-path collective), wall clock between barriers"}
 
     def phase(fn):
         """run fn locally; (all ranks ok?, max seconds over ranks, local error text)"""
@@ -809,10 +878,14 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
             continue
         opts = bofhip.default_options(gemm_blk=args.blk, n_io_threads=args.io_threads,
                                       use_odirect=1 if mode == "odirect" else 0)
+        last = {}
 
         def run():
-            bofhip.flash_gemm("R", "N", "N", m_local, n, k, 1.0, 0.0, bofhip.FPtr(fds[0], r0 * k * 4),
-                              bofhip.FPtr(fds[1], 0), bofhip.FPtr(fds[2], r0 * n * 4), 0, 0, 0, opts)
+            # every rank runs the level-3 pipeline on its slab; B's panels are read from the file once per
+            # node (panel l by rank l % world) and passed on through the node-shared staging segment
+            import bof_dist
+            last.update(bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], 0, 0, 0, opts,
+                                                        b_once=True))
         times = []
         for rep in range(2):
             if mode == "odirect" and rank == 0:
@@ -823,6 +896,9 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
             if not good:
                 break
         stats = bofhip.flash_last_stats()
+        agg = torch.tensor([float(last.get(q, 0)) for q in ("bytes_read", "bytes_written", "bytes_peer")],
+                           dtype=torch.float64, device=red_dev)
+        dist.all_reduce(agg)
         for fd in fds:
             bofhip.lib().bof_file_forget(fd)
             os.close(fd)
@@ -848,6 +924,12 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
         best = min(times) if mode == "odirect" else times[-1]
         out[mode] = {"seconds_all": [round(x, 3) for x in times], "seconds": round(best, 3),
                      "gflops": round(flops / best / 1e9, 1),
+                     "aggregate_read_GBps": round(float(agg[0]) / best / 1e9, 2),
+                     "aggregate_write_GBps": round(float(agg[1]) / best / 1e9, 2),
+                     # bytes read from the files by ALL ranks over the compulsory A + B (C is beta = 0): 1.0 = B once per node
+                     "read_amplification": round(float(agg[0]) / (4.0 * (m * k + k * n)), 3),
+                     "write_amplification": round(float(agg[1]) / (4.0 * m * n), 3),
+                     "B_bytes_taken_from_peers": int(agg[2]),
                      "rank0_read_GBps": round(stats["bytes_read"] / best / 1e9, 2),
                      "rank0_write_GBps": round(stats["bytes_written"] / best / 1e9, 2),
                      "rank0_requests": stats["read_ops"] + stats["write_ops"],
@@ -927,7 +1009,8 @@ def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps, mo
                        "gflops": round(2.0 * nnz / best / 1e9, 2), "read_GBps": round(stats["bytes_read"] / best / 1e9, 2),
                        "algorithmic_GBps": round(alg / best / 1e9, 2),
                        "overlap_kernel_over_e2e": round(kernel_ms[tr] * 1e-3 / best, 3) if kernel_ms and tr in kernel_ms else None,
-                       "sha256_y_matches_reference": bool(hashlib.sha256(y.tobytes()).hexdigest() == CFG5_Y_SHA256[tr])}
+                       "sha256_y_matches_reference": bool(hashlib.sha256(y.tobytes()).hexdigest() == CFG5_Y_SHA256[tr]),
+                       "stats": stats}
         for fd in fds.values():
             bofhip.lib().bof_file_forget(fd)
             os.close(fd)
@@ -956,6 +1039,10 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
                                 "loadavg_1min": round(os.getloadavg()[0], 1)}
         n = args.e2e_size
         bofhip.lib().bof_flash_release()
+        try:
+            out["ceilings"] = io_ceilings(bofhip, torch, dev, st, workdir, args.io_threads)
+        except Exception as e:
+            out["ceilings"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         if free > 3 * n * n * 4 + (2 << 30):
             out["gemm"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s, args.io_threads,
                                    args.e2e_reps)
@@ -989,6 +1076,21 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
         out["error"] = f"{type(e).__name__}: {str(e)[:300]}"
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
+    # roofline of every leg against the ceilings of this run
+    ceil = out.get("ceilings") or {}
+    work = {"gemm": (2.0 * args.e2e_size ** 3, gemm_kernel_s), "gemm_65536": (2.0 * 65536.0 ** 3, gemm64_kernel_s),
+            "csrmm": (2.0 * 1e9 * 128, csrmm_kernel_s),
+            "csrgemv": (2.0 * 5e8, (gemv_kernel_ms or {}).get("N", 0) * 1e-3 if gemv_kernel_ms else None)}
+    if "error" not in ceil:
+        for name, (flops, ks) in work.items():
+            legs = out.get(name)
+            if not isinstance(legs, dict):
+                continue
+            for mode in ("odirect", "buffered"):
+                tgt = legs.get(mode) if name != "csrgemv" else (legs.get(mode) or {}).get("N")
+                if isinstance(tgt, dict) and "stats" in tgt and "seconds" in tgt:
+                    tgt.setdefault("gflops", round(flops / tgt["seconds"] / 1e9, 1))
+                    tgt["roofline"] = roofline_e2e(tgt, ceil, flops, ks, mode)
     return out
 
 
@@ -1017,15 +1119,38 @@ def main():
     ap.add_argument("--io-threads", type=int, default=8)
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks this run consists of.  Launched by a torchrun-style launcher
+    # (WORLD_SIZE set) it must agree with it; launched bare with N > 1, this process -- which has not
+    # touched the GPU -- starts the N ranks as fresh children (never re-exec a process that has) and
+    # leaves with the launcher's exit code.
+    one_gpu = os.environ.get("BOF_BENCH_ONE_GPU", "0") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE="
+                         f"{os.environ.get('WORLD_SIZE', '1')} ranks; refusing to print a line for a run that is not "
+                         f"the one asked for\n")
+        sys.exit(2)
+
     import torch
     import bofhip
 
+    if not one_gpu and torch.cuda.device_count() < args.gpus:       # (counting devices does not initialise the GPU)
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible "
+                         f"(BOF_BENCH_ONE_GPU=1 runs every rank on device 0 for debugging)\n")
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # debug only: BOF_BENCH_ONE_GPU=1 runs every rank on cuda:0 with the gloo backend, so the
     # N > 1 code path can be exercised on a single-GPU box (RCCL refuses two ranks per device)
-    one_gpu = os.environ.get("BOF_BENCH_ONE_GPU", "0") == "1"
     if one_gpu:
         local = 0
     if world > 1:
@@ -1040,6 +1165,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     red_dev = torch.device("cpu") if one_gpu else dev     # where cross-rank reductions live
+    ranks_seen = 1
+    if world > 1:
+        # every rank adds a one through the data-path backend (RCCL over xGMI on the GPU box): the sum is
+        # the number of ranks that really took part, printed so the driver can check it against --gpus
+        ones = torch.ones(1, dtype=torch.float32, device=red_dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        if ranks_seen != args.gpus:
+            sys.stderr.write(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus says {args.gpus}\n")
+            sys.exit(2)
 
     n_gpus = max(world, 1)
     shard_of = args.as_shard_of if world == 1 else 0
@@ -1188,7 +1323,10 @@ def main():
             "data": "synthetic " + ("uniform[-1,1) fp32 (counter hash)" if args.data == "u"
                                     else "dense_create mode s (i%10)") + ", generated in HBM",
             "config": {"workload": workload, "tile": args.blk, "tile_tasks_per_step": launches_per_step,
-                       "compute_streams": args.streams, "parallelism": f"row-block x{n_gpus}"},
+                       "compute_streams": args.streams, "parallelism": f"row-block x{n_gpus}",
+                       "ranks_seen": ranks_seen,
+                       "backend": "single process" if world == 1 else ("gloo (one-GPU debug)" if one_gpu else "nccl (RCCL)")},
+            "ranks_seen": ranks_seen,
             "roofline": {"bound": "mfma", "kernel": kernel_label,
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
@@ -1203,7 +1341,7 @@ def main():
             "parity_first_tile_row_rel_err_vs_float64": rel,
         }
         if not args.no_cpu and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(bofhip, dev, st, with_csr=not args.no_csr and not args.size)
+            out["cpu_baseline"] = cpu_baseline(with_csr=not args.no_csr and not args.size)
         if not args.no_csr and n_gpus == 1 and not args.size:
             del a, b, c
             torch.cuda.empty_cache()
@@ -1239,6 +1377,50 @@ def main():
             out["e2e"] = e2e_block(bofhip, torch, dev, st, args, dt / args.steps if not args.size else None,
                                    csr_ms * 1e-3 if csr_ms else None, g64_ms * 1e-3 if g64_ms else None,
                                    gv_ms if all(gv_ms.values()) else None)
+        # ---- the out-of-core numbers where the driver's `parsed` record keeps them: flat scalars inside
+        # `roofline` (e2e_*), plus value_e2e / roofline_e2e at the top level ----------------------------
+        e2e = out.get("e2e") or {}
+        ceil = e2e.get("ceilings") if isinstance(e2e.get("ceilings"), dict) else {}
+        rf = out["roofline"]
+        for key in ("disk_read_GBps", "disk_write_GBps", "disk_read_GBps_while_writing",
+                    "disk_write_GBps_while_reading", "page_cache_read_GBps", "pcie_h2d_GBps", "pcie_d2h_GBps"):
+            if key in ceil:
+                rf["e2e_ceiling_" + key] = ceil[key]
+        for name, tag in (("gemm", "cfg2"), ("gemm_65536", "64k"), ("csrmm", "cfg3")):
+            for mode, mt in (("odirect", ""), ("buffered", "_pagecache")):
+                leg = (e2e.get(name) or {}).get(mode) if isinstance(e2e.get(name), dict) else None
+                if not isinstance(leg, dict) or "roofline" not in leg:
+                    continue
+                r = leg["roofline"]
+                pre = f"e2e_{tag}{mt}_"
+                rf[pre + "s"] = r["seconds"]
+                rf[pre + "gflops"] = r["gflops"]
+                rf[pre + "bound"] = r["bound"]
+                rf[pre + "tbound_s"] = r["t_bound_s"]
+                rf[pre + "frac"] = r["frac"]
+                rf[pre + "read_amp"] = leg.get("read_amplification")
+                ok = leg.get("whole_C_file_matches_closed_form", leg.get("C_total_matches_reference"))
+                rf[pre + "verified"] = bool(ok)
+        g2 = (e2e.get("gemm") or {}).get("odirect") if isinstance(e2e.get("gemm"), dict) else None
+        if isinstance(g2, dict) and "roofline" in g2:
+            out["value_e2e"] = g2["gflops"]
+            out["roofline_e2e"] = dict(g2["roofline"], workload=e2e["gemm"].get("workload", ""), ceilings=ceil,
+                                       unit_of_value_e2e="GFLOP/s, wall clock around bof_flash_gemm on O_DIRECT files, "
+                                                         "page cache dropped, write-back included")
+        sec0 = out.get("secondary") or {}
+        if isinstance(sec0.get("csrmm"), dict) and "roofline" in sec0["csrmm"]:
+            r3 = sec0["csrmm"]["roofline"]
+            rf["csrmm_kernel_ms"] = sec0["csrmm"]["ms"]
+            rf["csrmm_bytes_frac_of_hbm"] = r3["frac"]
+            rf["csrmm_gather_frac_of_ceiling"] = r3["gather_frac_of_ceiling"]
+            rf["csrmm_traffic_over_algorithmic"] = r3.get("traffic_over_algorithmic")
+        for tr in "NT":
+            gv = sec0.get("csrgemv_" + tr)
+            if isinstance(gv, dict) and "roofline" in gv:
+                rf[f"csrgemv_{tr}_kernel_ms"] = gv["ms"]
+                rf[f"csrgemv_{tr}_bytes_frac_of_hbm"] = gv["roofline"]["frac"]
+        if isinstance(sec0.get("kmeans"), dict) and "roofline" in sec0["kmeans"]:
+            rf["kmeans_frac_of_mfma"] = sec0["kmeans"]["roofline"]["frac"]
         if sharded is not None:
             sec = {"scaling": "strong (the BASELINE matrices row-sharded over the ranks; max over ranks)",
                    "ok": sharded["ok"]}

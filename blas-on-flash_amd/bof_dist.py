@@ -79,110 +79,65 @@ def allreduce_partial(y, group=None, algo="allreduce"):
     return y
 
 
+_share_seq = 0
+
+
 def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0, ldc=0, opts=None, group=None,
-                           device=None, one_gpu_debug=False, b_once_per_node=False):
-    """Multi-GPU flash::gemm('R','N','N') on FILE-resident matrices (BASELINE configs[3]; SURVEY 8e):
-    rank g owns the C rows [r0, r1) (tile-aligned, `row_shard`).
+                           b_once=True):
+    """Multi-GPU flash::gemm('R','N','N') on FILE-resident matrices (BASELINE configs[3]; SURVEY 8e), one
+    process per GPU: rank g owns the C rows [r0, r1) (tile-aligned, `row_shard`) and calls the
+    single-GPU file pipeline on its slab -- bof_flash_gemm with the A and C pointers advanced to row
+    r0.  In level 3 that is the row-panel pipeline: the rank's A panels stream through a ring, C panels
+    are written back while later ones compute; reads, PCIe copies, MFMA work and write-back all overlap
+    inside the library (flash_gemm_panels.cpp), nothing is staged in Python, and there is no data-path
+    collective (BASELINE configs[3]).
 
-    Default (no collective, as BASELINE configs[3] says): every rank simply calls the single-GPU
-    file pipeline on its slab -- bof_flash_gemm with the A and C pointers advanced to row r0.  In
-    level 3 that is the row-panel pipeline: the rank's A panels stream through a ring, B is read by
-    the rank itself (large sequential requests; from the page cache once another rank has touched
-    it), C panels are written back while later ones compute -- reads, PCIe copies, MFMA work and
-    write-back all overlap inside the library (flash_gemm_panels.cpp), nothing is staged in Python.
+    b_once=True (default for world > 1): B is read from storage ONCE PER NODE instead of
+    once per rank -- inside the same pipeline.  The ranks that own rows pass share_world / share_rank /
+    share_name to bof_flash_gemm: panel l of B is read from the file by rank l % share_world, which
+    publishes it in a node-shared staging segment; the others take it from there (bof_options in
+    include/bof_hip.h).  At cfg4 that is 16 + 16 GiB of reads per node instead of 16 + 8 x 16.  The
+    only torch.distributed call is the barrier behind which the staging segment is removed.
+    b_once=False: every rank reads B itself.
 
-    b_once_per_node=True: B is read from storage ONCE per node instead of once per
-    GPU.  The k-panels of the tile grid are dealt round-robin to the ranks; the owner reads its
-    panels from the file and broadcasts them (RCCL over xGMI, asynchronous, in k order) while the
-    A / C slabs stream in; the tile DAG of each k range is queued behind "its" broadcast only, so
-    MFMA work on panel l overlaps the arrival of panels l+1, ...; same tiles, same k-order as the
-    single call, so the C file is bit-identical.  Pays when the storage, not PCIe, is the
-    bottleneck (8 x 16 GiB of B reads at cfg4: 144 GiB through one device vs 32 GiB).
-
-    Returns {bytes_read, bytes_written, rows, b_panel_rows} of this rank.  `one_gpu_debug` runs the
-    collective through host memory (gloo) so that two ranks can share one device."""
-    import torch
+    Returns {rows, bytes_read, bytes_written, bytes_peer, seconds} of this rank."""
+    global _share_seq
+    import os
     import torch.distributed as dist
     import bofhip
     lda, ldb, ldc = lda or k, ldb or n, ldc or n
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     o = opts if opts is not None else bofhip.default_options()
     tile = int(o.gemm_blk)
     r0, r1 = row_shard(m, world, rank, tile)
     rows = r1 - r0
-    if not b_once_per_node:
-        stats = {"bytes_read": 0, "bytes_written": 0, "rows": rows, "b_panel_rows": k if rows > 0 else 0}
-        if rows > 0:
-            bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, r0 * lda * 4),
-                              bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * ldc * 4), lda, ldb, ldc, o)
-            st_ = bofhip.flash_last_stats()
-            stats["bytes_read"], stats["bytes_written"] = st_["bytes_read"], st_["bytes_written"]
-            stats["seconds"] = st_["seconds"]
-        return stats
-    st = torch.cuda.current_stream(dev).cuda_stream
-    rd = wr = 0
-    # --- k-panels of B: the tile grid's own k blocks (tail-merge rule of src/blas/gemm.cpp:69-75),
-    # dealt round-robin to the ranks.  Owner reads its panels from the file; every panel is then
-    # broadcast (RCCL over xGMI, asynchronous, in k order) and consumed by the tile DAG of THAT k
-    # range as soon as it has landed -- the accumulate chains run l = 0, 1, ... exactly as in the
-    # single call, so the C file is bit-identical.
-    nkb = max(1, k // tile) if (k % tile) < 128 and k >= tile else k // tile + (1 if k % tile else 0)
-    nkb = max(nkb, 1)
-    kb = [(l * tile, k if l == nkb - 1 else (l + 1) * tile) for l in range(nkb)]
-    b_elems = (k - 1) * ldb + n
-    b_dev = torch.empty(b_elems, dtype=torch.float32, device=dev)
-
-    def region(l):
-        k0, k1 = kb[l]
-        return k0 * ldb, ((k1 - k0 - 1) * ldb + n)          # element offset, element count
-
-    mine = [l for l in range(nkb) if l % world == rank]
-    for l in mine:
-        off, cnt = region(l)
-        bofhip.file_to_device(bofhip.FPtr(fd_b, off * 4), cnt * 4, b_dev.data_ptr() + off * 4, o, st)
-        rd += cnt * 4
-    works = [None] * nkb
-    if world > 1:
-        for l in range(nkb):
-            off, cnt = region(l)
-            if one_gpu_debug:          # two ranks on one device: the collective goes through host memory
-                h = b_dev[off:off + cnt].cpu() if l % world == rank else torch.empty(cnt, dtype=torch.float32)
-                dist.broadcast(h, src=l % world, group=group)
-                if l % world != rank:
-                    b_dev[off:off + cnt].copy_(h)
-            else:
-                works[l] = dist.broadcast(b_dev[off:off + cnt], src=l % world, group=group, async_op=True)
-    stats = {"bytes_read": 0, "bytes_written": 0, "rows": rows,
-             "b_panel_rows": sum(kb[l][1] - kb[l][0] for l in mine)}
+    stats = {"rows": rows, "bytes_read": 0, "bytes_written": 0, "bytes_peer": 0, "seconds": 0.0}
+    # the ranks that own rows, in rank order: the share group (the same on every rank)
+    owners = [g for g in range(world) if row_shard(m, world, g, tile)[1] > row_shard(m, world, g, tile)[0]]
+    name = None
+    if world > 1 and b_once and len(owners) > 1:
+        _share_seq += 1                      # every rank makes the same sequence of calls
+        name = f"/bof_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}_{_share_seq}"
+        if rank == 0:
+            bofhip.lib().bof_share_cleanup(name.encode())    # leftovers of a crashed earlier run
+        dist.barrier(group)
     if rows > 0:
-        # A / C slabs stream in while the broadcasts are in flight
-        a_dev = torch.empty(rows * lda, dtype=torch.float32, device=dev)
-        a_bytes = ((rows - 1) * lda + k) * 4
-        bofhip.file_to_device(bofhip.FPtr(fd_a, r0 * lda * 4), a_bytes, a_dev.data_ptr(), o, st)
-        rd += a_bytes
-        c_dev = torch.empty(rows * ldc, dtype=torch.float32, device=dev)
-        c_bytes = ((rows - 1) * ldc + n) * 4
-        if beta != 0.0 or ldc != n:       # padded rows: keep what lies between the row ends
-            bofhip.file_to_device(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o, st)
-            rd += c_bytes
-        for l in range(nkb):
-            k0, k1 = kb[l]
-            if works[l] is not None:
-                works[l].wait()           # the CURRENT STREAM waits for panel l; the host does not
-            bofhip.gemm_resident("R", "N", "N", rows, n, k1 - k0, alpha, beta if l == 0 else 1.0,
-                                 a_dev.data_ptr() + k0 * 4, b_dev.data_ptr() + k0 * ldb * 4, c_dev.data_ptr(),
-                                 lda, ldb, ldc, o, st)
-        # the write-back is ordered behind the DAG through its stream argument
-        bofhip.device_to_file(bofhip.FPtr(fd_c, r0 * ldc * 4), c_bytes, c_dev.data_ptr(), o, st)
-        wr += c_bytes
-    else:
-        for w in works:
-            if w is not None:
-                w.wait()
-    torch.cuda.current_stream(dev).synchronize()
-    stats["bytes_read"], stats["bytes_written"] = rd, wr
+        import ctypes
+        call = bofhip.Options()
+        ctypes.memmove(ctypes.byref(call), ctypes.byref(o), ctypes.sizeof(o))
+        if name is not None:
+            call.share_world, call.share_rank, call.share_name = len(owners), owners.index(rank), name.encode()
+        bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, r0 * lda * 4),
+                          bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * ldc * 4), lda, ldb, ldc, call)
+        st_ = bofhip.flash_last_stats()
+        for q in ("bytes_read", "bytes_written", "bytes_peer", "seconds"):
+            stats[q] = st_[q]
+    if name is not None:
+        dist.barrier(group)                  # everybody is out of the call: the segment can go
+        if rank == 0:
+            bofhip.lib().bof_share_cleanup(name.encode())
     return stats
 
 

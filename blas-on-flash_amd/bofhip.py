@@ -28,7 +28,9 @@ class Options(C.Structure):
                 # ABI v3: in-process device list + per-call forms of the environment knobs
                 ("n_devices", C.c_int32), ("devices", C.c_int32 * 16), ("io_engine", C.c_int32),
                 ("io_request_kib", C.c_int32), ("panel_group", C.c_int32), ("panel_streams", C.c_int32),
-                ("panel_writers", C.c_int32), ("panel_kmajor", C.c_int32)]
+                ("panel_writers", C.c_int32), ("panel_kmajor", C.c_int32),
+                # one process per GPU: the shared operand read once per node (see include/bof_hip.h)
+                ("share_world", C.c_int32), ("share_rank", C.c_int32), ("share_name", C.c_char * 48)]
 
 
 class GemmTask(C.Structure):
@@ -52,7 +54,7 @@ class PanelPlan(C.Structure):
 class FlashStats(C.Structure):
     _fields_ = [("bytes_read", u64), ("bytes_written", u64), ("bytes_h2d", u64),
                 ("bytes_d2h", u64), ("tasks", u64), ("tile_hits", u64), ("tile_misses", u64),
-                ("seconds", C.c_double), ("read_ops", u64), ("write_ops", u64)]
+                ("seconds", C.c_double), ("read_ops", u64), ("write_ops", u64), ("bytes_peer", u64)]
 
 
 # every symbol include/bof_hip.h declares: (name, restype, argtypes)
@@ -106,6 +108,7 @@ SYMBOLS = [
     ("bof_flash_last_stats", C.c_int, [C.POINTER(FlashStats)]),
     ("bof_flash_last_device_stats", C.c_int, [C.POINTER(FlashStats), C.c_int]),
     ("bof_flash_release", C.c_int, []),
+    ("bof_share_cleanup", C.c_int, [C.c_char_p]),
     ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
                                           C.c_int32, C.POINTER(FlashStats)]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
@@ -162,7 +165,9 @@ def default_options(**kw):
     o = Options()
     lib().bof_default_options(C.byref(o))
     for k, v in kw.items():
-        if k == "devices":          # devices=[0, 1, ...]: the in-process device list (repeats allowed)
+        if k == "share_name":
+            o.share_name = v.encode() if isinstance(v, str) else v
+        elif k == "devices":        # devices=[0, 1, ...]: the in-process device list (repeats allowed)
             v = list(v)
             o.n_devices = len(v)
             for i, d in enumerate(v):

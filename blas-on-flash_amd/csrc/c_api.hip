@@ -48,6 +48,12 @@ bof_options resolved(const bof_options *o) {
   if (o->panel_streams > 0) r.panel_streams = o->panel_streams;
   if (o->panel_writers > 0) r.panel_writers = o->panel_writers;
   if (o->panel_kmajor > 0) r.panel_kmajor = o->panel_kmajor;
+  if (o->share_world > 1) {
+    r.share_world = o->share_world;
+    r.share_rank = o->share_rank;
+    memcpy(r.share_name, o->share_name, sizeof(r.share_name));
+    r.share_name[sizeof(r.share_name) - 1] = 0;
+  }
   return r;
 }
 
@@ -155,6 +161,9 @@ void bof_default_options(bof_options *o) {
   o->panel_streams = 0;
   o->panel_writers = 0;
   o->panel_kmajor = 0;
+  o->share_world = 0;
+  o->share_rank = 0;
+  memset(o->share_name, 0, sizeof(o->share_name));
 }
 
 int bof_device_count(void) {

@@ -18,7 +18,7 @@
 namespace bof {
 
 struct Counters {
-  std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0};
+  std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0}, peer{0};
   uint64_t ops0[2];  // file_io_ops() when the call began
   Counters() { file_io_ops(&ops0[0], &ops0[1]); }
 };

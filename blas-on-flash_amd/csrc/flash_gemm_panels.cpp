@@ -51,13 +51,29 @@
 // its own PCIe link -- storage sees A, B and C once whatever the number of devices.  Readers,
 // the read ring and the writers serve all devices; panel slots, copy streams, write ring,
 // flusher and dispatcher are per device.
+//
+// One PROCESS per GPU (bof_options.share_world > 1, bof_dist.flash_gemm_row_sharded): every rank
+// makes this call on its slab, and a shared panel is read from the file by ONE rank of the node
+// (panel l by rank l % share_world), which publishes its chunks in a node-shared staging segment
+// (ShareSeg: POSIX shared memory + one futex flag per chunk); the other ranks' readers wait for
+// the flag and copy the chunk out of the segment instead of reading the file.  All ranks queue
+// the shared panels in the same order and readers take requests in queue order, so the earliest
+// unpublished chunk is always being read by its owner: no cycle of waits.
 #ifndef _GNU_SOURCE
 #define _GNU_SOURCE
 #endif
 #include <hip/hip_runtime.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <linux/futex.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -165,6 +181,45 @@ int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel re
 }
 bool trace_on() { return trace_level() >= 1; }
 
+// A shared operand staged in node-shared memory by the ranks of a share_world > 1 call: the matrix
+// image in file layout (tmpfs pages are allocated as they are written) and one flag per chunk
+// (0 not there yet, 1 published, 2 the owner failed).
+struct ShareSeg {
+  char *base = nullptr;
+  size_t bytes = 0;
+  uint32_t *flag = nullptr;           // accessed through __atomic builtins + futex
+  size_t n_flags = 0;
+  std::vector<size_t> first_flag;     // per panel
+  void unmap() {
+    if (base) ::munmap(base, bytes);
+    if (flag) ::munmap(flag, n_flags * sizeof(uint32_t));
+    base = nullptr; flag = nullptr;
+  }
+};
+void *shm_map(const std::string &name, size_t bytes) {
+  const int fd = ::shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return nullptr;
+  void *p = MAP_FAILED;
+  if (::ftruncate(fd, (off_t) bytes) == 0) p = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  ::close(fd);
+  return p == MAP_FAILED ? nullptr : p;
+}
+void flag_publish(uint32_t *f, uint32_t v) {
+  __atomic_store_n(f, v, __ATOMIC_RELEASE);
+  ::syscall(SYS_futex, f, FUTEX_WAKE, INT32_MAX, nullptr, nullptr, 0);
+}
+// waits until *f != 0; returns its value, or 0 after `timeout_s` / once `stop` is set
+uint32_t flag_wait(uint32_t *f, double timeout_s, const std::atomic<int> &stop) {
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
+  for (;;) {
+    const uint32_t v = __atomic_load_n(f, __ATOMIC_ACQUIRE);
+    if (v) return v;
+    if (stop.load() || std::chrono::steady_clock::now() >= t_end) return 0;
+    struct timespec ts = {0, 200 * 1000 * 1000};   // re-check the stop flag / deadline five times a second
+    ::syscall(SYS_futex, f, FUTEX_WAIT, 0, &ts, nullptr, 0);
+  }
+}
+
 struct PanelHub;
 
 // One device's share of the call: the single-device schedule over its slab of C.
@@ -226,6 +281,9 @@ struct PanelHub {
   WorkQueue<ChunkReq> fetch_q;
   WorkQueue<WriteReq> write_q;
   std::vector<char> issued[2];   // shared operand panels whose read has been queued
+  ShareSeg seg[2];               // share_world > 1: the shared operands' node-wide staging
+  int share_world = 1, share_rank = 0;
+  double share_timeout_s = 120;
   std::mutex mu;
   std::condition_variable cv;
   std::atomic<int> io_error{0};
@@ -341,13 +399,33 @@ void PanelHub::reader_main(int home) {
     Mat &M0 = R0.mat[rq.mat];
     const int ps = rring->acquire();
     int rc = 0;
-    if (!io_error.load()) {
-      TraceRange r("panel chunk read");
-      rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, rring->ptr(ps), M0.aio);
+    ShareSeg *sg = rq.di < 0 && share_world > 1 && seg[rq.mat].base ? &seg[rq.mat] : nullptr;
+    const size_t seg_off = (size_t) ((uint64_t) M0.panels[(size_t) rq.panel].r0 * (uint64_t) M0.ld * 4 + rq.off);
+    uint32_t *flag = sg ? sg->flag + sg->first_flag[(size_t) rq.panel] + (size_t) (rq.off / R0.chunk) : nullptr;
+    const bool from_peer = sg && rq.panel % share_world != share_rank;
+    if (from_peer) {
+      // another rank of the node reads this panel from the file: its chunk, out of the staging segment
+      if (!io_error.load()) {
+        TraceRange r("panel chunk from a peer");
+        const uint32_t v = flag_wait(flag, share_timeout_s, io_error);
+        if (v == 1) memcpy(rring->ptr(ps), sg->base + seg_off, rq.bytes);
+        else if (!io_error.load()) rc = v == 2 ? -EIO : -ETIMEDOUT;
+      }
+      if (rc) fail_io(rc);
+      cnt.peer += rq.bytes;
+    } else {
+      if (!io_error.load()) {
+        TraceRange r("panel chunk read");
+        rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, rring->ptr(ps), M0.aio);
+      }
+      if (sg) {   // publish (or tell the peers that it will not come)
+        if (!rc && !io_error.load()) memcpy(sg->base + seg_off, rring->ptr(ps), rq.bytes);
+        flag_publish(flag, !rc && !io_error.load() ? 1u : 2u);
+      }
+      if (rc) fail_io(rc);
+      cnt.rd += rq.bytes;
+      if (rq.di >= 0) R0.cnt.rd += rq.bytes;
     }
-    if (rc) fail_io(rc);
-    cnt.rd += rq.bytes;
-    if (rq.di >= 0) R0.cnt.rd += rq.bytes;
     const size_t d0 = rq.di < 0 ? 0 : (size_t) rq.di, d1 = rq.di < 0 ? runs.size() : (size_t) rq.di + 1;
     hipError_t e = hipSuccess;
     for (size_t d = d0; d < d1 && e == hipSuccess; d++) {
@@ -873,6 +951,46 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     }
   }
   for (int x = 0; x < 2; x++) H.issued[x].assign(H.runs[0]->mat[x].panels.size(), 0);
+  guard.add([&H] {
+    // an owner that gives up tells the peers so (they would wait for the timeout otherwise)
+    for (int x = 0; x < 2; x++) {
+      ShareSeg &sg = H.seg[x];
+      if (sg.flag && H.io_error.load())
+        for (size_t p = 0; p + 1 <= sg.first_flag.size(); p++)
+          if ((int) (p % (size_t) H.share_world) == H.share_rank) {
+            const size_t f1 = p + 1 < sg.first_flag.size() ? sg.first_flag[p + 1] : sg.n_flags;
+            for (size_t f = sg.first_flag[p]; f < f1; f++)
+              if (__atomic_load_n(sg.flag + f, __ATOMIC_ACQUIRE) == 0) flag_publish(sg.flag + f, 2u);
+          }
+      sg.unmap();
+    }
+  });
+  if (o.share_world > 1) {
+    if (o.share_rank < 0 || o.share_rank >= o.share_world || !o.share_name[0] || strlen(o.share_name) > 40) {
+      set_error("bof_flash_gemm: share_world > 1 needs share_rank in [0, share_world) and a share_name of 1..40 characters");
+      return BOF_EINVAL;
+    }
+    H.share_world = o.share_world;
+    H.share_rank = o.share_rank;
+    H.share_timeout_s = (double) env_long("BOF_SHARE_TIMEOUT_S", 120);
+    for (int x = 0; x < 2; x++) {
+      const Mat &M = H.runs[0]->mat[x];
+      if (!M.shared) continue;
+      ShareSeg &sg = H.seg[x];
+      for (const Panel &P : M.panels) {
+        sg.first_flag.push_back(sg.n_flags);
+        sg.n_flags += (size_t) ((P.bytes + H.runs[0]->chunk - 1) / H.runs[0]->chunk);
+      }
+      sg.bytes = M.total_bytes;
+      const std::string base = std::string(o.share_name) + "." + "AB"[x];
+      sg.base = (char *) shm_map(base + ".data", sg.bytes);
+      sg.flag = (uint32_t *) shm_map(base + ".flags", sg.n_flags * sizeof(uint32_t));
+      if (!sg.base || !sg.flag) {
+        set_error(std::string("bof_flash_gemm: cannot map the node-shared staging segment ") + base + ": " + strerror(errno));
+        return BOF_EIO;
+      }
+    }
+  }
   H.trace("plan");
 
   // ---- per-device events, streams, write rings; the shared read ring --------------------------------
@@ -962,3 +1080,10 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
 }
 
 }  // namespace bof
+
+extern "C" int bof_share_cleanup(const char *share_name) {
+  if (!share_name || !share_name[0]) return BOF_EINVAL;
+  for (const char *m : {".A", ".B"})
+    for (const char *k : {".data", ".flags"}) (void) ::shm_unlink((std::string(share_name) + m + k).c_str());
+  return BOF_OK;
+}

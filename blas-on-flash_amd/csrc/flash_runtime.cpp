@@ -77,6 +77,7 @@ void publish_stats(const Counters &c, double seconds) {
   g_last_stats.bytes_h2d = c.h2d; g_last_stats.bytes_d2h = c.d2h;
   g_last_stats.tasks = c.tasks; g_last_stats.tile_hits = c.hits;
   g_last_stats.tile_misses = c.misses; g_last_stats.seconds = seconds;
+  g_last_stats.bytes_peer = c.peer;
   uint64_t r = 0, w = 0;
   file_io_ops(&r, &w);
   g_last_stats.read_ops = r - c.ops0[0]; g_last_stats.write_ops = w - c.ops0[1];

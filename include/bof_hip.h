@@ -103,6 +103,20 @@ typedef struct {
   int32_t panel_writers;  /* writer threads, panel path    ($BOF_PANEL_WRITERS, n_io_threads / 2)  */
   int32_t panel_kmajor;   /* k-major panel copies: 1 off, 2 on, 3 on even for tiles reused
                              fewer than 4 times            ($BOF_PANEL_KMAJOR + 1, 2)       */
+  /* One PROCESS per GPU on one node (torchrun-style), every rank calling bof_flash_gemm on its
+   * row slab of the same A / B / C files: with share_world > 1 the operand every rank needs (B for
+   * row-major) is read from storage ONCE PER NODE instead of once per rank.  Its row panels are
+   * dealt round-robin to the ranks (panel l belongs to rank l % share_world); the owner reads a
+   * panel from the file (O_DIRECT, as always) and, besides copying it to its own GPU, publishes it
+   * in a node-shared staging segment (POSIX shared memory `share_name`.*, one ready flag per chunk,
+   * futex wake-ups); the other ranks take the chunk from there instead of from the file.  Same
+   * panels, same order, same bits.  Every participating rank must make the same call (same
+   * problem, same options) with its own share_rank in [0, share_world); share_name must be new
+   * for every collective call and is removed with bof_share_cleanup once all ranks have returned.
+   * Row-panel path only (the tile cache reads its tiles itself). */
+  int32_t share_world;    /* 0 / 1: off */
+  int32_t share_rank;
+  char share_name[48];    /* e.g. "/bof_29500_7"; at most 40 characters */
 } bof_options;
 #define BOF_MAX_DEVICES 16
 void bof_default_options(bof_options *o);
@@ -306,6 +320,8 @@ typedef struct {
   double seconds;                     /* wall time of the call         */
   uint64_t read_ops, write_ops;       /* requests handed to the kernel
                                          (iocbs + pread/pwrite calls)  */
+  uint64_t bytes_peer;                /* bytes of a shared operand taken from another rank's
+                                         staging segment instead of the file (share_world > 1) */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
 /* The same counters per device of the last level-3 call, in the order of the device list
@@ -348,6 +364,9 @@ int bof_flash_gemm_panel_plan(char ord, char trans_a, char trans_b, uint64_t m, 
  * reference keeps its program cache for the life of the process, src/lib_funcs.cpp:9);
  * this frees them (and unmaps the write mappings of buffered files). */
 int bof_flash_release(void);
+/* Removes the node-shared staging objects of a finished share_world > 1 call (every rank has
+ * returned from it: the caller's barrier); harmless if they are gone already. */
+int bof_share_cleanup(const char *share_name);
 
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
  * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided

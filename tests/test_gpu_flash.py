@@ -647,17 +647,21 @@ def test_csrcsc_driver_and_csrmm_driver_trans(dev, tmp_path, golden_tr):
 
 
 @pytest.mark.parametrize("b_once", ["0", "1"])
-@pytest.mark.parametrize("nproc", [1, 2])
-def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc, b_once):
-    """Multi-GPU file path.  b_once = 0: every rank runs the level-3 pipeline on its
-    row slab (flash_ptr + offset), no collective.  b_once = 1: A / C row slabs resident, B read once
-    per node (one k-row panel per rank + all-gather), tile DAG over the resident slabs.  Either way
-    the C file equals the restated flash::gemm bit for bit.  nproc = 2 shares cuda:0 between the
-    ranks and routes the collective through gloo (single-GPU box)."""
+@pytest.mark.parametrize("padded", [False, True])
+@pytest.mark.parametrize("nproc", [1, 2, 3])
+def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc, b_once, padded):
+    """Multi-GPU file path, one process per GPU: every rank runs the level-3
+    pipeline on its row slab (flash_ptr + offset), no data-path collective.  b_once = 1 (the default
+    of bof_dist.flash_gemm_row_sharded): B's panels are read from the file once per NODE -- panel l by
+    rank l % world, published in a node-shared staging segment, taken from there by the others --
+    so the ranks' bytes_read add up to A + B + C, and bytes_peer to (world - 1) x B.  padded: leading
+    dimensions with gaps send the call to the tile cache, which reads its tiles itself.  Either way
+    the C file equals the restated flash::gemm bit for bit.  nproc > 1 shares cuda:0 between the
+    ranks (single-GPU box; gloo for the barriers)."""
     import json
     import sys
-    m, k, n, blk = 1100, 600, 500, 256
-    lda, ldb, ldc = k + 8, n + 4, n + 12
+    m, k, n, blk = 1100, 600, 500, 128
+    lda, ldb, ldc = (k + 8, n + 4, n + 12) if padded else (k, n, n)
     alpha, beta = 0.5, 2.0
     rng = np.random.default_rng(23)
     a = rng.uniform(-1, 1, (m, lda)).astype(np.float32)
@@ -672,19 +676,23 @@ def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc, b_once):
         cmd = [sys.executable, tool]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-               "--master-addr", "127.0.0.1", "--master-port", str(29577 + int(b_once)), tool]
+               "--master-addr", "127.0.0.1", "--master-port", str(29577 + int(b_once) + 2 * int(padded)), tool]
     r = subprocess.run(cmd + [str(x) for x in args], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, BOF_BENCH_ONE_GPU="1", BOF_B_ONCE=b_once))
+                       env=dict(os.environ, BOF_BENCH_ONE_GPU="1", BOF_B_ONCE=b_once, BOF_IO_CHUNK_MIB="1"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(recs) == nproc
     assert sum(x["rows"] for x in recs) == m
-    if b_once == "1":
-        assert sum(x["b_panel_rows"] for x in recs) == k      # B read from storage exactly once
-    else:
-        assert all(x["b_panel_rows"] == k for x in recs)      # every rank streams B itself
     got = np.fromfile(pc, np.float32).reshape(m, ldc)
     assert np.array_equal(got, ref)
+    if not padded:
+        rd = sum(x["bytes_read"] for x in recs)
+        peer = sum(x["bytes_peer"] for x in recs)
+        if b_once == "1":
+            assert rd == 4 * (a.size + b.size + c0.size) and peer == (nproc - 1) * 4 * b.size
+        else:
+            assert rd == 4 * (a.size + nproc * b.size + c0.size) and peer == 0
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("bof_2957")]     # staging removed
 
 
 @pytest.mark.parametrize("nproc", [1, 2])

@@ -3,8 +3,8 @@
 
     python -m torch.distributed.run --nproc-per-node N tools/dist_file_gemm.py A.bin B.bin C.bin m n k alpha beta [lda ldb ldc blk]
 
-BOF_BENCH_ONE_GPU=1 puts every rank on cuda:0 and routes the collective through gloo (debugging
-the N > 1 path on a single-GPU box)."""
+BOF_BENCH_ONE_GPU=1 puts every rank on cuda:0 with the gloo backend (the N > 1 path on a single-GPU
+box; the only torch.distributed calls are barriers)."""
 import json
 import os
 import sys
@@ -38,15 +38,15 @@ def main():
     bofhip.require_device()
     flags = os.O_RDWR | (os.O_DIRECT if os.environ.get("BOF_ODIRECT", "0") == "1" else 0)
     fds = [os.open(p, flags) for p in (pa, pb, pc)]
-    opts = bofhip.default_options(gemm_blk=blk or 4096, use_odirect=int(os.environ.get("BOF_ODIRECT", "0")))
+    opts = bofhip.default_options(gemm_blk=blk or 4096, use_odirect=int(os.environ.get("BOF_ODIRECT", "0")),
+                                  io_chunk_mib=int(os.environ.get("BOF_IO_CHUNK_MIB", "32")))
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    # BOF_B_ONCE=1: B is read from storage once per node (k-row panel per rank + all-gather);
-    # default: every rank runs the level-3 file pipeline on its slab, no collective
+    # every rank runs the level-3 file pipeline on its slab; BOF_B_ONCE=1 (default): B is read from storage
+    # once per node (panel l by rank l % world, published in node-shared memory), 0: by every rank
     st = bof_dist.flash_gemm_row_sharded(m, n, k, alpha, beta, fds[0], fds[1], fds[2], lda, ldb, ldc, opts,
-                                         one_gpu_debug=one_gpu,
-                                         b_once_per_node=os.environ.get("BOF_B_ONCE", "0") == "1")
+                                         b_once=os.environ.get("BOF_B_ONCE", "1") == "1")
     for fd in fds:
         os.fsync(fd)
         os.close(fd)

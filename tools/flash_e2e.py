@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--budget-gib", type=float, default=0.0,
                     help="HBM budget (0 = library default: most of the free HBM); 8 = the reference's PROGRAM_BUDGET")
+    ap.add_argument("--devices", default="", help="in-process device list, e.g. 0,0 (one GPU playing two devices)")
     ap.add_argument("--pre", default="", help="diagnostic: alloc,resident,dgemm,release stages run first")
     ap.add_argument("--cpu-warm", type=int, default=0,
                     help="diagnostic: run a torch CPU sgemm of this edge first (what bench.py's cpu_baseline does)")
@@ -80,7 +81,9 @@ def main():
     try:
         out = bench.e2e_gemm(bofhip, torch, dev, st, work, args.n, args.blk, None, args.io_threads, args.reps,
                              modes=modes, gemm_path=args.path, io_chunk_mib=args.chunk_mib, n_streams=args.streams,
-                             pinned_slots=args.pinned, hbm_budget=int(args.budget_gib * 2**30))
+                             pinned_slots=args.pinned, hbm_budget=int(args.budget_gib * 2**30),
+                             **({"devices": [int(x) for x in args.devices.split(",")]} if args.devices else {}))
+        out["per_device"] = bofhip.flash_last_device_stats()
     finally:
         shutil.rmtree(work, ignore_errors=True)
     out["args"] = vars(args)
