@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -247,6 +248,7 @@ struct MapEntry {
   dev_t dev = 0;
   ino_t ino = 0;
   bool no_holes = false;   // every block of the file is allocated (checked until it is)
+  int users = 0;           // stores in flight through the mapping (guarded by g_map_mu): nobody unmaps under them
 };
 
 // A store into a hole has its block allocated at fault / write-back time, where a full disk means
@@ -262,11 +264,19 @@ bool file_has_no_holes(int fd, uint64_t size) {
   return hole >= 0 && (uint64_t) hole >= size;
 }
 std::mutex g_map_mu;
+std::condition_variable g_map_cv;    // a mapping's last user has left
 std::unordered_map<int, MapEntry> g_map;
 std::atomic<uint64_t> g_mapped_bytes{0};
 
-void unmap_locked(int fd) {
+// Drops the mapping of fd once no store is in flight through it (file_forget and
+// bof_flash_release may run while another thread is inside mapped_write's memcpy).
+void unmap_locked(int fd, std::unique_lock<std::mutex> &lk) {
   auto it = g_map.find(fd);
+  if (it == g_map.end()) return;
+  g_map_cv.wait(lk, [&] {
+    it = g_map.find(fd);
+    return it == g_map.end() || it->second.users == 0;
+  });
   if (it == g_map.end()) return;
   if (it->second.base) ::munmap(it->second.base, it->second.size);
   g_map.erase(it);
@@ -279,10 +289,10 @@ bool mapped_write(int fd, const char *buf, uint64_t len, uint64_t off) {
   if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || off + len > (uint64_t) sb.st_size) return false;
   char *base = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_map_mu);
+    std::unique_lock<std::mutex> lk(g_map_mu);
     auto it = g_map.find(fd);
     if (it != g_map.end() && (it->second.dev != sb.st_dev || it->second.ino != sb.st_ino)) {
-      unmap_locked(fd);   // the descriptor number now names another file: nobody can be using the old mapping
+      unmap_locked(fd, lk);   // the descriptor number now names another file
       it = g_map.end();
     }
     // same file, other size (it grew under pwrite): other threads may be storing through the
@@ -302,29 +312,39 @@ bool mapped_write(int fd, const char *buf, uint64_t len, uint64_t off) {
       if (e.base && !e.no_holes) return false;
     }
     base = it->second.base;
+    if (!base) return false;
+    it->second.users++;      // from here to the end of the copy the mapping cannot go away
   }
-  if (!base) return false;
+  bool done = false;
   const uint64_t pg = 4096, a0 = off / pg * pg, a1 = (off + len + pg - 1) / pg * pg;
   std::vector<unsigned char> vec((size_t) ((a1 - a0) / pg));
-  if (::mincore(base + a0, (size_t) (a1 - a0), vec.data()) != 0) return false;
-  for (unsigned char v : vec)
-    if (!(v & 1)) return false;
-  memcpy(base + off, buf, (size_t) len);
-  g_mapped_bytes += len;
-  return true;
+  if (::mincore(base + a0, (size_t) (a1 - a0), vec.data()) == 0) {
+    done = true;
+    for (unsigned char v : vec)
+      if (!(v & 1)) { done = false; break; }
+  }
+  if (done) {
+    memcpy(base + off, buf, (size_t) len);
+    g_mapped_bytes += len;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_map_mu);
+    auto it = g_map.find(fd);
+    if (it != g_map.end()) it->second.users--;
+  }
+  g_map_cv.notify_all();
+  return done;
 }
 }  // namespace
 uint64_t file_mapped_write_bytes() { return g_mapped_bytes.load(); }
 void unmap_for_forget(int fd) {
-  std::lock_guard<std::mutex> lk(g_map_mu);
-  unmap_locked(fd);
+  std::unique_lock<std::mutex> lk(g_map_mu);
+  unmap_locked(fd, lk);
 }
-// every write mapping goes (bof_flash_release: no level-3 call is running then)
+// every write mapping goes (bof_flash_release), each once its stores in flight are done
 void file_unmap_all() {
-  std::lock_guard<std::mutex> lk(g_map_mu);
-  for (auto &kv : g_map)
-    if (kv.second.base) ::munmap(kv.second.base, kv.second.size);
-  g_map.clear();
+  std::unique_lock<std::mutex> lk(g_map_mu);
+  while (!g_map.empty()) unmap_locked(g_map.begin()->first, lk);
 }
 
 static int rw_full(int fd, bool wr, char *buf, uint64_t len, uint64_t off) {

@@ -834,6 +834,12 @@ int bof_device_to_file(bof_fptr f, uint64_t bytes, const void *dptr, const bof_o
 }
 
 int bof_flash_release(void) {
+  // waits for level-2 / level-3 calls that are running on any device (their slabs, rings and scratch go)
+  std::vector<int> all;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) { (void) hipGetLastError(); count = 0; }
+  for (int d = 0; d < std::min(count, 64); d++) all.push_back(d);
+  DeviceCallLock quiesce(all);
   scratch_release_all();
   panel_resources_release();
   std::lock_guard<std::mutex> lk(g_res_mu);

@@ -193,7 +193,7 @@ int uring_run(const std::vector<IoPiece> &pieces) {
   r.sync_buffers();
   // placed: SQEs written into the ring; consumed: taken by the kernel; done: completions reaped
   size_t placed = 0, consumed = 0, done = 0;
-  int first_err = 0;
+  int first_err = 0, soft_retries = 0;
   // as with the AIO engine: after an error nothing new goes out, but everything in flight is
   // reaped before returning (the kernel owns the caller's buffer until then)
   while (done < placed || (!first_err && placed < pieces.size())) {
@@ -222,34 +222,52 @@ int uring_run(const std::vector<IoPiece> &pieces) {
     }
     const unsigned to_submit = (unsigned) (placed - consumed);
     if (to_submit == 0 && consumed == done) break;
+    auto reap = [&] {
+      unsigned head = *r.cq_head;
+      const unsigned ctail = __atomic_load_n(r.cq_tail, __ATOMIC_ACQUIRE);
+      while (head != ctail) {
+        const struct io_uring_cqe &c = r.cqes[head & *r.cq_mask];
+        const IoPiece &p = pieces[(size_t) c.user_data];
+        if (c.res < 0) { if (!first_err) first_err = c.res; }
+        else if ((uint64_t) c.res != p.len) { if (!first_err) first_err = -EIO; }   // short transfer
+        head++;
+        done++;
+      }
+      __atomic_store_n(r.cq_head, head, __ATOMIC_RELEASE);
+    };
     const long rc = syscall(__NR_io_uring_enter, r.fd, to_submit, 1u, IORING_ENTER_GETEVENTS, nullptr, 0);
     if (rc < 0) {
       if (errno == EINTR) continue;
-      if ((errno == EAGAIN || errno == EBUSY) && consumed > done) {
+      const int e = -errno;
+      if ((e == -EAGAIN || e == -EBUSY) && consumed > done) {
         // completion queue pressure: reap what is there and try again
         (void) syscall(__NR_io_uring_enter, r.fd, 0u, 1u, IORING_ENTER_GETEVENTS, nullptr, 0);
+      } else if ((e == -EAGAIN || e == -EBUSY) && ++soft_retries <= 5) {
+        usleep(200u << soft_retries);     // transient (memory pressure, io-wq limits): nothing in flight, try again
+        continue;
       } else {
-        // the ring itself is unusable: closing it makes the kernel cancel / wait for whatever it
-        // still holds, so the caller's buffer is quiescent when we return
-        const int e = -errno;
+        // The ring cannot take this submission.  Closing an io_uring descriptor only QUEUES its
+        // teardown, so what the kernel already holds is reaped first: the caller's buffer (a pinned
+        // ring slot that will be reused) must be quiescent when we return.
+        while (done < consumed) {
+          const long w = syscall(__NR_io_uring_enter, r.fd, 0u, (unsigned) std::min<size_t>(consumed - done, r.entries),
+                                 IORING_ENTER_GETEVENTS, nullptr, 0);
+          if (w < 0 && errno != EINTR && errno != EAGAIN && errno != EBUSY) break;
+          reap();
+        }
+        const bool quiescent = done == consumed;
+        // SQEs that were placed but never consumed must not survive into a later call: new ring
         r.~Uring();
         new (&r) Uring();
-        return first_err ? first_err : e;
+        if (first_err) return first_err;
+        // nothing was taken by the kernel at all: let the AIO engine do the whole transfer
+        if (quiescent && consumed == 0 && (e == -EAGAIN || e == -EBUSY || e == -ENOMEM)) return -ENOSYS;
+        return e;
       }
     } else {
       consumed += (size_t) rc;
     }
-    unsigned head = *r.cq_head;
-    const unsigned ctail = __atomic_load_n(r.cq_tail, __ATOMIC_ACQUIRE);
-    while (head != ctail) {
-      const struct io_uring_cqe &c = r.cqes[head & *r.cq_mask];
-      const IoPiece &p = pieces[(size_t) c.user_data];
-      if (c.res < 0) { if (!first_err) first_err = c.res; }
-      else if ((uint64_t) c.res != p.len) { if (!first_err) first_err = -EIO; }   // short transfer
-      head++;
-      done++;
-    }
-    __atomic_store_n(r.cq_head, head, __ATOMIC_RELEASE);
+    reap();
     // (after an error, SQEs the kernel has not taken yet stay valid requests: the next enter
     //  consumes them and they are reaped like the others -- they cannot be recalled)
   }

@@ -380,9 +380,14 @@ int bof_file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides
  * MAX_CHUNK_SIZE, flash_file_handle.cpp:25). */
 int bof_file_set_request_bytes(uint64_t bytes);
 /* Unaligned requests on an O_DIRECT descriptor go through a cached buffered descriptor of
- * the same file, and large buffered writes into cached pages through a shared mapping of it;
- * call this before close(fd) so that both are dropped too (FlashFileHandle::close does;
- * bof_flash_release drops every mapping). */
+ * the same file, and large buffered writes into cached pages through a shared mapping of it
+ * (BOF_MMAP_WRITES=0 turns the mapping off).  Both are keyed by the descriptor NUMBER: calling
+ * this before close(fd) is MANDATORY for callers of the C ABI (FlashFileHandle::close does it;
+ * bof_flash_release drops every mapping) -- otherwise the twin and the mapping stay alive (an
+ * unlinked file keeps its blocks) until the number is reused or the library is released.  It
+ * waits for stores that are in flight through the mapping.  A file must not be truncated by
+ * anybody while a level-3 call writes it: a store into a mapped page beyond the new end raises
+ * SIGBUS where pwrite would have re-extended the file. */
 int bof_file_forget(int fd);
 
 /* ---- synthetic inputs generated in HBM (bench / tests) ---------------------- */
