@@ -603,8 +603,11 @@ def _leg_summary(runs, flops, kernel_s, compulsory_rd, compulsory_wr, units):
 
 
 def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps, modes=("odirect", "buffered"),
-             **extra_opts):
-    """cfg2 through bof_flash_gemm on three n*n*4-byte files (A, B mode 's'; C zeros)."""
+             rank_calls=0, **extra_opts):
+    """cfg2 through bof_flash_gemm on three n*n*4-byte files (A, B mode 's'; C zeros).
+    rank_calls = W > 1: instead of one call, the W calls the ranks of a W-GPU run make (bof_dist.row_shard:
+    rank g's C rows, A and C pointers advanced to its slab, all of B), one after the other on this GPU
+    against the same three files -- the composition the multi-GPU run relies on, whole C verified."""
     import numpy as np
     nbytes = n * n * 4
     pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
@@ -678,10 +681,23 @@ def e2e_gemm(bofhip, torch, dev, st, workdir, n, blk, kernel_s, io_threads, reps
             if mode == "odirect":
                 _drop_cache((pa, pb, pc))
             t0 = time.perf_counter()
-            bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
-                              bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
+            if rank_calls > 1:
+                import bof_dist
+                tot = None
+                for g in range(rank_calls):
+                    r0, r1 = bof_dist.row_shard(n, rank_calls, g, blk)
+                    if r1 > r0:
+                        bofhip.flash_gemm("R", "N", "N", r1 - r0, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], r0 * n * 4),
+                                          bofhip.FPtr(fds[1], 0), bofhip.FPtr(fds[2], r0 * n * 4), 0, 0, 0, opts)
+                        s1 = bofhip.flash_last_stats()
+                        tot = s1 if tot is None else {q: tot[q] + s1[q] for q in tot}
+                stats_now = tot
+            else:
+                bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                                  bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
+                stats_now = bofhip.flash_last_stats()
             dt = time.perf_counter() - t0
-            runs.append({"seconds": dt, "stats": bofhip.flash_last_stats()})
+            runs.append({"seconds": dt, "stats": stats_now})
             last = rep == total - 1
             if rep == 0 or last:
                 verified = verified and verify()      # every element of the C file

@@ -215,6 +215,88 @@ def test_cfg4_rank0_slab_8192x65536x65536_closed_form(dev):
     bofhip.lib().bof_flash_release()
 
 
+@pytest.mark.parametrize("how", ["eight_rank_calls", "eight_devices_in_process"])
+def test_cfg4_composition_65536_files(dev, tmp_path, how):
+    """BASELINE configs[3] as a COMPOSITION on one GPU, on one shared A / B / C file set (3 x 16 GiB;
+    32768 x 65536 x 65536 when the scratch disk is short): (a) the eight calls the ranks of the 8-GPU run
+    make (bof_dist.row_shard: 8192 C rows each, A and C pointers advanced, all of B), one after the
+    other; (b) ONE call with an in-process device list of eight (device 0 eight times): C panels dealt
+    2 + 2 + ... to the devices, B read once and fanned out.  Either way every element of the whole C file
+    must equal the closed form -- the sharding arithmetic the SCALE run relies on, end to end."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    free = shutil.disk_usage(str(tmp_path)).free
+    if free < 14 * 2**30:
+        pytest.skip("needs at least 12 GiB of scratch disk")
+    n = 65536 if free > 52 * 2**30 else 32768
+    torch.cuda.empty_cache()
+    extra = ["--rank-calls", "8"] if how == "eight_rank_calls" else ["--devices", "0,0,0,0,0,0,0,0"]
+    # (a) from the page cache (B is re-read by every call: 8 x 16 GiB would take a minute from the device)
+    direct = "0" if how == "eight_rank_calls" else "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "flash_e2e.py"), "--dir", str(tmp_path),
+                        "--n", str(n), "--direct", direct, "--reps", "1"] + extra,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    leg = out["buffered"] if direct == "0" else (out["odirect"] if "seconds" in out["odirect"] else out["buffered"])
+    assert leg["whole_C_file_matches_closed_form"] is True
+    st = leg["stats"]
+    tiles = n // 4096
+    assert st["tasks"] == tiles ** 3 and st["bytes_written"] == 4 * n * n
+    if how == "eight_rank_calls":
+        assert st["bytes_read"] == 4 * n * n * (1 + 8)           # A once, B by every rank call
+    else:
+        assert st["bytes_read"] == 2 * 4 * n * n                 # A once, B once for all eight devices
+        assert st["bytes_h2d"] == 4 * n * n * (1 + 8)            # ... and copied to each of them
+        assert len(out["per_device"]) == 8 and all(p["tasks"] == tiles ** 3 // 8 for p in out["per_device"])
+
+
+def test_cfg5_csrgemv_composition_8_shards(dev):
+    """cfg5 size as 8 row shards on one GPU (the per-rank calls of the 8-GPU run, bof_dist.csr_row_shard):
+    'N' -- every shard fills its slice of y; 'T' -- every shard yields a full-length partial and the partials
+    are summed on the device (what the RCCL reduce does); sha256(y) = the reference's known answers."""
+    import bof_dist
+    m = n = 50_000_000
+    npr = 10
+    val = torch.empty(m * npr, dtype=torch.float32, device=dev)
+    col = torch.empty(m * npr, dtype=torch.int64, device=dev)
+    off = torch.empty(m + 1, dtype=torch.int64, device=dev)
+    chunk = 5_000_000
+    for r0 in range(0, m, chunk):
+        bofhip.gen_sparse_rows(r0, chunk, n, npr, ptr(val) + 4 * r0 * npr, ptr(col) + 8 * r0 * npr,
+                               ptr(off) + 8 * r0, stream())
+    x = (torch.arange(n, device=dev) % 10).float()
+    torch.cuda.synchronize()
+    ia = off.cpu().numpy()
+    opts = bofhip.default_options()
+    yn = torch.full((m,), -1.0, dtype=torch.float32, device=dev)
+    yt = torch.zeros(n, dtype=torch.float32, device=dev)
+    part = torch.empty(n, dtype=torch.float32, device=dev)
+    seen = 0
+    for g in range(8):
+        r0, r1 = bof_dist.csr_row_shard(ia, 8, g, 128)
+        assert r0 == seen and r1 > r0
+        seen = r1
+        sl = ia[r0:r1 + 1]                 # absolute offsets, as a row shard of the files has them
+        bofhip.csrgemv_resident("N", r1 - r0, n, ptr(val), sl.ctypes.data, ptr(off) + 8 * r0, ptr(col), ptr(x),
+                                ptr(yn) + 4 * r0, opts, stream())
+        part.fill_(-7.0)                   # 'T' overwrites / zeroes its output itself
+        bofhip.csrgemv_resident("T", r1 - r0, n, ptr(val), sl.ctypes.data, ptr(off) + 8 * r0, ptr(col),
+                                ptr(x) + 4 * r0, ptr(part), opts, stream())
+        yt += part
+    assert seen == m
+    torch.cuda.synchronize()
+    assert sha(yn) == "1c0a44dbb962be0a2d7027f5f298ff94ab5b2ee66c8fe467c0408b286b1881e4"
+    assert sha(yt) == "486766062199bef476611a2675893df3266338c91bfc30db4640ef5dbc2cbf40"
+    del val, col, off, x, yn, yt, part
+    torch.cuda.empty_cache()
+    bofhip.lib().bof_flash_release()
+
+
 def test_cfg2_gemm_random_data_vs_float64(dev):
     """cfg2 size on uniform-random fp32 (integer data cannot expose rounding-order or precision bugs,
     SURVEY 8d): the 512-task tile DAG at 32768^3, then two full tile-rows of C (rows [0, 4096) and

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--budget-gib", type=float, default=0.0,
                     help="HBM budget (0 = library default: most of the free HBM); 8 = the reference's PROGRAM_BUDGET")
+    ap.add_argument("--rank-calls", type=int, default=0,
+                    help="run the W per-rank calls of a W-GPU row-sharded run one after the other (composition check)")
     ap.add_argument("--devices", default="", help="in-process device list, e.g. 0,0 (one GPU playing two devices)")
     ap.add_argument("--pre", default="", help="diagnostic: alloc,resident,dgemm,release stages run first")
     ap.add_argument("--cpu-warm", type=int, default=0,
@@ -82,6 +84,7 @@ def main():
         out = bench.e2e_gemm(bofhip, torch, dev, st, work, args.n, args.blk, None, args.io_threads, args.reps,
                              modes=modes, gemm_path=args.path, io_chunk_mib=args.chunk_mib, n_streams=args.streams,
                              pinned_slots=args.pinned, hbm_budget=int(args.budget_gib * 2**30),
+                             rank_calls=args.rank_calls,
                              **({"devices": [int(x) for x in args.devices.split(",")]} if args.devices else {}))
         out["per_device"] = bofhip.flash_last_device_stats()
     finally:
