@@ -424,6 +424,68 @@ static int strided_io(int fd, bool wr, uint64_t offset, uint64_t stride, uint64_
   return 0;
 }
 
+// ---- unaligned regions of an O_DIRECT file without giving up O_DIRECT ---------------------------------
+// The reference keeps O_DIRECT for leading dimensions that are not multiples of a sector: it reads the
+// sector-aligned superset into a bounce buffer and, for writes, read-modify-writes the first and last
+// sector, ordering overlapping writes of neighbouring tiles (src/file_handles/flash_file_handle.cpp:462-506,
+// 558-716; src/scheduler/io_executor.cpp:28-156).  Here:
+//  * read: the aligned superset goes straight into the caller's (pinned) buffer, *delta tells where the
+//    first requested byte landed; what lies beyond the last whole sector of the FILE (an unaligned file
+//    size) comes through the buffered twin;
+//  * write: the whole PAGES of the region are written with O_DIRECT from the caller's buffer, the partial
+//    first / last page through the buffered twin (then pushed to the device).  A page is therefore never
+//    written by both paths -- the lost-update case the reference's ordering exists for -- and two
+//    neighbours that share an edge page both go through the page cache, which merges byte ranges.
+//    The caller's buffer must hold the region at an address congruent to its file offset modulo the page.
+int file_read_widened(int fd, uint64_t off, uint64_t len, void *buf, uint64_t *delta, bool use_aio) {
+  const uint64_t A = file_dio_align(fd);
+  const uint64_t lo = off / A * A, end = off + len;
+  *delta = off - lo;
+  if (len == 0) return 0;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) return -errno;
+  if ((uint64_t) sb.st_size < end) return -EIO;                     // the region itself ends beyond the file
+  const uint64_t hi_direct = std::min((end + A - 1) / A * A, (uint64_t) sb.st_size / A * A);
+  char *p = static_cast<char *>(buf);
+  if (hi_direct > lo) {
+    const int rc = strided_io(fd, false, lo, 0, 1, hi_direct - lo, p, use_aio);
+    if (rc) return rc;
+  }
+  if (hi_direct < end) {                                             // tail inside the file's last, partial sector
+    const int twin = buffered_twin(fd);
+    if (twin < 0) return -EBADF;
+    const uint64_t from = std::max(hi_direct, off);
+    return rw_full(twin, false, p + (from - lo), end - from, from);
+  }
+  return 0;
+}
+
+int file_write_split(int fd, uint64_t off, uint64_t len, const void *buf, bool use_aio) {
+  if (len == 0) return 0;
+  const uint64_t P = std::max<uint64_t>(4096, file_dio_align(fd));
+  if (reinterpret_cast<uintptr_t>(buf) % P != off % P) return -EINVAL;
+  const uint64_t end = off + len;
+  const uint64_t f0 = std::min((off + P - 1) / P * P, end), f1 = std::max(end / P * P, f0);
+  const char *p = static_cast<const char *>(buf);
+  int rc = 0;
+  if (f1 > f0) rc = strided_io(fd, true, f0, 0, 1, f1 - f0, const_cast<char *>(p + (f0 - off)), use_aio);
+  if (rc || (f0 == off && f1 == end)) return rc;
+  const int twin = buffered_twin(fd);
+  if (twin < 0) return -EBADF;
+  const uint64_t edge[2][2] = {{off, f0}, {f1, end}};
+  for (const auto &e : edge) {
+    if (e[1] <= e[0]) continue;
+    rc = rw_full(twin, true, const_cast<char *>(p + (e[0] - off)), e[1] - e[0], e[0]);
+    if (rc) return rc;
+    // O_DIRECT semantics for the edge as well: on its way to the device before the call returns
+    if (sync_file_range(twin, (off64_t) e[0], (off64_t) (e[1] - e[0]),
+                        SYNC_FILE_RANGE_WAIT_BEFORE | SYNC_FILE_RANGE_WRITE | SYNC_FILE_RANGE_WAIT_AFTER) != 0 &&
+        errno != ENOSYS && errno != EINVAL && errno != ESPIPE)
+      return -errno;
+  }
+  return 0;
+}
+
 int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
                void *buf, bool use_aio) {
   return strided_io(fd, false, offset, stride, n_strides, len, buf, use_aio);

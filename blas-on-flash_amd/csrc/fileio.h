@@ -10,6 +10,11 @@ int file_sread(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uin
                void *buf, bool use_aio);
 int file_swrite(int fd, uint64_t offset, uint64_t stride, uint64_t n_strides, uint64_t len,
                 const void *buf, bool use_aio);
+// unaligned regions of an O_DIRECT descriptor, still through O_DIRECT (see fileio.cpp): the read puts
+// the sector-aligned superset into buf (capacity >= len + 2 * file_dio_align, sector-aligned address) and
+// sets *delta to where byte `off` landed; the write needs buf % page == off % page.
+int file_read_widened(int fd, uint64_t off, uint64_t len, void *buf, uint64_t *delta, bool use_aio);
+int file_write_split(int fd, uint64_t off, uint64_t len, const void *buf, bool use_aio);
 bool file_is_direct(int fd);
 uint64_t file_dio_align(int fd);  // O_DIRECT offset/length alignment of this file (>= 512)
 // a buffered descriptor of the same file (fd itself unless it is O_DIRECT; cached; -1 on failure)

@@ -130,10 +130,30 @@ struct Mat {
   char *tpanel_ptr(int p) const { return (*tslots)[(size_t) slot_of(p)]; }
   bool slot_ready(int p) const { return panel_ptr(p) && (!kmajor_copy || tpanel_ptr(p)); }
   uint64_t file_off(int p) const { return f.foffset + (uint64_t) panels[(size_t) p].r0 * (uint64_t) ld * 4; }
+  // O_DIRECT kept although some request of the call is not sector aligned (an unaligned leading dimension
+  // or file offset, a file whose size is no multiple of a sector): reads fetch the aligned superset, writes
+  // send their whole pages direct and the partial edge pages through the page cache (fileio.cpp).  The
+  // chunks of a panel are then cut at page-aligned FILE positions, so only a panel's two ends have edges.
+  bool widen = false;
+  static constexpr uint64_t kPage = 4096;
+  int n_chunks(int p, size_t chunk) const { return (int) ((panels[(size_t) p].bytes + chunk - 1) / chunk); }
+  // panel-relative [off, off + len) of chunk c
+  void chunk_span(int p, int c, size_t chunk, uint64_t *off, uint64_t *len) const {
+    const uint64_t bytes = panels[(size_t) p].bytes, b0 = file_off(p);
+    const int n = n_chunks(p, chunk);
+    auto start = [&](int i) -> uint64_t {
+      if (i <= 0) return 0;
+      if (i >= n) return bytes;
+      const uint64_t s = (uint64_t) i * chunk;
+      return widen ? std::min(bytes, std::max<uint64_t>((b0 + s) / kPage * kPage, b0) - b0) : s;
+    };
+    *off = start(c);
+    *len = start(c + 1) - *off;
+  }
 };
 
-struct ChunkReq { int di, mat, panel; uint64_t off, bytes; };   // di < 0: a shared panel (every device)
-struct WriteReq { int di, wslot; uint64_t file_off, bytes; int panel; bool last; };
+struct ChunkReq { int di, mat, panel, c; uint64_t off, bytes; };   // di < 0: a shared panel (every device)
+struct WriteReq { int di, wslot; uint64_t file_off, bytes, delta; int panel; bool last; };
 
 // Per device (and per repetition of one ordinal in the device list): the HBM panel slots and the
 // write ring, kept between calls.
@@ -314,7 +334,14 @@ struct PanelHub {
     const int x = R.order[R.next_fetch].first, p = R.order[R.next_fetch].second;
     Mat &M = R.mat[x];
     Panel &P = M.panels[(size_t) p];
-    const int n_chunks = (int) ((P.bytes + R.chunk - 1) / R.chunk);
+    const int n_chunks = M.n_chunks(p, R.chunk);
+    auto push_chunks = [&](int di) {
+      for (int c = 0; c < n_chunks; c++) {
+        uint64_t off, len;
+        M.chunk_span(p, c, R.chunk, &off, &len);
+        fetch_q.push(ChunkReq{di, x, p, c, off, len});
+      }
+    };
     if (M.shared) {
       if (!issued[x][(size_t) p]) {
         for (auto &Q : runs)
@@ -325,10 +352,7 @@ struct PanelHub {
           PQ.state = 1;
           PQ.remaining = n_chunks;
         }
-        for (int c = 0; c < n_chunks; c++) {
-          const uint64_t off = (uint64_t) c * R.chunk;
-          fetch_q.push(ChunkReq{-1, x, p, off, std::min<uint64_t>(R.chunk, P.bytes - off)});
-        }
+        push_chunks(-1);
         cnt.misses++;
       }
       R.next_fetch++;
@@ -339,10 +363,7 @@ struct PanelHub {
     if (!M.slot_ready(p)) return false;
     P.state = 1;
     P.remaining = n_chunks;
-    for (int c = 0; c < n_chunks; c++) {
-      const uint64_t off = (uint64_t) c * R.chunk;
-      fetch_q.push(ChunkReq{R.di, x, p, off, std::min<uint64_t>(R.chunk, P.bytes - off)});
-    }
+    push_chunks(R.di);
     cnt.misses++;
     R.next_fetch++;
     return true;
@@ -401,14 +422,16 @@ void PanelHub::reader_main(int home) {
     int rc = 0;
     ShareSeg *sg = rq.di < 0 && share_world > 1 && seg[rq.mat].base ? &seg[rq.mat] : nullptr;
     const size_t seg_off = (size_t) ((uint64_t) M0.panels[(size_t) rq.panel].r0 * (uint64_t) M0.ld * 4 + rq.off);
-    uint32_t *flag = sg ? sg->flag + sg->first_flag[(size_t) rq.panel] + (size_t) (rq.off / R0.chunk) : nullptr;
+    uint32_t *flag = sg ? sg->flag + sg->first_flag[(size_t) rq.panel] + (size_t) rq.c : nullptr;
     const bool from_peer = sg && rq.panel % share_world != share_rank;
+    uint64_t delta = 0;                 // where the chunk's first byte sits in the pinned slot
+    char *const slot = (char *) rring->ptr(ps);
     if (from_peer) {
       // another rank of the node reads this panel from the file: its chunk, out of the staging segment
       if (!io_error.load()) {
         TraceRange r("panel chunk from a peer");
         const uint32_t v = flag_wait(flag, share_timeout_s, io_error);
-        if (v == 1) memcpy(rring->ptr(ps), sg->base + seg_off, rq.bytes);
+        if (v == 1) memcpy(slot, sg->base + seg_off, rq.bytes);
         else if (!io_error.load()) rc = v == 2 ? -EIO : -ETIMEDOUT;
       }
       if (rc) fail_io(rc);
@@ -416,10 +439,11 @@ void PanelHub::reader_main(int home) {
     } else {
       if (!io_error.load()) {
         TraceRange r("panel chunk read");
-        rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, rring->ptr(ps), M0.aio);
+        if (M0.widen) rc = file_read_widened(M0.fd, M0.file_off(rq.panel) + rq.off, rq.bytes, slot, &delta, M0.aio);
+        else rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, slot, M0.aio);
       }
       if (sg) {   // publish (or tell the peers that it will not come)
-        if (!rc && !io_error.load()) memcpy(sg->base + seg_off, rring->ptr(ps), rq.bytes);
+        if (!rc && !io_error.load()) memcpy(sg->base + seg_off, slot + delta, rq.bytes);
         flag_publish(flag, !rc && !io_error.load() ? 1u : 2u);
       }
       if (rc) fail_io(rc);
@@ -437,7 +461,7 @@ void PanelHub::reader_main(int home) {
         for (hipEvent_t w : M.panels[(size_t) prev].retire_ev)
           if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, w, 0);
       if (e == hipSuccess && !rc)
-        e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, rring->ptr(ps), rq.bytes, hipMemcpyHostToDevice, R.h2d);
+        e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, slot + delta, rq.bytes, hipMemcpyHostToDevice, R.h2d);
       if (e == hipSuccess) (void) rring->mark_busy(ps, R.h2d, R.di);
       cnt.h2d += rq.bytes;
       R.cnt.h2d += rq.bytes;
@@ -479,15 +503,19 @@ void PanelRun::flusher_main() {
     hipError_t e = hipSuccess;
     for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
       if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
-    for (uint64_t off = 0; off < P.bytes && e == hipSuccess && !hub->io_error.load(); off += chunk) {
-      const uint64_t len = std::min<uint64_t>(chunk, P.bytes - off);
+    const int nc = C.n_chunks(pc, chunk);
+    for (int c = 0; c < nc && e == hipSuccess && !hub->io_error.load(); c++) {
+      uint64_t off, len;
+      C.chunk_span(pc, c, chunk, &off, &len);
+      // a widened C panel lands in the pinned slot at its file offset modulo the page (file_write_split)
+      const uint64_t delta = C.widen ? (C.file_off(pc) + off) % Mat::kPage : 0;
       const int ws = res->wring.acquire();
-      e = hipMemcpyAsync(res->wring.ptr(ws), C.panel_ptr(pc) + off, len, hipMemcpyDeviceToHost, d2h);
+      e = hipMemcpyAsync((char *) res->wring.ptr(ws) + delta, C.panel_ptr(pc) + off, len, hipMemcpyDeviceToHost, d2h);
       if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
       if (e != hipSuccess) { res->wring.release(ws); break; }
       cnt.d2h += len;
       hub->cnt.d2h += len;
-      hub->write_q.push(WriteReq{di, ws, C.file_off(pc) + off, len, pc, off + len >= P.bytes});
+      hub->write_q.push(WriteReq{di, ws, C.file_off(pc) + off, len, delta, pc, c == nc - 1});
     }
     if (e == hipSuccess) e = hipEventRecord(P.d2h_done, d2h);
     if (e != hipSuccess) hub->fail_io(-1000 - (int) e);
@@ -514,7 +542,10 @@ void PanelHub::writer_main(int home) {
     int rc = 0;
     if (!io_error.load()) {
       TraceRange r("panel chunk write");
-      rc = file_swrite(R.mat[2].fd, rq.file_off, 0, 1, rq.bytes, R.res->wring.ptr(rq.wslot), R.mat[2].aio);
+      if (R.mat[2].widen)
+        rc = file_write_split(R.mat[2].fd, rq.file_off, rq.bytes, (char *) R.res->wring.ptr(rq.wslot) + rq.delta, R.mat[2].aio);
+      else
+        rc = file_swrite(R.mat[2].fd, rq.file_off, 0, 1, rq.bytes, R.res->wring.ptr(rq.wslot), R.mat[2].aio);
     }
     if (rc) fail_io(rc);
     cnt.wr += rq.bytes;
@@ -537,10 +568,14 @@ bool requests_aligned(const Mat &M, size_t chunk) {
 void pick_descriptor(Mat &M, bool aligned, bool use_odirect) {
   M.fd = M.f.fd;
   M.aio = false;
+  M.widen = false;
   if (file_is_direct(M.f.fd)) {
     if (aligned && use_odirect) M.aio = true;
     else if (aligned) M.aio = false;               // direct descriptor, synchronous requests
-    else M.fd = file_buffered_fd(M.f.fd);
+    else if (use_odirect && file_dio_align(M.f.fd) <= Mat::kPage && env_long("BOF_UNALIGNED_DIRECT", 1) != 0) {
+      M.aio = true;                                // O_DIRECT kept: widened reads, page-split writes
+      M.widen = true;
+    } else M.fd = file_buffered_fd(M.f.fd);
   }
 }
 
@@ -735,7 +770,7 @@ int PanelRun::prepare() {
       BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       v.push_back(e);
     }
-  const int rc = res->wring.init(std::max(2, o.pinned_slots), chunk);
+  const int rc = res->wring.init(std::max(2, o.pinned_slots), chunk + 2 * Mat::kPage);   // slack: widened / page-congruent placement
   if (rc) return rc;
   BOF_HIP_TRY(copy_stream_create(&h2d));
   BOF_HIP_TRY(copy_stream_create(&d2h));
@@ -1011,7 +1046,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     H.rring = g_rring;
   }
   // a chunk copied to D devices stays in its slot until the slowest copy is done: two more slots per extra device
-  int rc = H.rring->init(std::max(2, o.pinned_slots) + 2 * ((int) H.runs.size() - 1), H.runs[0]->chunk, &used);
+  int rc = H.rring->init(std::max(2, o.pinned_slots) + 2 * ((int) H.runs.size() - 1), H.runs[0]->chunk + 2 * Mat::kPage, &used);
   if (rc) return rc;
   H.trace("rings/streams ready");
 

@@ -86,7 +86,7 @@ def main():
                              pinned_slots=args.pinned, hbm_budget=int(args.budget_gib * 2**30),
                              rank_calls=args.rank_calls,
                              **({"devices": [int(x) for x in args.devices.split(",")]} if args.devices else {}))
-        out["per_device"] = bofhip.flash_last_device_stats()
+
     finally:
         shutil.rmtree(work, ignore_errors=True)
     out["args"] = vars(args)
