@@ -100,6 +100,7 @@ struct Tile {
   int state = 0;                     // 0 absent, 1 fetch queued, 2 usable (guarded by mu)
   bool pinned_c = false;             // C accumulator in the middle of its chain
   std::vector<hipEvent_t> launch_waits;  // events the first kernel must wait for (no-fetch alloc)
+  int rb = 0, cb = 0;                // block row / block column of the STORED matrix
 };
 
 struct DevSlot {
@@ -121,8 +122,25 @@ struct GemmResources {
 static std::mutex g_res_mu;
 static GemmResources *g_res[64];
 
-struct FetchReq { int tile; int slot; std::vector<hipEvent_t> waits; };
-struct WriteReq { int wslot; int tile; };
+// I/O unit of the tile cache: a ROW GROUP -- up to kMaxGroup horizontally adjacent tiles of one block
+// row of a stored matrix.  Its rows are wide, contiguous file extents (the whole stored row when the
+// group spans the matrix: then a chunk of rows is ONE contiguous extent), so the requests are
+// group-width x rows instead of the reference's 16 KiB tile rows (one iocb per tile row,
+// src/file_handles/flash_file_handle.cpp:444-460: 8.4 GB/s on the box's NVMe against 19 GB/s for
+// requests of a MiB and more); a chunk of rows lands in one pinned slot and is scattered into the
+// packed tile slots by 2-D copies (53 GB/s, profiles/r2/iobench_*), C row groups take the way back.
+// The HBM side is untouched: packed tiles, Belady replacement tile by tile.
+constexpr int kMaxGroup = 16;
+struct RowGroup {
+  int mat = 0;
+  std::vector<int> tiles, slots;            // ascending block column
+  std::vector<std::vector<hipEvent_t>> waits;   // per tile: WAR events of its slot's previous occupant
+  int64_t nrows = 0, width = 0, col0 = 0;   // rows of the block row; elements per group row; first stored column
+  int64_t rows_per_chunk = 0;
+  int remaining = 0;                        // chunks whose copies are not enqueued yet (guarded by mu)
+};
+struct FetchReq { RowGroup *grp; int64_t r0, nr; };
+struct WriteReq { int wslot; uint64_t file_off, stride, nrows, len; };
 
 // ---- schedule construction and slot replacement: pure host logic, shared by the real
 // ---- pipeline and by bof_flash_gemm_simulate (so the policy is testable without a GPU)
@@ -139,10 +157,12 @@ static void build_tiles(const GemmGeometry &g, float beta, std::vector<Tile> &ti
         gemm_task_at(g, l, i, j, beta, &t);
         const int ids[3] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
                             (int) (Nm * Nk + Nk * Nn + i * Nn + j)};
+        const int64_t idx[3] = {i, l, j};
         for (int x = 0; x < 3; x++) {
           Tile &T = tiles[ids[x]];
           T.mat = x; T.off = t.off[x]; T.nrows = t.nrows[x]; T.ncols = t.ncols[x];
           T.ld = t.ld_file[x];
+          T.rb = (int) idx[g.rdim[x]]; T.cb = (int) idx[g.cdim[x]];
           max_tile = std::max(max_tile, tile_bytes_of(T));
         }
       }
@@ -168,22 +188,28 @@ static void build_order(const GemmGeometry &g, float beta, int64_t n_slots, std:
     const int64_t fit = (n_slots - Nk * Nn) / (Nn + 2);
     gi = std::max<int64_t>(1, std::min(fit, (Nm + 7) / 8));
   }
+  // inside a block and a k step the tiles of one STORED row of C follow each other (row-major C: j inner;
+  // column-major C: i inner), so finished C tiles leave as row groups and the operand that runs along
+  // that row is requested tile after adjacent tile
+  const bool c_rows_along_m = g.rdim[2] == 0;
   for (int64_t I0 = 0; I0 < Nm; I0 += gi)
     for (int64_t J0 = 0; J0 < Nn; J0 += gj)
-      for (int64_t l = 0; l < Nk; l++)
-        for (int64_t i = I0; i < std::min(I0 + gi, Nm); i++)
-          for (int64_t j = J0; j < std::min(J0 + gj, Nn); j++) {
-            bof_gemm_task t;
-            gemm_task_at(g, l, i, j, beta, &t);
-            const int pos = (int) tasks.size();
-            tasks.push_back(t);
-            const int ids[3] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
-                                (int) (Nm * Nk + Nk * Nn + i * Nn + j)};
-            for (int x = 0; x < 3; x++) {
-              task_tiles.push_back(ids[x]);
-              tiles[ids[x]].uses.push_back(pos);
-            }
+      for (int64_t l = 0; l < Nk; l++) {
+        const int64_t ni = std::min(I0 + gi, Nm) - I0, nj = std::min(J0 + gj, Nn) - J0;
+        for (int64_t q = 0; q < ni * nj; q++) {
+          const int64_t i = I0 + (c_rows_along_m ? q / nj : q % ni), j = J0 + (c_rows_along_m ? q % nj : q / ni);
+          bof_gemm_task t;
+          gemm_task_at(g, l, i, j, beta, &t);
+          const int pos = (int) tasks.size();
+          tasks.push_back(t);
+          const int ids[3] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
+                              (int) (Nm * Nk + Nk * Nn + i * Nn + j)};
+          for (int x = 0; x < 3; x++) {
+            task_tiles.push_back(ids[x]);
+            tiles[ids[x]].uses.push_back(pos);
           }
+        }
+      }
 }
 
 // A slot for a tile that is not resident: a free one, else the resident, idle tile whose
@@ -216,6 +242,58 @@ static int claim_slot(std::vector<Tile> &tiles, std::vector<int> &slot_tile, std
   return sl;
 }
 
+// tile id of the tile at stored block (rb, cb) of matrix `mat`, or -1
+static int tile_at(const GemmGeometry &g, int mat, int rb, int cb) {
+  const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
+  int64_t idx[3] = {0, 0, 0};
+  if (rb < 0 || cb < 0 || rb >= g.nblk[g.rdim[mat]] || cb >= g.nblk[g.cdim[mat]]) return -1;
+  idx[g.rdim[mat]] = rb;
+  idx[g.cdim[mat]] = cb;
+  if (mat == 0) return (int) (idx[0] * Nk + idx[1]);
+  if (mat == 1) return (int) (Nm * Nk + idx[1] * Nn + idx[2]);
+  return (int) (Nm * Nk + Nk * Nn + idx[0] * Nn + idx[2]);
+}
+
+// The row group fetched together with tile `tid`: its absent, still-needed neighbours in the same block
+// row, as many as fit into slots that are FREE or hold DEAD tiles (no use left) beyond a small reserve --
+// a prefetch never costs a live tile its slot.  C tiles join only when they have to be read (beta != 0,
+// chain not started).  Pure host logic: shared with bof_flash_gemm_simulate.
+static void select_row_group(const GemmGeometry &g, const std::vector<Tile> &tiles, const std::vector<int> &slot_tile,
+                             const std::vector<int> &free_slots, int tid, int max_group, int64_t reach,
+                             std::vector<int> &out) {
+  out.assign(1, tid);
+  if (max_group <= 1) return;
+  // a neighbour is read ahead only if its next use lies within `reach` tasks of this tile's: under a
+  // tight budget a tile wanted much later would be the replacement policy's next victim (farthest next
+  // use) and be read twice
+  const int64_t now = tiles[tid].next_use < tiles[tid].uses.size() ? tiles[tid].uses[tiles[tid].next_use] : 0;
+  int64_t spare = (int64_t) free_slots.size() - 4;     // this task's own tiles come first
+  for (int ot : slot_tile)
+    if (ot >= 0 && tiles[ot].state == 2 && !tiles[ot].pinned_c && tiles[ot].next_use >= tiles[ot].uses.size()) spare++;
+  const Tile &T = tiles[tid];
+  auto eligible = [&](int id) {
+    if (id < 0) return false;
+    const Tile &S = tiles[id];
+    if (S.slot >= 0 || S.state != 0 || S.next_use >= S.uses.size()) return false;
+    if (S.mat == 2 && S.next_use != 0) return false;     // a chain that has started holds its tile already
+    return (int64_t) S.uses[S.next_use] - now <= reach;
+  };
+  for (int step = 1; (int64_t) out.size() <= spare && (int) out.size() < max_group; step++) {   // to the right ...
+    const int id = tile_at(g, T.mat, T.rb, T.cb + step);
+    if (!eligible(id)) break;
+    out.push_back(id);
+  }
+  for (int step = 1; (int64_t) out.size() <= spare && (int) out.size() < max_group; step++) {   // ... then to the left
+    const int id = tile_at(g, T.mat, T.rb, T.cb - step);
+    if (!eligible(id)) break;
+    out.insert(out.begin(), id);
+  }
+}
+
+static int tile_group_max() {
+  const long v = env_long("BOF_TILE_GROUP", kMaxGroup);      // 1: one tile per request, as the reference reads
+  return (int) std::max<long>(1, std::min<long>(v, kMaxGroup));
+}
 
 struct GemmRun {
   bof_options o;
@@ -262,31 +340,53 @@ struct GemmRun {
     cv.notify_all();
   }
 
+  // file -> pinned slot (a chunk of the group's rows, group-wide) -> 2-D copies into the packed tile slots
   void reader_main() {
     (void) hipSetDevice(dev);
     (void) bind_thread_near_device(dev);
     FetchReq rq;
     while (fetch_q.pop(rq)) {
-      Tile &t = tiles[rq.tile];
+      RowGroup &G = *rq.grp;
+      const Tile &t0 = tiles[G.tiles[0]];
       const int ps = res->rring.acquire();
+      const uint64_t row_bytes = (uint64_t) G.width * 4, bytes = row_bytes * (uint64_t) rq.nr;
       int rc = 0;
       if (!io_error.load())
-        rc = file_sread(fd_io[t.mat], f[t.mat].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
-                        (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->rring.ptr(ps), aio_io[t.mat]);
+        rc = file_sread(fd_io[G.mat], f[G.mat].foffset + ((uint64_t) t0.off + (uint64_t) rq.r0 * (uint64_t) t0.ld) * 4,
+                        (uint64_t) t0.ld * 4, (uint64_t) rq.nr, row_bytes, res->rring.ptr(ps), aio_io[G.mat]);
       if (rc) fail_io(rc);
-      cnt.rd += tile_bytes(t);
-      DevSlot &s = slots[rq.slot];
+      cnt.rd += bytes;
       hipError_t e = hipSuccess;
-      for (hipEvent_t w : rq.waits)  // WAR: previous occupant's kernels / write-back
-        if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(s.ptr, res->rring.ptr(ps), tile_bytes(t), hipMemcpyHostToDevice, h2d);
-      if (e == hipSuccess) e = hipEventRecord(s.ready, h2d);
+      int64_t col = 0;
+      for (size_t q = 0; q < G.tiles.size() && e == hipSuccess; q++) {
+        const Tile &t = tiles[G.tiles[q]];
+        DevSlot &s = slots[G.slots[q]];
+        for (hipEvent_t w : G.waits[q])  // WAR: previous occupant's kernels / write-back (every chunk: cheap, order-free)
+          if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
+        const size_t tw = (size_t) t.ncols * 4;
+        if (e == hipSuccess && !rc)
+          e = hipMemcpy2DAsync(s.ptr + (size_t) rq.r0 * tw, tw, (const char *) res->rring.ptr(ps) + (size_t) col * 4,
+                               (size_t) row_bytes, tw, (size_t) rq.nr, hipMemcpyHostToDevice, h2d);
+        col += t.ncols;
+      }
       if (e == hipSuccess) res->rring.mark_busy(ps, h2d);
-      if (e != hipSuccess) fail_io(-1000 - (int) e);
-      cnt.h2d += tile_bytes(t);
+      cnt.h2d += bytes;
       res->rring.release(ps);
-      { std::lock_guard<std::mutex> lk(mu); t.state = 2; }
+      bool last = false;
+      {
+        // every chunk's copies are enqueued before its decrement: whoever reaches zero records the tiles'
+        // `ready` events behind all of them
+        std::lock_guard<std::mutex> lk(mu);
+        if (--G.remaining == 0) {
+          last = true;
+          for (size_t q = 0; q < G.tiles.size(); q++) {
+            if (e == hipSuccess) e = hipEventRecord(slots[G.slots[q]].ready, h2d);
+            tiles[G.tiles[q]].state = 2;
+          }
+        }
+      }
+      if (e != hipSuccess) fail_io(-1000 - (int) e);
+      if (last) delete &G;
       cv.notify_all();
     }
   }
@@ -296,44 +396,140 @@ struct GemmRun {
     (void) bind_thread_near_device(dev);
     WriteReq rq;
     while (write_q.pop(rq)) {
-      Tile &t = tiles[rq.tile];
       hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
       if (e != hipSuccess) fail_io(-1000 - (int) e);
       int rc = 0;
       if (!io_error.load())
-        rc = file_swrite(fd_io[2], f[2].foffset + (uint64_t) t.off * 4, (uint64_t) t.ld * 4,
-                         (uint64_t) t.nrows, (uint64_t) t.ncols * 4, res->wring.ptr(rq.wslot), aio_io[2]);
+        rc = file_swrite(fd_io[2], rq.file_off, rq.stride, rq.nrows, rq.len, res->wring.ptr(rq.wslot), aio_io[2]);
       if (rc) fail_io(rc);
-      cnt.wr += tile_bytes(t);
+      cnt.wr += rq.nrows * rq.len;
       res->wring.release(rq.wslot);
     }
   }
 
-  // Find a device slot for `tid`; tiles needed by tasks in [launch_pos, horizon] are
-  // not evictable.  Returns false when nothing can be evicted right now.
-  bool make_resident(int tid, int launch_pos, int horizon, bool fetch) {
-    Tile &t = tiles[tid];
-    if (t.slot >= 0) { cnt.hits++; return true; }
+  // a slot for `tid`, with the events of its previous occupant; -1 when nothing can be evicted right now
+  int take_slot(int tid, int horizon, std::vector<hipEvent_t> &waits) {
     const int sl = claim_slot(tiles, slot_tile, free_slots, horizon);
-    if (sl < 0) return false;
-    (void) launch_pos;
+    if (sl < 0) return -1;
     cnt.misses++;
     DevSlot &s = slots[sl];
-    std::vector<hipEvent_t> waits;
     for (int q = 0; q <= kMaxStreams; q++)
       if (s.used[q]) { waits.push_back(s.use[q]); s.used[q] = false; }
     s.tile = tid;
     slot_tile[sl] = tid;
-    t.slot = sl;
-    if (fetch) {
-      t.state = 1;
-      fetch_q.push(FetchReq{tid, sl, waits});
-    } else {
+    tiles[tid].slot = sl;
+    return sl;
+  }
+
+  // Find a device slot for `tid`; tiles needed by tasks up to `horizon` are not evictable.  With `fetch`
+  // the tile's row group (select_row_group) is read with it.  Returns false when nothing can be evicted
+  // right now.  Caller holds mu.
+  bool make_resident(int tid, int horizon, bool fetch) {
+    Tile &t = tiles[tid];
+    if (t.slot >= 0) { cnt.hits++; return true; }
+    if (!fetch) {
+      std::vector<hipEvent_t> waits;
+      if (take_slot(tid, horizon, waits) < 0) return false;
       t.state = 2;
       t.launch_waits = waits;
+      return true;
+    }
+    std::vector<int> want;
+    select_row_group(g, tiles, slot_tile, free_slots, tid, group_max, group_reach, want);
+    // the tile itself first (if even that fails nothing has changed), then its neighbours outwards; the
+    // selection only counts free and dead slots, so their claims do not fail -- if one does, the group ends there
+    std::vector<hipEvent_t> w0;
+    if (take_slot(tid, horizon, w0) < 0) return false;
+    RowGroup *G = new RowGroup();
+    G->mat = t.mat;
+    const size_t at = (size_t) (std::find(want.begin(), want.end(), tid) - want.begin());
+    std::vector<std::pair<int, std::vector<hipEvent_t>>> left, right;     // (tile, waits)
+    for (size_t q = at + 1; q < want.size(); q++) {
+      std::vector<hipEvent_t> w;
+      if (take_slot(want[q], horizon, w) < 0) break;
+      right.emplace_back(want[q], w);
+    }
+    for (size_t q = at; q-- > 0;) {
+      std::vector<hipEvent_t> w;
+      if (take_slot(want[q], horizon, w) < 0) break;
+      left.emplace_back(want[q], w);
+    }
+    auto add = [&](int id, const std::vector<hipEvent_t> &w) {
+      tiles[id].state = 1;
+      if (tiles[id].mat == 2) tiles[id].pinned_c = true;    // its chain is about to start: not evictable
+      G->tiles.push_back(id); G->slots.push_back(tiles[id].slot); G->waits.push_back(w);
+    };
+    for (size_t q = left.size(); q-- > 0;) add(left[q].first, left[q].second);
+    add(tid, w0);
+    for (auto &r : right) add(r.first, r.second);
+    const Tile &first = tiles[G->tiles.front()], &lastt = tiles[G->tiles.back()];
+    G->nrows = t.nrows;
+    G->col0 = first.off;
+    G->width = (lastt.off - first.off) + lastt.ncols;        // adjacent tiles of one block row: contiguous columns
+    G->rows_per_chunk = std::max<int64_t>(1, (int64_t) (res->rring.bytes / ((size_t) G->width * 4)));
+    const int64_t n_chunks = (G->nrows + G->rows_per_chunk - 1) / G->rows_per_chunk;
+    G->remaining = (int) n_chunks;
+    for (int64_t c = 0; c < n_chunks; c++) {
+      const int64_t r0 = c * G->rows_per_chunk;
+      fetch_q.push(FetchReq{G, r0, std::min(G->rows_per_chunk, G->nrows - r0)});
     }
     return true;
   }
+
+  // ---- write-back of finished C tiles, a row group at a time --------------------------------------------
+  std::vector<int> wgroup;              // finished, adjacent C tiles of one block row, not flushed yet
+  std::vector<int> wgroup_stream;       // the compute stream each one's last task ran on
+  hipError_t flush_wgroup() {
+    if (wgroup.empty()) return hipSuccess;
+    const Tile &first = tiles[wgroup.front()], &lastt = tiles[wgroup.back()];
+    const int64_t width = (lastt.off - first.off) + lastt.ncols, nrows = first.nrows;
+    const int64_t rpc = std::max<int64_t>(1, (int64_t) (res->wring.bytes / ((size_t) width * 4)));
+    hipError_t e = hipSuccess;
+    for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++)
+      e = hipStreamWaitEvent(d2h, slots[tiles[wgroup[q]].slot].use[wgroup_stream[q]], 0);
+    for (int64_t r0 = 0; r0 < nrows && e == hipSuccess; r0 += rpc) {
+      const int64_t nr = std::min(rpc, nrows - r0);
+      const int ws = res->wring.acquire();
+      int64_t col = 0;
+      for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++) {
+        const Tile &t = tiles[wgroup[q]];
+        const size_t tw = (size_t) t.ncols * 4;
+        e = hipMemcpy2DAsync((char *) res->wring.ptr(ws) + (size_t) col * 4, (size_t) width * 4,
+                             slots[t.slot].ptr + (size_t) r0 * tw, tw, tw, (size_t) nr, hipMemcpyDeviceToHost, d2h);
+        col += t.ncols;
+      }
+      if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
+      if (e != hipSuccess) { res->wring.release(ws); break; }
+      cnt.d2h += (uint64_t) nr * (uint64_t) width * 4;
+      write_q.push(WriteReq{ws, f[2].foffset + ((uint64_t) first.off + (uint64_t) r0 * (uint64_t) first.ld) * 4,
+                            (uint64_t) first.ld * 4, (uint64_t) nr, (uint64_t) width * 4});
+    }
+    for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++) {
+      DevSlot &sc = slots[tiles[wgroup[q]].slot];
+      e = hipEventRecord(sc.use[kMaxStreams], d2h);
+      sc.used[kMaxStreams] = true;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (int id : wgroup) tiles[id].pinned_c = false;      // written back (queued): evictable from now on
+    }
+    wgroup.clear();
+    wgroup_stream.clear();
+    return e;
+  }
+  // a chain has finished on stream `sidx`: its C tile joins the row group being collected
+  hipError_t finish_c_tile(int tid, int sidx) {
+    hipError_t e = hipSuccess;
+    if (!wgroup.empty()) {
+      const Tile &b = tiles[wgroup.back()], &t = tiles[tid];
+      if (t.rb != b.rb || t.cb != b.cb + 1 || (int) wgroup.size() >= group_max) e = flush_wgroup();
+    }
+    wgroup.push_back(tid);
+    wgroup_stream.push_back(sidx);
+    return e;
+  }
+  int group_max = kMaxGroup;
+  int64_t group_reach = INT64_MAX;     // how many tasks ahead a neighbour's next use may lie (select_row_group)
 };
 
 }  // namespace
@@ -350,6 +546,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
   R.f[0] = fa; R.f[1] = fb; R.f[2] = fc;
   R.use_aio = R.o.use_odirect != 0;
+  R.group_max = tile_group_max();
   BOF_HIP_TRY(hipGetDevice(&R.dev));
   R.g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, R.o.gemm_blk);
   const GemmGeometry &g = R.g;
@@ -406,6 +603,8 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   n_slots = std::min<int64_t>(n_slots, (int64_t) R.tiles.size());
   int64_t gi, gj;
   build_order(g, beta, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
+  // everything resident: read ahead freely; else at most two k steps of the current C block
+  R.group_reach = n_slots >= (int64_t) R.tiles.size() ? INT64_MAX : 2 * gi * gj;
   const int T = (int) R.tasks.size();
 
   // ---- resources ----------------------------------------------------------------------
@@ -474,18 +673,25 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       while (fetch_pos < T && fetch_pos <= t + lookahead) {
         const bof_gemm_task &ft = R.tasks[fetch_pos];
         const int *ids = &R.task_tiles[(size_t) fetch_pos * 3];
-        bool ok = R.make_resident(ids[0], t, fetch_pos, true) &&
-                  R.make_resident(ids[1], t, fetch_pos, true);
+        bool ok = R.make_resident(ids[0], fetch_pos, true) &&
+                  R.make_resident(ids[1], fetch_pos, true);
         if (ok) {
           Tile &C = R.tiles[ids[2]];
           if (C.slot < 0) {
-            ok = R.make_resident(ids[2], t, fetch_pos, ft.beta != 0.0f);
+            ok = R.make_resident(ids[2], fetch_pos, ft.beta != 0.0f);
             if (ok) C.pinned_c = true;
           }
         }
         if (!ok) break;
         fetch_pos++;
       }
+    }
+    if (fetch_pos <= t && !R.wgroup.empty()) {
+      // finished C tiles waiting for their row group hold slots: write them back and look again
+      herr = R.flush_wgroup();
+      if (herr != hipSuccess) break;
+      t--;
+      continue;
     }
     if (fetch_pos <= t) {
       set_error("bof_flash_gemm: HBM tile budget too small for one task's working set");
@@ -536,22 +742,17 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       std::lock_guard<std::mutex> lk(R.mu);
       for (int x = 0; x < 3; x++) R.tiles[ids[x]].next_use++;
     }
-    if (tk.l == Nk - 1) {  // chain finished: write the C tile back, then it becomes evictable
-      Tile &C = R.tiles[ids[2]];
-      const int ws = R.res->wring.acquire();
-      herr = hipStreamWaitEvent(R.d2h, sc.use[sidx], 0);
-      if (herr == hipSuccess)
-        herr = hipMemcpyAsync(R.res->wring.ptr(ws), sc.ptr, R.tile_bytes(C), hipMemcpyDeviceToHost, R.d2h);
-      if (herr == hipSuccess) herr = hipEventRecord(R.res->wring.event(ws), R.d2h);
-      if (herr == hipSuccess) herr = hipEventRecord(sc.use[kMaxStreams], R.d2h);
+    if (tk.l == Nk - 1) {  // chain finished: the C tile joins its row group; written back, it becomes evictable
+      herr = R.finish_c_tile(ids[2], sidx);
       if (herr != hipSuccess) break;
-      sc.used[kMaxStreams] = true;
-      R.cnt.d2h += R.tile_bytes(C);
-      R.write_q.push(WriteReq{ws, ids[2]});
-      std::lock_guard<std::mutex> lk(R.mu);
-      C.pinned_c = false;
+      // the last chain of this block row in the current super-block: nothing more will join
+      const bool row_done = t + 1 >= T || R.tasks[t + 1].l != Nk - 1 ||
+                            R.tiles[R.task_tiles[(size_t) (t + 1) * 3 + 2]].rb != R.tiles[ids[2]].rb;
+      if (row_done) herr = R.flush_wgroup();
+      if (herr != hipSuccess) break;
     }
   }
+  if (herr == hipSuccess && !fail) herr = R.flush_wgroup();
 
   // ---- drain ---------------------------------------------------------------------------
   BOF_TRACE_T("all tasks dispatched");
@@ -757,20 +958,38 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
   n_slots = std::min<int64_t>(n_slots, (int64_t) tiles.size());
   int64_t gi, gj;
   build_order(g, beta, n_slots, tiles, tasks, task_tiles, gi, gj);
+  const int64_t group_reach = n_slots >= (int64_t) tiles.size() ? INT64_MAX : 2 * gi * gj;
   std::vector<int> slot_tile((size_t) n_slots, -1), free_slots;
   for (int64_t s = 0; s < n_slots; s++) free_slots.push_back((int) (n_slots - 1 - s));
   const int T = (int) tasks.size();
   int fetch_pos = 0;
-  auto resident = [&](int tid, int horizon, bool fetch) {
-    Tile &t = tiles[tid];
-    if (t.slot >= 0) { out->tile_hits++; return true; }
+  auto take = [&](int tid, int horizon, bool fetch) {
     const int sl = claim_slot(tiles, slot_tile, free_slots, horizon);
     if (sl < 0) return false;
     out->tile_misses++;
     slot_tile[sl] = tid;
-    t.slot = sl;
-    t.state = 2;  // I/O completes instantly in the simulation
-    if (fetch) out->bytes_read += tile_bytes_of(t);
+    tiles[tid].slot = sl;
+    tiles[tid].state = 2;  // I/O completes instantly in the simulation
+    if (fetch) out->bytes_read += tile_bytes_of(tiles[tid]);
+    return true;
+  };
+  const int group_max = tile_group_max();
+  auto resident = [&](int tid, int horizon, bool fetch) {   // GemmRun::make_resident without the I/O
+    Tile &t = tiles[tid];
+    if (t.slot >= 0) { out->tile_hits++; return true; }
+    if (!fetch) return take(tid, horizon, false);
+    std::vector<int> want;
+    select_row_group(g, tiles, slot_tile, free_slots, tid, group_max, group_reach, want);
+    if (!take(tid, horizon, true)) return false;
+    const size_t at = (size_t) (std::find(want.begin(), want.end(), tid) - want.begin());
+    for (size_t q = at + 1; q < want.size(); q++) {
+      if (!take(want[q], horizon, true)) break;
+      if (tiles[want[q]].mat == 2) tiles[want[q]].pinned_c = true;
+    }
+    for (size_t q = at; q-- > 0;) {
+      if (!take(want[q], horizon, true)) break;
+      if (tiles[want[q]].mat == 2) tiles[want[q]].pinned_c = true;
+    }
     return true;
   };
   for (int t = 0; t < T; t++) {
