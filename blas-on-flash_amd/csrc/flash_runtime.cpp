@@ -290,6 +290,13 @@ static void select_row_group(const GemmGeometry &g, const std::vector<Tile> &til
   }
 }
 
+static int64_t group_reach_of(const GemmGeometry &g, int64_t n_slots, int64_t n_tiles, int64_t gi, int64_t gj) {
+  if (n_slots >= n_tiles) return INT64_MAX;
+  const int64_t Nk = g.nblk[1], Nn = g.nblk[2];
+  const bool b_resident = !(Nk * Nn + Nn + 2 > n_slots || g.nblk[0] == 1);     // build_order's branches
+  return b_resident ? Nk * gi * gj : 2 * gi * gj;
+}
+
 static int tile_group_max() {
   const long v = env_long("BOF_TILE_GROUP", kMaxGroup);      // 1: one tile per request, as the reference reads
   return (int) std::max<long>(1, std::min<long>(v, kMaxGroup));
@@ -604,7 +611,9 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   int64_t gi, gj;
   build_order(g, beta, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
   // everything resident: read ahead freely; else at most two k steps of the current C block
-  R.group_reach = n_slots >= (int64_t) R.tiles.size() ? INT64_MAX : 2 * gi * gj;
+  // (with B resident beside a row block of C -- build_order's second branch -- the A tiles of the block's
+  //  rows are all used within the block: the whole block is within reach)
+  R.group_reach = group_reach_of(g, n_slots, (int64_t) R.tiles.size(), gi, gj);
   const int T = (int) R.tasks.size();
 
   // ---- resources ----------------------------------------------------------------------
@@ -958,7 +967,7 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
   n_slots = std::min<int64_t>(n_slots, (int64_t) tiles.size());
   int64_t gi, gj;
   build_order(g, beta, n_slots, tiles, tasks, task_tiles, gi, gj);
-  const int64_t group_reach = n_slots >= (int64_t) tiles.size() ? INT64_MAX : 2 * gi * gj;
+  const int64_t group_reach = group_reach_of(g, n_slots, (int64_t) tiles.size(), gi, gj);
   std::vector<int> slot_tile((size_t) n_slots, -1), free_slots;
   for (int64_t s = 0; s < n_slots; s++) free_slots.push_back((int) (n_slots - 1 - s));
   const int T = (int) tasks.size();
