@@ -103,6 +103,10 @@ StreamSet *stream_set(int n_streams) {
 }
 
 static bool flag_ok(char c, char a, char b) { return c == a || c == b; }
+static bool env_fuse_tasks() {
+  const char *e = getenv("BOF_GEMM_FUSE_TASKS");
+  return !e || atoi(e) != 0;
+}
 
 // ---- grow-only device scratch, per device -----------------------------------------
 struct Scratch { void *p = nullptr; size_t bytes = 0; };
@@ -334,6 +338,15 @@ static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, 
   if (g.nblk[1] == 0) {  // k == 0: C = beta*C through a single degenerate pass
     // (kmeans: nothing to do, C stays -- the reference's tiler divides by zero for k = 0, kmeans.cpp:52, 76-77)
     if (!kv) BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, 0, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], ss->s[0]));
+    return ss->join(parent);
+  }
+  // One k block = no accumulate chains: the tile tasks are independent and every output element is one
+  // k-ordered chain whatever tile it falls into, so the DAG is ONE launch over the whole matrix -- the
+  // short-K kernel then runs persistent over ~128 tiles per workgroup instead of one 256-tile launch per
+  // task (flash::kmeans: k = the point dimension).  Bit-identical to the task-by-task launches
+  // (BOF_GEMM_FUSE_TASKS=0 keeps those).
+  if (g.nblk[1] == 1 && g.nblk[0] * g.nblk[2] > 1 && m <= INT32_MAX && n <= INT32_MAX && env_fuse_tasks()) {
+    BOF_HIP_TRY(tile_sgemm(ord, ta, tb, m, n, k, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], kv, 0, 0, ss->s[0]));
     return ss->join(parent);
   }
   bof_gemm_task t;

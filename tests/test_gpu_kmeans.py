@@ -60,6 +60,30 @@ def test_kmeans_task_vs_oracle_all_layouts(dev, ord_, ta, tb, m, n, k, alpha, be
     assert np.array_equal(got, ref.reshape(sc))
 
 
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+@pytest.mark.parametrize("m,n,k,alpha,beta", [(4096, 4096, 256, -2.0, 0.0), (2048, 8192, 96, 1.5, 0.5)])
+def test_short_k_stream_kernel_vs_oracle(dev, ord_, ta, tb, m, n, k, alpha, beta):
+    """K < 512 with >= 1024 aligned 128 x 128 tiles: the persistent short-K kernel (sgemm_stream_kernel: the
+    slab pipeline runs across tile boundaries, a workgroup walks a run of tiles), all 8 layouts, with the
+    kmeans store (non-constant `ones`) and as a plain sgemm; bit-exact against the oracle's k-ordered chains."""
+    rng = np.random.default_rng(m + n + k)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    cl = rng.uniform(0, 8, m).astype(np.float32)
+    pl = rng.uniform(0, 8, n).astype(np.float32)
+    ones = rng.uniform(0.5, 1.5, max(m, n)).astype(np.float32)
+    got = run_task(ord_, ta, tb, m, n, k, alpha, beta, a, sa[1], b, sb[1], c0, sc[1], cl, pl, ones)
+    ref = orc.skmeans_task(ord_, ta, tb, m, n, k, alpha, a, sa[1], b, sb[1], beta, c0.copy(), sc[1], cl, pl, ones)
+    assert np.array_equal(got, ref.reshape(sc))
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c0)
+    bofhip.sgemm(ord_, ta, tb, m, n, k, alpha, ptr(da), sa[1], ptr(db), sb[1], beta, ptr(dc), sc[1], stream())
+    torch.cuda.synchronize()
+    ref = orc.sgemm(ord_, ta, tb, m, n, k, alpha, a, sa[1], b, sb[1], beta, c0.copy(), sc[1])
+    assert np.array_equal(dc.cpu().numpy(), ref.reshape(sc))
+
+
 @pytest.mark.parametrize("ord_,ta,tb", [("C", "T", "N"), ("C", "N", "T"), ("R", "N", "T"), ("R", "T", "N")])
 def test_kmeans_resident_vs_flash_oracle(dev, ord_, ta, tb):
     """Tile DAG (level 2): tail-merged tiles, k spanning two blocks (the updates are then added twice,
