@@ -28,6 +28,9 @@ hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64
                          const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                          int64_t ldc, const float *u1, const float *v1, const float *u2, const float *v2,
                          hipStream_t st);
+// dst[i] = src[i - min(i / blk, nblk - 1) * blk]: a vector indexed inside a tile (the tiler's blocks, last one
+// tail-merged) unrolled over the whole dimension
+hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t blk, int64_t nblk, hipStream_t st);
 // the norm vectors of flash::kmeans in HBM (null pointer to the struct: plain gemm)
 struct KmeansVecs {
   const float *c_l2sq, *p_l2sq, *ones;
@@ -61,9 +64,9 @@ hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float
 // grow-only per-device scratch, freed by bof_flash_release.  Slots: 0 row-major copy of a
 // column-major B; 1..16 per-stream row-major C blocks; 17 csrcsc workspace; 18..20 transposed
 // CSR (values, indices, offsets) of csrmm 'T'
-// 21, 22 k-major copies of GEMM operands (bof_gemm_resident)
+// 21, 22 k-major copies of GEMM operands (bof_gemm_resident); 23 `ones` of flash::kmeans unrolled over rows / columns
 enum { SCR_B_RM = 0, SCR_C_RM0 = 1, SCR_CSRCSC = 17, SCR_TR_VAL = 18, SCR_TR_COL = 19, SCR_TR_PTR = 20,
-       SCR_GEMM_A = 21, SCR_GEMM_B = 22, SCR_COUNT = 23 };
+       SCR_GEMM_A = 21, SCR_GEMM_B = 22, SCR_KM_ONES = 23, SCR_COUNT = 24 };
 int scratch_get(int which, size_t bytes, void **ptr);
 void scratch_release_all();
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,

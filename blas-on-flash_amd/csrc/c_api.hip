@@ -346,7 +346,22 @@ static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, 
   // task (flash::kmeans: k = the point dimension).  Bit-identical to the task-by-task launches
   // (BOF_GEMM_FUSE_TASKS=0 keeps those).
   if (g.nblk[1] == 1 && g.nblk[0] * g.nblk[2] > 1 && m <= INT32_MAX && n <= INT32_MAX && env_fuse_tasks()) {
-    BOF_HIP_TRY(tile_sgemm(ord, ta, tb, m, n, k, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], kv, 0, 0, ss->s[0]));
+    hipStream_t q = ss->s[0];
+    if (!kv) {
+      BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, k, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], q));
+    } else {
+      // the reference hands every tile task the UN-offset `ones` (kmeans.cpp:115-118): it is indexed by the
+      // row / column inside the tile.  For the single launch that indexing is unrolled into two vectors
+      // over the whole matrix: ones_by_row[r] = ones[r - first row of r's tile], same for columns.
+      void *p = nullptr;
+      rc = scratch_get(SCR_KM_ONES, (size_t) (m + n) * sizeof(float), &p);
+      if (rc) return rc;
+      float *by_row = (float *) p, *by_col = by_row + m;
+      BOF_HIP_TRY(expand_tile_local(kv->ones, by_row, m, g.blk[0], g.nblk[0], q));
+      BOF_HIP_TRY(expand_tile_local(kv->ones, by_col, n, g.blk[2], g.nblk[2], q));
+      BOF_HIP_TRY(sgemm_rank1x2(ord, ta, tb, m, n, k, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], kv->c_l2sq, by_col,
+                                by_row, kv->p_l2sq, q));
+    }
     return ss->join(parent);
   }
   bof_gemm_task t;

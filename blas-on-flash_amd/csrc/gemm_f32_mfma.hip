@@ -970,6 +970,150 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
 }
 
 // ---------------------------------------------------------------------------------------
+// Persistent form of sgemm_tile256_1w3_kernel for SHORT K (flash::kmeans: K = the point dimension).
+// At K = 256 a 256 x 256 tile is 8 slabs = 131 k cycles of matrix-pipe time per wave; launched one
+// workgroup per tile the kernel above spends a comparable time in its prologue (first slabs
+// through an empty pipeline) and its 256 KB store with nothing else resident on the CU (one
+// workgroup per CU), which is why short K used to go to the 128 x 128 kernel (three workgroups per
+// CU, 97-106 TFLOP/s).  Here one workgroup per CU walks a run of tiles and the hand-scheduled slab
+// pipeline simply continues across tile boundaries; between two tiles there is only the store
+// (256 fire-and-forget instructions per wave) and the clearing of the accumulators.
+template <int AMODE, int BMODE, class EP = NoEpi>
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                         int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                         float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
+  constexpr int LDS_A = (AMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_B = (BMODE == XMAJOR) ? 256 * XLD : BK * 256;
+  constexpr int LDS_BUF = LDS_A + LDS_B;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF];
+  // persistent: this workgroup walks the tiles [t0, t1) of the linear order tm * tiles_n + tn (tn fastest:
+  // the tiles of a run share their A row block); workgroups b and b + 8 share an XCD and get adjacent runs
+  const int G = (int) gridDim.x, w = ((int) blockIdx.x & 7) * (G >> 3) + ((int) blockIdx.x >> 3);
+  const int64_t nt_all = (int64_t) tiles_m * tiles_n;
+  const int t0 = (int) (nt_all * w / G), t1 = (int) (nt_all * (w + 1) / G);
+  if (t0 >= t1) return;
+  const int m0 = (t0 / tiles_n) * 256, n0 = (t0 % tiles_n) * 256;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) lds;
+  // per-thread element offsets inside one buffer (same maps as the 1w2 kernel)
+  const int a_rd_e = (AMODE == XMAJOR) ? (wm * 128 + i) * XLD + 4 * h : h * 256 + wm * 128 + i;
+  const int b_rd_e = LDS_A + ((BMODE == XMAJOR) ? (wn * 128 + i) * XLD + 4 * h : h * 256 + wn * 128 + i);
+  const int a_wr_e = (AMODE == XMAJOR) ? (t >> 3) * XLD + 8 * ((t & 7) >> 1) + 2 * (t & 1)
+                                       : (t >> 6) * 256 + 4 * (t & 63);
+  const int b_wr_e = LDS_A + ((BMODE == XMAJOR) ? (t >> 3) * XLD + 8 * ((t & 7) >> 1) + 2 * (t & 1)
+                                                : (t >> 6) * 256 + 4 * (t & 63));
+  uint32_t a_rd[2], b_rd[2], a_wr[2], b_wr[2];
+#pragma unroll
+  for (int bf = 0; bf < 2; bf++) {
+    a_rd[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + a_rd_e);
+    b_rd[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + b_rd_e);
+    a_wr[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + a_wr_e);
+    b_wr[bf] = lds0 + 4u * (unsigned) (bf * LDS_BUF + b_wr_e);
+  }
+  const unsigned a_goff = 4u * (unsigned) ((AMODE == XMAJOR) ? (t >> 3) * (int) lda + 4 * (t & 7)
+                                                              : (t >> 6) * (int) lda + 4 * (t & 63));
+  const unsigned b_goff = 4u * (unsigned) ((BMODE == XMAJOR) ? (t >> 3) * (int) ldb + 4 * (t & 7)
+                                                              : (t >> 6) * (int) ldb + 4 * (t & 63));
+  // piece origins: x-major piece p = rows 32p.. (step 32 rows), slab = +32 floats along the row;
+  // k-major piece p = k-rows 4p.. (step 4 rows), slab = +32 rows
+  auto a_origin = [&](int mm) { return reinterpret_cast<uint64_t>((AMODE == XMAJOR) ? A + (int64_t) mm * lda : A + mm); };
+  auto b_origin = [&](int nn) { return reinterpret_cast<uint64_t>((BMODE == XMAJOR) ? B + (int64_t) nn * ldb : B + nn); };
+  const uint64_t a_org = a_origin(m0), b_org = b_origin(n0);
+  const uint64_t a_step = (AMODE == XMAJOR) ? (uint64_t) lda * 128 : (uint64_t) lda * 16;
+  const uint64_t b_step = (BMODE == XMAJOR) ? (uint64_t) ldb * 128 : (uint64_t) ldb * 16;
+  const uint64_t a_slab = (AMODE == XMAJOR) ? 128 : (uint64_t) lda * 128;
+  const uint64_t b_slab = (BMODE == XMAJOR) ? 128 : (uint64_t) ldb * 128;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nkt = K / BK;   // even, >= 2 (launch_modes)
+  f32x4 ra[8], rb[8];
+  // prologue: slab 0 -> buffer 0 through the registers, slab 1 -> registers
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    ra[p] = gld128(a_goff, a_org + (uint64_t) p * a_step);
+    rb[p] = gld128(b_goff, b_org + (uint64_t) p * b_step);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]),
+               "+v"(ra[6]), "+v"(ra[7]) :: "memory");
+  asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]),
+               "+v"(rb[7]) :: "memory");
+  wr_piece<AMODE, 0>(a_wr[0], ra[0]); wr_piece<AMODE, 1>(a_wr[0], ra[1]); wr_piece<AMODE, 2>(a_wr[0], ra[2]);
+  wr_piece<AMODE, 3>(a_wr[0], ra[3]); wr_piece<AMODE, 4>(a_wr[0], ra[4]); wr_piece<AMODE, 5>(a_wr[0], ra[5]);
+  wr_piece<AMODE, 6>(a_wr[0], ra[6]); wr_piece<AMODE, 7>(a_wr[0], ra[7]);
+  wr_piece<BMODE, 0>(b_wr[0], rb[0]); wr_piece<BMODE, 1>(b_wr[0], rb[1]); wr_piece<BMODE, 2>(b_wr[0], rb[2]);
+  wr_piece<BMODE, 3>(b_wr[0], rb[3]); wr_piece<BMODE, 4>(b_wr[0], rb[4]); wr_piece<BMODE, 5>(b_wr[0], rb[5]);
+  wr_piece<BMODE, 6>(b_wr[0], rb[6]); wr_piece<BMODE, 7>(b_wr[0], rb[7]);
+  // the stores above read ra/rb: make the refills below wait for them (asm order is program order)
+#pragma unroll
+  for (int p = 0; p < 8; p++) ra[p] = gld128(a_goff, a_org + a_slab + (uint64_t) p * a_step);
+#pragma unroll
+  for (int p = 0; p < 8; p++) rb[p] = gld128(b_goff, b_org + b_slab + (uint64_t) p * b_step);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 fa[2][4], fb[2][4];
+  fa[0][0] = rd_frag_m<AMODE, 0, 0>(a_rd[0]); fa[0][1] = rd_frag_m<AMODE, 0, 1>(a_rd[0]);
+  fa[0][2] = rd_frag_m<AMODE, 0, 2>(a_rd[0]); fa[0][3] = rd_frag_m<AMODE, 0, 3>(a_rd[0]);
+  fb[0][0] = rd_frag_m<BMODE, 0, 0>(b_rd[0]); fb[0][1] = rd_frag_m<BMODE, 0, 1>(b_rd[0]);
+  fb[0][2] = rd_frag_m<BMODE, 0, 2>(b_rd[0]); fb[0][3] = rd_frag_m<BMODE, 0, 3>(b_rd[0]);
+#pragma unroll
+  for (int x = 0; x < 4; x++) { fa[1][x] = fa[0][x]; fb[1][x] = fb[0][x]; }
+
+  // Slab n stores slab n+1 (already in ra/rb) and fetches slab n+2 -- of THIS tile or, at a tile's end, the
+  // first slabs of the NEXT one: when the last slab of a tile has been multiplied, buffer 0 holds the next
+  // tile's slab 0, the staging registers its slab 1 and the fragment registers its first k-group, i.e. the
+  // state the prologue above creates, so the next tile starts without one.  Past the run's last tile the
+  // fetch address stops advancing (valid memory, data never used).
+  // running prefetch cursor: the slab two ahead of the one being multiplied
+  int pf_tile = t0, pf_kt = 2;
+  uint64_t pf_a = a_org + 2 * a_slab, pf_b = b_org + 2 * b_slab;
+  if (nkt <= 2) {                       // the tile has only slabs 0 and 1: two ahead is the next tile's slab 0
+    pf_kt = 0;
+    pf_tile = t0 + 1 < t1 ? t0 + 1 : t0;
+    pf_a = a_origin((pf_tile / tiles_n) * 256);
+    pf_b = b_origin((pf_tile % tiles_n) * 256);
+  }
+  auto pf_advance = [&]() {
+    if (++pf_kt < nkt) { pf_a += a_slab; pf_b += b_slab; return; }
+    if (pf_tile + 1 < t1) {
+      pf_tile++;
+      pf_kt = 0;
+      pf_a = a_origin((pf_tile / tiles_n) * 256);
+      pf_b = b_origin((pf_tile % tiles_n) * 256);
+    } else {
+      pf_kt = nkt - 1;                  // past the run: stay on valid memory
+    }
+  };
+  for (int tile = t0; tile < t1; tile++) {
+    for (int kt = 0; kt < nkt; kt += 2) {
+      slab_1w3<AMODE, BMODE, 0>(a_rd, b_rd, a_wr, b_wr, pf_a, pf_b, a_step, b_step, a_goff, b_goff, ra, rb, fa, fb, acc);
+      pf_advance();
+      slab_1w3<AMODE, BMODE, 1>(a_rd, b_rd, a_wr, b_wr, pf_a, pf_b, a_step, b_step, a_goff, b_goff, ra, rb, fa, fb, acc);
+      pf_advance();
+    }
+    // the look-ahead loads were issued during the last slab and have had most of it to land
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    store_wave_tile_128(C, ldc, (tile / tiles_n) * 256, (tile % tiles_n) * 256, wm, wn, h, i, acc, alpha, beta, ep);
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Short K (flash::kmeans: K = the point dimension, 256): a tile's MFMA work no longer hides its
 // own prologue (first slabs' loads) and epilogue (the store, the update vectors).  A 128 x 128
 // tile at K = 256 is 13.6 us of matrix-pipe time per CU; launched as one workgroup per tile the
@@ -1105,6 +1249,12 @@ sgemm_stream_kernel(const float *__restrict__ A, int64_t lda, const float *__res
   }
 }
 
+// debug / test knobs of the kernel choice, read at every launch
+static int knob(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
 template <int AMODE, int BMODE, class EP>
 static hipError_t launch_guarded(const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                                  int64_t ldc, int M, int N, int K, float alpha, float beta,
@@ -1142,7 +1292,7 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   // K < 512 (flash::kmeans: K = the point dimension): a 256 x 256 tile then has less MFMA work than
   // its prologue + 256 KB store cost with one workgroup per CU; the 128 x 128 kernel keeps three
   // workgroups per CU in flight (1M x 1024 x 256: 5.7-6.0 ms against 6.5-8.4).  BOF_GEMM_SHORT_K overrides.
-  static const int short_k = getenv("BOF_GEMM_SHORT_K") ? atoi(getenv("BOF_GEMM_SHORT_K")) : 512;
+  const int short_k = knob("BOF_GEMM_SHORT_K", 512);
   if (vec_ld && k_ok && K >= short_k && (int64_t) (Mi / 256) * (Ni / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
     const int tiles_m = Mi / 256, tiles_n = Ni / 256;
     if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
@@ -1176,7 +1326,17 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   dim3 grid(tiles_m * tiles_n), block(256);
   // short K with many aligned tiles: the persistent, cross-tile pipelined kernel (at least two tiles per
   // workgroup of the 512 that fit the chip; fewer tiles than that have no next tile to prefetch)
-  static const bool stream_on = !getenv("BOF_GEMM_STREAM") || atoi(getenv("BOF_GEMM_STREAM")) != 0;
+  // short K, 256-aligned, at least four tiles for each of the 256 persistent workgroups: the persistent
+  // one-wave-per-SIMD kernel (BOF_GEMM_PERSIST=0: off)
+  // (BOF_GEMM_PERSIST_MIN_TILES lowers the tile count for tests)
+  const bool persist_on = knob("BOF_GEMM_PERSIST", 1) != 0;
+  if (persist_on && vec_ld && K % (2 * BK) == 0 && K >= 2 * BK && K < short_k && M % 256 == 0 && N % 256 == 0 &&
+      (int64_t) (M / 256) * (N / 256) >= knob("BOF_GEMM_PERSIST_MIN_TILES", 1024) && lda < (1 << 22) && ldb < (1 << 22)) {
+    hipLaunchKernelGGL((sgemm_tile256_p1w3_kernel<AMODE, BMODE, EP>), dim3(256), dim3(256), 0, st, A, lda, B, ldb, C,
+                       ldc, M, N, K, alpha, beta, M / 256, N / 256, ep);
+    return hipGetLastError();
+  }
+  const bool stream_on = knob("BOF_GEMM_STREAM", 0) != 0;
   if (stream_on && vec_ok && M % 128 == 0 && N % 128 == 0 && K >= 2 * BK && K < short_k &&
       (int64_t) tiles_m * tiles_n >= 1024 && lda < (1 << 22) && ldb < (1 << 22)) {
     hipLaunchKernelGGL((sgemm_stream_kernel<AMODE, BMODE, EP>), dim3(512), block, 0, st, A, lda, B, ldb, C, ldc, K,
@@ -1203,6 +1363,20 @@ static hipError_t sgemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, c
   if (!ta && tb)  return launch_modes<XMAJOR, XMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
   if (ta && !tb)  return launch_modes<KMAJOR, KMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
   return launch_modes<KMAJOR, XMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);
+}
+
+__global__ void __launch_bounds__(256)
+expand_tile_local_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t len, int64_t blk, int64_t nblk) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  const int64_t tile = i / blk < nblk - 1 ? i / blk : nblk - 1;
+  dst[i] = src[i - tile * blk];
+}
+hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t blk, int64_t nblk, hipStream_t st) {
+  if (len <= 0) return hipSuccess;
+  hipLaunchKernelGGL(expand_tile_local_kernel, dim3((unsigned) ((len + 255) / 256)), dim3(256), 0, st, src, dst, len,
+                     blk, nblk);
+  return hipGetLastError();
 }
 
 // cblas_sgemm argument meaning.  Column-major: C^T = op(B)^T * op(A)^T.
