@@ -977,7 +977,14 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
 // workgroup per CU), which is why short K used to go to the 128 x 128 kernel (three workgroups per
 // CU, 97-106 TFLOP/s).  Here one workgroup per CU walks a run of tiles and the hand-scheduled slab
 // pipeline simply continues across tile boundaries; between two tiles there is only the store
-// (256 fire-and-forget instructions per wave) and the clearing of the accumulators.
+// (256 instructions per wave) and the clearing of the accumulators.  1M x 1024 x 256 'N','T':
+// 116 -> 126 TFLOP/s (128 with 'N','N'), K = 128: 107 -> 111; without the store the loop runs at 139.6 / 135.3,
+// i.e. what is left is the issue time of the store itself (256 KB per CU and tile through one
+// 64 B/clk path, ~16 k cycles of a tile's 147 k), which cannot overlap the next tile's MFMAs
+// because they overwrite the accumulators it reads.  Measured and not kept: a 128 x 128 persistent
+// double-buffered kernel (2 workgroups per CU: 114, below the single-buffer kernel's 117-121 in
+// one big launch), per-lane store offsets instead of scalar row addresses (the compiler hoists 64
+// row offsets out of the tile loop into scratch: 94), non-temporal stores (no change).
 template <int AMODE, int BMODE, class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
@@ -1113,142 +1120,6 @@ sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float 
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// Short K (flash::kmeans: K = the point dimension, 256): a tile's MFMA work no longer hides its
-// own prologue (first slabs' loads) and epilogue (the store, the update vectors).  A 128 x 128
-// tile at K = 256 is 13.6 us of matrix-pipe time per CU; launched as one workgroup per tile the
-// single-buffer kernel above needed 53-60 us per 256-tile task and relied on two more workgroups
-// per CU (from other streams' tasks) to fill the pipe: 97 TFLOP/s = 62 % of peak.
-// Here a workgroup is PERSISTENT over a contiguous run of tiles and the slab pipeline runs across
-// tile boundaries: slab s is multiplied out of LDS buffer s & 1 while slab s + 1 (fetched one slab
-// earlier) is written to the other buffer and slab s + 2's global loads are in flight -- whatever
-// tile those slabs belong to.  So the next tile's first two slabs arrive during the current tile's
-// last two, the update vectors of the epilogue are fetched under the last slab's MFMAs, and the
-// store is 64 fire-and-forget instructions between two slabs.  Same tile shape, same k-ordered
-// chains: bit-identical to the other kernels.  Tiles of one run share their A row block (the run
-// walks tn fastest), runs of the same XCD are adjacent.  Two workgroups per CU (72 KB of LDS each).
-template <int AMODE, int BMODE, class EP>
-__global__ void __launch_bounds__(256, 2)
-sgemm_stream_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
-                    float *__restrict__ C, int64_t ldc, int K, float alpha, float beta, int tiles_m, int tiles_n,
-                    EP ep) {
-  constexpr int BM = 128, BN = 128, NTHR = 256, MT = 2, NT = 2;
-  constexpr int LDS_A = (AMODE == XMAJOR) ? BM * XLD : BK * BM;
-  constexpr int LDS_B = (BMODE == XMAJOR) ? BN * XLD : BK * BN;
-  constexpr int LDS_BUF = LDS_A + LDS_B;
-  __shared__ __attribute__((aligned(16))) float lds[2 * LDS_BUF];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  // this workgroup's run of tiles (linear order tm * tiles_n + tn); workgroups b and b + 8 share an XCD
-  const int G = (int) gridDim.x, w = ((int) blockIdx.x & 7) * (G >> 3) + ((int) blockIdx.x >> 3);
-  const int64_t nt_all = (int64_t) tiles_m * tiles_n;
-  const int t0 = (int) (nt_all * w / G), t1 = (int) (nt_all * (w + 1) / G);
-  const int nkt = K / BK;
-  const int S = (t1 - t0) * nkt;
-  if (S <= 0) return;
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int a = 0; a < MT; a++)
-#pragma unroll
-    for (int b = 0; b < NT; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-
-  // (tile, slab) of the next global fetch
-  int f_tile = t0, f_kt = 0;
-  auto fetch = [&](Stage<BM * 8 / NTHR> &ra, Stage<BN * 8 / NTHR> &rb) {
-    const int m0 = (f_tile / tiles_n) * BM, n0 = (f_tile % tiles_n) * BN;
-    ra = g2r<AMODE, BM, NTHR, false>(A, lda, m0, f_kt * BK, 0, 0, t);
-    rb = g2r<BMODE, BN, NTHR, false>(B, ldb, n0, f_kt * BK, 0, 0, t);
-    if (++f_kt == nkt) { f_kt = 0; f_tile++; }
-  };
-  Stage<BM * 8 / NTHR> ra;
-  Stage<BN * 8 / NTHR> rb;
-  fetch(ra, rb);
-  r2s<AMODE, BM, NTHR>(lds, ra, t);
-  r2s<BMODE, BN, NTHR>(lds + LDS_A, rb, t);
-  if (S > 1) fetch(ra, rb);
-  __syncthreads();
-
-  int c_tile = t0, c_kt = 0;     // (tile, slab) being multiplied
-  for (int s = 0; s < S; s++) {
-    const float *sA = lds + ((s & 1) ? LDS_BUF : 0);
-    const float *sB = sA + LDS_A;
-    if (s + 1 < S) {  // slab s+1 (loaded during slab s-1) -> the other buffer
-      float *nA = lds + ((s & 1) ? 0 : LDS_BUF);
-      r2s<AMODE, BM, NTHR>(nA, ra, t);
-      r2s<BMODE, BN, NTHR>(nA + LDS_A, rb, t);
-    }
-    if (s + 2 < S) fetch(ra, rb);   // slab s+2's global loads fly under this slab's MFMAs
-    const bool last = c_kt == nkt - 1;
-    const int m0 = (c_tile / tiles_n) * BM, n0 = (c_tile % tiles_n) * BN;
-    const int lrow = wm * 64 + 4 * h, lcol = wn * 64 + i;
-    // the update vectors of the store, fetched under the last slab's MFMAs
-    float v1c[NT], v2c[NT], u1r[MT][16], u2r[MT][16];
-    if constexpr (EP::active) {
-      if (last) {
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          v1c[nt] = ep.v1[n0 + lcol + nt * 32];
-          v2c[nt] = ep.v2[n0 + lcol + nt * 32];
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            u1r[mt][r] = ep.u1[m0 + lrow + mt * 32 + (r & 3) + 8 * (r >> 2)];
-            u2r[mt][r] = ep.u2[m0 + lrow + mt * 32 + (r & 3) + 8 * (r >> 2)];
-          }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < BK / 8; q++) {
-      f32x4 a[MT], b[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) a[mt] = s2op<AMODE, BM>(sA, wm * 64 + mt * 32 + i, q, h);
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) b[nt] = s2op<BMODE, BN>(sB, wn * 64 + nt * 32 + i, q, h);
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][c], b[nt][c], acc[mt][nt], 0, 0, 0);
-    }
-    if (last) {
-      // store: 32x32 accumulator map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-      float *ctile = C + (int64_t) m0 * ldc + n0;
-      const int lane_off = lrow * (int) ldc + lcol;
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          f32x16 old;
-          if (beta != 0.f) {
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-              old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-            float v = (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
-            if constexpr (EP::active) {
-              v = __fadd_rn(v, __fmul_rn(u1r[mt][r], v1c[nt]));
-              v = __fadd_rn(v, __fmul_rn(u2r[mt][r], v2c[nt]));
-            }
-            dst[lane_off] = v;
-            acc[mt][nt][r] = 0.f;
-          }
-        }
-    }
-    __syncthreads();
-    if (++c_kt == nkt) { c_kt = 0; c_tile++; }
-  }
-}
-
 // debug / test knobs of the kernel choice, read at every launch
 static int knob(const char *name, int dflt) {
   const char *e = getenv(name);
@@ -1324,23 +1195,14 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   }
   const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
   dim3 grid(tiles_m * tiles_n), block(256);
-  // short K with many aligned tiles: the persistent, cross-tile pipelined kernel (at least two tiles per
-  // workgroup of the 512 that fit the chip; fewer tiles than that have no next tile to prefetch)
   // short K, 256-aligned, at least four tiles for each of the 256 persistent workgroups: the persistent
   // one-wave-per-SIMD kernel (BOF_GEMM_PERSIST=0: off)
   // (BOF_GEMM_PERSIST_MIN_TILES lowers the tile count for tests)
   const bool persist_on = knob("BOF_GEMM_PERSIST", 1) != 0;
-  if (persist_on && vec_ld && K % (2 * BK) == 0 && K >= 2 * BK && K < short_k && M % 256 == 0 && N % 256 == 0 &&
+  if (persist_on && vec_ld && K % (2 * BK) == 0 && K >= 4 * BK && K < short_k && M % 256 == 0 && N % 256 == 0 &&
       (int64_t) (M / 256) * (N / 256) >= knob("BOF_GEMM_PERSIST_MIN_TILES", 1024) && lda < (1 << 22) && ldb < (1 << 22)) {
     hipLaunchKernelGGL((sgemm_tile256_p1w3_kernel<AMODE, BMODE, EP>), dim3(256), dim3(256), 0, st, A, lda, B, ldb, C,
                        ldc, M, N, K, alpha, beta, M / 256, N / 256, ep);
-    return hipGetLastError();
-  }
-  const bool stream_on = knob("BOF_GEMM_STREAM", 0) != 0;
-  if (stream_on && vec_ok && M % 128 == 0 && N % 128 == 0 && K >= 2 * BK && K < short_k &&
-      (int64_t) tiles_m * tiles_n >= 1024 && lda < (1 << 22) && ldb < (1 << 22)) {
-    hipLaunchKernelGGL((sgemm_stream_kernel<AMODE, BMODE, EP>), dim3(512), block, 0, st, A, lda, B, ldb, C, ldc, K,
-                       alpha, beta, tiles_m, tiles_n, ep);
     return hipGetLastError();
   }
   if (vec_ok && M % 128 == 0 && N % 128 == 0)
