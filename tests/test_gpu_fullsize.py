@@ -253,7 +253,7 @@ def test_cfg4_composition_65536_files(dev, tmp_path, how):
     else:
         assert st["bytes_read"] == 2 * 4 * n * n                 # A once, B once for all eight devices
         assert st["bytes_h2d"] == 4 * n * n * (1 + 8)            # ... and copied to each of them
-        assert len(out["per_device"]) == 8 and all(p["tasks"] == tiles ** 3 // 8 for p in out["per_device"])
+        assert len(leg["per_device"]) == 8 and all(p["tasks"] == tiles ** 3 // 8 for p in leg["per_device"])
 
 
 def test_cfg5_csrgemv_composition_8_shards(dev):
