@@ -984,7 +984,9 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
 // because they overwrite the accumulators it reads.  Measured and not kept: a 128 x 128 persistent
 // double-buffered kernel (2 workgroups per CU: 114, below the single-buffer kernel's 117-121 in
 // one big launch), per-lane store offsets instead of scalar row addresses (the compiler hoists 64
-// row offsets out of the tile loop into scratch: 94), non-temporal stores (no change).
+// row offsets out of the tile loop into scratch: 94), non-temporal stores (no change), 16-byte stores after
+// a 4 x 4 DPP transposition inside each lane quad (64 instead of 256 store instructions per wave: 124, no
+// gain -- it is the bytes of the store burst, all CUs at once, not its instruction count).
 template <int AMODE, int BMODE, class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
