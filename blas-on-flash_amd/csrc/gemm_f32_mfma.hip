@@ -986,7 +986,10 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
 // one big launch), per-lane store offsets instead of scalar row addresses (the compiler hoists 64
 // row offsets out of the tile loop into scratch: 94), non-temporal stores (no change), 16-byte stores after
 // a 4 x 4 DPP transposition inside each lane quad (64 instead of 256 store instructions per wave: 124, no
-// gain -- it is the bytes of the store burst, all CUs at once, not its instruction count).
+// gain), workgroups started in eight phases an eighth of a tile apart so that the CUs do not all store at
+// the same moment (no gain either).  What the numbers say: a CU stores one dword per lane at ~10-16 B/clk
+// (the guide's 6 TB/s chip-wide for this store shape = 9.9 B/clk/CU), so a tile's 256 KB are 16-26 k cycles
+// whatever the instruction width or the neighbours do.
 template <int AMODE, int BMODE, class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
