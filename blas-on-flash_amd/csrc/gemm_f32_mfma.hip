@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace bof {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1206,7 +1208,9 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   const bool persist_on = knob("BOF_GEMM_PERSIST", 1) != 0;
   if (persist_on && vec_ld && K % (2 * BK) == 0 && K >= 4 * BK && K < short_k && M % 256 == 0 && N % 256 == 0 &&
       (int64_t) (M / 256) * (N / 256) >= knob("BOF_GEMM_PERSIST_MIN_TILES", 1024) && lda < (1 << 22) && ldb < (1 << 22)) {
-    hipLaunchKernelGGL((sgemm_tile256_p1w3_kernel<AMODE, BMODE, EP>), dim3(256), dim3(256), 0, st, A, lda, B, ldb, C,
+    // one workgroup per CU; BOF_GEMM_PERSIST_WGS (a multiple of 8) makes the runs longer on small test problems
+    const int wgs = std::max(8, knob("BOF_GEMM_PERSIST_WGS", 256) / 8 * 8);
+    hipLaunchKernelGGL((sgemm_tile256_p1w3_kernel<AMODE, BMODE, EP>), dim3(wgs), dim3(256), 0, st, A, lda, B, ldb, C,
                        ldc, M, N, K, alpha, beta, M / 256, N / 256, ep);
     return hipGetLastError();
   }

@@ -61,14 +61,17 @@ def test_kmeans_task_vs_oracle_all_layouts(dev, ord_, ta, tb, m, n, k, alpha, be
 
 
 @pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
-@pytest.mark.parametrize("m,n,k,alpha,beta", [(4096, 4096, 256, -2.0, 0.0), (2048, 8192, 96, 1.5, 0.5), (6400, 4352, 128, 1.0, 1.0)])
-def test_short_k_persistent_kernel_vs_oracle(dev, monkeypatch, ord_, ta, tb, m, n, k, alpha, beta):
+@pytest.mark.parametrize("m,n,k,alpha,beta,wgs", [(2048, 2048, 256, -2.0, 0.0, 8), (1024, 4096, 96, 1.5, 0.5, 8),
+                                                  (2304, 1792, 128, 1.0, 1.0, 24), (1280, 1536, 320, 0.5, 0.0, 256)])
+def test_short_k_persistent_kernel_vs_oracle(dev, monkeypatch, ord_, ta, tb, m, n, k, alpha, beta, wgs):
     """K < 512 with many aligned tiles: sgemm_tile256_p1w3_kernel (one workgroup per CU walks a run of
     256 x 256 tiles, the hand-scheduled slab pipeline continues across tile boundaries; K % 64 == 0, K >= 128),
     all 8 layouts, with the kmeans store (non-constant `ones`) and as a plain sgemm; bit-exact against the
-    oracle's k-ordered chains.  The tile threshold is lowered so that these sizes reach the kernel (256
-    workgroups with one tile or a few each, some with none); K = 96 takes the 128 x 128 kernel instead."""
+    oracle's k-ordered chains.  The tile threshold is lowered and the number of workgroups cut down so that
+    small problems give runs of several tiles (8 workgroups x 8 tiles; 24 x 2-3 of unequal length; 256
+    workgroups for 30 tiles: most with none); K = 96 takes the 128 x 128 kernel instead."""
     monkeypatch.setenv("BOF_GEMM_PERSIST_MIN_TILES", "1")
+    monkeypatch.setenv("BOF_GEMM_PERSIST_WGS", str(wgs))
     rng = np.random.default_rng(m + n + k)
     sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
     a = rng.uniform(-1, 1, sa).astype(np.float32)
