@@ -1107,6 +1107,13 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
             out["gemm_budget_8GiB"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s, args.io_threads,
                                                2, modes=("odirect",), hbm_budget=8 << 30)
             bofhip.lib().bof_flash_release()
+        # the in-process device list (what an unchanged reference driver gets on a multi-GPU node): device 0
+        # listed twice, i.e. one GPU playing two -- the point of the leg is the byte counters (B read once,
+        # copied twice) and the whole-C check, not the time
+        if args.e2e_size == 32768 and shutil.disk_usage(workdir).free > 3 * n * n * 4 + (2 << 30):
+            out["gemm_two_devices_in_process"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s,
+                                                          args.io_threads, 1, modes=("odirect",), devices=[0, 0])
+            bofhip.lib().bof_flash_release()
         if args.no_csr or args.e2e_size != 32768:
             pass
         elif free > 19e9:
@@ -1129,6 +1136,7 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
     work = {"gemm": (2.0 * args.e2e_size ** 3, gemm_kernel_s), "gemm_65536": (2.0 * 65536.0 ** 3, gemm64_kernel_s),
             "gemm_31000": (2.0 * 31000.0 ** 3, (gemm_kernel_s or 0) * (31000.0 / 32768.0) ** 3 or None),
             "gemm_tile_cache": (2.0 * args.e2e_size ** 3, gemm_kernel_s), "gemm_budget_8GiB": (2.0 * args.e2e_size ** 3, gemm_kernel_s),
+            "gemm_two_devices_in_process": (2.0 * args.e2e_size ** 3, gemm_kernel_s),
             "csrmm": (2.0 * 1e9 * 128, csrmm_kernel_s),
             "csrgemv": (2.0 * 5e8, (gemv_kernel_ms or {}).get("N", 0) * 1e-3 if gemv_kernel_ms else None)}
     if "error" not in ceil:
@@ -1437,7 +1445,8 @@ def main():
             if key in ceil:
                 rf["e2e_ceiling_" + key] = ceil[key]
         for name, tag in (("gemm", "cfg2"), ("gemm_65536", "64k"), ("csrmm", "cfg3"), ("gemm_31000", "31000"),
-                          ("gemm_tile_cache", "cfg2_tilecache"), ("gemm_budget_8GiB", "cfg2_8GiB")):
+                          ("gemm_tile_cache", "cfg2_tilecache"), ("gemm_budget_8GiB", "cfg2_8GiB"),
+                          ("gemm_two_devices_in_process", "cfg2_2dev_1gpu")):
             for mode, mt in (("odirect", ""), ("buffered", "_pagecache")):
                 leg = (e2e.get(name) or {}).get(mode) if isinstance(e2e.get(name), dict) else None
                 if not isinstance(leg, dict) or "roofline" not in leg:
