@@ -1052,6 +1052,20 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     double seconds = 0;
   };
   std::vector<Shard> sh((size_t) D);
+  // csrgemv 'T': peer access between every pair of distinct devices (xGMI), enabled BEFORE the partial
+  // vectors are allocated; without it the partials cross through staging copies (hipMemcpyPeer)
+  bool peers = true;
+  if (!is_mm && trans == 'T')
+    for (int a = 0; a < D && peers; a++)
+      for (int b = 0; b < D && peers; b++) {
+        if (used[(size_t) a] == used[(size_t) b]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, used[(size_t) a], used[(size_t) b]) != hipSuccess || !can) { peers = false; break; }
+        DeviceScope ds(used[(size_t) a]);
+        const hipError_t e = hipDeviceEnablePeerAccess(used[(size_t) b], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
+        (void) hipGetLastError();
+      }
   const bool share_op = is_mm || trans == 'N';           // csrgemv 'T' uses a private slice of x per device
   const uint64_t op_bytes = is_mm ? (uint64_t) n * k * 4 : (uint64_t) n * 4;
   Cleanup guard;
@@ -1144,18 +1158,6 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
 
   // ---- csrgemv 'T': reduce-scatter of the partials between the devices, every segment home over its own link ----
   if (!rc && !is_mm && trans == 'T' && n > 0) {
-    // peer access between every pair of distinct devices (xGMI); without it the partials cross through a staging copy
-    bool peers = true;
-    for (int a = 0; a < D && peers; a++)
-      for (int b = 0; b < D && peers; b++) {
-        if (sh[(size_t) a].dev == sh[(size_t) b].dev) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, sh[(size_t) a].dev, sh[(size_t) b].dev) != hipSuccess || !can) { peers = false; break; }
-        DeviceScope ds(sh[(size_t) a].dev);
-        const hipError_t e = hipDeviceEnablePeerAccess(sh[(size_t) b].dev, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
-        (void) hipGetLastError();
-      }
     for (Shard &S : sh) {   // every partial complete before anybody reads it
       DeviceScope ds(S.dev);
       (void) hipDeviceSynchronize();
