@@ -300,8 +300,8 @@ static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, 
   // buys the faster path for all of them; the tiles and their k-order are unchanged, so is
   // every bit of the result.
   {
-    static const bool pre = !getenv("BOF_GEMM_PRETRANSPOSE") || atoi(getenv("BOF_GEMM_PRETRANSPOSE")) != 0;
-    static const bool dma = !getenv("BOF_GEMM_VARIANT") || atoi(getenv("BOF_GEMM_VARIANT")) >= 3;
+    const bool pre = !getenv("BOF_GEMM_PRETRANSPOSE") || atoi(getenv("BOF_GEMM_PRETRANSPOSE")) != 0;
+    const bool dma = !getenv("BOF_GEMM_VARIANT") || atoi(getenv("BOF_GEMM_VARIANT")) >= 3;
     const bool xm[2] = {g.cdim[0] == 1, g.cdim[1] == 1};  // k is the stored column dimension
     const int64_t reuse[2] = {g.nblk[2], g.nblk[0]};
     size_t need = 0;

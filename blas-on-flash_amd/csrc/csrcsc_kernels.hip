@@ -416,12 +416,12 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // digit width of the transposition sort: at most RS_MAXBITS (BOF_SORT_BITS narrows it for
 // experiments)
 inline int sort_digit_bits() {
-  static const int v = getenv("BOF_SORT_BITS") ? atoi(getenv("BOF_SORT_BITS")) : 8;
+  const int v = getenv("BOF_SORT_BITS") ? atoi(getenv("BOF_SORT_BITS")) : 8;
   return v < 4 ? 4 : (v > RS_MAXBITS ? RS_MAXBITS : v);
 }
 
 inline int sort_xcd_order() {
-  static const int v = getenv("BOF_SORT_XCD") ? atoi(getenv("BOF_SORT_XCD")) : 1;
+  const int v = getenv("BOF_SORT_XCD") ? atoi(getenv("BOF_SORT_XCD")) : 1;
   return v;
 }
 

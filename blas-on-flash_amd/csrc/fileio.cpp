@@ -283,7 +283,7 @@ void unmap_locked(int fd, std::unique_lock<std::mutex> &lk) {
 }
 
 bool mapped_write(int fd, const char *buf, uint64_t len, uint64_t off) {
-  static const bool on = !getenv("BOF_MMAP_WRITES") || atoi(getenv("BOF_MMAP_WRITES")) != 0;
+  const bool on = !getenv("BOF_MMAP_WRITES") || atoi(getenv("BOF_MMAP_WRITES")) != 0;
   if (!on || len < (1u << 20)) return false;
   struct stat sb;
   if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || off + len > (uint64_t) sb.st_size) return false;

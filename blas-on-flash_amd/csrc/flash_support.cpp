@@ -228,7 +228,7 @@ bool read_small(const std::string &path, char *buf, size_t cap) {
 }  // namespace
 
 int bind_thread_near_device(int dev) {
-  static const bool enabled = !getenv("BOF_NUMA_BIND") || atoi(getenv("BOF_NUMA_BIND")) != 0;
+  const bool enabled = !getenv("BOF_NUMA_BIND") || atoi(getenv("BOF_NUMA_BIND")) != 0;
   if (!enabled || dev < 0 || dev >= 64) return -1;
   NodeCpus nc;
   {
