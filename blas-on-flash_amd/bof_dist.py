@@ -120,9 +120,21 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     if world > 1 and b_once and len(owners) > 1:
         _share_seq += 1                      # every rank makes the same sequence of calls
         name = f"/bof_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}_{_share_seq}"
+        # the staging segment holds one image of B in /dev/shm (tmpfs): a store into a tmpfs page that cannot
+        # be allocated is a SIGBUS, so the segment is only used when it fits with room to spare; the first
+        # rank decides for everybody (a container's /dev/shm may be tiny)
+        fits = [True]
         if rank == 0:
             bofhip.lib().bof_share_cleanup(name.encode())    # leftovers of a crashed earlier run
-        dist.barrier(group)
+            try:
+                sv = os.statvfs("/dev/shm")
+                fits[0] = sv.f_bavail * sv.f_frsize > ((k - 1) * ldb + n) * 4 * 1.25 + (64 << 20)
+            except OSError:
+                fits[0] = False
+        dist.broadcast_object_list(fits, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not fits[0]:
+            name = None
+            stats["b_once"] = "off: /dev/shm cannot hold B"
     if rows > 0:
         import ctypes
         call = bofhip.Options()
