@@ -95,8 +95,8 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     b_once=True (default for world > 1): B is read from storage ONCE PER NODE instead of
     once per rank -- inside the same pipeline.  The ranks that own rows pass share_world / share_rank /
     share_name to bof_flash_gemm: panel l of B is read from the file by rank l % share_world, which
-    publishes it in a node-shared staging segment; the others take it from there (bof_options in
-    include/bof_hip.h).  At cfg4 that is 16 + 16 GiB of reads per node instead of 16 + 8 x 16.  The
+    publishes it chunk by chunk in a node-shared staging ring; the others take it from there (bof_options
+    in include/bof_hip.h).  At cfg4 that is 16 + 16 GiB of reads per node instead of 16 + 8 x 16.  The
     only torch.distributed call is the barrier behind which the staging segment is removed.
     b_once=False: every rank reads B itself.
 
@@ -120,21 +120,23 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     if world > 1 and b_once and len(owners) > 1:
         _share_seq += 1                      # every rank makes the same sequence of calls
         name = f"/bof_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}_{_share_seq}"
-        # the staging segment holds one image of B in /dev/shm (tmpfs): a store into a tmpfs page that cannot
-        # be allocated is a SIGBUS, so the segment is only used when it fits with room to spare; the first
-        # rank decides for everybody (a container's /dev/shm may be tiny)
+        # the staging ring (64 chunk slots per shared operand, ~2 GiB at the default 32 MiB chunk) lives in
+        # /dev/shm (tmpfs): a store into a tmpfs page that cannot be allocated is a SIGBUS, so the ring is only
+        # used when it fits with room to spare; the first rank decides for everybody (a container's /dev/shm
+        # may be tiny)
         fits = [True]
         if rank == 0:
             bofhip.lib().bof_share_cleanup(name.encode())    # leftovers of a crashed earlier run
             try:
                 sv = os.statvfs("/dev/shm")
-                fits[0] = sv.f_bavail * sv.f_frsize > ((k - 1) * ldb + n) * 4 * 1.25 + (64 << 20)
+                ring = 2 * 64 * ((max(int(o.io_chunk_mib), 1) << 20) + 8192)
+                fits[0] = sv.f_bavail * sv.f_frsize > ring * 1.25 + (64 << 20)
             except OSError:
                 fits[0] = False
         dist.broadcast_object_list(fits, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if not fits[0]:
             name = None
-            stats["b_once"] = "off: /dev/shm cannot hold B"
+            stats["b_once"] = "off: /dev/shm cannot hold the staging ring"
     if rows > 0:
         import ctypes
         call = bofhip.Options()

@@ -55,8 +55,8 @@
 // One PROCESS per GPU (bof_options.share_world > 1, bof_dist.flash_gemm_row_sharded): every rank
 // makes this call on its slab, and a shared panel is read from the file by ONE rank of the node
 // (panel l by rank l % share_world), which publishes its chunks in a node-shared staging segment
-// (ShareSeg: POSIX shared memory + one futex flag per chunk); the other ranks' readers wait for
-// the flag and copy the chunk out of the segment instead of reading the file.  All ranks queue
+// (ShareSeg: a ring of chunk slots in POSIX shared memory, futex words per slot); the other ranks' readers
+// wait for the chunk and copy it out of the ring instead of reading the file.  All ranks queue
 // the shared panels in the same order and readers take requests in queue order, so the earliest
 // unpublished chunk is always being read by its owner: no cycle of waits.
 #ifndef _GNU_SOURCE
@@ -201,21 +201,31 @@ int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel re
 }
 bool trace_on() { return trace_level() >= 1; }
 
-// A shared operand staged in node-shared memory by the ranks of a share_world > 1 call: the matrix
-// image in file layout (tmpfs pages are allocated as they are written) and one flag per chunk
-// (0 not there yet, 1 published, 2 the owner failed).
+// A shared operand on its way through node-shared memory between the ranks of a share_world > 1 call: a RING
+// of `n_slots` chunk-sized slots in POSIX shared memory (the pages are allocated on the first lap and
+// reused: a whole image of B in tmpfs cost a page fault + a zeroed page per 4 KiB, 16 GiB published at
+// ~4 GB/s) with two words per slot: `ready` = 1 + the index of the chunk it holds (0: none yet, ~0: its
+// owner failed) and `consumed` = how many peers have copied that chunk out.  Chunk c goes to slot c %
+// n_slots; its owner waits until the slot's previous occupant (chunk c - n_slots) has been taken by all
+// world - 1 peers, copies the chunk in and publishes; a peer waits for `ready` == c + 1, copies the chunk
+// out and adds itself to `consumed`.  Both waits are futex waits.  All ranks handle the shared chunks in
+// the same order and their readers take requests in queue order, so whoever the earliest unfinished chunk
+// waits for has already passed everything that chunk's slot depends on: no cycle of waits.
+struct ShareSlot { uint32_t ready, consumed; };
 struct ShareSeg {
   char *base = nullptr;
-  size_t bytes = 0;
-  uint32_t *flag = nullptr;           // accessed through __atomic builtins + futex
-  size_t n_flags = 0;
-  std::vector<size_t> first_flag;     // per panel
+  size_t slot_bytes = 0;
+  int n_slots = 0;
+  ShareSlot *st = nullptr;
+  size_t n_chunks = 0;
+  std::vector<size_t> first_chunk;    // per panel: index of its first chunk in the operand's chunk order
   void unmap() {
-    if (base) ::munmap(base, bytes);
-    if (flag) ::munmap(flag, n_flags * sizeof(uint32_t));
-    base = nullptr; flag = nullptr;
+    if (base) ::munmap(base, slot_bytes * (size_t) n_slots);
+    if (st) ::munmap(st, sizeof(ShareSlot) * (size_t) n_slots);
+    base = nullptr; st = nullptr;
   }
 };
+constexpr uint32_t kShareFailed = 0xFFFFFFFFu;
 void *shm_map(const std::string &name, size_t bytes) {
   const int fd = ::shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
   if (fd < 0) return nullptr;
@@ -224,19 +234,24 @@ void *shm_map(const std::string &name, size_t bytes) {
   ::close(fd);
   return p == MAP_FAILED ? nullptr : p;
 }
-void flag_publish(uint32_t *f, uint32_t v) {
+void word_publish(uint32_t *f, uint32_t v) {
   __atomic_store_n(f, v, __ATOMIC_RELEASE);
   ::syscall(SYS_futex, f, FUTEX_WAKE, INT32_MAX, nullptr, nullptr, 0);
 }
-// waits until *f != 0; returns its value, or 0 after `timeout_s` / once `stop` is set
-uint32_t flag_wait(uint32_t *f, double timeout_s, const std::atomic<int> &stop) {
+void word_add_publish(uint32_t *f) {
+  __atomic_fetch_add(f, 1u, __ATOMIC_ACQ_REL);
+  ::syscall(SYS_futex, f, FUTEX_WAKE, INT32_MAX, nullptr, nullptr, 0);
+}
+// waits until done(*f); returns false after `timeout_s` / once `stop` is set
+template <class Pred>
+bool word_wait(uint32_t *f, Pred done, double timeout_s, const std::atomic<int> &stop) {
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
   for (;;) {
     const uint32_t v = __atomic_load_n(f, __ATOMIC_ACQUIRE);
-    if (v) return v;
-    if (stop.load() || std::chrono::steady_clock::now() >= t_end) return 0;
+    if (done(v)) return true;
+    if (stop.load() || std::chrono::steady_clock::now() >= t_end) return false;
     struct timespec ts = {0, 200 * 1000 * 1000};   // re-check the stop flag / deadline five times a second
-    ::syscall(SYS_futex, f, FUTEX_WAIT, 0, &ts, nullptr, 0);
+    ::syscall(SYS_futex, f, FUTEX_WAIT, v, &ts, nullptr, 0);
   }
 }
 
@@ -421,18 +436,26 @@ void PanelHub::reader_main(int home) {
     const int ps = rring->acquire();
     int rc = 0;
     ShareSeg *sg = rq.di < 0 && share_world > 1 && seg[rq.mat].base ? &seg[rq.mat] : nullptr;
-    const size_t seg_off = (size_t) ((uint64_t) M0.panels[(size_t) rq.panel].r0 * (uint64_t) M0.ld * 4 + rq.off);
-    uint32_t *flag = sg ? sg->flag + sg->first_flag[(size_t) rq.panel] + (size_t) rq.c : nullptr;
+    const size_t ci = sg ? sg->first_chunk[(size_t) rq.panel] + (size_t) rq.c : 0;     // the chunk's index in the operand
+    ShareSlot *sl = sg ? sg->st + ci % (size_t) sg->n_slots : nullptr;
+    char *ring = sg ? sg->base + (ci % (size_t) sg->n_slots) * sg->slot_bytes : nullptr;
     const bool from_peer = sg && rq.panel % share_world != share_rank;
     uint64_t delta = 0;                 // where the chunk's first byte sits in the pinned slot
     char *const slot = (char *) rring->ptr(ps);
     if (from_peer) {
-      // another rank of the node reads this panel from the file: its chunk, out of the staging segment
+      // another rank of the node reads this panel from the file: its chunk, out of the staging ring
       if (!io_error.load()) {
         TraceRange r("panel chunk from a peer");
-        const uint32_t v = flag_wait(flag, share_timeout_s, io_error);
-        if (v == 1) memcpy(slot, sg->base + seg_off, rq.bytes);
-        else if (!io_error.load()) rc = v == 2 ? -EIO : -ETIMEDOUT;
+        const uint32_t want = (uint32_t) ci + 1;
+        uint32_t seen = 0;
+        const bool ok = word_wait(&sl->ready, [&](uint32_t v) { seen = v; return v == want || v == kShareFailed; },
+                                  share_timeout_s, io_error);
+        if (ok && seen == want) {
+          memcpy(slot, ring, rq.bytes);
+          word_add_publish(&sl->consumed);
+        } else if (!io_error.load()) {
+          rc = ok ? -EIO : -ETIMEDOUT;
+        }
       }
       if (rc) fail_io(rc);
       cnt.peer += rq.bytes;
@@ -443,8 +466,20 @@ void PanelHub::reader_main(int home) {
         else rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, slot, M0.aio);
       }
       if (sg) {   // publish (or tell the peers that it will not come)
-        if (!rc && !io_error.load()) memcpy(sg->base + seg_off, slot + delta, rq.bytes);
-        flag_publish(flag, !rc && !io_error.load() ? 1u : 2u);
+        bool ok = !rc && !io_error.load();
+        if (ok && ci >= (size_t) sg->n_slots) {   // the slot's previous occupant must have been taken by every peer
+          const uint32_t prev = (uint32_t) (ci - (size_t) sg->n_slots) + 1, peers = (uint32_t) share_world - 1;
+          ok = word_wait(&sl->consumed, [&](uint32_t v) {
+                 return __atomic_load_n(&sl->ready, __ATOMIC_ACQUIRE) == prev && v >= peers; }, share_timeout_s, io_error);
+          if (!ok && !io_error.load()) rc = -ETIMEDOUT;
+        }
+        if (ok) {
+          __atomic_store_n(&sl->consumed, 0u, __ATOMIC_RELAXED);
+          memcpy(ring, slot + delta, rq.bytes);
+          word_publish(&sl->ready, (uint32_t) ci + 1);
+        } else {
+          word_publish(&sl->ready, kShareFailed);
+        }
       }
       if (rc) fail_io(rc);
       cnt.rd += rq.bytes;
@@ -987,16 +1022,11 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   }
   for (int x = 0; x < 2; x++) H.issued[x].assign(H.runs[0]->mat[x].panels.size(), 0);
   guard.add([&H] {
-    // an owner that gives up tells the peers so (they would wait for the timeout otherwise)
+    // a rank that gives up tells the peers so (they would wait for the timeout otherwise): every slot failed
     for (int x = 0; x < 2; x++) {
       ShareSeg &sg = H.seg[x];
-      if (sg.flag && H.io_error.load())
-        for (size_t p = 0; p + 1 <= sg.first_flag.size(); p++)
-          if ((int) (p % (size_t) H.share_world) == H.share_rank) {
-            const size_t f1 = p + 1 < sg.first_flag.size() ? sg.first_flag[p + 1] : sg.n_flags;
-            for (size_t f = sg.first_flag[p]; f < f1; f++)
-              if (__atomic_load_n(sg.flag + f, __ATOMIC_ACQUIRE) == 0) flag_publish(sg.flag + f, 2u);
-          }
+      if (sg.st && H.io_error.load())
+        for (int q = 0; q < sg.n_slots; q++) word_publish(&sg.st[q].ready, kShareFailed);
       sg.unmap();
     }
   });
@@ -1012,15 +1042,17 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       const Mat &M = H.runs[0]->mat[x];
       if (!M.shared) continue;
       ShareSeg &sg = H.seg[x];
-      for (const Panel &P : M.panels) {
-        sg.first_flag.push_back(sg.n_flags);
-        sg.n_flags += (size_t) ((P.bytes + H.runs[0]->chunk - 1) / H.runs[0]->chunk);
+      for (size_t p = 0; p < M.panels.size(); p++) {
+        sg.first_chunk.push_back(sg.n_chunks);
+        sg.n_chunks += (size_t) M.n_chunks((int) p, H.runs[0]->chunk);
       }
-      sg.bytes = M.total_bytes;
+      // ring depth: what the readers of every rank can have in flight, twice over; 2 GiB at the defaults
+      sg.n_slots = (int) std::min<size_t>(sg.n_chunks, (size_t) std::max<long>(8, env_long("BOF_SHARE_SLOTS", 64)));
+      sg.slot_bytes = H.runs[0]->chunk + 2 * Mat::kPage;
       const std::string base = std::string(o.share_name) + "." + "AB"[x];
-      sg.base = (char *) shm_map(base + ".data", sg.bytes);
-      sg.flag = (uint32_t *) shm_map(base + ".flags", sg.n_flags * sizeof(uint32_t));
-      if (!sg.base || !sg.flag) {
+      sg.base = (char *) shm_map(base + ".data", sg.slot_bytes * (size_t) sg.n_slots);
+      sg.st = (ShareSlot *) shm_map(base + ".flags", sizeof(ShareSlot) * (size_t) sg.n_slots);
+      if (!sg.base || !sg.st) {
         set_error(std::string("bof_flash_gemm: cannot map the node-shared staging segment ") + base + ": " + strerror(errno));
         return BOF_EIO;
       }

@@ -108,8 +108,9 @@ typedef struct {
    * row-major) is read from storage ONCE PER NODE instead of once per rank.  Its row panels are
    * dealt round-robin to the ranks (panel l belongs to rank l % share_world); the owner reads a
    * panel from the file (O_DIRECT, as always) and, besides copying it to its own GPU, publishes it
-   * in a node-shared staging segment (POSIX shared memory `share_name`.*, one ready flag per chunk,
-   * futex wake-ups); the other ranks take the chunk from there instead of from the file.  Same
+   * chunk by chunk in a node-shared staging ring (POSIX shared memory `share_name`.*: 64 chunk slots,
+   * reused once every peer has taken a slot's chunk; futex wake-ups); the other ranks take the chunk
+   * from there instead of from the file.  Same
    * panels, same order, same bits.  Every participating rank must make the same call (same
    * problem, same options) with its own share_rank in [0, share_world); share_name must be new
    * for every collective call and is removed with bof_share_cleanup once all ranks have returned.
