@@ -26,6 +26,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <map>
 #include <mutex>
 #include <string>
@@ -627,7 +628,10 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
 struct CsrExtra {
   const int64_t *ia = nullptr;     // the offsets of this device's rows, already on the host
   char *shared_op = nullptr;       // B (csrmm) / x (csrgemv 'N') already on its way into THIS device's HBM ...
-  hipEvent_t shared_ready = nullptr;  // ... complete when this event (of this device) has fired
+  hipEvent_t shared_ready = nullptr;  // ... complete when this event (of this device) has fired;
+  std::shared_future<int> *shared_fed = nullptr;   // ... which is RECORDED once this future is set (its value: the
+                                                   // feed's return code).  Waiting on an event that has not been
+                                                   // recorded yet is a no-op, so the host waits for the future first.
   float *partial_y = nullptr;      // csrgemv 'T': zeroed full-length vector in this device's HBM that takes
                                    // the partial sums and STAYS there (the caller reduces the partials)
   int64_t c_ld = 0;                // column-major C: rows of the whole matrix (0: this call's m)
@@ -761,6 +765,10 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   auto upload_resident = [&]() -> int {
     (void) hipSetDevice(R.dev);
     if (ext_op) {   // on its way already (multi-device call): order this device's streams behind it
+      if (ex->shared_fed) {
+        const int fed = ex->shared_fed->get();      // the feeder has queued every copy and recorded the event
+        if (fed) return fed;
+      }
       BOF_HIP_TRY(hipStreamWaitEvent(R.h2d, ex->shared_ready, 0));
       if (!is_mm && trans == 'T' && !ext_y) BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
       BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
@@ -1097,7 +1105,13 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   // ---- the shared operand goes to every device while the pipelines start ------------------------------
   int feed_rc = BOF_OK;
   std::string feed_err;
+  std::promise<int> fed_promise;
+  std::shared_future<int> fed = fed_promise.get_future().share();
   std::thread feeder([&] {
+    struct SetOnExit {     // the pipelines wait for this future before they wait for the device-side events
+      std::promise<int> &p; int &rc;
+      ~SetOnExit() { p.set_value(rc); }
+    } set_on_exit{fed_promise, feed_rc};
     if (!share_op) return;
     std::vector<char *> dst;
     std::vector<hipStream_t> sts;
@@ -1125,7 +1139,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     CsrExtra ex;
     ex.ia = ia.data() + S.row0;
     ex.out = &S.cnt;
-    if (share_op) { ex.shared_op = S.op; ex.shared_ready = S.ready; }
+    if (share_op) { ex.shared_op = S.op; ex.shared_ready = S.ready; ex.shared_fed = &fed; }
     bof_fptr c_f = fc;
     const float *b_h = hb;
     float *c_h = hc;

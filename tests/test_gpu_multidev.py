@@ -156,6 +156,38 @@ def test_flash_csrmm_devices(dev, tmp_path, ord_b, k, alpha, beta, ndev):
 
 
 @pytest.mark.parametrize("ord_b", ["R", "C"])
+@pytest.mark.parametrize("direct", [False, True])
+def test_flash_csrmm_devices_large_b(dev, tmp_path, ord_b, direct):
+    """A B operand of 400 MB and few non-zeros: the row blocks are in HBM long before B is.  Every device's
+    pipeline has to wait for the ONE feed of B (read once, fanned out) on the host first -- the event the
+    feed records behind its last copy does not exist for the device until it has been recorded (a pipeline
+    that only queued a wait for it ran ahead of B at cfg3 size: caught by the full-size run, then here)."""
+    m, n, k = 8192, 400_000, 256
+    val, ja, ia = orc.sparse_create(m, n, 2.5e-5)
+    rng = np.random.default_rng(3)
+    b = rng.integers(0, 9, (n, k)).astype(np.float32)
+    c0 = np.zeros((m, k), np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    ref = orc.flash_csrmm(ord_b, m, n, k, 1.0, 0.0, val, ia, ja, b, c0.copy(), 1000, 5000, 1024)
+    F = Files(tmp_path, direct=direct, val=val, ja=ja, ia=ia, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(max_nnzs=5000, csrmm_rblk=1000, n_io_threads=4, use_odirect=int(direct),
+                                      devices=[0, 0, 0])
+        for _ in range(3):
+            bofhip.flash_csrmm("N", m, n, k, 1.0, 0.0, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), ord_b, F.fptr("b"),
+                               F.fptr("c"), opts)
+            assert np.array_equal(F.read("c", np.float32, c0.shape), ref)
+            c0.tofile(F.paths["c"])
+        x = (np.arange(n) % 10).astype(np.float32)
+        y = np.full(m, -1.0, np.float32)
+        bofhip.flash_csrgemv("N", m, n, F.fptr("val"), F.fptr("ia"), F.fptr("ja"), x.ctypes.data, y.ctypes.data, opts)
+        assert np.array_equal(y, orc.flash_csrgemv("N", m, n, val, ia, ja, x, np.zeros(m, np.float32), 1000, 5000))
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_b", ["R", "C"])
 def test_flash_csrmm_inmem_devices(dev, tmp_path, ord_b):
     m, n, k = 4096, 2048, 136
     val, ja, ia = orc.sparse_create(m, n, 0.01)
