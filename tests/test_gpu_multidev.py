@@ -97,6 +97,43 @@ def test_flash_gemm_devices_ring_reuse(dev, tmp_path, ord_, ta, tb, beta):
         F.close()
 
 
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_flash_gemm_devices_equals_single_at_scale(dev, tmp_path, ord_, ta, tb):
+    """6144 x 5120 x 4096 with 1024-tiles (6 / 5 C panels of 16-24 MiB, several 4 MiB chunks each, k chains of
+    4), beta != 0, uniform-random data, O_DIRECT: the C file of the three-device call equals the C file of the
+    single-device call bit for bit, in all 8 layouts (including those whose A / B is paneled along k and so
+    shared with a column offset per device), and both agree with float64 on sampled rows."""
+    m, n, k, blk = 6144, 5120, 4096, 1024
+    rng = np.random.default_rng(12)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        res = []
+        for devices in (None, [0, 0, 0]):
+            kw = dict(gemm_blk=blk, n_io_threads=6, pinned_slots=6, gemm_path=2, io_chunk_mib=4)
+            if devices:
+                kw["devices"] = devices
+            bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 1.5, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              bofhip.default_options(**kw))
+            st = bofhip.flash_last_stats()
+            assert st["bytes_read"] == 4 * (a.size + b.size + c0.size) and st["bytes_written"] == 4 * c0.size
+            res.append(F.read("c", np.float32, sc).copy())
+            c0.tofile(F.paths["c"])
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+        assert np.array_equal(res[0], res[1])
+        A = a.astype(np.float64) if (ta == "T") == (ord_ == "C") else a.T.astype(np.float64)     # logical m x k
+        B = b.astype(np.float64) if (tb == "T") == (ord_ == "C") else b.T.astype(np.float64)     # logical k x n
+        rows = [0, 1023, 1024, 3071, m - 1]
+        want = 0.5 * (A[rows] @ B) + 1.5 * (c0 if ord_ == "R" else c0.T)[rows].astype(np.float64)
+        got = (res[1] if ord_ == "R" else res[1].T)[rows]
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+    finally:
+        F.close()
+
+
 @pytest.mark.parametrize("ord_,ta,tb", [("C", "T", "N"), ("R", "N", "T")])
 @pytest.mark.parametrize("path", [1, 2])
 def test_flash_kmeans_devices(dev, tmp_path, ord_, ta, tb, path):
