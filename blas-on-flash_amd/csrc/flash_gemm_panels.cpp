@@ -85,6 +85,7 @@
 #include <vector>
 
 #include "flash_common.h"
+#include "share_ring.h"
 
 namespace bof {
 namespace {
@@ -201,59 +202,13 @@ int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel re
 }
 bool trace_on() { return trace_level() >= 1; }
 
-// A shared operand on its way through node-shared memory between the ranks of a share_world > 1 call: a RING
-// of `n_slots` chunk-sized slots in POSIX shared memory (the pages are allocated on the first lap and
-// reused: a whole image of B in tmpfs cost a page fault + a zeroed page per 4 KiB, 16 GiB published at
-// ~4 GB/s) with two words per slot: `ready` = 1 + the index of the chunk it holds (0: none yet, ~0: its
-// owner failed) and `consumed` = how many peers have copied that chunk out.  Chunk c goes to slot c %
-// n_slots; its owner waits until the slot's previous occupant (chunk c - n_slots) has been taken by all
-// world - 1 peers, copies the chunk in and publishes; a peer waits for `ready` == c + 1, copies the chunk
-// out and adds itself to `consumed`.  Both waits are futex waits.  All ranks handle the shared chunks in
-// the same order and their readers take requests in queue order, so whoever the earliest unfinished chunk
-// waits for has already passed everything that chunk's slot depends on: no cycle of waits.
-struct ShareSlot { uint32_t ready, consumed; };
+// A shared operand's way between the ranks of a share_world > 1 call: the staging ring of share_ring.h plus
+// the place of every panel's chunks in the operand's chunk order.
 struct ShareSeg {
-  char *base = nullptr;
-  size_t slot_bytes = 0;
-  int n_slots = 0;
-  ShareSlot *st = nullptr;
+  ShareRing ring;
   size_t n_chunks = 0;
   std::vector<size_t> first_chunk;    // per panel: index of its first chunk in the operand's chunk order
-  void unmap() {
-    if (base) ::munmap(base, slot_bytes * (size_t) n_slots);
-    if (st) ::munmap(st, sizeof(ShareSlot) * (size_t) n_slots);
-    base = nullptr; st = nullptr;
-  }
 };
-constexpr uint32_t kShareFailed = 0xFFFFFFFFu;
-void *shm_map(const std::string &name, size_t bytes) {
-  const int fd = ::shm_open(name.c_str(), O_CREAT | O_RDWR, 0600);
-  if (fd < 0) return nullptr;
-  void *p = MAP_FAILED;
-  if (::ftruncate(fd, (off_t) bytes) == 0) p = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  ::close(fd);
-  return p == MAP_FAILED ? nullptr : p;
-}
-void word_publish(uint32_t *f, uint32_t v) {
-  __atomic_store_n(f, v, __ATOMIC_RELEASE);
-  ::syscall(SYS_futex, f, FUTEX_WAKE, INT32_MAX, nullptr, nullptr, 0);
-}
-void word_add_publish(uint32_t *f) {
-  __atomic_fetch_add(f, 1u, __ATOMIC_ACQ_REL);
-  ::syscall(SYS_futex, f, FUTEX_WAKE, INT32_MAX, nullptr, nullptr, 0);
-}
-// waits until done(*f); returns false after `timeout_s` / once `stop` is set
-template <class Pred>
-bool word_wait(uint32_t *f, Pred done, double timeout_s, const std::atomic<int> &stop) {
-  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s);
-  for (;;) {
-    const uint32_t v = __atomic_load_n(f, __ATOMIC_ACQUIRE);
-    if (done(v)) return true;
-    if (stop.load() || std::chrono::steady_clock::now() >= t_end) return false;
-    struct timespec ts = {0, 200 * 1000 * 1000};   // re-check the stop flag / deadline five times a second
-    ::syscall(SYS_futex, f, FUTEX_WAIT, v, &ts, nullptr, 0);
-  }
-}
 
 struct PanelHub;
 
@@ -435,10 +390,8 @@ void PanelHub::reader_main(int home) {
     Mat &M0 = R0.mat[rq.mat];
     const int ps = rring->acquire();
     int rc = 0;
-    ShareSeg *sg = rq.di < 0 && share_world > 1 && seg[rq.mat].base ? &seg[rq.mat] : nullptr;
+    ShareSeg *sg = rq.di < 0 && share_world > 1 && seg[rq.mat].ring.base ? &seg[rq.mat] : nullptr;
     const size_t ci = sg ? sg->first_chunk[(size_t) rq.panel] + (size_t) rq.c : 0;     // the chunk's index in the operand
-    ShareSlot *sl = sg ? sg->st + ci % (size_t) sg->n_slots : nullptr;
-    char *ring = sg ? sg->base + (ci % (size_t) sg->n_slots) * sg->slot_bytes : nullptr;
     const bool from_peer = sg && rq.panel % share_world != share_rank;
     uint64_t delta = 0;                 // where the chunk's first byte sits in the pinned slot
     char *const slot = (char *) rring->ptr(ps);
@@ -446,16 +399,8 @@ void PanelHub::reader_main(int home) {
       // another rank of the node reads this panel from the file: its chunk, out of the staging ring
       if (!io_error.load()) {
         TraceRange r("panel chunk from a peer");
-        const uint32_t want = (uint32_t) ci + 1;
-        uint32_t seen = 0;
-        const bool ok = word_wait(&sl->ready, [&](uint32_t v) { seen = v; return v == want || v == kShareFailed; },
-                                  share_timeout_s, io_error);
-        if (ok && seen == want) {
-          memcpy(slot, ring, rq.bytes);
-          word_add_publish(&sl->consumed);
-        } else if (!io_error.load()) {
-          rc = ok ? -EIO : -ETIMEDOUT;
-        }
+        rc = sg->ring.consume(ci, slot, rq.bytes, share_timeout_s, io_error);
+        if (rc == -ECANCELED) rc = 0;    // this call is failing for another reason already
       }
       if (rc) fail_io(rc);
       cnt.peer += rq.bytes;
@@ -466,20 +411,9 @@ void PanelHub::reader_main(int home) {
         else rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, slot, M0.aio);
       }
       if (sg) {   // publish (or tell the peers that it will not come)
-        bool ok = !rc && !io_error.load();
-        if (ok && ci >= (size_t) sg->n_slots) {   // the slot's previous occupant must have been taken by every peer
-          const uint32_t prev = (uint32_t) (ci - (size_t) sg->n_slots) + 1, peers = (uint32_t) share_world - 1;
-          ok = word_wait(&sl->consumed, [&](uint32_t v) {
-                 return __atomic_load_n(&sl->ready, __ATOMIC_ACQUIRE) == prev && v >= peers; }, share_timeout_s, io_error);
-          if (!ok && !io_error.load()) rc = -ETIMEDOUT;
-        }
-        if (ok) {
-          __atomic_store_n(&sl->consumed, 0u, __ATOMIC_RELAXED);
-          memcpy(ring, slot + delta, rq.bytes);
-          word_publish(&sl->ready, (uint32_t) ci + 1);
-        } else {
-          word_publish(&sl->ready, kShareFailed);
-        }
+        const bool ok = !rc && !io_error.load();
+        const int prc = sg->ring.produce(ci, ok ? slot + delta : nullptr, rq.bytes, share_world, share_timeout_s, io_error);
+        if (prc && prc != -ECANCELED && !rc) rc = prc;
       }
       if (rc) fail_io(rc);
       cnt.rd += rq.bytes;
@@ -1022,12 +956,10 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   }
   for (int x = 0; x < 2; x++) H.issued[x].assign(H.runs[0]->mat[x].panels.size(), 0);
   guard.add([&H] {
-    // a rank that gives up tells the peers so (they would wait for the timeout otherwise): every slot failed
+    // a rank that gives up tells the peers so (they would wait for the timeout otherwise)
     for (int x = 0; x < 2; x++) {
-      ShareSeg &sg = H.seg[x];
-      if (sg.st && H.io_error.load())
-        for (int q = 0; q < sg.n_slots; q++) word_publish(&sg.st[q].ready, kShareFailed);
-      sg.unmap();
+      if (H.io_error.load()) H.seg[x].ring.fail_all();
+      H.seg[x].ring.unmap();
     }
   });
   if (o.share_world > 1) {
@@ -1047,13 +979,10 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
         sg.n_chunks += (size_t) M.n_chunks((int) p, H.runs[0]->chunk);
       }
       // ring depth: what the readers of every rank can have in flight, twice over; 2 GiB at the defaults
-      sg.n_slots = (int) std::min<size_t>(sg.n_chunks, (size_t) std::max<long>(8, env_long("BOF_SHARE_SLOTS", 64)));
-      sg.slot_bytes = H.runs[0]->chunk + 2 * Mat::kPage;
+      const int n_slots = (int) std::min<size_t>(sg.n_chunks, (size_t) std::max<long>(8, env_long("BOF_SHARE_SLOTS", 64)));
       const std::string base = std::string(o.share_name) + "." + "AB"[x];
-      sg.base = (char *) shm_map(base + ".data", sg.slot_bytes * (size_t) sg.n_slots);
-      sg.st = (ShareSlot *) shm_map(base + ".flags", sizeof(ShareSlot) * (size_t) sg.n_slots);
-      if (!sg.base || !sg.st) {
-        set_error(std::string("bof_flash_gemm: cannot map the node-shared staging segment ") + base + ": " + strerror(errno));
+      if (!sg.ring.map(base, H.runs[0]->chunk + 2 * Mat::kPage, n_slots)) {
+        set_error(std::string("bof_flash_gemm: cannot map the node-shared staging ring ") + base + ": " + strerror(errno));
         return BOF_EIO;
       }
     }
@@ -1150,7 +1079,36 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
 
 extern "C" int bof_share_cleanup(const char *share_name) {
   if (!share_name || !share_name[0]) return BOF_EINVAL;
-  for (const char *m : {".A", ".B"})
-    for (const char *k : {".data", ".flags"}) (void) ::shm_unlink((std::string(share_name) + m + k).c_str());
+  for (const char *m : {".A", ".B"}) bof::ShareRing::unlink(std::string(share_name) + m);
   return BOF_OK;
+}
+
+// Diagnostic (no GPU involved): `world` processes call this with the same name / sizes and their own rank; chunk
+// c belongs to rank c % world, which fills it with a pattern of (c, position) and produces it; everybody else
+// consumes it and checks the pattern.  Returns the number of chunks verified (n_chunks - the own ones) or a
+// negative errno.  What tests/test_dist_gloo.py runs with several processes on the CPU box.
+extern "C" int64_t bof_share_selftest(const char *share_name, int rank, int world, int64_t n_chunks,
+                                      int64_t chunk_bytes, int n_slots, double timeout_s) {
+  if (!share_name || world < 2 || rank < 0 || rank >= world || n_chunks <= 0 || chunk_bytes < 8 || n_slots < 1)
+    return -EINVAL;
+  bof::ShareRing ring;
+  if (!ring.map(std::string(share_name) + ".A", (size_t) chunk_bytes, n_slots)) return -errno;
+  std::atomic<int> stop{0};
+  std::vector<uint64_t> buf((size_t) chunk_bytes / 8);
+  int64_t verified = 0;
+  int rc = 0;
+  for (int64_t c = 0; c < n_chunks && !rc; c++) {
+    if (c % world == rank) {
+      for (size_t i = 0; i < buf.size(); i++) buf[i] = (uint64_t) c * 0x9E3779B97F4A7C15ull + i;
+      rc = ring.produce((size_t) c, buf.data(), buf.size() * 8, world, timeout_s, stop);
+    } else {
+      rc = ring.consume((size_t) c, buf.data(), buf.size() * 8, timeout_s, stop);
+      for (size_t i = 0; i < buf.size() && !rc; i++)
+        if (buf[i] != (uint64_t) c * 0x9E3779B97F4A7C15ull + i) rc = -EILSEQ;
+      if (!rc) verified++;
+    }
+  }
+  if (rc) ring.fail_all();
+  ring.unmap();
+  return rc ? rc : verified;
 }

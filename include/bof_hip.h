@@ -368,6 +368,13 @@ int bof_flash_release(void);
 /* Removes the node-shared staging objects of a finished share_world > 1 call (every rank has
  * returned from it: the caller's barrier); harmless if they are gone already. */
 int bof_share_cleanup(const char *share_name);
+/* Diagnostic of the staging ring alone (pure host code, no GPU): `world` processes call this with the same
+ * name and sizes and their own rank; chunk c is produced by rank c % world (a pattern of (c, position)) and
+ * consumed and checked by all others, through a ring of n_slots slots.  Returns the number of chunks this
+ * rank verified or a negative errno (-ETIMEDOUT when a peer never delivers).  Remove with
+ * bof_share_cleanup. */
+int64_t bof_share_selftest(const char *share_name, int rank, int world, int64_t n_chunks,
+                           int64_t chunk_bytes, int n_slots, double timeout_s);
 
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
  * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided

@@ -97,3 +97,51 @@ def test_csrgemv_two_rank_reduce(tmp_path, golden):
     assert parts[0][1] == parts[1][0]
     yN = np.concatenate([p[2:] for p in parts]).astype(np.float32)
     assert hashlib.sha256(yN.tobytes()).hexdigest() == want["gen_csrgemv_N"]
+
+
+# ---- node-shared staging ring of the one-process-per-GPU GEMM (share_world > 1): host code only ---------
+def _ring_worker(rank, world, name, n_chunks, chunk_bytes, n_slots, timeout_s, skip, q):
+    import bofhip
+    if rank in skip:                       # a rank that never shows up
+        q.put((rank, None))
+        return
+    q.put((rank, int(bofhip.lib().bof_share_selftest(name.encode(), rank, world, n_chunks, chunk_bytes, n_slots,
+                                                     timeout_s))))
+
+
+def _run_ring(world, n_chunks, chunk_bytes, n_slots, timeout_s, skip=()):
+    import bofhip
+    name = f"/bof_test_{os.getpid()}_{world}_{n_slots}_{len(skip)}"
+    bofhip.lib().bof_share_cleanup(name.encode())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, name, n_chunks, chunk_bytes, n_slots, timeout_s, skip, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    bofhip.lib().bof_share_cleanup(name.encode())
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith(name[1:])]
+    return res
+
+
+@pytest.mark.parametrize("world,n_slots", [(2, 1), (2, 8), (3, 4), (4, 64)])
+def test_share_ring_delivers_every_chunk_once_to_every_peer(world, n_slots):
+    """What bof_dist.flash_gemm_row_sharded relies on for "B once per node": chunk c is produced by rank
+    c % world and taken by all others through a ring of n_slots reused slots (a slot is refilled only after
+    every peer has taken its chunk); content checked chunk by chunk; no GPU involved."""
+    n_chunks = 150
+    res = _run_ring(world, n_chunks, 256 << 10, n_slots, 30.0)
+    for r in range(world):
+        own = len(range(r, n_chunks, world))
+        assert res[r] == n_chunks - own, res
+
+
+def test_share_ring_missing_peer_times_out():
+    """A rank that never delivers: the others give up after the timeout with -ETIMEDOUT (or -EIO once a
+    peer has marked the ring failed) instead of waiting forever."""
+    res = _run_ring(3, 20, 64 << 10, 4, 1.5, skip=(1,))
+    assert res[1] is None
+    assert res[0] in (-110, -5) and res[2] in (-110, -5), res
