@@ -561,6 +561,8 @@ def roofline_e2e(leg, ceil, flops, kernel_s, mode):
     if ceil.get("pcie_h2d_GBps"):
         terms["pcie_h2d"] = st["bytes_h2d"] / (ceil["pcie_h2d_GBps"] * 1e9)
         terms["pcie_d2h"] = st["bytes_d2h"] / (ceil["pcie_d2h_GBps"] * 1e9)
+        if ceil.get("pcie_each_way_when_both_GBps"):     # both directions at once share the link's controllers
+            terms["pcie_both_ways"] = (st["bytes_h2d"] + st["bytes_d2h"]) / (2e9 * ceil["pcie_each_way_when_both_GBps"])
     raised = False
     if mode == "odirect" and ceil.get("disk_read_GBps"):
         terms["disk_read"] = st["bytes_read"] / (ceil["disk_read_GBps"] * 1e9)
