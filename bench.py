@@ -918,7 +918,7 @@ def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local
 
         def run():
             # every rank runs the level-3 pipeline on its slab; B's panels are read from the file once per
-            # node (panel l by rank l % world) and passed on through the node-shared staging segment
+            # node (panel l by rank l % world) and passed on through the node-shared staging ring
             import bof_dist
             last.update(bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], 0, 0, 0, opts,
                                                         b_once=True))

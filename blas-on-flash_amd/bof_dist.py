@@ -97,7 +97,7 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     share_name to bof_flash_gemm: panel l of B is read from the file by rank l % share_world, which
     publishes it chunk by chunk in a node-shared staging ring; the others take it from there (bof_options
     in include/bof_hip.h).  At cfg4 that is 16 + 16 GiB of reads per node instead of 16 + 8 x 16.  The
-    only torch.distributed call is the barrier behind which the staging segment is removed.
+    only torch.distributed call is the barrier behind which the staging ring is removed.
     b_once=False: every rank reads B itself.
 
     Returns {rows, bytes_read, bytes_written, bytes_peer, seconds} of this rank."""

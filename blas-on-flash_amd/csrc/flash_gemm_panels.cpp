@@ -54,7 +54,7 @@
 //
 // One PROCESS per GPU (bof_options.share_world > 1, bof_dist.flash_gemm_row_sharded): every rank
 // makes this call on its slab, and a shared panel is read from the file by ONE rank of the node
-// (panel l by rank l % share_world), which publishes its chunks in a node-shared staging segment
+// (panel l by rank l % share_world), which publishes its chunks in a node-shared staging ring
 // (ShareSeg: a ring of chunk slots in POSIX shared memory, futex words per slot); the other ranks' readers
 // wait for the chunk and copy it out of the ring instead of reading the file.  All ranks queue
 // the shared panels in the same order and readers take requests in queue order, so the earliest

@@ -322,7 +322,7 @@ typedef struct {
   uint64_t read_ops, write_ops;       /* requests handed to the kernel
                                          (iocbs + pread/pwrite calls)  */
   uint64_t bytes_peer;                /* bytes of a shared operand taken from another rank's
-                                         staging segment instead of the file (share_world > 1) */
+                                         staging ring instead of the file (share_world > 1) */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
 /* The same counters per device of the last level-3 call, in the order of the device list

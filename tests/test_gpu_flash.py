@@ -701,7 +701,7 @@ def test_flash_gemm_row_sharded_files(dev, tmp_path, nproc, b_once, padded):
     """Multi-GPU file path, one process per GPU: every rank runs the level-3
     pipeline on its row slab (flash_ptr + offset), no data-path collective.  b_once = 1 (the default
     of bof_dist.flash_gemm_row_sharded): B's panels are read from the file once per NODE -- panel l by
-    rank l % world, published in a node-shared staging segment, taken from there by the others --
+    rank l % world, published in a node-shared staging ring, taken from there by the others --
     so the ranks' bytes_read add up to A + B + C, and bytes_peer to (world - 1) x B.  padded: leading
     dimensions with gaps send the call to the tile cache, which reads its tiles itself.  Either way
     the C file equals the restated flash::gemm bit for bit.  nproc > 1 shares cuda:0 between the
