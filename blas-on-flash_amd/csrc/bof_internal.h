@@ -18,6 +18,10 @@ int hip_fail(hipError_t e, const char *what);  // records message, returns BOF_E
     hipError_t _e = (expr);                                           \
     if (_e != hipSuccess) return ::bof::hip_fail(_e, #expr);          \
   } while (0)
+// hipGetLastError() after a launch returns the thread's last unconsumed error, whichever call left it
+// there -- a cleanup call whose status was dropped, perhaps in an earlier library call on this thread.
+// The launch wrappers drop such leftovers first, so the status they return is the launch's own.
+inline void drop_stale_error() { (void) hipGetLastError(); }
 
 // ---- kernels (gemm_f32_mfma.hip, csr_kernels.hip, gen_kernels.hip) -------------
 hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,

@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "bof_hip.h"
+#include "bof_internal.h"
 
 namespace bof {
 
@@ -162,6 +163,7 @@ transpose_kernel(const float *__restrict__ in, int64_t ld_in, int64_t rows, int6
 
 hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out,
                          int64_t ld_out, hipStream_t st) {
+  drop_stale_error();
   if (rows == 0 || cols == 0) return hipSuccess;
   dim3 grid((unsigned) ((cols + 63) / 64), (unsigned) ((rows + 63) / 64)), block(256);
   hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, in, ld_in, rows, cols, out, ld_out);
@@ -171,6 +173,7 @@ hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t c
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
                   float *c, int64_t ldc, hipStream_t st) {
+  drop_stale_error();
   (void) k;
   if (m == 0 || n == 0) return hipSuccess;
   if (ord_b == 'R') {
@@ -267,6 +270,7 @@ csrgemv_t_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
 
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
                     const int64_t *col, const float *x, float *y, hipStream_t st) {
+  drop_stale_error();
   (void) n;
   if (m == 0) return hipSuccess;
   dim3 grid((unsigned) ((m + 255) / 256)), block(256);
@@ -292,6 +296,7 @@ sum_partials_kernel(float *dst, PartialPtrs src, int n_src, int64_t len) {
   }
 }
 hipError_t sum_partials(float *dst, const float *const *srcs, int n_src, int64_t len, hipStream_t st) {
+  drop_stale_error();
   if (len <= 0 || n_src <= 0) return hipSuccess;
   if (n_src > BOF_MAX_DEVICES) return hipErrorInvalidValue;
   PartialPtrs pp;

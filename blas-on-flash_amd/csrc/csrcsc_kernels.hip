@@ -588,6 +588,7 @@ size_t csrgemv_t_workspace_bytes(int64_t n, int64_t nnz) { return make_gemv_layo
 hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
                                   const int64_t *col, const float *x, float *y, void *workspace,
                                   hipStream_t st) {
+  drop_stale_error();
   hipError_t e;
   if (n <= 0) return hipSuccess;
   if (m <= 0 || nnz <= 0) return hipMemsetAsync(y, 0, (size_t) n * 4, st);
@@ -642,6 +643,7 @@ size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz) { return make_layout(n, nn
 hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr,
                    const int64_t *col, float *val_tr, int64_t *ptr_tr, int64_t *col_tr,
                    void *workspace, hipStream_t st) {
+  drop_stale_error();
   hipError_t e;
   if (m <= 0 || nnz <= 0) return hipMemsetAsync(ptr_tr, 0, (size_t) (n + 1) * 8, st);
   const Layout L = make_layout(n, nnz);

@@ -675,6 +675,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   const int lookahead = std::max(2, R.o.pinned_slots) * 2;
   int fetch_pos = 0;
   hipError_t herr = hipSuccess;
+  const char *where = "bof_flash_gemm dispatch";   // which step of the loop a HIP error came from
   int fail = 0;
   for (int t = 0; t < T && !fail; t++) {
     {
@@ -698,7 +699,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
     if (fetch_pos <= t && !R.wgroup.empty()) {
       // finished C tiles waiting for their row group hold slots: write them back and look again
       herr = R.flush_wgroup();
-      if (herr != hipSuccess) break;
+      if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (row-group write-back)"; break; }
       t--;
       continue;
     }
@@ -732,36 +733,39 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
         if (herr == hipSuccess) herr = hipStreamWaitEvent(st, w, 0);
       tl.launch_waits.clear();
     }
-    if (herr != hipSuccess) break;
+    if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (hipStreamWaitEvent)"; break; }
     DevSlot &sa = R.slots[R.tiles[ids[0]].slot], &sb = R.slots[R.tiles[ids[1]].slot],
             &sc = R.slots[R.tiles[ids[2]].slot];
     // packed tiles: leading dim = stored column count (reference gemm.cpp:117-120)
     herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
                       (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], kv,
                       tk.i * g.blk[0], tk.j * g.blk[2], st);
-    if (herr != hipSuccess) break;
+    if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (tile kernel launch)"; break; }
     R.cnt.tasks++;
     DevSlot *used[3] = {&sa, &sb, &sc};
     for (int x = 0; x < 3 && herr == hipSuccess; x++) {
       herr = hipEventRecord(used[x]->use[sidx], st);
       used[x]->used[sidx] = true;
     }
-    if (herr != hipSuccess) break;
+    if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (hipEventRecord)"; break; }
     {
       std::lock_guard<std::mutex> lk(R.mu);
       for (int x = 0; x < 3; x++) R.tiles[ids[x]].next_use++;
     }
     if (tk.l == Nk - 1) {  // chain finished: the C tile joins its row group; written back, it becomes evictable
       herr = R.finish_c_tile(ids[2], sidx);
-      if (herr != hipSuccess) break;
+      if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (C tile hand-over)"; break; }
       // the last chain of this block row in the current super-block: nothing more will join
       const bool row_done = t + 1 >= T || R.tasks[t + 1].l != Nk - 1 ||
                             R.tiles[R.task_tiles[(size_t) (t + 1) * 3 + 2]].rb != R.tiles[ids[2]].rb;
       if (row_done) herr = R.flush_wgroup();
-      if (herr != hipSuccess) break;
+      if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (row-group write-back)"; break; }
     }
   }
-  if (herr == hipSuccess && !fail) herr = R.flush_wgroup();
+  if (herr == hipSuccess && !fail) {
+    herr = R.flush_wgroup();
+    if (herr != hipSuccess) where = "bof_flash_gemm dispatch (row-group write-back)";
+  }
 
   // ---- drain ---------------------------------------------------------------------------
   BOF_TRACE_T("all tasks dispatched");
@@ -771,7 +775,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   for (auto &th : writers) th.join();
   (void) hipDeviceSynchronize();
   BOF_TRACE_T("drained (writes done)");
-  if (herr != hipSuccess && !fail) fail = hip_fail(herr, "bof_flash_gemm dispatch");
+  if (herr != hipSuccess && !fail) fail = hip_fail(herr, where);
   if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
     const int e = R.io_error.load();
     set_error("bof_flash_gemm: I/O pipeline failed: " +

@@ -21,6 +21,8 @@
 
 #include <algorithm>
 
+#include "bof_internal.h"
+
 namespace bof {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1244,6 +1246,7 @@ expand_tile_local_kernel(const float *__restrict__ src, float *__restrict__ dst,
   dst[i] = src[i - tile * blk];
 }
 hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t blk, int64_t nblk, hipStream_t st) {
+  drop_stale_error();
   if (len <= 0) return hipSuccess;
   hipLaunchKernelGGL(expand_tile_local_kernel, dim3((unsigned) ((len + 255) / 256)), dim3(256), 0, st, src, dst, len,
                      blk, nblk);
@@ -1254,6 +1257,7 @@ hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t 
 hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                  const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                  int64_t ldc, hipStream_t st) {
+  drop_stale_error();
   if (m == 0 || n == 0) return hipSuccess;
   if (ord == 'C')
     return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta,
@@ -1271,6 +1275,7 @@ hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64
                          const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                          int64_t ldc, const float *u1, const float *v1, const float *u2, const float *v2,
                          hipStream_t st) {
+  drop_stale_error();
   if (m == 0 || n == 0) return hipSuccess;
   if (ord == 'C')
     return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta,

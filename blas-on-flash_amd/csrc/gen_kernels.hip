@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bof_internal.h"
+
 namespace bof {
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -34,6 +36,7 @@ gen_dense_kernel(float *__restrict__ d, int64_t first, int64_t count, int mode, 
 
 hipError_t gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed,
                      hipStream_t st) {
+  drop_stale_error();
   if (count == 0) return hipSuccess;
   int64_t blocks = (count + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -128,6 +131,7 @@ gen_sparse_kernel(int64_t row0, int64_t nrows, int64_t ncols, int nnz_per_row,
 
 hipError_t gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols, int64_t nnz_per_row,
                            float *csr, int64_t *col, int64_t *off, hipStream_t st) {
+  drop_stale_error();
   if (nrows == 0) return hipSuccess;
   const int64_t ndraw = nnz_per_row + 40;
   if (ndraw > 2048) return hipErrorInvalidValue;
