@@ -542,10 +542,12 @@ struct GemmRun {
 }  // namespace
 
 // The tile-cache pipeline on the CURRENT device (the caller holds the device's call lock).
-// out: the call's counters (the caller publishes them).
+// out: the call's counters (the caller publishes them).  check_only: stop behind the budget check -- a call
+// over several devices asks every slab first, so that BOF_ENOMEM comes before any slab has written C.
 static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                                 float beta, bof_fptr fa, bof_fptr fb, bof_fptr fc, int64_t lda,
-                                int64_t ldb, int64_t ldc, const bof_options &o, const KmeansHost *kh, Counters *out) {
+                                int64_t ldb, int64_t ldc, const bof_options &o, const KmeansHost *kh, Counters *out,
+                                bool check_only = false) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc;
   GemmRun R;
@@ -562,7 +564,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   KmeansVecs kvd{nullptr, nullptr, nullptr};
   const KmeansVecs *kv = nullptr;
   Cleanup kv_guard;
-  if (kh) {
+  if (kh && !check_only) {
     rc = kmeans_upload(*kh, &kvd);
     if (rc) return rc;
     kv = &kvd;
@@ -607,6 +609,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
     set_error("bof_flash_gemm: HBM budget below 6 tile slots");
     return BOF_ENOMEM;
   }
+  if (check_only) return BOF_OK;
   n_slots = std::min<int64_t>(n_slots, (int64_t) R.tiles.size());
   int64_t gi, gj;
   build_order(g, beta, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
@@ -878,6 +881,12 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   if (slabs.size() == 1) {
     run_slab(*slabs[0]);
   } else {
+    for (auto &S : slabs) {     // every slab's budget first: BOF_ENOMEM must not leave C half written
+      DeviceScope ds(S->dev);
+      rc = flash_gemm_tilecache(ord, ta, tb, S->m, S->n, k, alpha, beta, S->f[0], S->f[1], S->f[2], g.ld[0], g.ld[1],
+                                g.ld[2], o, nullptr, nullptr, true);
+      if (rc) return rc;
+    }
     // one thread per distinct ordinal: slabs that share a device (an ordinal listed twice) run one after
     // the other -- they share that device's tile slab and rings
     std::vector<int> ords;

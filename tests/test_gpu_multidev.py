@@ -309,6 +309,29 @@ def test_devices_bad_list(dev, tmp_path):
         F.close()
 
 
+def test_devices_budget_error_leaves_c_untouched(dev, tmp_path):
+    """A budget one device's slab fits and another's does not (the slab with the merged tail has tiles
+    of 243 rows): BOF_ENOMEM must come BEFORE any slab writes C (found by tests/test_gpu_fuzz.py: slab 0
+    had been written when slab 1 reported the budget)."""
+    m, n, k, blk, ldc = 371, 353, 112, 128, 1024
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, (k, 384)).astype(np.float32)          # 'T': A stored k x m, lda 384
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, ldc)).astype(np.float32)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, gemm_path=1, hbm_budget=983040, devices=[0, 0], use_odirect=0)
+        with pytest.raises(bofhip.BofError, match="budget"):
+            bofhip.flash_gemm("R", "T", "N", m, n, k, 2.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 384, n, ldc, opts)
+        assert np.array_equal(F.read("c", np.float32, c0.shape), c0)
+        opts.hbm_budget = 0
+        bofhip.flash_gemm("R", "T", "N", m, n, k, 2.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 384, n, ldc, opts)
+        ref = orc.flash_gemm("R", "T", "N", m, n, k, 2.0, 0.0, a, b, c0.copy(), 384, n, ldc, blk)
+        assert np.array_equal(F.read("c", np.float32, c0.shape), ref)
+    finally:
+        F.close()
+
+
 def _run(binary, args, env_extra):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([binary] + [str(a) for a in args], capture_output=True, text=True, env=env, timeout=300)
