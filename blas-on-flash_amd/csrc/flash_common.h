@@ -4,11 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bof_hip.h"
@@ -206,6 +213,56 @@ struct DeviceScope {
 };
 // environment knob read at every call (never cached): `dflt` when unset or empty
 long env_long(const char *name, long dflt);
+
+// what a pipeline's io_error code says (negative errno, or -1000 - hipError_t)
+inline std::string io_error_text(int e) {
+  if (e == -ETIMEDOUT) return "timed out: no progress within $BOF_STALL_TIMEOUT_S, or a peer rank did not deliver its chunk";
+  return e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e);
+}
+
+// Watches one level-3 pipeline: `progress` is any number that changes while the call advances (bytes moved +
+// tasks launched).  When it has stood still for $BOF_STALL_TIMEOUT_S seconds (default 600; 0 = off) one line
+// goes to stderr and `on_stall` fails the call (-ETIMEDOUT -> BOF_EIO), so that everything parked on the
+// pipeline's condition variable returns instead of waiting forever.  The reference's counterpart is the fatal
+// exit after five failed submit / reap rounds (src/file_handles/flash_file_handle.cpp:28-76).  A thread stuck
+// INSIDE a system call or a HIP call is not released by this; the line on stderr then says how far the call got.
+class StallWatch {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+
+ public:
+  StallWatch(const char *what, std::function<uint64_t()> progress, std::function<void()> on_stall) {
+    const long limit = env_long("BOF_STALL_TIMEOUT_S", 600);
+    if (limit <= 0) return;
+    th = std::thread([this, what, progress, on_stall, limit] {
+      using clock = std::chrono::steady_clock;
+      std::unique_lock<std::mutex> lk(mu);
+      uint64_t last = progress();
+      clock::time_point since = clock::now();
+      const auto step = std::chrono::milliseconds(std::max<long>(50, std::min<long>(limit * 250, 5000)));
+      while (!cv.wait_for(lk, step, [this] { return done; })) {
+        const uint64_t now = progress();
+        if (now != last) { last = now; since = clock::now(); continue; }
+        const double idle = std::chrono::duration<double>(clock::now() - since).count();
+        if (idle < (double) limit) continue;
+        fprintf(stderr, "[bof] %s: no progress for %.0f s (progress counter at %llu): failing the call\n", what, idle,
+                (unsigned long long) now);
+        on_stall();
+        return;
+      }
+    });
+  }
+  ~StallWatch() {
+    if (!th.joinable()) return;
+    { std::lock_guard<std::mutex> lk(mu); done = true; }
+    cv.notify_all();
+    th.join();
+  }
+  StallWatch(const StallWatch &) = delete;
+  StallWatch &operator=(const StallWatch &) = delete;
+};
 
 // BOF_TRACE=1: wall-clock milestones of a level-3 call on stderr (t_begin = the call's start)
 inline bool trace_enabled() {

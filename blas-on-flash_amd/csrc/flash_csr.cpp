@@ -843,6 +843,9 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   std::vector<std::thread> retirers;
   for (int i = 0; i < std::max(1, std::min(4, R.depth / 2)); i++) retirers.emplace_back([&R] { R.retire_main(); });
 
+  StallWatch watch("flash csr pipeline",
+                   [&R] { return R.cnt.rd.load() + R.cnt.wr.load() + R.cnt.h2d.load() + R.cnt.d2h.load() + R.cnt.tasks.load(); },
+                   [&R] { R.fail_io(-ETIMEDOUT); });
   hipError_t herr = hipSuccess;
   int fail = 0;
   resident_thread.join();
@@ -922,8 +925,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, "flash csr dispatch");
   if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
     const int e = R.io_error.load();
-    set_error("flash csr: I/O pipeline failed: " +
-              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
+    set_error("flash csr: I/O pipeline failed: " + io_error_text(e));
     fail = BOF_EIO;
   }
   if (ex && ex->out) {

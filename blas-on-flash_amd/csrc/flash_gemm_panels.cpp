@@ -1028,6 +1028,10 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     H.pump_fetches();
   }
 
+  StallWatch watch("bof_flash_gemm (panels)",
+                   [&H] { return H.cnt.rd.load() + H.cnt.wr.load() + H.cnt.h2d.load() + H.cnt.d2h.load() + H.cnt.peer.load() +
+                                 H.cnt.tasks.load(); },
+                   [&H] { H.fail_io(-ETIMEDOUT); });
   // ---- dispatch: the caller drives the first device, a thread each of the others ---------------------
   for (int d = 1; d < nd; d++) {
     PanelRun *r = H.runs[(size_t) d].get();
@@ -1057,8 +1061,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   }
   if (H.io_error.load() && (!fail || fail == BOF_EIO)) {
     const int e = H.io_error.load();
-    set_error("bof_flash_gemm: I/O pipeline failed: " +
-              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
+    set_error("bof_flash_gemm: I/O pipeline failed: " + io_error_text(e));
     fail = e == -ENOMEM ? BOF_ENOMEM : BOF_EIO;
   }
   H.cnt.hits = 3 * H.cnt.tasks.load() - std::min<uint64_t>(H.cnt.misses.load(), 3 * H.cnt.tasks.load());

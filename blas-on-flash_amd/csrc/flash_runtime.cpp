@@ -674,6 +674,9 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   for (int i = 0; i < std::max(1, R.o.n_io_threads); i++) readers.emplace_back([&R] { R.reader_main(); });
   for (int i = 0; i < n_writers; i++) writers.emplace_back([&R] { R.writer_main(); });
 
+  StallWatch watch("bof_flash_gemm (tile cache)",
+                   [&R] { return R.cnt.rd.load() + R.cnt.wr.load() + R.cnt.h2d.load() + R.cnt.d2h.load() + R.cnt.tasks.load(); },
+                   [&R] { R.fail_io(-ETIMEDOUT); });
   // ---- dispatch loop ------------------------------------------------------------------
   const int lookahead = std::max(2, R.o.pinned_slots) * 2;
   int fetch_pos = 0;
@@ -781,8 +784,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, where);
   if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
     const int e = R.io_error.load();
-    set_error("bof_flash_gemm: I/O pipeline failed: " +
-              (e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e)));
+    set_error("bof_flash_gemm: I/O pipeline failed: " + io_error_text(e));
     fail = BOF_EIO;
   }
   // the pinned rings and the device slab stay cached for the next call (bof_flash_release)

@@ -244,3 +244,33 @@ def test_csrcsc_output_no_space(dev, tmp_path, golden_tr, budget_mib):
     finally:
         os.close(full)
         F.close()
+
+
+def test_stall_watchdog_fails_a_call_that_stops_moving(dev, tmp_path, monkeypatch, capfd):
+    """A call that stops making progress must not wait forever: rank 0 of a two-rank shared-B call whose
+    peer never shows up parks its reader on panel 1 of B (the peer's to publish).  The peer time-out is set
+    far away (60 s); the stall watchdog (BOF_STALL_TIMEOUT_S = 2) notices that no byte moves and no task
+    starts, says so on stderr and fails the call -- BOF_EIO with the time-out text, all threads joined, next
+    call fine."""
+    good_call(tmp_path, 2)
+    monkeypatch.setenv("BOF_SHARE_TIMEOUT_S", "60")
+    monkeypatch.setenv("BOF_STALL_TIMEOUT_S", "2")
+    a, b, c0 = gemm_inputs()
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    name = f"/bof_test_stall_{os.getpid()}"
+    try:
+        import time
+        t0 = time.time()
+        def call():
+            bofhip.lib().bof_share_cleanup(name.encode())       # the failed attempt left its "gave up" marks in the ring
+            bofhip.flash_gemm("R", "N", "N", M, N, K, 1.0, 0.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              gemm_opts(2, share_world=2, share_rank=0, share_name=name))
+        expect_failure(call, -3, "timed out")
+        assert time.time() - t0 < 30
+        assert "no progress for" in capfd.readouterr().err
+    finally:
+        bofhip.lib().bof_share_cleanup(name.encode())
+        F.close()
+    monkeypatch.delenv("BOF_STALL_TIMEOUT_S")
+    good_call(tmp_path, 2)
+
