@@ -1174,7 +1174,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-resident (out-of-core) legs")
     ap.add_argument("--e2e-dir", default="", help="directory for the matrix files (default $BOF_BENCH_DIR, $TMPDIR, /tmp)")
     ap.add_argument("--e2e-size", type=int, default=32768, help="edge of the file-resident GEMM")
-    ap.add_argument("--e2e-reps", type=int, default=2)
+    ap.add_argument("--e2e-reps", type=int, default=3)
     ap.add_argument("--no-e2e-64k", action="store_true", help="skip the 65536^3 file-resident leg (48 GiB of files)")
     ap.add_argument("--io-threads", type=int, default=8)
     args = ap.parse_args()
