@@ -287,6 +287,59 @@ def csr_case(rng, tmp):
     return desc
 
 
+def kernel_case(rng):
+    """Level 1: one bof_sgemm / bof_skmeans_task on HBM-resident operands, shapes that mix the 256 x 256
+    kernels' interior with ragged strips, K on and off the 64-slab grid, tight / padded leading dimensions."""
+    import torch
+    ord_, ta, tb = pick(rng, "RC"), pick(rng, "NT"), pick(rng, "NT")
+
+    def edge():
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            return 256 * int(rng.integers(1, 5))
+        if kind == 1:
+            return 256 * int(rng.integers(1, 4)) + int(rng.integers(1, 256))
+        if kind == 2:
+            return 128 * int(rng.integers(1, 6))
+        return int(rng.integers(1, 1100))
+    m, n = edge(), edge()
+    k = 64 * int(rng.integers(1, 9)) if int(rng.integers(0, 2)) else int(rng.integers(1, 600))
+    alpha, beta = pick(rng, [(1.0, 0.0), (0.5, 2.0), (-1.5, 0.25), (1.0, 1.0), (0.0, 1.0)])
+    kmeans = int(rng.integers(0, 5)) == 0
+    shp = stored_shapes(ord_, ta, tb, m, n, k)
+
+    def ld(c):
+        kind = int(rng.integers(0, 3))
+        return c if kind == 0 else ((c + 3) // 4 * 4 + 4 if kind == 1 else c + int(rng.integers(1, 9)))
+    lds = [ld(sh[1]) for sh in shp]
+    mats = [rng.uniform(-1, 1, (sh[0], l)).astype(np.float32) for sh, l in zip(shp, lds)]
+    LAST.clear()
+    LAST.update(kind="kernel kmeans" if kmeans else "kernel sgemm", ord=ord_, ta=ta, tb=tb, m=m, n=n, k=k, alpha=alpha,
+                beta=beta, lds=lds)
+    dev = [torch.from_numpy(x).cuda() for x in mats]
+    st = torch.cuda.current_stream().cuda_stream
+    ref = mats[2].copy()
+    if kmeans:
+        cl = rng.uniform(0, 8, m).astype(np.float32)
+        pl = rng.uniform(0, 8, n).astype(np.float32)
+        ones = rng.uniform(0.5, 1.5, max(m, n)).astype(np.float32)     # not constant: a swapped vector would show
+        orc.skmeans_task(ord_, ta, tb, m, n, k, alpha, mats[0], lds[0], mats[1], lds[1], beta, ref, lds[2], cl, pl, ones)
+        dv = [torch.from_numpy(x).cuda() for x in (cl, pl, ones)]
+        bofhip.skmeans_task(ord_, ta, tb, m, n, k, alpha, dev[0].data_ptr(), lds[0], dev[1].data_ptr(), lds[1], beta,
+                            dev[2].data_ptr(), lds[2], dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), st)
+    else:
+        orc.sgemm(ord_, ta, tb, m, n, k, alpha, mats[0], lds[0], mats[1], lds[1], beta, ref, lds[2])
+        bofhip.sgemm(ord_, ta, tb, m, n, k, alpha, dev[0].data_ptr(), lds[0], dev[1].data_ptr(), lds[1], beta,
+                     dev[2].data_ptr(), lds[2], st)
+    torch.cuda.synchronize()
+    got = dev[2].cpu().numpy()
+    if not np.array_equal(got, ref):
+        bad = np.argwhere(got != ref)
+        raise AssertionError(f"C differs at {len(bad)} elements, first {bad[0].tolist()}: got {got[tuple(bad[0])]} "
+                             f"want {ref[tuple(bad[0])]}")
+    return dict(LAST)
+
+
 def one_case(seed, index, tmp):
     rng = np.random.default_rng([seed, index])
     kind = int(rng.integers(0, 10))
@@ -295,8 +348,10 @@ def one_case(seed, index, tmp):
     for f in os.listdir(tmp):
         os.unlink(os.path.join(tmp, f))
     if FORCE_KIND:
-        kind = {"gemm": 0, "kmeans": 5, "csr": 9}[FORCE_KIND]
+        kind = {"gemm": 0, "kmeans": 5, "csr": 9, "kernel": -1}[FORCE_KIND]
     try:
+        if kind < 0:
+            return kernel_case(rng)
         if kind < 5:
             return gemm_case(rng, tmp)
         if kind < 6:
@@ -318,6 +373,19 @@ def test_fuzz_level3(dev, tmp_path, seed):
                                  f"(python tests/test_gpu_fuzz.py --seed {seed} --only {i})") from e
 
 
+@pytest.mark.parametrize("seed", [4])
+def test_fuzz_kernels(dev, seed):
+    """60 drawn level-1 cases (bof_sgemm / bof_skmeans_task), bit-exact against the oracle."""
+    for i in range(60):
+        try:
+            rng = np.random.default_rng([seed, i])
+            rng.integers(0, 10)            # the draw one_case spends on the kind: --only reproduces the case
+            kernel_case(rng)
+        except Exception as e:
+            raise AssertionError(f"kernel fuzz case seed={seed} index={i} failed: {e}; case {LAST} "
+                                 f"(python tests/test_gpu_fuzz.py --kind kernel --seed {seed} --only {i})") from e
+
+
 if __name__ == "__main__":
     import argparse
     import tempfile
@@ -328,7 +396,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", type=int, nargs="*", default=[])
     ap.add_argument("--dir", default=None)
     ap.add_argument("--range", type=int, nargs=2, default=None, help="run the cases A .. B-1 (instead of --only)")
-    ap.add_argument("--kind", default="", choices=["", "gemm", "kmeans", "csr"])
+    ap.add_argument("--kind", default="", choices=["", "gemm", "kmeans", "csr", "kernel"])
     ap.add_argument("--repeat", type=int, default=1, help="with --only: run every listed case this many times")
     ap.add_argument("--set", default="", help="with --only: override options of the drawn case, e.g. 'devices=None;n_streams=1'")
     a = ap.parse_args()
@@ -338,7 +406,7 @@ if __name__ == "__main__":
     a.only = [i for i in a.only for _ in range(max(1, a.repeat))]
     for kv in [x for x in a.set.split(";") if x]:
         OVERRIDE[kv.split("=")[0]] = eval(kv.split("=", 1)[1])
-    FORCE_KIND = a.kind
+    globals()["FORCE_KIND"] = a.kind
     bofhip.require_device()
     fails, i, t0 = 0, 0, time.time()
     with tempfile.TemporaryDirectory(dir=a.dir) as tmp:
