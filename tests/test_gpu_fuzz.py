@@ -190,8 +190,23 @@ def gemm_case(rng, tmp, kmeans=False):
         except AssertionError:
             if os.environ.get("BOF_FUZZ_DUMP"):      # everything needed to look at the failure offline
                 got = np.fromfile(files[2].path, np.uint8)
-                np.savez_compressed(os.path.join(os.environ["BOF_FUZZ_DUMP"], f"fuzz_fail_{os.getpid()}_{len(LAST)}_{int(time.time())}.npz"),
-                                    a=mats[0], b=mats[1], c0=mats[2], ref=ref, got_file=got, desc=repr(desc),
+                # the same call once more on a restored C: does the mismatch come back?
+                with open(files[2].path, "r+b") as f:
+                    f.seek(files[2].head)
+                    f.write(mats[2].tobytes())
+                again = "not run"
+                try:
+                    if kmeans:
+                        bofhip.flash_kmeans(*args, cl.ctypes.data, pl.ctypes.data, ones.ctypes.data, opts)
+                    else:
+                        bofhip.flash_gemm(*args, opts)
+                    files[2].check_against(ref)
+                    again = "second attempt matches"
+                except Exception as e2:
+                    again = f"second attempt: {e2}"
+                print("     ", again)
+                np.savez_compressed(os.path.join(os.environ["BOF_FUZZ_DUMP"], f"fuzz_fail_{os.getpid()}_{int(time.time())}.npz"),
+                                    a=mats[0], b=mats[1], c0=mats[2], ref=ref, got_file=got, desc=repr(desc), again=again,
                                     **({"cl": cl, "pl": pl} if kmeans else {}))
             raise
         files[0].check_against(mats[0])
