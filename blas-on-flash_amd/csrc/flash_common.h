@@ -242,7 +242,10 @@ class StallWatch {
       uint64_t last = progress();
       clock::time_point since = clock::now();
       const auto step = std::chrono::milliseconds(std::max<long>(50, std::min<long>(limit * 250, 5000)));
-      while (!cv.wait_for(lk, step, [this] { return done; })) {
+      // (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer understands; wait_for
+      //  goes through pthread_cond_clockwait, which GCC 11's does not.  Only the polling step hangs on that
+      //  clock: the idle time is measured on the steady one.)
+      while (!cv.wait_until(lk, std::chrono::system_clock::now() + step, [this] { return done; })) {
         const uint64_t now = progress();
         if (now != last) { last = now; since = clock::now(); continue; }
         const double idle = std::chrono::duration<double>(clock::now() - since).count();

@@ -33,3 +33,27 @@ def test_plan_fileio_and_schedule_under_asan_ubsan(tmp_path):
         import pytest
         pytest.skip("io_uring is not available in this sandbox (engine fell back to kernel AIO)")
     assert int(line[2]) > 0 and int(line[4]) > 0, line        # both opcodes exercised
+
+
+def test_ordering_pieces_under_tsan(tmp_path):
+    """ThreadSanitizer over the pieces whose correctness is an ordering argument: the node-shared staging ring
+    (its ranks as threads on one mapping), large buffered writes through the shared file mapping against
+    file_forget / file_unmap_all, O_DIRECT requests from eight threads (kernel AIO, then io_uring), WorkQueue and
+    the stall watchdog."""
+    exe = str(tmp_path / "host_tsan")
+    csrc = os.path.join(ROOT, "blas-on-flash_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(csrc, "fileio.cpp"),
+           os.path.join(csrc, "uring_io.cpp"), os.path.join(ROOT, "tests", "native", "host_tsan.cpp"), "-o", exe,
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl", "-lrt"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for engine in ("", "uring"):
+        r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, BOF_IO_ENGINE=engine, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
+        if "unexpected memory mapping" in r.stderr:
+            import pytest
+            pytest.skip("ThreadSanitizer cannot run under this kernel's address-space layout")
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+        assert "host_tsan ok" in r.stdout
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
