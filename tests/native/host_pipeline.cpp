@@ -1,0 +1,288 @@
+// host_pipeline.cpp -- TEST INFRASTRUCTURE ONLY: the level-3 entry points of the C ABI run end to end on the
+// mock HIP runtime of mock_hip.cpp (several DISTINCT mock devices, every rule of that file's header fatal),
+// under AddressSanitizer + UBSan and under ThreadSanitizer (tests/test_host_sanitizers.py).  What is checked is
+// the host side: tiling, panel / tile-cache / CSR pipelines, device lists (contiguous C panels and nnz-balanced
+// row blocks per device, shared operands fanned out, device-to-device segment sums), file engines, budgets --
+// with integer-valued data, so that every result is exact whatever the order of the sums and can be compared
+// with a plain host computation.  Arithmetic parity of the real kernels is the business of the -m gpu suite.
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "bof_hip.h"
+
+extern "C" uint64_t mock_hip_kernel_launches();
+extern "C" size_t mock_hip_bytes_in_use(int dev);
+extern "C" uint64_t mock_hip_pageable_h2d_bytes();
+extern "C" int64_t mock_hip_live_streams();
+extern "C" int64_t mock_hip_live_events();
+
+#define CHECK(c)                                                                                  \
+  do {                                                                                            \
+    if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d): %s\n", #c, __LINE__, bof_last_error()); exit(1); } \
+  } while (0)
+
+static std::string g_dir;
+static bool g_truncate_a = false;    // the next gemm_case cuts its A file in half (a reader's request comes back short)
+static std::mt19937_64 g_rng(12345);
+static int ri(int lo, int hi) { return lo + (int) (g_rng() % (uint64_t) (hi - lo + 1)); }
+
+struct TmpFile {
+  std::string path;
+  int fd = -1;
+  uint64_t head = 0;
+  template <class T>
+  TmpFile(const std::string &name, const std::vector<T> &data, uint64_t head_bytes, bool direct) : head(head_bytes) {
+    path = g_dir + "/" + name;
+    FILE *f = fopen(path.c_str(), "wb");
+    CHECK(f);
+    std::vector<char> hdr(head, (char) 0x5A);
+    if (head) CHECK(fwrite(hdr.data(), 1, head, f) == head);
+    if (!data.empty()) CHECK(fwrite(data.data(), sizeof(T), data.size(), f) == data.size());
+    const char tail[16] = "trailer-bytes..";
+    CHECK(fwrite(tail, 1, 16, f) == 16);
+    fclose(f);
+    if (direct) fd = open(path.c_str(), O_RDWR | O_DIRECT);
+    if (fd < 0) fd = open(path.c_str(), O_RDWR);
+    CHECK(fd >= 0);
+  }
+  bof_fptr ptr() const { return bof_fptr{fd, head}; }
+  template <class T>
+  std::vector<T> read(size_t n) const {
+    std::vector<T> out(n);
+    FILE *f = fopen(path.c_str(), "rb");
+    CHECK(f && fseek(f, (long) head, SEEK_SET) == 0);
+    CHECK(n == 0 || fread(out.data(), sizeof(T), n, f) == n);
+    char tail[16];
+    CHECK(fread(tail, 1, 16, f) == 16 && memcmp(tail, "trailer-bytes..", 16) == 0);
+    fclose(f);
+    return out;
+  }
+  ~TmpFile() {
+    bof_file_forget(fd);
+    close(fd);
+    unlink(path.c_str());
+  }
+};
+
+static bof_options options(const std::vector<int> &devs) {
+  bof_options o;
+  bof_default_options(&o);
+  o.n_devices = (int) devs.size();
+  for (size_t i = 0; i < devs.size(); i++) o.devices[i] = devs[i];
+  return o;
+}
+
+// ---- gemm / kmeans ----------------------------------------------------------------------------------------------
+static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, float beta, int64_t blk, int path,
+                      int64_t pad_c, const std::vector<int> &devs, bool direct, bool kmeans, uint64_t budget, int expect_rc = BOF_OK) {
+  const bool a_mk = (ta == 'N') == (ord == 'R'), b_kn = (tb == 'N') == (ord == 'R');
+  const int64_t ar = a_mk ? m : k, ac = a_mk ? k : m, br = b_kn ? k : n, bc = b_kn ? n : k, cr = ord == 'R' ? m : n, cc = ord == 'R' ? n : m;
+  const int64_t lda = ac, ldb = bc + 4, ldc = cc + pad_c;
+  std::vector<float> A((size_t) (ar * lda)), B((size_t) (br * ldb)), C((size_t) (cr * ldc));
+  for (auto &x : A) x = (float) ri(-3, 3);
+  for (auto &x : B) x = (float) ri(-3, 3);
+  for (auto &x : C) x = (float) ri(-5, 5);
+  std::vector<float> cl((size_t) m), pl((size_t) n), ones((size_t) std::max(m, n), 1.0f);
+  for (auto &x : cl) x = (float) ri(0, 9);
+  for (auto &x : pl) x = (float) ri(0, 9);
+  // expected: exact in fp32 (|sums| < 2^24).  kmeans: every k-block task adds the two rank-1 terms
+  // (include/tasks/kmeans_task.h:53-82), i.e. (number of k blocks) x (cl[i] + pl[j])
+  int64_t nkb = 1;
+  {
+    const int64_t full = k / blk, rem = k % blk;
+    nkb = std::max<int64_t>(1, full + ((rem >= 128 || full == 0) && rem ? 1 : 0));
+  }
+  std::vector<float> want = C;
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t j = 0; j < n; j++) {
+      double acc = 0;
+      for (int64_t l = 0; l < k; l++)
+        acc += (double) (a_mk ? A[(size_t) (i * lda + l)] : A[(size_t) (l * lda + i)]) *
+               (double) (b_kn ? B[(size_t) (l * ldb + j)] : B[(size_t) (j * ldb + l)]);
+      float &w = ord == 'R' ? want[(size_t) (i * ldc + j)] : want[(size_t) (j * ldc + i)];
+      double r = (double) alpha * acc + (double) beta * (double) w;
+      if (kmeans) r += (double) nkb * ((double) cl[(size_t) i] + (double) pl[(size_t) j]);
+      w = (float) r;
+    }
+  TmpFile fa("A.bin", A, 0, direct), fb("B.bin", B, direct ? 4096 : 52, direct), fc("C.bin", C, 512, direct);
+  if (g_truncate_a) CHECK(truncate(fa.path.c_str(), (off_t) (A.size() * 2)) == 0);
+  bof_options o = options(devs);
+  o.gemm_blk = blk;
+  o.gemm_path = path;
+  o.io_chunk_mib = 1;
+  o.n_io_threads = 3;
+  o.pinned_slots = 3;
+  o.use_odirect = direct ? 1 : 0;
+  o.hbm_budget = budget;
+  const uint64_t launches0 = mock_hip_kernel_launches();
+  int rc;
+  if (kmeans)
+    rc = bof_flash_kmeans(ord, ta, tb, (uint64_t) m, (uint64_t) n, (uint64_t) k, alpha, beta, fa.ptr(), fb.ptr(), fc.ptr(), (uint64_t) lda,
+                          (uint64_t) ldb, (uint64_t) ldc, cl.data(), pl.data(), ones.data(), &o);
+  else
+    rc = bof_flash_gemm(ord, ta, tb, (uint64_t) m, (uint64_t) n, (uint64_t) k, alpha, beta, fa.ptr(), fb.ptr(), fc.ptr(), (uint64_t) lda,
+                        (uint64_t) ldb, (uint64_t) ldc, &o);
+  if (rc != expect_rc) fprintf(stderr, "gemm_case %c%c%c %ldx%ldx%ld path %d devs %zu: rc %d (%s)\n", ord, ta, tb, (long) m, (long) n, (long) k, path, devs.size(), rc, bof_last_error());
+  CHECK(rc == expect_rc);
+  const std::vector<float> got = fc.read<float>(C.size());
+  if (rc == BOF_EIO) return;   // failed half way: C is whatever was written until then
+  if (rc != BOF_OK) {          // a refused call leaves C alone
+    CHECK(got == C);
+    return;
+  }
+  CHECK(mock_hip_kernel_launches() > launches0);
+  for (size_t i = 0; i < got.size(); i++)
+    if (got[i] != want[i]) {
+      fprintf(stderr, "gemm_case %c%c%c %ldx%ldx%ld blk %ld path %d devs %zu kmeans %d: C[%zu] = %g, want %g\n", ord, ta, tb, (long) m,
+              (long) n, (long) k, (long) blk, path, devs.size(), (int) kmeans, i, got[i], want[i]);
+      exit(1);
+    }
+  CHECK(fa.read<float>(A.size()) == A);
+  CHECK(fb.read<float>(B.size()) == B);
+  bof_flash_stats per[BOF_MAX_DEVICES];
+  const int nd = bof_flash_last_device_stats(per, BOF_MAX_DEVICES);
+  if (devs.size() > 1) {
+    CHECK(nd >= 2);                       // at least two slabs exist at these sizes
+    uint64_t tasks = 0;
+    for (int d = 0; d < nd; d++) { CHECK(per[d].tasks > 0); tasks += per[d].tasks; }
+    bof_flash_stats tot;
+    CHECK(bof_flash_last_stats(&tot) == BOF_OK && tot.tasks == tasks);
+  }
+}
+
+// ---- CSR ------------------------------------------------------------------------------------------------------
+struct Csr { std::vector<float> val; std::vector<int64_t> ja, ia; };
+static Csr random_csr(int64_t m, int64_t n) {
+  Csr c;
+  c.ia.push_back(0);
+  for (int64_t r = 0; r < m; r++) {
+    const int cnt = ri(0, (int) std::min<int64_t>(n, 12));
+    std::vector<int64_t> cols;
+    while ((int) cols.size() < cnt) {
+      const int64_t x = ri(0, (int) n - 1);
+      if (std::find(cols.begin(), cols.end(), x) == cols.end()) cols.push_back(x);
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int64_t x : cols) { c.ja.push_back(x); c.val.push_back((float) ri(1, 9)); }
+    c.ia.push_back((int64_t) c.ja.size());
+  }
+  if (c.val.empty()) { c.val.push_back(0); c.ja.push_back(0); }   // files are never empty; nnz stays 0
+  return c;
+}
+static void csr_case(int64_t m, int64_t n, int64_t k, char ord_b, float alpha, float beta, const std::vector<int> &devs, bool direct) {
+  const Csr a = random_csr(m, n);
+  TmpFile fv("val.bin", a.val, 0, direct), fj("ja.bin", a.ja, 0, direct), fi("ia.bin", a.ia, 0, direct);
+  bof_options o = options(devs);
+  o.max_nnzs = 700;
+  o.csrmm_rblk = 300;
+  o.n_io_threads = 3;
+  o.use_odirect = direct ? 1 : 0;
+  // csrmm 'N'
+  {
+    std::vector<float> B((size_t) (n * k)), C((size_t) (m * k));
+    for (auto &x : B) x = (float) ri(0, 6);
+    for (auto &x : C) x = (float) ri(0, 4);
+    std::vector<float> want = C;
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t j = 0; j < k; j++) {
+        double acc = 0;
+        for (int64_t p = a.ia[(size_t) i]; p < a.ia[(size_t) i + 1]; p++)
+          acc += (double) a.val[(size_t) p] * (double) (ord_b == 'R' ? B[(size_t) (a.ja[(size_t) p] * k + j)] : B[(size_t) (j * n + a.ja[(size_t) p])]);
+        float &w = ord_b == 'R' ? want[(size_t) (i * k + j)] : want[(size_t) (j * m + i)];
+        w = (float) ((double) alpha * acc + (double) beta * (double) w);
+      }
+    TmpFile fb("b.bin", B, 0, direct), fc("c.bin", C, 0, direct);
+    const int rc = bof_flash_csrmm('N', (uint64_t) m, (uint64_t) n, (uint64_t) k, alpha, beta, fv.ptr(), fi.ptr(), fj.ptr(), ord_b, fb.ptr(), fc.ptr(), &o);
+    if (rc) fprintf(stderr, "csrmm %ldx%ldx%ld %c devs %zu: rc %d (%s)\n", (long) m, (long) n, (long) k, ord_b, devs.size(), rc, bof_last_error());
+    CHECK(rc == BOF_OK);
+    const std::vector<float> got = fc.read<float>(C.size());
+    for (size_t i = 0; i < got.size(); i++)
+      if (got[i] != want[i]) {
+        fprintf(stderr, "csrmm %ldx%ldx%ld %c devs %zu: C[%zu] = %g, want %g\n", (long) m, (long) n, (long) k, ord_b, devs.size(), i, got[i], want[i]);
+        exit(1);
+      }
+    CHECK(fb.read<float>(B.size()) == B);
+  }
+  // csrgemv 'N' and 'T' (vectors in host memory)
+  for (char trans : {'N', 'T'}) {
+    const int64_t xl = trans == 'N' ? n : m, yl = trans == 'N' ? m : n;
+    std::vector<float> x((size_t) xl), y((size_t) yl, -7.f), want((size_t) yl, 0.f);
+    for (auto &v : x) v = (float) ri(0, 9);
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t p = a.ia[(size_t) i]; p < a.ia[(size_t) i + 1]; p++) {
+        if (trans == 'N') want[(size_t) i] += a.val[(size_t) p] * x[(size_t) a.ja[(size_t) p]];
+        else want[(size_t) a.ja[(size_t) p]] += a.val[(size_t) p] * x[(size_t) i];
+      }
+    const int rc = bof_flash_csrgemv(trans, (uint64_t) m, (uint64_t) n, fv.ptr(), fi.ptr(), fj.ptr(), x.data(), y.data(), &o);
+    if (rc) fprintf(stderr, "csrgemv %c %ldx%ld devs %zu: rc %d (%s)\n", trans, (long) m, (long) n, devs.size(), rc, bof_last_error());
+    CHECK(rc == BOF_OK);
+    for (size_t i = 0; i < y.size(); i++)
+      if (y[i] != want[i]) {
+        fprintf(stderr, "csrgemv %c %ldx%ld devs %zu: y[%zu] = %g, want %g\n", trans, (long) m, (long) n, devs.size(), i, y[i], want[i]);
+        exit(1);
+      }
+  }
+  CHECK(fj.read<int64_t>(a.ja.size()) == a.ja);
+}
+
+static int run_all(const std::vector<std::vector<int>> &lists) {
+  int cases = 0;
+  for (const auto &devs : lists)
+    for (int direct = 0; direct < 2; direct++) {
+      // row panels (default path), all k-chains; separate and merged tails; beta = 0 and != 0
+      gemm_case('R', 'N', 'N', 400, 300, 390, 1.f, 0.f, 128, 0, 0, devs, direct, false, 0);
+      gemm_case('C', 'T', 'N', 390, 256, 260, 2.f, 1.f, 128, 2, 0, devs, direct, false, 0);
+      gemm_case('R', 'T', 'T', 256, 400, 256, 1.f, 1.f, 128, 2, 0, devs, direct, false, 0);
+      gemm_case('C', 'N', 'T', 300, 390, 130, 1.f, 0.f, 128, 0, 0, devs, direct, false, 0);
+      // tile cache: forced, and chosen because C's rows have gaps (ldc > stored width)
+      gemm_case('R', 'N', 'T', 390, 300, 256, 1.f, 1.f, 128, 1, 0, devs, direct, false, 0);
+      gemm_case('C', 'N', 'N', 256, 390, 300, 2.f, 0.f, 128, 0, 8, devs, direct, false, 0);
+      // tile cache under a budget of a dozen tiles (eviction, write-back of finished row groups)
+      gemm_case('R', 'N', 'N', 384, 384, 384, 1.f, 1.f, 128, 1, 0, devs, direct, false, 12 * 128 * 128 * 4);
+      // flash::kmeans on both paths
+      gemm_case('C', 'T', 'N', 256, 520, 200, -2.f, 0.f, 128, 0, 0, devs, direct, true, 0);
+      gemm_case('R', 'N', 'T', 300, 390, 260, -2.f, 0.f, 128, 1, 0, devs, direct, true, 0);
+      // CSR: row blocks dealt by nnz, B / x fanned out, partial sums of 'T' reduced device to device
+      csr_case(1200, 900, 32, 'R', 1.f, 0.f, devs, direct);
+      csr_case(900, 600, 24, 'C', 2.f, 1.f, devs, direct);
+      cases += 11;
+    }
+  // a budget that one device's slab fits and another's does not: refused before anything is written
+  gemm_case('R', 'T', 'N', 371, 353, 112, 2.f, 0.f, 128, 1, 671, {0, 1}, false, false, 983040, BOF_ENOMEM);
+  // panels demanded where they cannot be used
+  gemm_case('R', 'N', 'N', 384, 384, 384, 1.f, 0.f, 128, 2, 8, {0, 1, 2}, false, false, 0, BOF_ENOMEM);
+  // a truncated operand on both paths over several devices: BOF_EIO, everything joined, the next call is fine
+  for (int path = 1; path <= 2; path++) {
+    g_truncate_a = true;
+    gemm_case('R', 'N', 'N', 400, 300, 390, 1.f, 0.f, 128, path, 0, {0, 1, 2, 3}, path == 2, false, 0, BOF_EIO);
+    g_truncate_a = false;
+    gemm_case('R', 'N', 'N', 400, 300, 390, 1.f, 0.f, 128, path, 0, {0, 1, 2, 3}, path == 2, false, 0);
+  }
+  CHECK(bof_flash_release() == BOF_OK);
+  for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);      // nothing left on any mock device
+  return cases + 6;
+}
+
+int main(int argc, char **argv) {
+  CHECK(argc > 1);
+  g_dir = argv[1];
+  CHECK(bof_device_count() == 4);
+  const bool brief = argc > 2 && !strcmp(argv[2], "brief");      // the ThreadSanitizer run: two device lists
+  int cases = brief ? run_all({{0, 1, 2, 3}, {0, 0, 1}}) : run_all({{0, 1, 2, 3}, {1, 3}, {2}, {0, 0, 1}, {3, 2, 1, 0}});
+  // what stays alive is the per-device compute-stream sets (process-lifetime singletons); a second pass must not add to it
+  const long long s1 = mock_hip_live_streams(), e1 = mock_hip_live_events();
+  cases += run_all({{2, 0, 3}});
+  CHECK(mock_hip_live_streams() == s1 && mock_hip_live_events() == e1);
+  printf("host_pipeline ok: %d level-3 call groups on 4 mock devices, %llu kernel stand-in launches, %llu bytes of async H2D from "
+         "pageable memory; %lld streams / %lld events stay with the per-device stream sets\n",
+         cases, (unsigned long long) mock_hip_kernel_launches(), (unsigned long long) mock_hip_pageable_h2d_bytes(), s1, e1);
+  return 0;
+}

@@ -57,3 +57,42 @@ def test_ordering_pieces_under_tsan(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
         assert "host_tsan ok" in r.stdout
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+
+
+def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
+    """The C ABI's level-3 entry points end to end on tests/native/mock_hip.cpp -- a stand-in HIP runtime with FOUR
+    DISTINCT mock devices whose rules (an event recorded on its own device's stream, no wait on a never-recorded
+    event, copies and kernel stand-ins only on memory of the stream's device or an enabled peer, pinned host sides,
+    nothing used after destruction) are fatal -- under ASan + UBSan + LeakSanitizer (all device lists) and under
+    ThreadSanitizer (two lists).  The pool's GPU boxes have one GPU: this is where the in-process multi-device
+    code meets more than one ordinal.  Test infrastructure only; the product refuses to run without a GPU."""
+    csrc = os.path.join(ROOT, "blas-on-flash_amd", "csrc")
+    native = os.path.join(ROOT, "tests", "native")
+    srcs = [os.path.join(csrc, f) for f in ("plan.cpp", "fileio.cpp", "uring_io.cpp", "flash_support.cpp", "flash_runtime.cpp",
+                                             "flash_csr.cpp", "flash_gemm_panels.cpp")]
+    base = ["g++", "-std=c++17", "-g", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+            "-I", csrc] + srcs + ["-x", "c++", os.path.join(csrc, "c_api.hip"), "-x", "none",
+                                  os.path.join(native, "mock_hip.cpp"), os.path.join(native, "host_pipeline.cpp"),
+                                  "-lpthread", "-ldl", "-lrt"]
+    builds = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], "tsan": ["-fsanitize=thread"]}
+    procs = {k: subprocess.Popen(base + fl + ["-o", str(tmp_path / f"host_pipeline_{k}")], stdout=subprocess.PIPE,
+                                 stderr=subprocess.STDOUT, text=True) for k, fl in builds.items()}      # no libamdhip64
+    for k, p in procs.items():
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, f"{k} build: {out[-3000:]}"
+    runs = {}
+    for k, extra in (("asan", []), ("tsan", ["brief"])):
+        d = tmp_path / f"files_{k}"
+        d.mkdir()
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:handle_abort=1", UBSAN_OPTIONS="print_stacktrace=1",
+                   TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", MOCK_HIP_DEVICES="4")
+        env.pop("BOF_DEVICES", None)
+        runs[k] = subprocess.Popen([str(tmp_path / f"host_pipeline_{k}"), str(d)] + extra, stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, text=True, env=env)
+    for k, p in runs.items():
+        out, err = p.communicate(timeout=900)
+        if k == "tsan" and "unexpected memory mapping" in err:
+            continue
+        assert p.returncode == 0, f"{k}: {out[-1500:]}{err[-6000:]}"
+        assert "host_pipeline ok" in out, out[-1500:]
+        assert "Sanitizer" not in err, err[-6000:]
