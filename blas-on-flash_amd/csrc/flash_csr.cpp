@@ -1120,16 +1120,20 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     for (Shard &S : sh) { dst.push_back(S.op); sts.push_back(S.st); }
     const bool from_file = is_mm && fb.fd >= 0;
     feed_rc = fan_out(from_file ? &fb : nullptr, (const char *) hb, op_bytes, used, dst, sts, use_aio, o.n_io_threads, total);
+    std::map<int, hipEvent_t> last_on_dev;    // shards that share an ordinal share its scratch slot: one after the other
     for (Shard &S : sh) {
       DeviceScope ds(S.dev);
       hipError_t e = hipSuccess;
       if (!feed_rc && is_mm && ord_b == 'C') {  // column-major B (n x k, ld = n) -> the row-major image the kernel reads
         void *tmp = nullptr;
         if (scratch_get(SCR_B_RM, (size_t) op_bytes, &tmp)) e = hipErrorOutOfMemory;
+        auto prev = last_on_dev.find(S.dev);
+        if (e == hipSuccess && prev != last_on_dev.end()) e = hipStreamWaitEvent(S.st, prev->second, 0);
         if (e == hipSuccess) e = hipMemcpyAsync(tmp, S.op, (size_t) op_bytes, hipMemcpyDeviceToDevice, S.st);
         if (e == hipSuccess) e = transpose_f32((const float *) tmp, n, k, n, (float *) S.op, k, S.st);
       }
       if (e == hipSuccess) e = hipEventRecord(S.ready, S.st);   // recorded even after a failed feed: nobody may wait forever
+      if (e == hipSuccess) last_on_dev[S.dev] = S.ready;
       if (e != hipSuccess && !feed_rc) feed_rc = hip_fail(e, "shared operand");
     }
     if (feed_rc) feed_err = bof_last_error();

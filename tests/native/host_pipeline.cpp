@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -31,6 +32,8 @@ extern "C" int64_t mock_hip_live_events();
 
 static std::string g_dir;
 static bool g_truncate_a = false;    // the next gemm_case cuts its A file in half (a reader's request comes back short)
+static bool g_accept_enomem = false; // stress mode: a drawn budget may legitimately be refused
+static struct { int io_threads = 3, pinned = 3, streams = 0, kmajor = 0, group = 0, chunk_mib = 1; } g_knobs;   // stress mode draws these
 static std::mt19937_64 g_rng(12345);
 static int ri(int lo, int hi) { return lo + (int) (g_rng() % (uint64_t) (hi - lo + 1)); }
 
@@ -117,9 +120,12 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   bof_options o = options(devs);
   o.gemm_blk = blk;
   o.gemm_path = path;
-  o.io_chunk_mib = 1;
-  o.n_io_threads = 3;
-  o.pinned_slots = 3;
+  o.io_chunk_mib = g_knobs.chunk_mib;
+  o.n_io_threads = g_knobs.io_threads;
+  o.pinned_slots = g_knobs.pinned;
+  if (g_knobs.streams) o.n_streams = g_knobs.streams;
+  o.panel_kmajor = g_knobs.kmajor;
+  o.panel_group = g_knobs.group;
   o.use_odirect = direct ? 1 : 0;
   o.hbm_budget = budget;
   const uint64_t launches0 = mock_hip_kernel_launches();
@@ -130,6 +136,7 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   else
     rc = bof_flash_gemm(ord, ta, tb, (uint64_t) m, (uint64_t) n, (uint64_t) k, alpha, beta, fa.ptr(), fb.ptr(), fc.ptr(), (uint64_t) lda,
                         (uint64_t) ldb, (uint64_t) ldc, &o);
+  if (g_accept_enomem && rc == BOF_ENOMEM) expect_rc = BOF_ENOMEM;
   if (rc != expect_rc) fprintf(stderr, "gemm_case %c%c%c %ldx%ldx%ld path %d devs %zu: rc %d (%s)\n", ord, ta, tb, (long) m, (long) n, (long) k, path, devs.size(), rc, bof_last_error());
   CHECK(rc == expect_rc);
   const std::vector<float> got = fc.read<float>(C.size());
@@ -149,8 +156,7 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   CHECK(fb.read<float>(B.size()) == B);
   bof_flash_stats per[BOF_MAX_DEVICES];
   const int nd = bof_flash_last_device_stats(per, BOF_MAX_DEVICES);
-  if (devs.size() > 1) {
-    CHECK(nd >= 2);                       // at least two slabs exist at these sizes
+  if (devs.size() > 1 && nd > 1) {       // (a C of one panel is one slab whatever the list)
     uint64_t tasks = 0;
     for (int d = 0; d < nd; d++) { CHECK(per[d].tasks > 0); tasks += per[d].tasks; }
     bof_flash_stats tot;
@@ -271,10 +277,55 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
   return cases + 6;
 }
 
+// drawn cases for a number of seconds (MOCK_HIP_ASYNC=1 + ThreadSanitizer: the stream-race hunt)
+static int stress(double seconds) {
+  const std::vector<std::vector<int>> lists = {{0, 1, 2, 3}, {0, 0, 0}, {2}, {0, 0, 1}, {1, 3}, {3, 3}};
+  const time_t t_end = time(nullptr) + (time_t) seconds;
+  int n = 0;
+  while (time(nullptr) < t_end) {
+    g_knobs.io_threads = ri(1, 4); g_knobs.pinned = ri(2, 4); g_knobs.streams = ri(1, 4);
+    g_knobs.kmajor = ri(0, 3); g_knobs.group = ri(0, 3); g_knobs.chunk_mib = ri(1, 2);
+    const char *grp[] = {"1", "3", "16"};
+    setenv("BOF_TILE_GROUP", grp[ri(0, 2)], 1);
+    const auto &devs = lists[(size_t) ri(0, (int) lists.size() - 1)];
+    const int64_t m = ri(100, 420), nn = ri(100, 420), k = ri(40, 420);
+    const bool kmeans = ri(0, 3) == 0;
+    const int path = ri(0, 2);
+    const bool pad = ri(0, 2) == 0;
+    const uint64_t budget = ri(0, 4) == 0 ? (uint64_t) ri(10, 30) * 128 * 128 * 4 : 0;
+    const char ord = "RC"[ri(0, 1)], ta = "NT"[ri(0, 1)], tb = "NT"[ri(0, 1)];
+    const float alpha = kmeans ? -2.f : (float) ri(1, 2), beta = kmeans ? 0.f : (float) ri(0, 1);
+    // panels demanded where they cannot be used, or a budget below one slab: refused (see run_all); otherwise exact
+    int expect = BOF_OK;
+    if (path == 2 && (pad || budget)) expect = -1000;       // may be refused or not: checked below
+    if (budget && path != 2) expect = -1000;
+    if (ri(0, 5) == 0) {
+      csr_case(ri(200, 900), ri(100, 700), ri(1, 40), "RC"[ri(0, 1)], (float) ri(1, 2), (float) ri(0, 1), devs, ri(0, 1));
+    } else if (expect == -1000) {
+      // outcome depends on the budget arithmetic: run it through the ABI directly and accept ENOMEM
+      g_accept_enomem = true;
+      gemm_case(ord, ta, tb, m, nn, k, alpha, beta, 128, path, pad ? 8 : 0, devs, ri(0, 1), kmeans, budget);
+      g_accept_enomem = false;
+    } else {
+      gemm_case(ord, ta, tb, m, nn, k, alpha, beta, 128, path, pad ? 8 : 0, devs, ri(0, 1), kmeans, budget);
+    }
+    n++;
+  }
+  unsetenv("BOF_TILE_GROUP");
+  CHECK(bof_flash_release() == BOF_OK);
+  return n;
+}
+
 int main(int argc, char **argv) {
   CHECK(argc > 1);
   g_dir = argv[1];
   CHECK(bof_device_count() == 4);
+  if (argc > 3 && !strcmp(argv[2], "stress")) {
+    g_rng.seed((uint64_t) atol(argv[3]) * 7919 + 1);
+    const int n = stress(argc > 4 ? atof(argv[4]) : 60);
+    printf("host_pipeline ok: %d drawn cases, %llu kernel stand-in launches\n", n, (unsigned long long) mock_hip_kernel_launches());
+    return 0;
+  }
   const bool brief = argc > 2 && !strcmp(argv[2], "brief");      // the ThreadSanitizer run: two device lists
   int cases = brief ? run_all({{0, 1, 2, 3}, {0, 0, 1}}) : run_all({{0, 1, 2, 3}, {1, 3}, {2}, {0, 0, 1}, {3, 2, 1, 0}});
   // what stays alive is the per-device compute-stream sets (process-lifetime singletons); a second pass must not add to it

@@ -8,9 +8,17 @@
 // the pool have one GPU, so the in-process multi-device code is otherwise only ever run with one ordinal
 // listed several times, which cannot show a stream, event or buffer used on the wrong device.
 //
-// "Device memory" is host memory tagged with its device; every operation executes immediately in the calling
-// thread (so only the HOST-side ordering of the pipelines is exercised, not the stream semantics).  What real
-// HIP enforces -- or silently gets wrong -- is checked and is fatal here:
+// "Device memory" is host memory tagged with its device.  Two modes:
+//   * immediate (default): every operation executes at once in the calling thread -- only the HOST-side ordering
+//     of the pipelines is exercised;
+//   * MOCK_HIP_ASYNC=1: every stream is a queue with a worker thread of its own (optionally jittered,
+//     MOCK_HIP_JITTER_US), copies and kernel stand-ins run when the queue reaches them, hipEventRecord /
+//     hipStreamWaitEvent / the synchronize calls have their HIP meaning (a wait captures the event's latest record
+//     at the time of the call).  The work of two streams is then ordered ONLY by the events the library put
+//     between them -- and ThreadSanitizer, which follows exactly those edges (queue hand-over, event completion),
+//     reports a buffer touched by two streams without such an edge: a stream-ordering race detector for the
+//     pipelines, on a machine without a GPU.  hipFree waits for the allocation's device like the real one.
+// What real HIP enforces -- or silently gets wrong -- is checked and is fatal in both modes:
 //   R1  an event is recorded on a stream of the event's own device;
 //   R2  hipStreamWaitEvent on an event that was never recorded (a no-op in HIP: the wait the caller wanted does
 //       not happen -- the class of the shared-operand race of round 3);
@@ -25,13 +33,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bof_hip.h"
@@ -51,6 +66,7 @@ std::vector<size_t> g_used;                            // bytes allocated per de
 std::set<std::pair<int, int>> g_peer;                  // (from, to)
 std::atomic<uint64_t> g_kernel_launches{0};
 std::atomic<int64_t> g_live_streams{0}, g_live_events{0};
+std::vector<struct MockStream *> &g_streams = *new std::vector<struct MockStream *>();   // alive ones (under g_mu)
 // every stream / event ever made: destroyed ones stay allocated so that a later use is reported; reachable from
 // here (a vector that is itself never destroyed), so LeakSanitizer does not count them
 std::vector<void *> &g_created = *new std::vector<void *>();
@@ -67,9 +83,89 @@ size_t capacity() {   // per mock device
 }
 hipError_t fail(hipError_t e) { t_last = e; return e; }
 
-struct MockStream { uint32_t magic; int dev; bool alive; };
-struct MockEvent { uint32_t magic; int dev; bool alive; std::atomic<uint64_t> records; };
+bool async_mode() {
+  static const bool on = getenv("MOCK_HIP_ASYNC") && atoi(getenv("MOCK_HIP_ASYNC")) != 0;
+  return on;
+}
+long jitter_us() {
+  static const long j = getenv("MOCK_HIP_JITTER_US") ? atol(getenv("MOCK_HIP_JITTER_US")) : 0;
+  return j;
+}
+// "everything queued on a stream up to a point has run": what an event record, a synchronize call stand for
+struct Completion {
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;
+  void set() { { std::lock_guard<std::mutex> lk(m); done = true; } cv.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); }
+};
 constexpr uint32_t kStreamMagic = 0x5354524du, kEventMagic = 0x45564e54u;
+struct MockStream {
+  uint32_t magic = kStreamMagic;
+  int dev = 0;
+  std::atomic<bool> alive{true};
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+  std::thread worker;
+  unsigned seed = 1;
+  void run() {
+    for (;;) {
+      std::function<void()> op;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        op = std::move(q.front());
+        q.pop_front();
+      }
+      if (jitter_us() > 0) usleep((useconds_t) (rand_r(&seed) % (unsigned) (jitter_us() + 1)));
+      op();
+    }
+  }
+  // in order behind everything queued so far; immediate mode: now
+  void enqueue(std::function<void()> op) {
+    if (!async_mode()) { op(); return; }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (!stop) {
+        q.push_back(std::move(op));
+        op = nullptr;
+      }
+    }
+    // (a stream being destroyed by another thread -- sync_device of a neighbour's hipFree may still hold it: its
+    //  queue has run dry, so "behind everything queued" is now)
+    if (op) op(); else cv.notify_one();
+  }
+  void drain() {
+    if (!async_mode()) return;
+    auto c = std::make_shared<Completion>();
+    enqueue([c] { c->set(); });
+    c->wait();
+  }
+};
+struct MockEvent {
+  uint32_t magic = kEventMagic;
+  int dev = 0;
+  std::atomic<bool> alive{true};
+  std::mutex m;
+  std::shared_ptr<Completion> last;      // the latest record (null: never recorded)
+};
+
+// every stream of `dev` (-1: of every device) has run what was queued on it
+void sync_device(int dev) {
+  if (!async_mode()) return;
+  std::vector<MockStream *> list;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (MockStream *s : g_streams)
+      if (dev < 0 || s->dev == dev) list.push_back(s);
+  }
+  // (a stream cannot be destroyed under this: the library never destroys a stream while another thread synchronises
+  //  its device -- the per-device call lock)
+  for (MockStream *s : list) s->drain();
+}
 
 MockStream *S(hipStream_t s, const char *who) {
   if (!s) violation("R5", std::string(who) + ": the null stream is never used by the library's pipelines");
@@ -114,13 +210,14 @@ void need_device_mem(const void *p, size_t bytes, int dev, const char *who, bool
     violation(peer_ok ? "R4 (peer access)" : "R4", std::string(who) + ": memory of device " + std::to_string(a.dev) +
                                                      " used on device " + std::to_string(dev));
 }
-int kernel_dev(hipStream_t st, const char *who) {
+// a kernel launch: the calling thread's current device must be the stream's
+MockStream *kernel_stream(hipStream_t st, const char *who) {
   MockStream *s = S(st, who);
   if (s->dev != t_dev)
     violation("R4", std::string(who) + ": launched with current device " + std::to_string(t_dev) + " on a stream of device " +
                         std::to_string(s->dev));
   g_kernel_launches++;
-  return s->dev;
+  return s;
 }
 
 }  // namespace
@@ -154,7 +251,7 @@ const char *hipGetErrorString(hipError_t e) {
     default: return "mock HIP error";
   }
 }
-hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { sync_device(t_dev); return hipSuccess; }
 hipError_t hipDeviceGetPCIBusId(char *id, int len, int device) {
   snprintf(id, (size_t) len, "0000:%02x:00.0", 0x10 + device);
   return hipSuccess;
@@ -186,6 +283,15 @@ hipError_t hipMalloc(void **p, size_t bytes) {
 }
 hipError_t hipFree(void *p) {
   if (!p) return hipSuccess;
+  {
+    int dev = -1;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      auto it = g_allocs.find((uintptr_t) p);
+      if (it != g_allocs.end()) dev = it->second.dev;
+    }
+    if (dev >= 0) sync_device(dev);      // hipFree waits for the device the memory belongs to
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_allocs.find((uintptr_t) p);
   if (it == g_allocs.end() || it->second.host) violation("R5", "hipFree of something hipMalloc did not return (or freed twice)");
@@ -204,6 +310,7 @@ hipError_t hipHostMalloc(void **p, size_t bytes, unsigned int) {
 }
 hipError_t hipHostFree(void *p) {
   if (!p) return hipSuccess;
+  sync_device(-1);
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_allocs.find((uintptr_t) p);
   if (it == g_allocs.end() || !it->second.host) violation("R5", "hipHostFree of something hipHostMalloc did not return (or freed twice)");
@@ -220,22 +327,33 @@ hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
 }
 
 static hipError_t new_stream(hipStream_t *s) {
-  MockStream *m = new MockStream{kStreamMagic, t_dev, true};
+  MockStream *m = new MockStream();
+  m->dev = t_dev;
+  m->seed = (unsigned) (uintptr_t) m;
+  if (async_mode()) m->worker = std::thread([m] { m->run(); });
   g_live_streams++;
-  { std::lock_guard<std::mutex> lk(g_mu); g_created.push_back(m); }
+  { std::lock_guard<std::mutex> lk(g_mu); g_created.push_back(m); g_streams.push_back(m); }
   *s = reinterpret_cast<hipStream_t>(m);
   return hipSuccess;
 }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) { return new_stream(s); }
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned int, int) { return new_stream(s); }
 hipError_t hipStreamDestroy(hipStream_t s) {
-  S(s, "hipStreamDestroy")->alive = false;     // kept allocated: a later use is reported, not a crash
+  MockStream *m = S(s, "hipStreamDestroy");
+  { std::lock_guard<std::mutex> lk(g_mu); g_streams.erase(std::find(g_streams.begin(), g_streams.end(), m)); }
+  if (async_mode()) {       // what is queued still runs (HIP destroys the stream once it is idle)
+    { std::lock_guard<std::mutex> lk(m->m); m->stop = true; }
+    m->cv.notify_all();
+    m->worker.join();
+  }
+  m->alive = false;         // kept allocated: a later use is reported, not a crash
   g_live_streams--;
   return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t s) { (void) S(s, "hipStreamSynchronize"); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { S(s, "hipStreamSynchronize")->drain(); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
-  MockEvent *m = new MockEvent{kEventMagic, t_dev, true, {0}};
+  MockEvent *m = new MockEvent();
+  m->dev = t_dev;
   g_live_events++;
   { std::lock_guard<std::mutex> lk(g_mu); g_created.push_back(m); }
   *e = reinterpret_cast<hipEvent_t>(m);
@@ -247,14 +365,26 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
   MockStream *st = S(s, "hipEventRecord");
   if (ev->dev != st->dev)
     violation("R1", "event of device " + std::to_string(ev->dev) + " recorded on a stream of device " + std::to_string(st->dev));
-  ev->records++;
+  auto c = std::make_shared<Completion>();
+  { std::lock_guard<std::mutex> lk(ev->m); ev->last = c; }
+  st->enqueue([c] { c->set(); });
   return hipSuccess;
 }
-hipError_t hipEventSynchronize(hipEvent_t e) { (void) E(e, "hipEventSynchronize"); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t e) {
+  MockEvent *ev = E(e, "hipEventSynchronize");
+  std::shared_ptr<Completion> c;
+  { std::lock_guard<std::mutex> lk(ev->m); c = ev->last; }
+  if (c) c->wait();
+  return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
-  (void) S(s, "hipStreamWaitEvent");
-  if (E(e, "hipStreamWaitEvent")->records.load() == 0)
+  MockStream *st = S(s, "hipStreamWaitEvent");
+  MockEvent *ev = E(e, "hipStreamWaitEvent");
+  std::shared_ptr<Completion> c;
+  { std::lock_guard<std::mutex> lk(ev->m); c = ev->last; }     // the record the event holds NOW
+  if (!c)
     violation("R2", "hipStreamWaitEvent on an event that has never been recorded (HIP treats it as complete: no wait happens)");
+  st->enqueue([c] { c->wait(); });
   return hipSuccess;
 }
 
@@ -288,8 +418,14 @@ static void check_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k
 }
 uint64_t mock_hip_pageable_h2d_bytes() { return g_pageable_h2d.load(); }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
-  check_copy(dst, src, bytes, kind, S(s, "hipMemcpyAsync")->dev, "hipMemcpyAsync");
-  memmove(dst, src, bytes);
+  MockStream *st = S(s, "hipMemcpyAsync");
+  check_copy(dst, src, bytes, kind, st->dev, "hipMemcpyAsync");
+  if (kind == hipMemcpyHostToDevice && !known(src)) {     // pageable source: staged before the call returns
+    auto staged = std::make_shared<std::vector<char>>((const char *) src, (const char *) src + bytes);
+    st->enqueue([dst, staged] { memcpy(dst, staged->data(), staged->size()); });
+    return hipSuccess;
+  }
+  st->enqueue([dst, src, bytes] { memmove(dst, src, bytes); });
   return hipSuccess;
 }
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
@@ -297,33 +433,37 @@ hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
   if (kind == hipMemcpyHostToDevice) need_device_mem(dst, bytes, t_dev, "hipMemcpy");
   else if (kind == hipMemcpyDeviceToHost) need_device_mem(src, bytes, t_dev, "hipMemcpy");
   else violation("R3", "hipMemcpy: copy kind the library never uses");
-  memmove(dst, src, bytes);
+  memmove(dst, src, bytes);      // synchronous, on no stream of the library's
   return hipSuccess;
 }
 hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height,
                             hipMemcpyKind kind, hipStream_t s) {
   if (width == 0 || height == 0) return hipSuccess;
   if (dpitch < width || spitch < width) return fail(hipErrorInvalidValue);
-  const int dev = S(s, "hipMemcpy2DAsync")->dev;
+  MockStream *st = S(s, "hipMemcpy2DAsync");
+  const int dev = st->dev;
   // extents: (height - 1) pitches + one width on either side
   const Alloc d = where(dst, (height - 1) * dpitch + width, "hipMemcpy2DAsync"), sa = where(src, (height - 1) * spitch + width, "hipMemcpy2DAsync");
   const Alloc &dv = kind == hipMemcpyHostToDevice ? d : sa, &hv = kind == hipMemcpyHostToDevice ? sa : d;
   if (kind != hipMemcpyHostToDevice && kind != hipMemcpyDeviceToHost) violation("R3", "hipMemcpy2DAsync: copy kind the library never uses");
   if (dv.host || dv.dev != dev) violation("R3", "hipMemcpy2DAsync: device side is not memory of the stream's device");
   if (!hv.host) violation("R3", "hipMemcpy2DAsync: host side is not pinned host memory");
-  for (size_t r = 0; r < height; r++) memcpy((char *) dst + r * dpitch, (const char *) src + r * spitch, width);
+  st->enqueue([=] {
+    for (size_t r = 0; r < height; r++) memcpy((char *) dst + r * dpitch, (const char *) src + r * spitch, width);
+  });
   return hipSuccess;
 }
 hipError_t hipMemcpyPeerAsync(void *dst, int ddev, const void *src, int sdev, size_t bytes, hipStream_t s) {
-  (void) S(s, "hipMemcpyPeerAsync");
+  MockStream *st = S(s, "hipMemcpyPeerAsync");
   need_device_mem(dst, bytes, ddev, "hipMemcpyPeerAsync");
   need_device_mem(src, bytes, sdev, "hipMemcpyPeerAsync");
-  memmove(dst, src, bytes);
+  st->enqueue([dst, src, bytes] { memmove(dst, src, bytes); });
   return hipSuccess;
 }
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s) {
-  need_device_mem(dst, bytes, S(s, "hipMemsetAsync")->dev, "hipMemsetAsync");
-  memset(dst, v, bytes);
+  MockStream *st = S(s, "hipMemsetAsync");
+  need_device_mem(dst, bytes, st->dev, "hipMemsetAsync");
+  st->enqueue([dst, v, bytes] { memset(dst, v, bytes); });
   return hipSuccess;
 }
 
@@ -331,41 +471,42 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s) {
 
 // ---- the kernel wrappers of the .hip files ---------------------------------------------------------------------
 // Plain loops with the product kernels' contract (k-ordered fmaf chain per element, alpha * acc + beta * c with
-// beta == 0 not reading c).  They exist to move data through the pipelines; arithmetic parity is the GPU suite's job.
+// beta == 0 not reading c), queued on their stream like everything else: pointers are checked and data is read when
+// the stream gets there.  They exist to move data through the pipelines; arithmetic parity is the GPU suite's job.
 namespace bof {
 
-static inline float op_at(const float *x, int64_t ld, bool row_is_outer, int64_t outer, int64_t inner) {
-  return row_is_outer ? x[outer * ld + inner] : x[inner * ld + outer];
-}
 static hipError_t gemm_any(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a, int64_t lda,
                            const float *b, int64_t ldb, float beta, float *c, int64_t ldc, const float *u1, const float *v1,
                            const float *u2, const float *v2, hipStream_t st, const char *who) {
-  const int dev = kernel_dev(st, who);
+  MockStream *ms = kernel_stream(st, who);
   if (m <= 0 || n <= 0) return hipSuccess;
-  // row-major view: for 'C' the stored matrices are the transposes
-  const bool a_mk = (ta == 'N') == (ord == 'R');     // A stored with m as the outer (row) index
-  const bool b_kn = (tb == 'N') == (ord == 'R');     // B stored with k as the outer index
-  const int64_t a_rows = a_mk ? m : k, a_cols = a_mk ? k : m, b_rows = b_kn ? k : n, b_cols = b_kn ? n : k;
-  if (k > 0) {
-    need_device_mem(a, (size_t) ((a_rows - 1) * lda + a_cols) * 4, dev, who);
-    need_device_mem(b, (size_t) ((b_rows - 1) * ldb + b_cols) * 4, dev, who);
-  }
-  const int64_t c_rows = ord == 'R' ? m : n, c_cols = ord == 'R' ? n : m;
-  need_device_mem(c, (size_t) ((c_rows - 1) * ldc + c_cols) * 4, dev, who);
-  if (u1) {
-    need_device_mem(u1, (size_t) m * 4, dev, who); need_device_mem(v1, (size_t) n * 4, dev, who);
-    need_device_mem(u2, (size_t) m * 4, dev, who); need_device_mem(v2, (size_t) n * 4, dev, who);
-  }
-  for (int64_t i = 0; i < m; i++)
-    for (int64_t j = 0; j < n; j++) {
-      float acc = 0.f;
-      for (int64_t l = 0; l < k; l++)
-        acc = fmaf(a_mk ? a[i * lda + l] : a[l * lda + i], b_kn ? b[l * ldb + j] : b[j * ldb + l], acc);
-      float *cp = ord == 'R' ? c + i * ldc + j : c + j * ldc + i;
-      float r = beta == 0.f ? alpha * acc : fmaf(alpha, acc, beta * *cp);
-      if (u1) r = fmaf(u2[i], v2[j], fmaf(u1[i], v1[j], r));
-      *cp = r;
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    // row-major view: for 'C' the stored matrices are the transposes
+    const bool a_mk = (ta == 'N') == (ord == 'R');     // A stored with m as the outer (row) index
+    const bool b_kn = (tb == 'N') == (ord == 'R');     // B stored with k as the outer index
+    const int64_t a_rows = a_mk ? m : k, a_cols = a_mk ? k : m, b_rows = b_kn ? k : n, b_cols = b_kn ? n : k;
+    if (k > 0) {
+      need_device_mem(a, (size_t) ((a_rows - 1) * lda + a_cols) * 4, dev, who);
+      need_device_mem(b, (size_t) ((b_rows - 1) * ldb + b_cols) * 4, dev, who);
     }
+    const int64_t c_rows = ord == 'R' ? m : n, c_cols = ord == 'R' ? n : m;
+    need_device_mem(c, (size_t) ((c_rows - 1) * ldc + c_cols) * 4, dev, who);
+    if (u1) {
+      need_device_mem(u1, (size_t) m * 4, dev, who); need_device_mem(v1, (size_t) n * 4, dev, who);
+      need_device_mem(u2, (size_t) m * 4, dev, who); need_device_mem(v2, (size_t) n * 4, dev, who);
+    }
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t j = 0; j < n; j++) {
+        float acc = 0.f;
+        for (int64_t l = 0; l < k; l++)
+          acc = fmaf(a_mk ? a[i * lda + l] : a[l * lda + i], b_kn ? b[l * ldb + j] : b[j * ldb + l], acc);
+        float *cp = ord == 'R' ? c + i * ldc + j : c + j * ldc + i;
+        float r = beta == 0.f ? alpha * acc : fmaf(alpha, acc, beta * *cp);
+        if (u1) r = fmaf(u2[i], v2[j], fmaf(u1[i], v1[j], r));
+        *cp = r;
+      }
+  });
   return hipSuccess;
 }
 hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a, int64_t lda,
@@ -378,75 +519,102 @@ hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64
   return gemm_any(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, u1, v1, u2, v2, st, "sgemm_rank1x2");
 }
 hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t blk, int64_t nblk, hipStream_t st) {
-  const int dev = kernel_dev(st, "expand_tile_local");
-  need_device_mem(dst, (size_t) len * 4, dev, "expand_tile_local");
-  for (int64_t i = 0; i < len; i++) dst[i] = src[i - std::min(i / blk, nblk - 1) * blk];
+  MockStream *ms = kernel_stream(st, "expand_tile_local");
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(dst, (size_t) len * 4, dev, "expand_tile_local");
+    for (int64_t i = 0; i < len; i++) dst[i] = src[i - std::min(i / blk, nblk - 1) * blk];
+  });
   return hipSuccess;
 }
 hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out, int64_t ld_out, hipStream_t st) {
-  const int dev = kernel_dev(st, "transpose_f32");
+  MockStream *ms = kernel_stream(st, "transpose_f32");
   if (rows <= 0 || cols <= 0) return hipSuccess;
-  need_device_mem(in, (size_t) ((rows - 1) * ld_in + cols) * 4, dev, "transpose_f32");
-  need_device_mem(out, (size_t) ((cols - 1) * ld_out + rows) * 4, dev, "transpose_f32");
-  std::vector<float> tmp((size_t) rows * (size_t) cols);       // in and out may be the same buffer
-  for (int64_t r = 0; r < rows; r++)
-    for (int64_t c = 0; c < cols; c++) tmp[(size_t) (c * rows + r)] = in[r * ld_in + c];
-  for (int64_t c = 0; c < cols; c++)
-    for (int64_t r = 0; r < rows; r++) out[c * ld_out + r] = tmp[(size_t) (c * rows + r)];
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(in, (size_t) ((rows - 1) * ld_in + cols) * 4, dev, "transpose_f32");
+    need_device_mem(out, (size_t) ((cols - 1) * ld_out + rows) * 4, dev, "transpose_f32");
+    std::vector<float> tmp((size_t) rows * (size_t) cols);       // in and out may be the same buffer
+    for (int64_t r = 0; r < rows; r++)
+      for (int64_t c = 0; c < cols; c++) tmp[(size_t) (c * rows + r)] = in[r * ld_in + c];
+    for (int64_t c = 0; c < cols; c++)
+      for (int64_t r = 0; r < rows; r++) out[c * ld_out + r] = tmp[(size_t) (c * rows + r)];
+  });
   return hipSuccess;
 }
 // mkl_scsrmm's naming: A is m x k, B k x n, C m x n
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val, const int64_t *col,
                   const int64_t *ptr, const float *b, int64_t ldb, float beta, float *c, int64_t ldc, hipStream_t st) {
-  const int dev = kernel_dev(st, "scsrmm");
+  MockStream *ms = kernel_stream(st, "scsrmm");
   if (m <= 0 || n <= 0) return hipSuccess;
-  need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrmm");
-  const int64_t base = ptr[0], nnz = ptr[m] - base;
-  need_device_mem(val, (size_t) nnz * 4, dev, "scsrmm");
-  need_device_mem(col, (size_t) nnz * 8, dev, "scsrmm");
-  if (k > 0) need_device_mem(b, (size_t) (ord_b == 'R' ? (k - 1) * ldb + n : (n - 1) * ldb + k) * 4, dev, "scsrmm");
-  need_device_mem(c, (size_t) (ord_b == 'R' ? (m - 1) * ldc + n : (n - 1) * ldc + m) * 4, dev, "scsrmm");
-  for (int64_t i = 0; i < m; i++)
-    for (int64_t j = 0; j < n; j++) {
-      float acc = 0.f;
-      for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++)
-        acc = fmaf(val[p], ord_b == 'R' ? b[col[p] * ldb + j] : b[j * ldb + col[p]], acc);
-      float *cp = ord_b == 'R' ? c + i * ldc + j : c + j * ldc + i;
-      *cp = beta == 0.f ? alpha * acc : fmaf(alpha, acc, beta * *cp);
-    }
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrmm");
+    const int64_t base = ptr[0], nnz = ptr[m] - base;
+    need_device_mem(val, (size_t) nnz * 4, dev, "scsrmm");
+    need_device_mem(col, (size_t) nnz * 8, dev, "scsrmm");
+    if (k > 0) need_device_mem(b, (size_t) (ord_b == 'R' ? (k - 1) * ldb + n : (n - 1) * ldb + k) * 4, dev, "scsrmm");
+    need_device_mem(c, (size_t) (ord_b == 'R' ? (m - 1) * ldc + n : (n - 1) * ldc + m) * 4, dev, "scsrmm");
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t j = 0; j < n; j++) {
+        float acc = 0.f;
+        for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++)
+          acc = fmaf(val[p], ord_b == 'R' ? b[col[p] * ldb + j] : b[j * ldb + col[p]], acc);
+        float *cp = ord_b == 'R' ? c + i * ldc + j : c + j * ldc + i;
+        *cp = beta == 0.f ? alpha * acc : fmaf(alpha, acc, beta * *cp);
+      }
+  });
   return hipSuccess;
 }
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr, const int64_t *col, const float *x,
                     float *y, hipStream_t st) {
-  const int dev = kernel_dev(st, "scsrgemv");
+  MockStream *ms = kernel_stream(st, "scsrgemv");
   if (m <= 0) return hipSuccess;
-  need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrgemv");
-  const int64_t base = ptr[0], nnz = ptr[m] - base;
-  need_device_mem(val, (size_t) nnz * 4, dev, "scsrgemv");
-  need_device_mem(col, (size_t) nnz * 8, dev, "scsrgemv");
-  need_device_mem(x, (size_t) (trans == 'N' ? n : m) * 4, dev, "scsrgemv");
-  need_device_mem(y, (size_t) (trans == 'N' ? m : n) * 4, dev, "scsrgemv");
-  for (int64_t i = 0; i < m; i++) {
-    if (trans == 'N') {
-      float acc = 0.f;
-      for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++) acc = fmaf(val[p], x[col[p]], acc);
-      y[i] = acc;
-    } else {
-      for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++) y[col[p]] += val[p] * x[i];
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrgemv");
+    const int64_t base = ptr[0], nnz = ptr[m] - base;
+    need_device_mem(val, (size_t) nnz * 4, dev, "scsrgemv");
+    need_device_mem(col, (size_t) nnz * 8, dev, "scsrgemv");
+    need_device_mem(x, (size_t) (trans == 'N' ? n : m) * 4, dev, "scsrgemv");
+    need_device_mem(y, (size_t) (trans == 'N' ? m : n) * 4, dev, "scsrgemv");
+    // 'T': the product kernel adds with fp32 atomics, so launches on different streams may share y; here
+    // the adds go through relaxed atomics for the same reason
+    for (int64_t i = 0; i < m; i++) {
+      if (trans == 'N') {
+        float acc = 0.f;
+        for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++) acc = fmaf(val[p], x[col[p]], acc);
+        y[i] = acc;
+      } else {
+        for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++) {
+          uint32_t *slot = reinterpret_cast<uint32_t *>(y + col[p]);
+          uint32_t old = __atomic_load_n(slot, __ATOMIC_RELAXED), want;
+          do {
+            float f;
+            memcpy(&f, &old, 4);
+            f += val[p] * x[i];
+            memcpy(&want, &f, 4);
+          } while (!__atomic_compare_exchange_n(slot, &old, want, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+        }
+      }
     }
-  }
+  });
   return hipSuccess;
 }
 hipError_t sum_partials(float *dst, const float *const *srcs, int n_src, int64_t len, hipStream_t st) {
-  const int dev = kernel_dev(st, "sum_partials");
+  MockStream *ms = kernel_stream(st, "sum_partials");
   if (len <= 0 || n_src <= 0) return hipSuccess;
-  need_device_mem(dst, (size_t) len * 4, dev, "sum_partials");
-  for (int s = 0; s < n_src; s++) need_device_mem(srcs[s], (size_t) len * 4, dev, "sum_partials", /*peer_ok=*/true);
-  for (int64_t i = 0; i < len; i++) {
-    float acc = srcs[0][i];
-    for (int s = 1; s < n_src; s++) acc += srcs[s][i];
-    dst[i] = acc;
-  }
+  const int dev = ms->dev;
+  const std::vector<const float *> src(srcs, srcs + n_src);      // the caller's array need not outlive the call
+  ms->enqueue([=] {
+    need_device_mem(dst, (size_t) len * 4, dev, "sum_partials");
+    for (const float *p : src) need_device_mem(p, (size_t) len * 4, dev, "sum_partials", /*peer_ok=*/true);
+    for (int64_t i = 0; i < len; i++) {
+      float acc = src[0][i];
+      for (size_t q = 1; q < src.size(); q++) acc += src[q][i];
+      dst[i] = acc;
+    }
+  });
   return hipSuccess;
 }
 // the transposition kernels and the generators are not on the paths this harness runs

@@ -63,8 +63,9 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     """The C ABI's level-3 entry points end to end on tests/native/mock_hip.cpp -- a stand-in HIP runtime with FOUR
     DISTINCT mock devices whose rules (an event recorded on its own device's stream, no wait on a never-recorded
     event, copies and kernel stand-ins only on memory of the stream's device or an enabled peer, pinned host sides,
-    nothing used after destruction) are fatal -- under ASan + UBSan + LeakSanitizer (all device lists) and under
-    ThreadSanitizer (two lists).  The pool's GPU boxes have one GPU: this is where the in-process multi-device
+    nothing used after destruction) are fatal -- under ASan + UBSan + LeakSanitizer (all device lists; then with
+    asynchronous, jittered mock streams) and under ThreadSanitizer with asynchronous streams, where a buffer touched
+    by two streams without an event between them is a reported race.  The pool's GPU boxes have one GPU: this is where the in-process multi-device
     code meets more than one ordinal.  Test infrastructure only; the product refuses to run without a GPU."""
     csrc = os.path.join(ROOT, "blas-on-flash_amd", "csrc")
     native = os.path.join(ROOT, "tests", "native")
@@ -80,16 +81,21 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     for k, p in procs.items():
         out, _ = p.communicate(timeout=600)
         assert p.returncode == 0, f"{k} build: {out[-3000:]}"
-    runs = {}
-    for k, extra in (("asan", []), ("tsan", ["brief"])):
-        d = tmp_path / f"files_{k}"
+    # asan: every device list, operations executed at once; then two lists with asynchronous, jittered streams.
+    # tsan: two lists with asynchronous streams -- the work of two streams is ordered only by the events the
+    # library put between them, and ThreadSanitizer follows exactly those edges: a stream-ordering race detector.
+    plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1"}),
+            ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"})]
+    runs = []
+    for i, (k, extra, env_extra) in enumerate(plan):
+        d = tmp_path / f"files_{i}"
         d.mkdir()
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:handle_abort=1", UBSAN_OPTIONS="print_stacktrace=1",
-                   TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", MOCK_HIP_DEVICES="4")
+                   TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", MOCK_HIP_DEVICES="4", **env_extra)
         env.pop("BOF_DEVICES", None)
-        runs[k] = subprocess.Popen([str(tmp_path / f"host_pipeline_{k}"), str(d)] + extra, stdout=subprocess.PIPE,
-                                   stderr=subprocess.PIPE, text=True, env=env)
-    for k, p in runs.items():
+        runs.append((k, subprocess.Popen(["timeout", "-s", "ABRT", "800", str(tmp_path / f"host_pipeline_{k}"), str(d)] + extra,
+                                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)))
+    for k, p in runs:
         out, err = p.communicate(timeout=900)
         if k == "tsan" and "unexpected memory mapping" in err:
             continue
