@@ -194,7 +194,10 @@ struct PanelResources {
 };
 std::mutex g_pres_mu;
 std::map<std::pair<int, int>, PanelResources *> g_pres;   // (ordinal, repetition) -> resources
-PinnedRing *g_rring = nullptr;                            // the read ring serves every device of a call
+// The read ring serves every device of a call; kept per FIRST (lowest) ordinal of the call's device list: a call
+// holds the call locks of all its devices, so two calls that run at the same time (disjoint device lists) never
+// share one.
+std::map<int, PinnedRing *> g_rring;
 
 int trace_level() {   // BOF_TRACE=1: dispatcher milestones; 2: + every panel read / flush / write
   static const int lvl = getenv("BOF_TRACE") ? std::max(1, atoi(getenv("BOF_TRACE"))) : 0;
@@ -847,11 +850,11 @@ void panel_resources_release() {
     delete kv.second;
   }
   g_pres.clear();
-  if (g_rring) {
-    g_rring->destroy();
-    delete g_rring;
-    g_rring = nullptr;
+  for (auto &kv : g_rring) {
+    kv.second->destroy();
+    delete kv.second;
   }
+  g_rring.clear();
 }
 
 void panel_resources_release_device(int dev) {
@@ -1003,8 +1006,9 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   BOF_HIP_TRY(hipSetDevice(caller_dev));
   {
     std::lock_guard<std::mutex> lk(g_pres_mu);
-    if (!g_rring) g_rring = new PinnedRing();
-    H.rring = g_rring;
+    PinnedRing *&rr = g_rring[*std::min_element(used.begin(), used.end())];
+    if (!rr) rr = new PinnedRing();
+    H.rring = rr;
   }
   // a chunk copied to D devices stays in its slot until the slowest copy is done: two more slots per extra device
   int rc = H.rring->init(std::max(2, o.pinned_slots) + 2 * ((int) H.runs.size() - 1), H.runs[0]->chunk + 2 * Mat::kPage, &used);

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bof_hip.h"
@@ -31,10 +32,11 @@ extern "C" int64_t mock_hip_live_events();
   } while (0)
 
 static std::string g_dir;
+static thread_local std::string t_prefix;      // concurrent callers keep their files apart
 static bool g_truncate_a = false;    // the next gemm_case cuts its A file in half (a reader's request comes back short)
 static bool g_accept_enomem = false; // stress mode: a drawn budget may legitimately be refused
 static struct { int io_threads = 3, pinned = 3, streams = 0, kmajor = 0, group = 0, chunk_mib = 1; } g_knobs;   // stress mode draws these
-static std::mt19937_64 g_rng(12345);
+static thread_local std::mt19937_64 g_rng(12345);
 static int ri(int lo, int hi) { return lo + (int) (g_rng() % (uint64_t) (hi - lo + 1)); }
 
 struct TmpFile {
@@ -43,7 +45,7 @@ struct TmpFile {
   uint64_t head = 0;
   template <class T>
   TmpFile(const std::string &name, const std::vector<T> &data, uint64_t head_bytes, bool direct) : head(head_bytes) {
-    path = g_dir + "/" + name;
+    path = g_dir + "/" + t_prefix + name;
     FILE *f = fopen(path.c_str(), "wb");
     CHECK(f);
     std::vector<char> hdr(head, (char) 0x5A);
@@ -156,7 +158,8 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   CHECK(fb.read<float>(B.size()) == B);
   bof_flash_stats per[BOF_MAX_DEVICES];
   const int nd = bof_flash_last_device_stats(per, BOF_MAX_DEVICES);
-  if (devs.size() > 1 && nd > 1) {       // (a C of one panel is one slab whatever the list)
+  if (devs.size() > 1 && nd > 1 && t_prefix.empty()) {   // (a C of one panel is one slab whatever the list; the "last call"
+                                                          //  statistics are the process's, so not with concurrent callers)
     uint64_t tasks = 0;
     for (int d = 0; d < nd; d++) { CHECK(per[d].tasks > 0); tasks += per[d].tasks; }
     bof_flash_stats tot;
@@ -265,6 +268,21 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
   gemm_case('R', 'T', 'N', 371, 353, 112, 2.f, 0.f, 128, 1, 671, {0, 1}, false, false, 983040, BOF_ENOMEM);
   // panels demanded where they cannot be used
   gemm_case('R', 'N', 'N', 384, 384, 384, 1.f, 0.f, 128, 2, 8, {0, 1, 2}, false, false, 0, BOF_ENOMEM);
+  // two host threads inside level 3 at the same time, on disjoint devices (the call locks are per device)
+  for (int round = 0; round < (getenv("HOST_PIPELINE_CONCURRENT_ROUNDS") ? atoi(getenv("HOST_PIPELINE_CONCURRENT_ROUNDS")) : 1); round++) {
+    std::vector<std::thread> th;
+    for (int t = 0; t < 2; t++)
+      th.emplace_back([t] {
+        t_prefix = "t" + std::to_string(t) + "_";
+        const std::vector<int> mine = t == 0 ? std::vector<int>{0, 1} : std::vector<int>{2, 3};
+        for (int rep = 0; rep < 2; rep++) {
+          gemm_case('R', 'N', 'N', 390, 300, 260, 1.f, 0.f, 128, 2, 0, mine, rep == 1, false, 0);
+          gemm_case('C', 'T', 'N', 300, 390, 260, 1.f, 1.f, 128, 1, 0, mine, rep == 1, false, 0);
+          csr_case(700, 500, 16, 'R', 1.f, 0.f, mine, rep == 1);
+        }
+      });
+    for (auto &t : th) t.join();
+  }
   // a truncated operand on both paths over several devices: BOF_EIO, everything joined, the next call is fine
   for (int path = 1; path <= 2; path++) {
     g_truncate_a = true;

@@ -84,7 +84,7 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     # asan: every device list, operations executed at once; then two lists with asynchronous, jittered streams.
     # tsan: two lists with asynchronous streams -- the work of two streams is ordered only by the events the
     # library put between them, and ThreadSanitizer follows exactly those edges: a stream-ordering race detector.
-    plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1"}),
+    plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1", "HOST_PIPELINE_CONCURRENT_ROUNDS": "2"}),
             ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"})]
     runs = []
     for i, (k, extra, env_extra) in enumerate(plan):
