@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "bof_hip.h"
 
 extern "C" uint64_t mock_hip_kernel_launches();
@@ -167,8 +169,137 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   }
 }
 
-// ---- CSR ------------------------------------------------------------------------------------------------------
 struct Csr { std::vector<float> val; std::vector<int64_t> ja, ia; };
+static Csr random_csr(int64_t m, int64_t n);
+
+// ---- level 2: the tile DAGs over HBM-resident operands, forked from and joined to the caller's stream -----------
+template <class T>
+static T *to_device(const std::vector<T> &v) {
+  T *d = nullptr;
+  CHECK(hipMalloc((void **) &d, std::max<size_t>(v.size(), 1) * sizeof(T)) == hipSuccess);
+  if (!v.empty()) CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) == hipSuccess);
+  return d;
+}
+template <class T>
+static std::vector<T> from_device(const T *d, size_t n) {
+  std::vector<T> v(n);
+  if (n) CHECK(hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) == hipSuccess);
+  return v;
+}
+static void resident_case(int dev) {
+  CHECK(hipSetDevice(dev) == hipSuccess);
+  hipStream_t st;
+  CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+  bof_options o;
+  bof_default_options(&o);
+  o.gemm_blk = 128;
+  o.n_streams = 3;
+  o.max_nnzs = 700;
+  o.csrmm_rblk = 300;
+  // gemm: 'T','N' row-major (A k-contiguous after the flip: the k-major copy of the resident DAG) and 'N','T'
+  for (int v = 0; v < 2; v++) {
+    const char ta = v ? 'N' : 'T', tb = v ? 'T' : 'N';
+    const int64_t m = 390, n = 300, k = 260;
+    const int64_t ar = ta == 'N' ? m : k, ac = ta == 'N' ? k : m, br = tb == 'N' ? k : n, bc = tb == 'N' ? n : k;
+    std::vector<float> A((size_t) (ar * ac)), B((size_t) (br * bc)), C((size_t) (m * n));
+    for (auto &x : A) x = (float) ri(-3, 3);
+    for (auto &x : B) x = (float) ri(-3, 3);
+    for (auto &x : C) x = (float) ri(-5, 5);
+    float *da = to_device(A), *db = to_device(B), *dc = to_device(C);
+    CHECK(bof_gemm_resident('R', ta, tb, m, n, k, 2.f, 1.f, da, db, dc, 0, 0, 0, &o, st) == BOF_OK);
+    CHECK(hipStreamSynchronize(st) == hipSuccess);
+    const std::vector<float> got = from_device(dc, C.size());
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t j = 0; j < n; j++) {
+        double acc = 0;
+        for (int64_t l = 0; l < k; l++)
+          acc += (double) (ta == 'N' ? A[(size_t) (i * k + l)] : A[(size_t) (l * m + i)]) * (double) (tb == 'N' ? B[(size_t) (l * n + j)] : B[(size_t) (j * k + l)]);
+        CHECK(got[(size_t) (i * n + j)] == (float) (2.0 * acc + (double) C[(size_t) (i * n + j)]));
+      }
+    CHECK(hipFree(da) == hipSuccess && hipFree(db) == hipSuccess && hipFree(dc) == hipSuccess);
+  }
+  // csrmm 'N' and csrgemv 'N' / 'T'
+  {
+    const int64_t m = 900, n = 700, k = 24;
+    const Csr a = random_csr(m, n);
+    std::vector<float> B((size_t) (n * k)), C((size_t) (m * k), 0.f), x((size_t) n), xt((size_t) m);
+    for (auto &v : B) v = (float) ri(0, 6);
+    for (auto &v : x) v = (float) ri(0, 9);
+    for (auto &v : xt) v = (float) ri(0, 9);
+    float *dv = to_device(a.val), *db = to_device(B), *dc = to_device(C), *dx = to_device(x), *dxt = to_device(xt);
+    int64_t *dja = to_device(a.ja), *dia = to_device(a.ia);
+    std::vector<float> y((size_t) m, -1.f), yt((size_t) n, -1.f);
+    float *dy = to_device(y), *dyt = to_device(yt);
+    CHECK(bof_csrmm_resident('N', m, n, k, 1.f, 0.f, dv, a.ia.data(), dia, dja, 'R', db, dc, &o, st) == BOF_OK);
+    CHECK(bof_csrgemv_resident('N', m, n, dv, a.ia.data(), dia, dja, dx, dy, &o, st) == BOF_OK);
+    CHECK(bof_csrgemv_resident('T', m, n, dv, a.ia.data(), dia, dja, dxt, dyt, &o, st) == BOF_OK);
+    CHECK(hipStreamSynchronize(st) == hipSuccess);
+    const std::vector<float> gc = from_device(dc, C.size()), gy = from_device(dy, y.size()), gyt = from_device(dyt, yt.size());
+    std::vector<double> wy((size_t) m, 0), wyt((size_t) n, 0);
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t p = a.ia[(size_t) i]; p < a.ia[(size_t) i + 1]; p++) {
+        wy[(size_t) i] += (double) a.val[(size_t) p] * x[(size_t) a.ja[(size_t) p]];
+        wyt[(size_t) a.ja[(size_t) p]] += (double) a.val[(size_t) p] * xt[(size_t) i];
+      }
+    for (int64_t i = 0; i < m; i++) CHECK(gy[(size_t) i] == (float) wy[(size_t) i]);
+    for (int64_t j = 0; j < n; j++) CHECK(gyt[(size_t) j] == (float) wyt[(size_t) j]);
+    for (int64_t i = 0; i < m; i += 7)
+      for (int64_t j = 0; j < k; j++) {
+        double acc = 0;
+        for (int64_t p = a.ia[(size_t) i]; p < a.ia[(size_t) i + 1]; p++) acc += (double) a.val[(size_t) p] * B[(size_t) (a.ja[(size_t) p] * k + j)];
+        CHECK(gc[(size_t) (i * k + j)] == (float) acc);
+      }
+    for (void *p : {(void *) dv, (void *) db, (void *) dc, (void *) dx, (void *) dxt, (void *) dja, (void *) dia, (void *) dy, (void *) dyt})
+      CHECK(hipFree(p) == hipSuccess);
+  }
+  CHECK(hipStreamDestroy(st) == hipSuccess);
+  CHECK(hipSetDevice(0) == hipSuccess);
+}
+
+// ---- one process per GPU, here one thread per "rank": B read once and passed on through the staging ring ---------
+static void share_case(int world, bool direct) {
+  const int64_t blk = 128, m = 128 * 2 * world, n = 300, k = 128 * 5;      // 5 panels of B: panel l read by rank l % world
+  std::vector<float> A((size_t) (m * k)), B((size_t) (k * n)), C((size_t) (m * n), 0.f);
+  for (auto &x : A) x = (float) ri(-3, 3);
+  for (auto &x : B) x = (float) ri(-3, 3);
+  TmpFile fa("sA.bin", A, 0, direct), fb("sB.bin", B, 0, direct), fc("sC.bin", C, 0, direct);
+  const std::string name = "/bof_mock_share_" + std::to_string(getpid());
+  bof_share_cleanup(name.c_str());
+  std::vector<std::thread> th;
+  std::vector<int> rcs((size_t) world, -1);
+  std::vector<bof_flash_stats> st((size_t) world);
+  for (int r = 0; r < world; r++)
+    th.emplace_back([&, r] {
+      bof_options o = options({r});
+      o.gemm_blk = blk;
+      o.gemm_path = 2;
+      o.io_chunk_mib = 1;
+      o.n_io_threads = 2;
+      o.use_odirect = direct ? 1 : 0;
+      o.share_world = world;
+      o.share_rank = r;
+      snprintf(o.share_name, sizeof(o.share_name), "%s", name.c_str());
+      const int64_t r0 = m / world * r, rows = m / world;
+      rcs[(size_t) r] = bof_flash_gemm('R', 'N', 'N', (uint64_t) rows, (uint64_t) n, (uint64_t) k, 1.f, 0.f, bof_fptr{fa.fd, (uint64_t) (r0 * k * 4)},
+                                       fb.ptr(), bof_fptr{fc.fd, (uint64_t) (r0 * n * 4)}, 0, 0, 0, &o);
+      if (rcs[(size_t) r]) fprintf(stderr, "share_case rank %d: rc %d (%s)\n", r, rcs[(size_t) r], bof_last_error());
+    });
+  for (auto &t : th) t.join();
+  bof_share_cleanup(name.c_str());
+  for (int r = 0; r < world; r++) CHECK(rcs[(size_t) r] == BOF_OK);
+  const std::vector<float> got = fc.read<float>(C.size());
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t j = 0; j < n; j++) {
+      double acc = 0;
+      for (int64_t l = 0; l < k; l++) acc += (double) A[(size_t) (i * k + l)] * (double) B[(size_t) (l * n + j)];
+      if (got[(size_t) (i * n + j)] != (float) acc) {
+        fprintf(stderr, "share_case world %d: C[%ld,%ld] = %g, want %g\n", world, (long) i, (long) j, got[(size_t) (i * n + j)], acc);
+        exit(1);
+      }
+    }
+}
+
+// ---- CSR ------------------------------------------------------------------------------------------------------
 static Csr random_csr(int64_t m, int64_t n) {
   Csr c;
   c.ia.push_back(0);
@@ -283,6 +414,13 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
       });
     for (auto &t : th) t.join();
   }
+  // level 2 on two of the devices
+  resident_case(1);
+  resident_case(3);
+  // "ranks" as threads, one mock device each: shared B through the node-shared staging ring
+  share_case(2, false);
+  share_case(4, true);
+  share_case(3, false);
   // a truncated operand on both paths over several devices: BOF_EIO, everything joined, the next call is fine
   for (int path = 1; path <= 2; path++) {
     g_truncate_a = true;
@@ -292,7 +430,7 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
   }
   CHECK(bof_flash_release() == BOF_OK);
   for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);      // nothing left on any mock device
-  return cases + 6;
+  return cases + 11;
 }
 
 // drawn cases for a number of seconds (MOCK_HIP_ASYNC=1 + ThreadSanitizer: the stream-race hunt)
