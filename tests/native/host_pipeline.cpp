@@ -171,6 +171,7 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
 
 struct Csr { std::vector<float> val; std::vector<int64_t> ja, ia; };
 static Csr random_csr(int64_t m, int64_t n);
+static void transpose_case(int64_t m, int64_t n, int64_t k, uint64_t budget, const std::vector<int> &devs, bool direct);
 
 // ---- level 2: the tile DAGs over HBM-resident operands, forked from and joined to the caller's stream -----------
 template <class T>
@@ -414,6 +415,11 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
       });
     for (auto &t : th) t.join();
   }
+  // transposition in HBM, out of core (a budget of a few hundred KiB: several row blocks, spill files, merge), csrmm 'T'
+  transpose_case(900, 700, 24, 0, {2}, false);
+  transpose_case(1200, 500, 16, 0, {1, 3}, true);
+  transpose_case(2500, 800, 0, 1500000, {0}, false);
+  transpose_case(2500, 800, 0, 1500000, {3}, true);
   // level 2 on two of the devices
   resident_case(1);
   resident_case(3);
@@ -430,7 +436,7 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
   }
   CHECK(bof_flash_release() == BOF_OK);
   for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);      // nothing left on any mock device
-  return cases + 11;
+  return cases + 15;
 }
 
 // drawn cases for a number of seconds (MOCK_HIP_ASYNC=1 + ThreadSanitizer: the stream-race hunt)
@@ -472,6 +478,61 @@ static int stress(double seconds) {
   return n;
 }
 
+// ---- flash::csrcsc (whole matrix in HBM, and out of core under a small budget) and flash::csrmm 'T' --------------
+static void transpose_case(int64_t m, int64_t n, int64_t k, uint64_t budget, const std::vector<int> &devs, bool direct) {
+  const Csr a = random_csr(m, n);
+  const int64_t nnz = a.ia.back();
+  // expected transpose: stable counting sort
+  std::vector<int64_t> it((size_t) n + 1, 0), jt((size_t) std::max<int64_t>(nnz, 1), 0);
+  std::vector<float> vt((size_t) std::max<int64_t>(nnz, 1), 0.f);
+  for (int64_t p = 0; p < nnz; p++) it[(size_t) a.ja[(size_t) p] + 1]++;
+  for (int64_t j = 0; j < n; j++) it[(size_t) j + 1] += it[(size_t) j];
+  {
+    std::vector<int64_t> fill(it.begin(), it.end() - 1);
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t p = a.ia[(size_t) i]; p < a.ia[(size_t) i + 1]; p++) {
+        const int64_t q = fill[(size_t) a.ja[(size_t) p]]++;
+        vt[(size_t) q] = a.val[(size_t) p];
+        jt[(size_t) q] = i;
+      }
+  }
+  TmpFile fv("val.bin", a.val, 0, direct), fj("ja.bin", a.ja, 0, direct), fi("ia.bin", a.ia, 0, direct);
+  bof_options o = options(devs);
+  o.n_io_threads = 3;
+  o.use_odirect = direct ? 1 : 0;
+  o.hbm_budget = budget;
+  o.max_nnzs = 700;
+  o.csrmm_rblk = 300;
+  {
+    TmpFile fvt("vt.bin", std::vector<float>(vt.size(), -1.f), 0, direct), fjt("jt.bin", std::vector<int64_t>(jt.size(), -1), 0, direct),
+        fit("it.bin", std::vector<int64_t>(it.size(), -1), 0, direct);
+    const int rc = bof_flash_csrcsc((uint64_t) m, (uint64_t) n, fi.ptr(), fj.ptr(), fv.ptr(), fit.ptr(), fjt.ptr(), fvt.ptr(), &o);
+    if (rc) fprintf(stderr, "csrcsc %ldx%ld budget %llu: rc %d (%s)\n", (long) m, (long) n, (unsigned long long) budget, rc, bof_last_error());
+    CHECK(rc == BOF_OK);
+    CHECK(fit.read<int64_t>(it.size()) == it);
+    if (nnz) {
+      CHECK(fjt.read<int64_t>((size_t) nnz) == std::vector<int64_t>(jt.begin(), jt.begin() + nnz));
+      CHECK(fvt.read<float>((size_t) nnz) == std::vector<float>(vt.begin(), vt.begin() + nnz));
+    }
+  }
+  if (budget) return;         // csrmm 'T' builds A^T in HBM whole
+  // C[n x k] = alpha A^T B[m x k] + beta C
+  std::vector<float> B((size_t) (m * k)), C((size_t) (n * k));
+  for (auto &x : B) x = (float) ri(0, 6);
+  for (auto &x : C) x = (float) ri(0, 4);
+  std::vector<double> want(C.begin(), C.end());
+  for (auto &w : want) w *= 2.0;
+  for (int64_t i = 0; i < m; i++)
+    for (int64_t p = a.ia[(size_t) i]; p < a.ia[(size_t) i + 1]; p++)
+      for (int64_t j = 0; j < k; j++) want[(size_t) (a.ja[(size_t) p] * k + j)] += (double) a.val[(size_t) p] * (double) B[(size_t) (i * k + j)];
+  TmpFile fb("b.bin", B, 0, direct), fc("c.bin", C, 0, direct);
+  const int rc = bof_flash_csrmm('T', (uint64_t) m, (uint64_t) n, (uint64_t) k, 1.f, 2.f, fv.ptr(), fi.ptr(), fj.ptr(), 'R', fb.ptr(), fc.ptr(), &o);
+  if (rc) fprintf(stderr, "csrmm T %ldx%ldx%ld: rc %d (%s)\n", (long) m, (long) n, (long) k, rc, bof_last_error());
+  CHECK(rc == BOF_OK);
+  const std::vector<float> got = fc.read<float>(C.size());
+  for (size_t i = 0; i < got.size(); i++) CHECK(got[i] == (float) want[i]);
+}
+
 int main(int argc, char **argv) {
   CHECK(argc > 1);
   g_dir = argv[1];
@@ -488,7 +549,7 @@ int main(int argc, char **argv) {
   const long long s1 = mock_hip_live_streams(), e1 = mock_hip_live_events();
   cases += run_all({{2, 0, 3}});
   CHECK(mock_hip_live_streams() == s1 && mock_hip_live_events() == e1);
-  printf("host_pipeline ok: %d level-3 call groups on 4 mock devices, %llu kernel stand-in launches, %llu bytes of async H2D from "
+  printf("host_pipeline ok: %d level-3 call groups on 4 mock devices, %llu kernel stand-in launches, %llu bytes of async copies from / to "
          "pageable memory; %lld streams / %lld events stay with the per-device stream sets\n",
          cases, (unsigned long long) mock_hip_kernel_launches(), (unsigned long long) mock_hip_pageable_h2d_bytes(), s1, e1);
   return 0;

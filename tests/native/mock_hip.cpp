@@ -23,7 +23,7 @@
 //   R2  hipStreamWaitEvent on an event that was never recorded (a no-op in HIP: the wait the caller wanted does
 //       not happen -- the class of the shared-operand race of round 3);
 //   R3  async copies: the device side belongs to the stream's device (or to a peer it has been given access to),
-//       the host side is pinned memory (a pageable SOURCE of a linear H2D copy is legal and only counted), the
+//       the host side is pinned memory (a pageable host side of a LINEAR copy is legal and only counted), the
 //       ranges lie inside their allocations;
 //   R4  kernel stand-ins: the calling thread's current device is the stream's device and every pointer is that
 //       device's memory -- except the sources of sum_partials, which need peer access;
@@ -388,7 +388,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
   return hipSuccess;
 }
 
-std::atomic<uint64_t> g_pageable_h2d{0};
+std::atomic<uint64_t> g_pageable_h2d{0}, g_pageable_d2h{0};
 static void check_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, int dev, const char *who) {
   if (bytes == 0) return;
   if (kind == hipMemcpyHostToDevice && !known(src)) {
@@ -396,6 +396,13 @@ static void check_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k
     // counted and reported, the device side still checked
     g_pageable_h2d += bytes;
     need_device_mem(dst, bytes, dev, who);
+    return;
+  }
+  if (kind == hipMemcpyDeviceToHost && !known(dst)) {
+    // pageable destination of an async D2H copy: legal too (complete once the stream has been synchronised, which
+    // is what ThreadSanitizer then checks the reader against); counted, the device side still checked
+    g_pageable_d2h += bytes;
+    need_device_mem(src, bytes, dev, who);
     return;
   }
   const Alloc d = where(dst, bytes, who), s = where(src, bytes, who);
@@ -416,7 +423,7 @@ static void check_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k
   else if (kind == hipMemcpyDeviceToDevice) { dev_ok(d); dev_ok(s); }
   else violation("R3", std::string(who) + ": copy kind the library never uses");
 }
-uint64_t mock_hip_pageable_h2d_bytes() { return g_pageable_h2d.load(); }
+uint64_t mock_hip_pageable_h2d_bytes() { return g_pageable_h2d.load() + g_pageable_d2h.load(); }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
   MockStream *st = S(s, "hipMemcpyAsync");
   check_copy(dst, src, bytes, kind, st->dev, "hipMemcpyAsync");
@@ -617,15 +624,73 @@ hipError_t sum_partials(float *dst, const float *const *srcs, int n_src, int64_t
   });
   return hipSuccess;
 }
-// the transposition kernels and the generators are not on the paths this harness runs
-size_t csrcsc_workspace_bytes(int64_t, int64_t) { return 0; }
-size_t csrgemv_t_workspace_bytes(int64_t, int64_t) { return 0; }
-hipError_t scsrcsc(int64_t, int64_t, int64_t, const float *, const int64_t *, const int64_t *, float *, int64_t *, int64_t *, void *,
-                   hipStream_t) { return hipErrorUnknown; }
-hipError_t csc_merge(int, int64_t, const int64_t *, const int64_t *, const int64_t *, const int64_t *, const float *,
-                     const int64_t *, float *, int64_t *, hipStream_t) { return hipErrorUnknown; }
-hipError_t scsrgemv_t_partitioned(int64_t, int64_t, int64_t, const float *, const int64_t *, const int64_t *, const float *, float *,
-                                  void *, hipStream_t) { return hipErrorUnknown; }
+// CSR transposition: stable (source rows ascending inside every output row), offsets of the result 0-based
+size_t csrcsc_workspace_bytes(int64_t, int64_t) { return 4096; }
+size_t csrgemv_t_workspace_bytes(int64_t, int64_t) { return 4096; }
+hipError_t scsrcsc(int64_t m, int64_t n, int64_t nnz, const float *val, const int64_t *ptr, const int64_t *col, float *val_tr,
+                   int64_t *ptr_tr, int64_t *col_tr, void *, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "scsrcsc");
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(ptr_tr, (size_t) (n + 1) * 8, dev, "scsrcsc");
+    if (m > 0) need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrcsc");
+    if (nnz > 0) {
+      need_device_mem(val, (size_t) nnz * 4, dev, "scsrcsc"); need_device_mem(col, (size_t) nnz * 8, dev, "scsrcsc");
+      need_device_mem(val_tr, (size_t) nnz * 4, dev, "scsrcsc"); need_device_mem(col_tr, (size_t) nnz * 8, dev, "scsrcsc");
+    }
+    const int64_t base = m > 0 ? ptr[0] : 0;
+    std::vector<int64_t> fill((size_t) n + 1, 0);
+    for (int64_t p = 0; p < nnz; p++) fill[(size_t) col[p] + 1]++;
+    for (int64_t j = 0; j < n; j++) fill[(size_t) j + 1] += fill[(size_t) j];
+    for (int64_t j = 0; j <= n; j++) ptr_tr[j] = fill[(size_t) j];
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++) {
+        const int64_t q = fill[(size_t) col[p]]++;
+        val_tr[q] = val[p];
+        col_tr[q] = i;
+      }
+  });
+  return hipSuccess;
+}
+// the out-of-core transposition's merge of the per-block results (csrcsc_kernels.hip: csc_merge_kernel)
+hipError_t csc_merge(int nb, int64_t cw, const int64_t *blk_ptr, const int64_t *seg_base, const int64_t *row0, const int64_t *out_ptr,
+                     const float *val_in, const int64_t *col_in, float *val_out, int64_t *col_out, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "csc_merge");
+  if (cw <= 0 || nb <= 0) return hipSuccess;
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(blk_ptr, (size_t) nb * (size_t) (cw + 1) * 8, dev, "csc_merge");
+    need_device_mem(seg_base, (size_t) nb * 8, dev, "csc_merge");
+    need_device_mem(row0, (size_t) nb * 8, dev, "csc_merge");
+    need_device_mem(out_ptr, (size_t) cw * 8, dev, "csc_merge");
+    for (int64_t c = 0; c < cw; c++) {
+      int64_t cursor = out_ptr[c];
+      for (int b = 0; b < nb; b++) {
+        const int64_t s0 = blk_ptr[(int64_t) b * (cw + 1) + c], e0 = blk_ptr[(int64_t) b * (cw + 1) + c + 1];
+        for (int64_t i = s0; i < e0; i++) {
+          val_out[cursor + (i - s0)] = val_in[seg_base[b] + i];
+          col_out[cursor + (i - s0)] = col_in[seg_base[b] + i] + row0[b];
+        }
+        cursor += e0 - s0;
+      }
+    }
+  });
+  return hipSuccess;
+}
+hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t, const float *val, const int64_t *ptr, const int64_t *col,
+                                  const float *x, float *y, void *, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "scsrgemv_t_partitioned");
+  if (n <= 0) return hipSuccess;
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(y, (size_t) n * 4, dev, "scsrgemv_t_partitioned");
+    for (int64_t j = 0; j < n; j++) y[j] = 0.f;
+    const int64_t base = m > 0 ? ptr[0] : 0;
+    for (int64_t i = 0; i < m; i++)
+      for (int64_t p = ptr[i] - base; p < ptr[i + 1] - base; p++) y[col[p]] += val[p] * x[i];
+  });
+  return hipSuccess;
+}
 hipError_t gen_dense(float *, int64_t, int64_t, char, uint64_t, hipStream_t) { return hipErrorUnknown; }
 hipError_t gen_sparse_rows(int64_t, int64_t, int64_t, int64_t, float *, int64_t *, int64_t *, hipStream_t) { return hipErrorUnknown; }
 
