@@ -461,7 +461,10 @@ static int stress(double seconds) {
     int expect = BOF_OK;
     if (path == 2 && (pad || budget)) expect = -1000;       // may be refused or not: checked below
     if (budget && path != 2) expect = -1000;
-    if (ri(0, 5) == 0) {
+    const int pick = ri(0, 11);
+    if (pick == 0) {
+      transpose_case(ri(200, 1500), ri(100, 700), ri(1, 24), ri(0, 1) ? (uint64_t) ri(700000, 2000000) : 0, {devs[0]}, ri(0, 1));
+    } else if (pick <= 2) {
       csr_case(ri(200, 900), ri(100, 700), ri(1, 40), "RC"[ri(0, 1)], (float) ri(1, 2), (float) ri(0, 1), devs, ri(0, 1));
     } else if (expect == -1000) {
       // outcome depends on the budget arithmetic: run it through the ABI directly and accept ENOMEM
