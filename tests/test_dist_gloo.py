@@ -145,3 +145,157 @@ def test_share_ring_missing_peer_times_out():
     res = _run_ring(3, 20, 64 << 10, 4, 1.5, skip=(1,))
     assert res[1] is None
     assert res[0] in (-110, -5) and res[2] in (-110, -5), res
+
+
+# ---- the whole one-process-per-GPU file GEMM on CPU: real ranks (gloo), the C library linked against the mock HIP
+# runtime of tests/native/mock_hip.cpp instead of libamdhip64 (test infrastructure only: nothing of it ships) ------
+def _build_mock_library(out_dir):
+    import subprocess
+    csrc = os.path.join(ROOT, "blas-on-flash_amd", "csrc")
+    so = os.path.join(out_dir, "libbof_hip_mock.so")
+    srcs = [os.path.join(csrc, f) for f in ("plan.cpp", "fileio.cpp", "uring_io.cpp", "flash_support.cpp", "flash_runtime.cpp",
+                                             "flash_csr.cpp", "flash_gemm_panels.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I",
+           os.path.join(ROOT, "include"), "-I", csrc] + srcs + ["-x", "c++", os.path.join(csrc, "c_api.hip"), "-x", "none",
+                                                               os.path.join(ROOT, "tests", "native", "mock_hip.cpp"), "-o", so,
+                                                               "-lpthread", "-ldl", "-lrt"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return so
+
+
+def _use_mock_library(so):
+    import ctypes as C
+    import bofhip
+    L = C.CDLL(so)
+    for name, res, args in bofhip.SYMBOLS:
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    bofhip._lib = L
+
+
+def _file_gemm_worker(rank, world, port, so, out_dir, m, n, k, blk):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MOCK_HIP_DEVICES"] = "1"
+    os.environ["MOCK_HIP_ASYNC"] = "1"
+    _use_mock_library(so)
+    import bofhip
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fds = [os.open(os.path.join(out_dir, f"{x}.bin"), os.O_RDWR) for x in "ABC"]
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, io_chunk_mib=1, n_io_threads=3, use_odirect=0)
+        st = bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], opts=opts)
+        np.save(os.path.join(out_dir, f"stats_{rank}.npy"),
+                np.array([st["rows"], st["bytes_read"], st["bytes_written"], st["bytes_peer"]], np.int64))
+    finally:
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def mock_lib(tmp_path_factory):
+    return _build_mock_library(str(tmp_path_factory.mktemp("mocklib")))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_file_gemm_ranks_on_mock_devices(tmp_path, mock_lib, world):
+    """bof_dist.flash_gemm_row_sharded with REAL ranks on the CPU box: every rank is a process whose libbof_hip
+    is the product's host code linked against the mock HIP runtime (asynchronous mock streams).  Rank g runs the
+    level-3 panel pipeline on its C rows; the panels of B are read from the file by one rank each and passed on
+    through the node-shared staging ring (POSIX shared memory between the processes); Python only broadcasts the
+    /dev/shm verdict, barriers and cleans up.  Whole C exact, B read once per node, nothing left in /dev/shm."""
+    so = mock_lib
+    blk, m, n, k = 128, 128 * 2 * world + 128, 300, 128 * 5 + 40        # a rank with one more panel; merged k tail
+    rng = np.random.default_rng(world)
+    a = rng.integers(-3, 4, (m, k)).astype(np.float32)
+    b = rng.integers(-3, 4, (k, n)).astype(np.float32)
+    a.tofile(tmp_path / "A.bin")
+    b.tofile(tmp_path / "B.bin")
+    np.zeros((m, n), np.float32).tofile(tmp_path / "C.bin")
+    before = set(os.listdir("/dev/shm"))
+    mp.spawn(_file_gemm_worker, args=(world, _free_port(), so, str(tmp_path), m, n, k, blk), nprocs=world, join=True)
+    got = np.fromfile(tmp_path / "C.bin", np.float32).reshape(m, n)
+    assert np.array_equal(got, (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32))
+    stats = np.stack([np.load(tmp_path / f"stats_{r}.npy") for r in range(world)])
+    assert stats[:, 0].sum() == m and (stats[:, 0] > 0).all()
+    assert stats[:, 1].sum() == a.nbytes + b.nbytes            # every byte of A and of B read from the files ONCE
+    assert stats[:, 2].sum() == m * n * 4
+    assert stats[:, 3].sum() == (world - 1) * b.nbytes         # ... and B taken from the peers world - 1 times
+    assert set(os.listdir("/dev/shm")) - before == set()
+
+
+def _kmeans_csr_worker(rank, world, port, so, out_dir, shp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MOCK_HIP_DEVICES"] = "1"
+    os.environ["MOCK_HIP_ASYNC"] = "1"
+    _use_mock_library(so)
+    import bofhip
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ncent, npts, dim, m, n, k = shp
+    names = ["centers", "points", "dist", "val", "ia", "ja", "b", "c"]
+    fd = {x: os.open(os.path.join(out_dir, f"{x}.bin"), os.O_RDWR) for x in names}
+    try:
+        cl, pl = np.load(os.path.join(out_dir, "cl.npy")), np.load(os.path.join(out_dir, "pl.npy"))
+        opts = bofhip.default_options(gemm_blk=128, io_chunk_mib=1, n_io_threads=2, use_odirect=0, max_nnzs=700, csrmm_rblk=300)
+        bof_dist.flash_kmeans_point_sharded(ncent, npts, dim, fd["centers"], fd["points"], fd["dist"], cl, pl, opts=opts)
+        ia = np.fromfile(os.path.join(out_dir, "ia.bin"), np.int64)
+        bof_dist.flash_csrmm_row_sharded(m, n, k, 2.0, 0.0, fd["val"], fd["ia"], fd["ja"], "R", fd["b"], fd["c"], ia, opts=opts)
+        x = np.load(os.path.join(out_dir, "x.npy"))
+        xt = np.load(os.path.join(out_dir, "xt.npy"))
+        yn = np.zeros(m, np.float32)
+        r0, r1 = bof_dist.flash_csrgemv_row_sharded("N", m, n, fd["val"], fd["ia"], fd["ja"], x, yn, ia, opts=opts)
+        yt = np.zeros(n, np.float32)
+        bof_dist.flash_csrgemv_row_sharded("T", m, n, fd["val"], fd["ia"], fd["ja"], xt, yt, ia, opts=opts)   # the one all-reduce
+        np.save(os.path.join(out_dir, f"yn_{rank}.npy"), np.concatenate([[r0, r1], yn[r0:r1]]))
+        np.save(os.path.join(out_dir, f"yt_{rank}.npy"), yt)
+    finally:
+        for f in fd.values():
+            bofhip.lib().bof_file_forget(f)
+            os.close(f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_kmeans_csrmm_csrgemv_ranks_on_mock_devices(tmp_path, mock_lib):
+    """The other sharded entry points of bof_dist with real ranks on the CPU box (same mock-linked library):
+    flash::kmeans by points, csrmm by nnz-balanced row ranges, csrgemv 'N' (disjoint slices) and 'T' (full-length
+    partials + the one all-reduce, over gloo here).  Integer data, exact against numpy."""
+    world = 2
+    ncent, npts, dim, m, n, k = 200, 128 * 5, 96, 1500, 900, 24
+    rng = np.random.default_rng(7)
+    centers = rng.integers(-3, 4, (ncent, dim)).astype(np.float32)
+    points = rng.integers(-3, 4, (npts, dim)).astype(np.float32)
+    cl = rng.integers(0, 9, ncent).astype(np.float32)
+    pl = rng.integers(0, 9, npts).astype(np.float32)
+    nnz_row = rng.integers(0, 13, m)
+    ia = np.concatenate([[0], np.cumsum(nnz_row)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in nnz_row]).astype(np.int64)
+    val = rng.integers(1, 10, int(ia[-1])).astype(np.float32)
+    b = rng.integers(0, 7, (n, k)).astype(np.float32)
+    x = rng.integers(0, 10, n).astype(np.float32)
+    xt = rng.integers(0, 10, m).astype(np.float32)
+    for name, arr in (("centers", centers), ("points", points), ("dist", np.zeros((npts, ncent), np.float32)), ("val", val),
+                      ("ia", ia), ("ja", ja), ("b", b), ("c", np.zeros((m, k), np.float32))):
+        arr.tofile(tmp_path / f"{name}.bin")
+    for name, arr in (("cl", cl), ("pl", pl), ("x", x), ("xt", xt)):
+        np.save(tmp_path / f"{name}.npy", arr)
+    mp.spawn(_kmeans_csr_worker, args=(world, _free_port(), mock_lib, str(tmp_path), (ncent, npts, dim, m, n, k)), nprocs=world,
+             join=True)
+    # kmeans: dist[p, c] = -2 <c, p> + |c|^2 + |p|^2 (one k block: the two rank-1 terms once)
+    want = -2.0 * (points.astype(np.float64) @ centers.astype(np.float64).T) + cl[None, :] + pl[:, None]
+    assert np.array_equal(np.fromfile(tmp_path / "dist.bin", np.float32).reshape(npts, ncent), want.astype(np.float32))
+    import scipy.sparse as sp
+    A = sp.csr_matrix((val.astype(np.float64), ja, ia), shape=(m, n))
+    assert np.array_equal(np.fromfile(tmp_path / "c.bin", np.float32).reshape(m, k), (2.0 * (A @ b.astype(np.float64))).astype(np.float32))
+    parts = sorted((np.load(tmp_path / f"yn_{r}.npy") for r in range(world)), key=lambda p: p[0])
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == m
+    assert np.array_equal(np.concatenate([p[2:] for p in parts]).astype(np.float32), (A @ x.astype(np.float64)).astype(np.float32))
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"yt_{r}.npy"), (A.T @ xt.astype(np.float64)).astype(np.float32))
+
