@@ -65,6 +65,16 @@ std::map<uintptr_t, Alloc> g_allocs;
 std::vector<size_t> g_used;                            // bytes allocated per device
 std::set<std::pair<int, int>> g_peer;                  // (from, to)
 std::atomic<uint64_t> g_kernel_launches{0};
+std::atomic<uint64_t> g_launches_on[64];              // per device
+struct Reporter {                                      // MOCK_HIP_REPORT=1: one line at exit, for tests that run a driver binary
+  ~Reporter() {
+    if (!getenv("MOCK_HIP_REPORT")) return;
+    fprintf(stderr, "mock_hip: kernel stand-in launches per device:");
+    const int n = getenv("MOCK_HIP_DEVICES") ? std::max(1, atoi(getenv("MOCK_HIP_DEVICES"))) : 4;
+    for (int d = 0; d < n && d < 64; d++) fprintf(stderr, " %llu", (unsigned long long) g_launches_on[d].load());
+    fprintf(stderr, "\n");
+  }
+} g_reporter;
 std::atomic<int64_t> g_live_streams{0}, g_live_events{0};
 std::vector<struct MockStream *> &g_streams = *new std::vector<struct MockStream *>();   // alive ones (under g_mu)
 // every stream / event ever made: destroyed ones stay allocated so that a later use is reported; reachable from
@@ -217,6 +227,7 @@ MockStream *kernel_stream(hipStream_t st, const char *who) {
     violation("R4", std::string(who) + ": launched with current device " + std::to_string(t_dev) + " on a stream of device " +
                         std::to_string(s->dev));
   g_kernel_launches++;
+  g_launches_on[s->dev & 63]++;
   return s;
 }
 
