@@ -539,6 +539,22 @@ static void transpose_case(int64_t m, int64_t n, int64_t k, uint64_t budget, con
 int main(int argc, char **argv) {
   CHECK(argc > 1);
   g_dir = argv[1];
+  if (bof_device_count() == 8) {       // MOCK_HIP_DEVICES=8: the shape of the 8-GPU node, C panels / row blocks over all eight
+    const std::vector<int> all = {0, 1, 2, 3, 4, 5, 6, 7};
+    for (int direct = 0; direct < 2; direct++) {
+      gemm_case('R', 'N', 'N', 128 * 17 + 40, 260, 300, 1.f, 0.f, 128, 2, 0, all, direct, false, 0);      // 17 panels: 3 + 7 x 2
+      gemm_case('C', 'T', 'N', 300, 128 * 9, 200, 1.f, 1.f, 128, 0, 0, {7, 6, 5, 4, 3, 2, 1, 0}, direct, false, 0);
+      gemm_case('R', 'N', 'T', 128 * 10, 260, 260, 2.f, 1.f, 128, 1, 0, all, direct, false, 0);
+      gemm_case('C', 'T', 'N', 200, 128 * 12, 96, -2.f, 0.f, 128, 0, 0, all, direct, true, 0);             // kmeans, driver shape
+      csr_case(4000, 900, 16, 'R', 1.f, 0.f, all, direct);
+      csr_case(3000, 700, 12, 'C', 2.f, 1.f, {1, 3, 5, 7, 0, 2, 4, 6}, direct);
+    }
+    share_case(8, false);
+    CHECK(bof_flash_release() == BOF_OK);
+    for (int d = 0; d < 8; d++) CHECK(mock_hip_bytes_in_use(d) == 0);
+    printf("host_pipeline ok: 8 mock devices, %llu kernel stand-in launches\n", (unsigned long long) mock_hip_kernel_launches());
+    return 0;
+  }
   CHECK(bof_device_count() == 4);
   if (argc > 3 && !strcmp(argv[2], "stress")) {
     g_rng.seed((uint64_t) atol(argv[3]) * 7919 + 1);

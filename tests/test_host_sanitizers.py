@@ -85,13 +85,16 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     # tsan: two lists with asynchronous streams -- the work of two streams is ordered only by the events the
     # library put between them, and ThreadSanitizer follows exactly those edges: a stream-ordering race detector.
     plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1", "HOST_PIPELINE_CONCURRENT_ROUNDS": "2"}),
-            ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"})]
+            ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"}),
+            # the 8-GPU node's shape: C panels / row blocks over eight devices, eight "ranks" through the staging ring
+            ("asan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8"})]
     runs = []
     for i, (k, extra, env_extra) in enumerate(plan):
         d = tmp_path / f"files_{i}"
         d.mkdir()
         env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:handle_abort=1", UBSAN_OPTIONS="print_stacktrace=1",
-                   TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", MOCK_HIP_DEVICES="4", **env_extra)
+                   TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", MOCK_HIP_DEVICES="4")
+        env.update(env_extra)
         env.pop("BOF_DEVICES", None)
         runs.append((k, subprocess.Popen(["timeout", "-s", "ABRT", "800", str(tmp_path / f"host_pipeline_{k}"), str(d)] + extra,
                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)))
