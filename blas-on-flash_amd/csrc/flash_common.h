@@ -80,8 +80,16 @@ class PinnedRing {
   size_t bytes = 0;
   int count() const { return (int) slots.size(); }
   int cols() const { return (int) ev_dev.size(); }
-  // devs: the ordinal of every event column (default: one column on the current device)
+  // devs: the ordinal of every event column (default: one column on the current device).  A ring that could not
+  // be built completely is taken down again before the error is returned.
   int init(int n, size_t nbytes, const std::vector<int> *devs = nullptr) {
+    const int rc = build(n, nbytes, devs);
+    if (rc) destroy();
+    return rc;
+  }
+
+ private:
+  int build(int n, size_t nbytes, const std::vector<int> *devs) {
     std::vector<int> want;
     if (devs) want = *devs;
     else {
@@ -116,6 +124,8 @@ class PinnedRing {
     }
     return BOF_OK;
   }
+
+ public:
   void destroy() {
     for (size_t i = 0; i < ev.size(); i++) {
       if (ev_set[i]) (void) hipEventSynchronize(ev[i]);

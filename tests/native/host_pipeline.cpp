@@ -27,6 +27,9 @@ extern "C" size_t mock_hip_bytes_in_use(int dev);
 extern "C" uint64_t mock_hip_pageable_h2d_bytes();
 extern "C" int64_t mock_hip_live_streams();
 extern "C" int64_t mock_hip_live_events();
+extern "C" void mock_hip_fail_malloc_after(long n);
+extern "C" void mock_hip_fail_hostmalloc_after(long n);
+extern "C" long mock_hip_fail_malloc_pending();
 
 #define CHECK(c)                                                                                  \
   do {                                                                                            \
@@ -36,6 +39,8 @@ extern "C" int64_t mock_hip_live_events();
 static std::string g_dir;
 static thread_local std::string t_prefix;      // concurrent callers keep their files apart
 static bool g_truncate_a = false;    // the next gemm_case cuts its A file in half (a reader's request comes back short)
+static thread_local int g_last_rc = 0, g_prev_rc = 0;   // allocation-failure sweep (single-threaded; concurrent cases write their own)
+static bool g_any_error_ok = false;
 static bool g_accept_enomem = false; // stress mode: a drawn budget may legitimately be refused
 static struct { int io_threads = 3, pinned = 3, streams = 0, kmajor = 0, group = 0, chunk_mib = 1; } g_knobs;   // stress mode draws these
 static thread_local std::mt19937_64 g_rng(12345);
@@ -141,6 +146,8 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     rc = bof_flash_gemm(ord, ta, tb, (uint64_t) m, (uint64_t) n, (uint64_t) k, alpha, beta, fa.ptr(), fb.ptr(), fc.ptr(), (uint64_t) lda,
                         (uint64_t) ldb, (uint64_t) ldc, &o);
   if (g_accept_enomem && rc == BOF_ENOMEM) expect_rc = BOF_ENOMEM;
+  g_last_rc = rc;
+  if (g_any_error_ok && rc != BOF_OK) return;      // an injected failure: any error code, C may be partly written
   if (rc != expect_rc) fprintf(stderr, "gemm_case %c%c%c %ldx%ldx%ld path %d devs %zu: rc %d (%s)\n", ord, ta, tb, (long) m, (long) n, (long) k, path, devs.size(), rc, bof_last_error());
   CHECK(rc == expect_rc);
   const std::vector<float> got = fc.read<float>(C.size());
@@ -342,6 +349,8 @@ static void csr_case(int64_t m, int64_t n, int64_t k, char ord_b, float alpha, f
       }
     TmpFile fb("b.bin", B, 0, direct), fc("c.bin", C, 0, direct);
     const int rc = bof_flash_csrmm('N', (uint64_t) m, (uint64_t) n, (uint64_t) k, alpha, beta, fv.ptr(), fi.ptr(), fj.ptr(), ord_b, fb.ptr(), fc.ptr(), &o);
+    g_last_rc = rc;
+    if (g_any_error_ok && rc != BOF_OK) return;
     if (rc) fprintf(stderr, "csrmm %ldx%ldx%ld %c devs %zu: rc %d (%s)\n", (long) m, (long) n, (long) k, ord_b, devs.size(), rc, bof_last_error());
     CHECK(rc == BOF_OK);
     const std::vector<float> got = fc.read<float>(C.size());
@@ -363,6 +372,8 @@ static void csr_case(int64_t m, int64_t n, int64_t k, char ord_b, float alpha, f
         else want[(size_t) a.ja[(size_t) p]] += a.val[(size_t) p] * x[(size_t) i];
       }
     const int rc = bof_flash_csrgemv(trans, (uint64_t) m, (uint64_t) n, fv.ptr(), fi.ptr(), fj.ptr(), x.data(), y.data(), &o);
+    if (rc != BOF_OK) g_last_rc = rc;
+    if (g_any_error_ok && rc != BOF_OK) return;
     if (rc) fprintf(stderr, "csrgemv %c %ldx%ld devs %zu: rc %d (%s)\n", trans, (long) m, (long) n, devs.size(), rc, bof_last_error());
     CHECK(rc == BOF_OK);
     for (size_t i = 0; i < y.size(); i++)
@@ -536,6 +547,60 @@ static void transpose_case(int64_t m, int64_t n, int64_t k, uint64_t budget, con
   for (size_t i = 0; i < got.size(); i++) CHECK(got[i] == (float) want[i]);
 }
 
+// ---- every allocation of a call fails once: an error code, nothing leaked, nothing hung, the next call fine ------
+static void alloc_failure_sweep() {
+  const std::vector<int> devs = {0, 1, 2};
+  for (int what = 0; what < 2; what++)            // 0: hipMalloc, 1: hipHostMalloc
+    for (int path = 1; path <= 2; path++) {
+      int failures = 0;
+      for (long n = 0; n < 400; n++) {
+        CHECK(bof_flash_release() == BOF_OK);        // cold caches: every allocation of the call is really made
+        (what ? mock_hip_fail_hostmalloc_after : mock_hip_fail_malloc_after)(n);
+        g_any_error_ok = true;
+        gemm_case('R', 'N', 'N', 390, 300, 260, 1.f, 1.f, 128, path, 0, devs, false, false, 0);
+        g_any_error_ok = false;
+        const bool fired = mock_hip_fail_malloc_pending() < 0 && !what;
+        (void) fired;
+        mock_hip_fail_malloc_after(-1);
+        mock_hip_fail_hostmalloc_after(-1);
+        if (g_last_rc != BOF_OK) failures++;
+        else if (n > 0 && g_last_rc == BOF_OK && g_prev_rc == BOF_OK) break;     // past the call's last allocation
+        g_prev_rc = g_last_rc;
+      }
+      CHECK(failures > 0);
+      gemm_case('R', 'N', 'N', 390, 300, 260, 1.f, 1.f, 128, path, 0, devs, false, false, 0);        // healthy afterwards
+      CHECK(bof_flash_release() == BOF_OK);
+      for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);
+      printf("allocation-failure sweep: %s, path %d: %d failing positions, all returned an error and left nothing behind\n",
+             what ? "hipHostMalloc" : "hipMalloc", path, failures);
+    }
+  // the CSR pipeline (csrmm, then csrgemv 'N' and 'T' with the device-to-device reduce) the same way
+  for (int what = 0; what < 2; what++) {
+    int failures = 0;
+    g_prev_rc = -1;
+    for (long n = 0; n < 600; n++) {
+      CHECK(bof_flash_release() == BOF_OK);
+      (what ? mock_hip_fail_hostmalloc_after : mock_hip_fail_malloc_after)(n);
+      g_any_error_ok = true;
+      g_last_rc = BOF_OK;
+      csr_case(700, 500, 16, 'C', 1.f, 1.f, devs, false);
+      g_any_error_ok = false;
+      const bool unused = (what ? 0 : mock_hip_fail_malloc_pending()) >= 0;
+      mock_hip_fail_malloc_after(-1);
+      mock_hip_fail_hostmalloc_after(-1);
+      if (g_last_rc != BOF_OK) failures++;
+      else if (g_prev_rc == BOF_OK && (what || unused)) break;
+      g_prev_rc = g_last_rc;
+    }
+    CHECK(failures > 0);
+    csr_case(700, 500, 16, 'C', 1.f, 1.f, devs, false);
+    CHECK(bof_flash_release() == BOF_OK);
+    for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);
+    printf("allocation-failure sweep: %s, CSR calls: %d failing positions, all returned an error and left nothing behind\n",
+           what ? "hipHostMalloc" : "hipMalloc", failures);
+  }
+}
+
 int main(int argc, char **argv) {
   CHECK(argc > 1);
   g_dir = argv[1];
@@ -560,6 +625,11 @@ int main(int argc, char **argv) {
     g_rng.seed((uint64_t) atol(argv[3]) * 7919 + 1);
     const int n = stress(argc > 4 ? atof(argv[4]) : 60);
     printf("host_pipeline ok: %d drawn cases, %llu kernel stand-in launches\n", n, (unsigned long long) mock_hip_kernel_launches());
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "allocfail")) {
+    alloc_failure_sweep();
+    printf("host_pipeline ok: allocation failures\n");
     return 0;
   }
   const bool brief = argc > 2 && !strcmp(argv[2], "brief");      // the ThreadSanitizer run: two device lists

@@ -233,6 +233,18 @@ MockStream *kernel_stream(hipStream_t st, const char *who) {
 
 }  // namespace
 
+// fault injection: the (n + 1)-th hipMalloc / hipHostMalloc from now on fails once with hipErrorOutOfMemory (-1: off)
+std::atomic<long> g_fail_malloc_in{-1}, g_fail_hostmalloc_in{-1};
+extern "C" void mock_hip_fail_malloc_after(long n) { g_fail_malloc_in.store(n); }
+extern "C" void mock_hip_fail_hostmalloc_after(long n) { g_fail_hostmalloc_in.store(n); }
+extern "C" long mock_hip_fail_malloc_pending() { return g_fail_malloc_in.load(); }
+static bool inject(std::atomic<long> &ctr) {
+  long v = ctr.load();
+  while (v >= 0) {
+    if (ctr.compare_exchange_weak(v, v - 1)) return v == 0;
+  }
+  return false;
+}
 extern "C" uint64_t mock_hip_kernel_launches() { return g_kernel_launches.load(); }
 extern "C" uint64_t mock_hip_pageable_h2d_bytes();
 extern "C" int64_t mock_hip_live_streams() { return g_live_streams.load(); }
@@ -281,6 +293,7 @@ hipError_t hipDeviceEnablePeerAccess(int peer, unsigned int) {
 }
 
 hipError_t hipMalloc(void **p, size_t bytes) {
+  if (inject(g_fail_malloc_in)) { *p = nullptr; t_last = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_used.empty()) g_used.assign((size_t) n_devices(), 0);
   if (g_used[(size_t) t_dev] + bytes > capacity()) { *p = nullptr; t_last = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
@@ -312,6 +325,10 @@ hipError_t hipFree(void *p) {
   return hipSuccess;
 }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned int) {
+  // (twice in a row: pinned_alloc retries once after emptying its cache)
+  static std::atomic<bool> again{false};
+  if (inject(g_fail_hostmalloc_in)) { again = true; *p = nullptr; t_last = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
+  if (again.exchange(false)) { *p = nullptr; t_last = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
   void *q = nullptr;
   if (posix_memalign(&q, 4096, std::max<size_t>(bytes, 1))) { t_last = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
   std::lock_guard<std::mutex> lk(g_mu);

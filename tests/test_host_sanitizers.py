@@ -87,7 +87,10 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1", "HOST_PIPELINE_CONCURRENT_ROUNDS": "2"}),
             ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"}),
             # the 8-GPU node's shape: C panels / row blocks over eight devices, eight "ranks" through the staging ring
-            ("asan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8"})]
+            ("asan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8"}),
+            # every hipMalloc / hipHostMalloc of a gemm call (both paths) and of the CSR calls fails once: an error code
+            # each time, nothing leaked (LeakSanitizer), nothing hung, the next call fine
+            ("asan", ["allocfail"], {"MOCK_HIP_ASYNC": "1", "ASAN_OPTIONS": "detect_leaks=1:handle_abort=1:fast_unwind_on_malloc=0"})]
     runs = []
     for i, (k, extra, env_extra) in enumerate(plan):
         d = tmp_path / f"files_{i}"
