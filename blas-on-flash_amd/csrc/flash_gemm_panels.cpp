@@ -434,7 +434,7 @@ void PanelHub::reader_main(int home) {
           if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, w, 0);
       if (e == hipSuccess && !rc)
         e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, slot + delta, rq.bytes, hipMemcpyHostToDevice, R.h2d);
-      if (e == hipSuccess) (void) rring->mark_busy(ps, R.h2d, R.di);
+      if (e == hipSuccess && rring->mark_busy(ps, R.h2d, R.di)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
       cnt.h2d += rq.bytes;
       R.cnt.h2d += rq.bytes;
     }

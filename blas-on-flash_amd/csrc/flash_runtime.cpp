@@ -376,7 +376,7 @@ struct GemmRun {
                                (size_t) row_bytes, tw, (size_t) rq.nr, hipMemcpyHostToDevice, h2d);
         col += t.ncols;
       }
-      if (e == hipSuccess) res->rring.mark_busy(ps, h2d);
+      if (e == hipSuccess && res->rring.mark_busy(ps, h2d)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
       cnt.h2d += bytes;
       res->rring.release(ps);
       bool last = false;

@@ -245,6 +245,13 @@ static bool inject(std::atomic<long> &ctr) {
   }
   return false;
 }
+// ... and the (n + 1)-th call of one API kind (1 hipMemcpyAsync / 2DAsync, 2 hipEventRecord, 3 hipStreamWaitEvent,
+// 4 hipEventCreateWithFlags, 5 hipStreamCreate*, 6 hipMemsetAsync) fails once with hipErrorUnknown
+std::atomic<long> g_fail_api_in{-1};
+std::atomic<int> g_fail_api_kind{0};
+extern "C" void mock_hip_fail_api_after(int kind, long n) { g_fail_api_kind.store(kind); g_fail_api_in.store(n); }
+extern "C" long mock_hip_fail_api_pending() { return g_fail_api_in.load(); }
+static bool inject_api(int kind) { return g_fail_api_kind.load() == kind && inject(g_fail_api_in); }
 extern "C" uint64_t mock_hip_kernel_launches() { return g_kernel_launches.load(); }
 extern "C" uint64_t mock_hip_pageable_h2d_bytes();
 extern "C" int64_t mock_hip_live_streams() { return g_live_streams.load(); }
@@ -355,6 +362,7 @@ hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
 }
 
 static hipError_t new_stream(hipStream_t *s) {
+  if (inject_api(5)) { *s = nullptr; return fail(hipErrorUnknown); }
   MockStream *m = new MockStream();
   m->dev = t_dev;
   m->seed = (unsigned) (uintptr_t) m;
@@ -380,6 +388,7 @@ hipError_t hipStreamDestroy(hipStream_t s) {
 }
 hipError_t hipStreamSynchronize(hipStream_t s) { S(s, "hipStreamSynchronize")->drain(); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
+  if (inject_api(4)) { *e = nullptr; return fail(hipErrorUnknown); }
   MockEvent *m = new MockEvent();
   m->dev = t_dev;
   g_live_events++;
@@ -389,6 +398,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
 }
 hipError_t hipEventDestroy(hipEvent_t e) { E(e, "hipEventDestroy")->alive = false; g_live_events--; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  if (inject_api(2)) return fail(hipErrorUnknown);
   MockEvent *ev = E(e, "hipEventRecord");
   MockStream *st = S(s, "hipEventRecord");
   if (ev->dev != st->dev)
@@ -406,6 +416,7 @@ hipError_t hipEventSynchronize(hipEvent_t e) {
   return hipSuccess;
 }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
+  if (inject_api(3)) return fail(hipErrorUnknown);
   MockStream *st = S(s, "hipStreamWaitEvent");
   MockEvent *ev = E(e, "hipStreamWaitEvent");
   std::shared_ptr<Completion> c;
@@ -453,6 +464,7 @@ static void check_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind k
 }
 uint64_t mock_hip_pageable_h2d_bytes() { return g_pageable_h2d.load() + g_pageable_d2h.load(); }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+  if (inject_api(1)) return fail(hipErrorUnknown);
   MockStream *st = S(s, "hipMemcpyAsync");
   check_copy(dst, src, bytes, kind, st->dev, "hipMemcpyAsync");
   if (kind == hipMemcpyHostToDevice && !known(src)) {     // pageable source: staged before the call returns
@@ -473,6 +485,7 @@ hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
 }
 hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height,
                             hipMemcpyKind kind, hipStream_t s) {
+  if (inject_api(1)) return fail(hipErrorUnknown);
   if (width == 0 || height == 0) return hipSuccess;
   if (dpitch < width || spitch < width) return fail(hipErrorInvalidValue);
   MockStream *st = S(s, "hipMemcpy2DAsync");
@@ -496,6 +509,7 @@ hipError_t hipMemcpyPeerAsync(void *dst, int ddev, const void *src, int sdev, si
   return hipSuccess;
 }
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s) {
+  if (inject_api(6)) return fail(hipErrorUnknown);
   MockStream *st = S(s, "hipMemsetAsync");
   need_device_mem(dst, bytes, st->dev, "hipMemsetAsync");
   st->enqueue([dst, v, bytes] { memset(dst, v, bytes); });

@@ -84,13 +84,17 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     # asan: every device list, operations executed at once; then two lists with asynchronous, jittered streams.
     # tsan: two lists with asynchronous streams -- the work of two streams is ordered only by the events the
     # library put between them, and ThreadSanitizer follows exactly those edges: a stream-ordering race detector.
-    plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1", "HOST_PIPELINE_CONCURRENT_ROUNDS": "2"}),
+    plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1", "HOST_PIPELINE_CONCURRENT_ROUNDS": "1"}),
             ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"}),
             # the 8-GPU node's shape: C panels / row blocks over eight devices, eight "ranks" through the staging ring
             ("asan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8"}),
             # every hipMalloc / hipHostMalloc of a gemm call (both paths) and of the CSR calls fails once: an error code
             # each time, nothing leaked (LeakSanitizer), nothing hung, the next call fine
-            ("asan", ["allocfail"], {"MOCK_HIP_ASYNC": "1", "ASAN_OPTIONS": "detect_leaks=1:handle_abort=1:fast_unwind_on_malloc=0"})]
+            ("asan", ["allocfail"], {"MOCK_HIP_ASYNC": "1", "ASAN_OPTIONS": "detect_leaks=1:handle_abort=1:fast_unwind_on_malloc=0"}),
+            # one call of a HIP API kind fails (copies, event records / waits / creations, stream creations, memsets),
+            # position by position: an error code or -- where the library has a fallback -- a correct result, never a
+            # wrong C behind BOF_OK
+            ("asan", ["apifail"], {"MOCK_HIP_ASYNC": "1", "BOF_STALL_TIMEOUT_S": "30", "HOST_PIPELINE_QUICK": "1"})]
     runs = []
     for i, (k, extra, env_extra) in enumerate(plan):
         d = tmp_path / f"files_{i}"
