@@ -266,6 +266,30 @@ static void resident_case(int dev) {
   CHECK(hipSetDevice(0) == hipSuccess);
 }
 
+// ---- bof_file_to_device / bof_device_to_file: whole arrays through the pinned rings, many workers ---------------
+static void file_device_roundtrip(int dev, bool direct) {
+  CHECK(hipSetDevice(dev) == hipSuccess);
+  hipStream_t st;
+  CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+  const size_t n = (size_t) 40 << 20 >> 2;                      // 40 MiB + an unaligned tail
+  std::vector<float> src(n + 77);
+  for (size_t i = 0; i < src.size(); i++) src[i] = (float) (i % 8191);
+  TmpFile fin("fd_in.bin", src, 0, direct), fout("fd_out.bin", std::vector<float>(src.size(), -1.f), 0, direct);
+  float *d = nullptr;
+  CHECK(hipMalloc((void **) &d, src.size() * 4) == hipSuccess);
+  bof_options o;
+  bof_default_options(&o);
+  o.n_io_threads = 4;
+  o.use_odirect = direct ? 1 : 0;
+  CHECK(bof_file_to_device(fin.ptr(), src.size() * 4, d, &o, st) == BOF_OK);
+  CHECK(hipStreamSynchronize(st) == hipSuccess);
+  CHECK(bof_device_to_file(fout.ptr(), src.size() * 4, d, &o, st) == BOF_OK);
+  CHECK(fout.read<float>(src.size()) == src);
+  CHECK(hipFree(d) == hipSuccess);
+  CHECK(hipStreamDestroy(st) == hipSuccess);
+  CHECK(hipSetDevice(0) == hipSuccess);
+}
+
 // ---- one process per GPU, here one thread per "rank": B read once and passed on through the staging ring ---------
 static void share_case(int world, bool direct) {
   const int64_t blk = 128, m = 128 * 2 * world, n = 300, k = 128 * 5;      // 5 panels of B: panel l read by rank l % world
@@ -433,6 +457,8 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
   transpose_case(1200, 500, 16, 0, {1, 3}, true);
   transpose_case(2500, 800, 0, 1500000, {0}, false);
   transpose_case(2500, 800, 0, 1500000, {3}, true);
+  file_device_roundtrip(2, false);
+  file_device_roundtrip(1, true);
   // level 2 on two of the devices
   resident_case(1);
   resident_case(3);
@@ -449,7 +475,7 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
   }
   CHECK(bof_flash_release() == BOF_OK);
   for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);      // nothing left on any mock device
-  return cases + 15;
+  return cases + 17;
 }
 
 // drawn cases for a number of seconds (MOCK_HIP_ASYNC=1 + ThreadSanitizer: the stream-race hunt)
