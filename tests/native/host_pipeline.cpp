@@ -420,9 +420,9 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
       gemm_case('C', 'T', 'N', 390, 256, 260, 2.f, 1.f, 128, 2, 0, devs, direct, false, 0);
       gemm_case('R', 'T', 'T', 256, 400, 256, 1.f, 1.f, 128, 2, 0, devs, direct, false, 0);
       gemm_case('C', 'N', 'T', 300, 390, 130, 1.f, 0.f, 128, 0, 0, devs, direct, false, 0);
-      // panels of several staging chunks each (2 MiB panels, 1 MiB chunks; B's rows are unaligned: with O_DIRECT the
+      // panels of several staging chunks each (1.15 MiB panels, 1 MiB chunks; B's rows are unaligned: with O_DIRECT the
       // sector-widened reads cut at page-aligned file positions), shared B fanned out chunk by chunk
-      if (devs.size() != 1) gemm_case('R', 'N', 'N', 256, 4096, 200, 1.f, 0.f, 128, 2, 0, devs, direct, false, 0);
+      if (devs.size() >= 3) gemm_case('R', 'N', 'N', 256, 2304, 160, 1.f, 0.f, 128, 2, 0, devs, direct, false, 0);
       // tile cache: forced, and chosen because C's rows have gaps (ldc > stored width)
       gemm_case('R', 'N', 'T', 390, 300, 256, 1.f, 1.f, 128, 1, 0, devs, direct, false, 0);
       gemm_case('C', 'N', 'N', 256, 390, 300, 2.f, 0.f, 128, 0, 8, devs, direct, false, 0);
