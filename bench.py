@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native BLAS-on-flash hot path.
 
-Metric (BASELINE.json): GFLOP/s of the out-of-core GEMM hot path, with the
-roofline fraction of the dominant kernel and the CPU path timed beside it.
+Metric (BASELINE.json): GFLOP/s of the out-of-core GEMM, with the roofline fraction of the dominant
+kernel and the CPU path timed beside it.
 
-Workload at N=1 (BASELINE.json configs[1]): flash _gemm fp32 32768 x 32768 x
-32768, 4096-tile (512 tile tasks in 64 accumulate chains of 8), A/B/C already
-resident in HBM when the timed region starts (12 GiB).  One "step" = one pass of
-the whole tile DAG (bof_gemm_resident): 70.37 TFLOP.
-At N>1 (configs[3] at N=8): the (8192*N) x 65536 x 65536 GEMM row-block sharded,
-rank g owns C rows [8192g, 8192(g+1)): per-GPU work is fixed at 70.37 TFLOP (weak
-scaling), no data-path collective.
+N = 1 (BASELINE.json configs[1]): flash _gemm fp32 32768 x 32768 x 32768, 4096-tile, A / B / C
+SSD-resident.  One "step" = ONE bof_flash_gemm call on three 4 GiB files through O_DIRECT
+descriptors with the page cache dropped: 8 GiB read, 512 tile tasks (64 accumulate chains of 8),
+4 GiB of C written back -- wall clock around the call, write-back included, the way the reference's
+driver times it (drivers/gemm.cpp:57-62).  70.37 TFLOP per step.
+N > 1 (configs[3] at N = 8): the (8192 N) x 65536 x 65536 product from ONE set of files, C rows
+sharded by rank, B read from storage once per node, no data-path collective; per-GPU flops fixed
+(weak scaling).
 
-One process per GPU; launched for N>1 as
+roofline: the dominant kernel's duration is measured live with HIP events around every tile launch
+on the stream it is launched on (bof_options.kernel_timing), inside the timed steps.
+
+One process per GPU; launched for N > 1 as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line (< 4 KiB, asserted); everything else goes to bench_detail.json.
 """
 import argparse
 import ctypes
@@ -552,10 +556,13 @@ def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
 
 
 def roofline_e2e(leg, ceil, flops, kernel_s, mode):
-    """Lower bound on the wall time of one out-of-core call from the ceilings measured in THIS run, and the
+    """Lower bound on the wall time of one out-of-core call from the ceilings PROBED in this run, and the
     fraction of it the call achieved: t_bound = max over the stages that all run concurrently in the
     pipeline -- kernel time at the measured kernel rate, bytes over PCIe each way, bytes read / written at
-    the disk's (odirect) or the page cache's (buffered) rate; frac = t_bound / seconds."""
+    the disk's (odirect) or the page cache's (buffered) rate; frac = t_bound / seconds.  The probe is
+    never adjusted to what the call achieved: the scratch disk's rate moves from minute to minute on the
+    pool's boxes, so a call can beat a probe taken a minute earlier (frac > 1 then says exactly that);
+    `run_disk_GBps` is what the call itself moved."""
     st = leg["stats"]
     terms = {"mfma" if flops > 1e13 else "hbm": kernel_s or 0.0}
     if ceil.get("pcie_h2d_GBps"):
@@ -563,30 +570,19 @@ def roofline_e2e(leg, ceil, flops, kernel_s, mode):
         terms["pcie_d2h"] = st["bytes_d2h"] / (ceil["pcie_d2h_GBps"] * 1e9)
         if ceil.get("pcie_each_way_when_both_GBps"):     # both directions at once share the link's controllers
             terms["pcie_both_ways"] = (st["bytes_h2d"] + st["bytes_d2h"]) / (2e9 * ceil["pcie_each_way_when_both_GBps"])
-    raised = False
     if mode == "odirect" and ceil.get("disk_read_GBps"):
         terms["disk_read"] = st["bytes_read"] / (ceil["disk_read_GBps"] * 1e9)
         terms["disk_write"] = st["bytes_written"] / (ceil["disk_write_GBps"] * 1e9)
-        # reads and writes share the device: all bytes over the best TOTAL rate it showed (one direction
-        # alone, or both at once) bound the call too.  The device's rate moves from minute to minute on
-        # these boxes; if this call moved bytes faster than the ceilings pass did, the ceiling is
-        # raised to what the call achieved (and flagged), so that frac never exceeds 1.
         total = max(ceil["disk_read_GBps"], ceil["disk_write_GBps"],
                     ceil.get("disk_read_GBps_while_writing", 0) + ceil.get("disk_write_GBps_while_reading", 0))
-        got = (st["bytes_read"] + st["bytes_written"]) / leg["seconds"] / 1e9
-        if got > total:
-            total, raised = got, True
         terms["disk_total"] = (st["bytes_read"] + st["bytes_written"]) / (total * 1e9)
-        for q, rate in (("disk_read", st["bytes_read"] / leg["seconds"] / 1e9), ("disk_write", st["bytes_written"] / leg["seconds"] / 1e9)):
-            if terms[q] > leg["seconds"]:
-                terms[q], raised = leg["seconds"], True
     elif mode == "buffered" and ceil.get("page_cache_read_GBps"):
         terms["page_cache_read"] = st["bytes_read"] / (ceil["page_cache_read_GBps"] * 1e9)
     bound = max(terms, key=terms.get)
     t_bound = terms[bound]
     return {"seconds": leg["seconds"], "gflops": leg["gflops"], "bound": bound, "t_bound_s": round(t_bound, 4),
-            "frac": round(min(t_bound / leg["seconds"], 1.0), 3), "terms_s": {k: round(v, 4) for k, v in terms.items()},
-            "disk_ceiling_raised_to_achieved": raised}
+            "frac": round(t_bound / leg["seconds"], 3), "terms_s": {k: round(v, 4) for k, v in terms.items()},
+            "run_disk_GBps": round((st["bytes_read"] + st["bytes_written"]) / leg["seconds"] / 1e9, 2)}
 
 
 def _leg_summary(runs, flops, kernel_s, compulsory_rd, compulsory_wr, units):
@@ -811,178 +807,6 @@ def e2e_csrmm(bofhip, torch, dev, st, workdir, kernel_s, io_threads, reps, **ext
     return out
 
 
-def e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local, n, k, kernel_s):
-    """N > 1: BASELINE configs[3] as files.  One A, B and C file shared by the ranks (written by them
-    in parallel, slab by slab); rank g then runs the level-3 pipeline on its C rows
-    [g*m_local, (g+1)*m_local) -- bof_flash_gemm with the A and C pointers advanced to its slab, B
-    read by every rank itself, no collective -- between two barriers; max over ranks.  Every rank
-    checks every element of its C slab against the closed form.  Local work runs inside `phase`,
-    which ends in a collective every rank reaches whatever happened locally, so one failing rank
-    ends the leg on all of them instead of leaving the others in a barrier."""
-    import shutil
-    import tempfile
-    import numpy as np
-    import torch.distributed as dist
-    out = {"what": f"{m_local * world}x{k}x{n} fp32 flash _gemm on files, row-block sharded over {world} ranks "
-                   f"(each: {m_local} C rows; B read from storage once per node: panel l by rank l % {world}, passed on "
-                   f"through node-shared memory; no data-path collective), wall clock between barriers"}
-
-    def phase(fn):
-        """run fn locally; (all ranks ok?, max seconds over ranks, local error text)"""
-        err = ""
-        t0 = time.perf_counter()
-        try:
-            fn()
-        except Exception as e:
-            err = f"{type(e).__name__}: {str(e)[:200]}"
-        v = torch.tensor([0.0 if err else 1.0, -(time.perf_counter() - t0)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MIN)
-        return bool(v[0].item() == 1.0), -float(v[1].item()), err
-
-    base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
-    m = m_local * world
-    box = [None]
-    if rank == 0:
-        try:
-            d = tempfile.mkdtemp(prefix="bof_bench_sharded_", dir=base)
-            need = 4 * (m * k + k * n + m * n) + (2 << 30)
-            if shutil.disk_usage(d).free > need:
-                box[0] = d
-                for name, sz in (("A.bin", m * k * 4), ("B.bin", k * n * 4), ("C.bin", m * n * 4)):
-                    with open(os.path.join(d, name), "wb") as f:
-                        f.truncate(sz)
-            else:
-                box[0] = "!not enough free disk"
-                shutil.rmtree(d, ignore_errors=True)
-        except OSError as e:
-            box[0] = f"!{e}"
-    dist.broadcast_object_list(box, src=0)
-    if box[0].startswith("!"):
-        out["skipped"] = box[0][1:]
-        return out
-    workdir = box[0]
-    pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
-    r0 = rank * m_local
-    kb = (k + world - 1) // world
-    k0, k1 = min(k, rank * kb), min(k, (rank + 1) * kb)
-    state = {}
-
-    def put(path, off_elems, count, first, mode):
-        if count <= 0:
-            return
-        t = state["t"]
-        bofhip.gen_dense(t.data_ptr(), first, count, mode, 0, st)
-        fd, d = _open(path, True)
-        try:
-            bofhip.device_to_file(bofhip.FPtr(fd, off_elems * 4), count * 4, t.data_ptr(),
-                                  bofhip.default_options(n_io_threads=args.io_threads, use_odirect=1 if d else 0), st)
-            os.fsync(fd)
-        finally:
-            bofhip.lib().bof_file_forget(fd)
-            os.close(fd)
-
-    def create():
-        state["t"] = torch.empty(max(m_local * max(k, n), (k1 - k0) * n), dtype=torch.float32, device=dev)
-        put(pa, r0 * k, m_local * k, r0 * k, "s")          # dense_create mode s, this rank's rows
-        put(pb, k0 * n, (k1 - k0) * n, k0 * n, "s")        # 1/world of B
-        put(pc, r0 * n, m_local * n, 0, "z")
-        kk = np.arange(k, dtype=np.int64)
-        a10 = (np.arange(10, dtype=np.int64)[:, None] * k + kk[None, :]) % 10
-        b10 = (kk[:, None] * n + np.arange(10, dtype=np.int64)[None, :]) % 10
-        pat = torch.from_numpy((a10 @ b10).astype(np.float32)).to(dev)
-        state["rowpat"] = pat[:, torch.arange(n, device=dev) % 10]
-
-    good, secs, err = phase(create)
-    out["create_files_s"] = round(secs, 1)
-    flops = 2.0 * m * n * k
-    for mode in ("odirect", "buffered"):
-        if not good:
-            break
-        fds = []
-
-        def opening():
-            for p in (pa, pb, pc):
-                fd, d = _open(p, mode == "odirect")
-                fds.append(fd)
-                if mode == "odirect" and not d:
-                    raise OSError("file system refuses O_DIRECT")
-        can, _, e1 = phase(opening)
-        if not can:
-            out[mode] = {"skipped": e1 or "another rank could not open the files"}
-            for fd in fds:
-                os.close(fd)
-            continue
-        opts = bofhip.default_options(gemm_blk=args.blk, n_io_threads=args.io_threads,
-                                      use_odirect=1 if mode == "odirect" else 0)
-        last = {}
-
-        def run():
-            # every rank runs the level-3 pipeline on its slab; B's panels are read from the file once per
-            # node (panel l by rank l % world) and passed on through the node-shared staging ring
-            import bof_dist
-            last.update(bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], 0, 0, 0, opts,
-                                                        b_once=True))
-        times = []
-        for rep in range(2):
-            if mode == "odirect" and rank == 0:
-                _drop_cache((pa, pb, pc))
-            dist.barrier()
-            good, secs, err = phase(run)
-            times.append(secs)
-            if not good:
-                break
-        stats = bofhip.flash_last_stats()
-        agg = torch.tensor([float(last.get(q, 0)) for q in ("bytes_read", "bytes_written", "bytes_peer")],
-                           dtype=torch.float64, device=red_dev)
-        dist.all_reduce(agg)
-        for fd in fds:
-            bofhip.lib().bof_file_forget(fd)
-            os.close(fd)
-        if not good:
-            break
-
-        def verify():
-            t = state["t"]
-            fd, _ = _open(pc, False)
-            try:
-                bofhip.file_to_device(bofhip.FPtr(fd, r0 * n * 4), m_local * n * 4, t.data_ptr(),
-                                      bofhip.default_options(use_odirect=0), st)
-            finally:
-                os.close(fd)
-            C = t[:m_local * n].view(m_local, n)
-            rows = max(1, (1 << 27) // n)
-            for q0 in range(0, m_local, rows):
-                q1 = min(m_local, q0 + rows)
-                gi = torch.arange(r0 + q0, r0 + q1, device=dev)
-                if not torch.equal(C[q0:q1], state["rowpat"][gi % 10]):
-                    raise AssertionError(f"C rows [{r0 + q0}, {r0 + q1}) differ from the closed form")
-        match, _, verr = phase(verify)
-        best = min(times) if mode == "odirect" else times[-1]
-        out[mode] = {"seconds_all": [round(x, 3) for x in times], "seconds": round(best, 3),
-                     "gflops": round(flops / best / 1e9, 1),
-                     "aggregate_read_GBps": round(float(agg[0]) / best / 1e9, 2),
-                     "aggregate_write_GBps": round(float(agg[1]) / best / 1e9, 2),
-                     # bytes read from the files by ALL ranks over the compulsory A + B (C is beta = 0): 1.0 = B once per node
-                     "read_amplification": round(float(agg[0]) / (4.0 * (m * k + k * n)), 3),
-                     "write_amplification": round(float(agg[1]) / (4.0 * m * n), 3),
-                     "B_bytes_taken_from_peers": int(agg[2]),
-                     "rank0_read_GBps": round(stats["bytes_read"] / best / 1e9, 2),
-                     "rank0_write_GBps": round(stats["bytes_written"] / best / 1e9, 2),
-                     "rank0_requests": stats["read_ops"] + stats["write_ops"],
-                     "overlap_kernel_over_e2e": round(kernel_s / best, 3),
-                     "every_C_slab_matches_closed_form": match}
-        if verr:
-            out[mode]["rank0_verify_error"] = verr
-    if not good:
-        out["error"] = err or "another rank failed"
-    state.clear()
-    dist.barrier()
-    if rank == 0:
-        shutil.rmtree(workdir, ignore_errors=True)
-    torch.cuda.empty_cache()
-    bofhip.lib().bof_flash_release()
-    return out
-
 CFG5_Y_SHA256 = {"N": "1c0a44dbb962be0a2d7027f5f298ff94ab5b2ee66c8fe467c0408b286b1881e4",
                  "T": "486766062199bef476611a2675893df3266338c91bfc30db4640ef5dbc2cbf40"}   # SURVEY App. A-3
 
@@ -1057,7 +881,8 @@ def e2e_csrgemv(bofhip, torch, dev, st, workdir, kernel_ms, io_threads, reps, mo
 
 
 
-def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm64_kernel_s=None, gemv_kernel_ms=None):
+def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm64_kernel_s=None, gemv_kernel_ms=None,
+              ceilings=None):
     import shutil
     import tempfile
     base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
@@ -1075,13 +900,11 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
                                 "loadavg_1min": round(os.getloadavg()[0], 1)}
         n = args.e2e_size
         bofhip.lib().bof_flash_release()
-        try:
-            out["ceilings"] = io_ceilings(bofhip, torch, dev, st, workdir, args.io_threads)
-        except Exception as e:
-            out["ceilings"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        out["ceilings"] = ceilings
         if free > 3 * n * n * 4 + (2 << 30):
+            # (the O_DIRECT form of this configuration is the headline itself)
             out["gemm"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s, args.io_threads,
-                                   args.e2e_reps)
+                                   args.e2e_reps, modes=("buffered",))
         else:
             out["gemm"] = {"skipped": "not enough free disk for three matrix files"}
         bofhip.lib().bof_flash_release()
@@ -1091,18 +914,18 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
             free = shutil.disk_usage(workdir).free
             if free > 3 * 65536 * 65536 * 4 + (4 << 30):
                 out["gemm_65536"] = e2e_gemm(bofhip, torch, dev, st, workdir, 65536, args.blk, gemm64_kernel_s,
-                                             args.io_threads, 1)
+                                             args.io_threads, 1, modes=("odirect",))
             else:
                 out["gemm_65536"] = {"skipped": f"needs 48 GiB of scratch disk, {free / 2**30:.0f} GiB free"}
             bofhip.lib().bof_flash_release()
         # the paper's unaligned case (Fig. 5 right: 31000-edge matrices; rows of 124000 bytes, a file size that is
         # no multiple of a sector): O_DIRECT kept through sector-widened reads / page-split writes
-        if args.e2e_size == 32768 and shutil.disk_usage(workdir).free > 3 * 31000 * 31000 * 4 + (2 << 30):
+        if args.more_legs and shutil.disk_usage(workdir).free > 3 * 31000 * 31000 * 4 + (2 << 30):
             out["gemm_31000"] = e2e_gemm(bofhip, torch, dev, st, workdir, 31000, args.blk, None, args.io_threads, 2)
             bofhip.lib().bof_flash_release()
         # the tile cache (what takes the call when the row-panel plan does not fit the budget or C's rows have
         # gaps), on cfg2: forced (gemm_path = 1), and chosen by a budget that cannot hold B
-        if args.e2e_size == 32768 and shutil.disk_usage(workdir).free > 3 * n * n * 4 + (2 << 30):
+        if args.more_legs and shutil.disk_usage(workdir).free > 3 * n * n * 4 + (2 << 30):
             out["gemm_tile_cache"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s, args.io_threads,
                                               2, modes=("odirect",), gemm_path=1)
             bofhip.lib().bof_flash_release()
@@ -1112,7 +935,7 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
         # the in-process device list (what an unchanged reference driver gets on a multi-GPU node): device 0
         # listed twice, i.e. one GPU playing two -- the point of the leg is the byte counters (B read once,
         # copied twice) and the whole-C check, not the time
-        if args.e2e_size == 32768 and shutil.disk_usage(workdir).free > 3 * n * n * 4 + (2 << 30):
+        if args.more_legs and shutil.disk_usage(workdir).free > 3 * n * n * 4 + (2 << 30):
             out["gemm_two_devices_in_process"] = e2e_gemm(bofhip, torch, dev, st, workdir, n, args.blk, gemm_kernel_s,
                                                           args.io_threads, 1, modes=("odirect",), devices=[0, 0])
             bofhip.lib().bof_flash_release()
@@ -1154,28 +977,608 @@ def e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csrmm_kernel_s, gemm6
     return out
 
 
+# =====================================================================================
+# The line the driver parses.  `value` = BASELINE configs[1] itself: wall clock around
+# bof_flash_gemm on three SSD-resident files (O_DIRECT descriptors, page cache dropped,
+# write-back of C included) -- what the reference's driver times (drivers/gemm.cpp:57-62).
+# Everything that is not part of the contract goes to bench_detail.json.
+# =====================================================================================
+LINE_CAP = 4096
+
+
+def emit(line, detail):
+    """Writes bench_detail.json (everything) and prints the ONE compact line (< 4 KiB, checked)."""
+    detail = dict(detail, line=line)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(detail, f, indent=1, default=str)
+            except OSError:
+                pass
+    s = json.dumps(line, separators=(",", ":"))
+    for victim in ("extras", "e2e"):          # never reached with the keys below; the cap is a contract
+        if len(s) >= LINE_CAP and victim in line:
+            line = {k: v for k, v in line.items() if k != victim}
+            s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_CAP, f"bench line is {len(s)} bytes"
+    assert json.loads(s)["metric"] == line["metric"]
+    print(s, flush=True)
+
+
+def _closed_form_rows(torch, dev, n, k, ncols):
+    """dense_create mode s operands: C[i, j] depends on (i mod 10, j mod 10) only (SURVEY App. A-3);
+    returns the 10 x ncols pattern (exact: every partial sum < 2^24)."""
+    import numpy as np
+    kk = np.arange(k, dtype=np.int64)
+    a10 = (np.arange(10, dtype=np.int64)[:, None] * k + kk[None, :]) % 10
+    b10 = (kk[:, None] * ncols + np.arange(10, dtype=np.int64)[None, :]) % 10
+    pat = torch.from_numpy((a10 @ b10).astype(np.float32)).to(dev)
+    return pat[:, torch.arange(ncols, device=dev) % 10]
+
+
+def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, steps, warmup, panel_streams):
+    """BASELINE configs[1]: flash _gemm fp32 n^3, blk-tile, A / B / C SSD-resident.  One step = one
+    bof_flash_gemm call on the three files: reads A and B (8 GiB), runs the 512 tile tasks, writes C
+    (4 GiB) back; beta = 0, so every step recomputes and rewrites the whole of C.  Returns the timed
+    region's wall clock, the per-step counters (bytes, tasks, event-timed kernel seconds) and the
+    whole-file verification before and after."""
+    nbytes = n * n * 4
+    pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
+    wopts = bofhip.default_options(n_io_threads=io_threads)
+    t0 = time.perf_counter()
+    t = torch.empty(n * n, dtype=torch.float32, device=dev)
+    bofhip.gen_dense(t.data_ptr(), 0, n * n, "s", 0, st)                  # dense_create mode s (A == B)
+    for path in (pa, pb):
+        _write_device_tensor(bofhip, t, path, True, wopts, st)
+    t.zero_()
+    _write_device_tensor(bofhip, t, pc, True, wopts, st)                    # dense_create mode z
+    create_s = time.perf_counter() - t0
+    rowpat = _closed_form_rows(torch, dev, n, n, n)
+    idx = torch.arange(n, device=dev)
+
+    def verify():
+        fd, _ = _open(pc, False)
+        try:
+            bofhip.file_to_device(bofhip.FPtr(fd, 0), nbytes, t.data_ptr(), bofhip.default_options(use_odirect=0), st)
+        finally:
+            os.close(fd)
+        C = t.view(n, n)
+        rows = max(1, (1 << 27) // n)
+        for r0 in range(0, n, rows):
+            r1 = min(n, r0 + rows)
+            if not torch.equal(C[r0:r1], rowpat[idx[r0:r1] % 10]):
+                return False
+        return True
+
+    def reset_c():
+        fd, d = _open(pc, True)
+        try:
+            t.zero_()
+            o = bofhip.default_options(n_io_threads=io_threads, use_odirect=1 if d else 0)
+            bofhip.device_to_file(bofhip.FPtr(fd, 0), nbytes, t.data_ptr(), o, st)
+        finally:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+
+    fds, direct = [], True
+    for p in (pa, pb, pc):
+        fd, d = _open(p, True)
+        fds.append(fd)
+        direct = direct and d
+    opts = bofhip.default_options(gemm_blk=blk, n_io_threads=io_threads, use_odirect=1 if direct else 0,
+                                  kernel_timing=1, panel_streams=panel_streams)
+
+    def step():
+        bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                          bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
+        return bofhip.flash_last_stats()
+    try:
+        warm = []
+        for _ in range(warmup):
+            _drop_cache((pa, pb, pc))
+            warm.append(step())
+        ok_warm = verify() if warmup else None
+        reset_c()                                   # the timed steps must produce C, not find it
+        _drop_cache((pa, pb, pc))
+        torch.cuda.synchronize()
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            per.append(step())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = verify()
+    finally:
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+        for p in (pa, pb, pc):
+            if os.path.exists(p):
+                os.remove(p)
+        del t
+        torch.cuda.empty_cache()
+    return {"dt": dt, "per_step": per, "warmup_steps": warm, "verified": bool(ok) and ok_warm is not False,
+            "verified_after_warmup": ok_warm, "odirect": direct, "create_files_s": round(create_s, 1),
+            "file_system": _fs_of(workdir)}
+
+
+def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
+    """Lower bound on one step's wall time from the ceilings PROBED in this run (never adjusted to
+    what the step achieved): the stages run concurrently, so t_bound = max over them."""
+    st = per_step
+    terms = {"mfma": kernel_s_per_step}
+    if ceil.get("pcie_h2d_GBps"):
+        terms["pcie_h2d"] = st["bytes_h2d"] / (ceil["pcie_h2d_GBps"] * 1e9)
+        terms["pcie_d2h"] = st["bytes_d2h"] / (ceil["pcie_d2h_GBps"] * 1e9)
+    if ceil.get("disk_read_GBps"):
+        terms["disk_read"] = st["bytes_read"] / (ceil["disk_read_GBps"] * 1e9)
+        terms["disk_write"] = st["bytes_written"] / (ceil["disk_write_GBps"] * 1e9)
+        total = max(ceil["disk_read_GBps"], ceil["disk_write_GBps"],
+                    ceil.get("disk_read_GBps_while_writing", 0) + ceil.get("disk_write_GBps_while_reading", 0))
+        terms["disk_total"] = (st["bytes_read"] + st["bytes_written"]) / (total * 1e9)
+    bound = max(terms, key=terms.get)
+    return bound, terms[bound], {k: round(v, 4) for k, v in terms.items()}
+
+
+def _mean(xs):
+    xs = list(xs)
+    return sum(xs) / max(len(xs), 1)
+
+
+def run_single(args, bofhip, torch, dev, st):
+    """N = 1: the headline on configs[1], then (unless --no-extras) the other configurations as flat
+    scalars; returns (line, detail)."""
+    import shutil
+    import tempfile
+    n, blk = args.size or 32768, args.blk
+    detail = {}
+    base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    workdir = tempfile.mkdtemp(prefix="bof_bench_", dir=base)
+    try:
+        free = shutil.disk_usage(workdir).free
+        if free < 3 * n * n * 4 + (6 << 30):
+            raise SystemExit(f"bench.py: {free / 2**30:.0f} GiB free under {base}; configs[1] needs three "
+                             f"{n * n * 4 / 2**30:.0f} GiB files (set BOF_BENCH_DIR)")
+        try:
+            ceil = io_ceilings(bofhip, torch, dev, st, workdir, args.io_threads)
+        except Exception as e:
+            ceil = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        detail["ceilings"] = ceil
+        bofhip.lib().bof_flash_release()
+        h = headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, args.io_threads, args.steps, args.warmup,
+                                args.streams)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    detail["headline"] = h
+    per = h["per_step"]
+    flops_step = 2.0 * n ** 3
+    dt = h["dt"]
+    value = flops_step * args.steps / dt / 1e9
+    launches = sum(p["kernel_launches"] for p in per)
+    ksec = sum(p["kernel_seconds"] for p in per)
+    avg_launch_ms = ksec / max(launches, 1) * 1e3
+    flops_per_launch = flops_step * args.steps / max(launches, 1)
+    achieved = flops_per_launch / max(avg_launch_ms, 1e-9) / 1e9          # TFLOP/s
+    traffic, traffic_src = pmc_traffic()
+    nk = max(n // blk, 1)
+    mean_step = {q: _mean(p[q] for p in per) for q in ("bytes_read", "bytes_written", "bytes_h2d", "bytes_d2h")}
+    bound, t_bound, terms = e2e_bound(mean_step, ceil if "error" not in ceil else {}, args.steps, ksec / args.steps)
+    secs = sorted(p["seconds"] for p in per)
+    line = {
+        "metric": "GFLOP/s, out-of-core GEMM (flash _gemm on SSD-resident A/B/C, wall clock around the call)",
+        "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic: dense_create mode s (i%10) A and B, zero C, written to the scratch disk; whole C file "
+                "checked against the closed form",
+        "config": {"workload": f"flash _gemm fp32 {n}x{n}x{n}, {blk}-tile, SSD-resident A/B/C, 1xMI355X",
+                   "what_is_timed": "bof_flash_gemm on O_DIRECT files, page cache dropped, C write-back included "
+                                    "(reference: drivers/gemm.cpp:57-62)",
+                   "odirect": h["odirect"], "file_system": h["file_system"], "io_threads": args.io_threads,
+                   "tile_tasks_per_step": int(_mean(p["tasks"] for p in per)),
+                   "GiB_read_per_step": round(mean_step["bytes_read"] / 2**30, 3),
+                   "GiB_written_per_step": round(mean_step["bytes_written"] / 2**30, 3),
+                   "step_s_min_med_max": [round(secs[0], 3), round(secs[len(secs) // 2], 3), round(secs[-1], 3)],
+                   "C_verified": h["verified"], "parallelism": "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel<NoEpi>",
+                     "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(avg_launch_ms, 4),
+                     "launches": launches, "timed_with": "HIP events around every tile launch on its compute stream, "
+                                                         "inside the timed steps (bof_options.kernel_timing)",
+                     "flops_per_launch": flops_per_launch,
+                     "algorithmic_bytes_per_launch": int(4 * blk * blk * (3 + (nk - 1) / nk)),
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel_s_per_step": round(ksec / args.steps, 4),
+                     "e2e_bound": bound, "e2e_t_bound_s": round(t_bound, 4),
+                     "e2e_frac": round(t_bound / (dt / args.steps), 3), "e2e_terms_s": terms,
+                     "e2e_probe": {k: ceil.get(k) for k in ("disk_read_GBps", "disk_write_GBps",
+                                                            "disk_read_GBps_while_writing",
+                                                            "disk_write_GBps_while_reading", "pcie_h2d_GBps",
+                                                            "pcie_d2h_GBps") if k in ceil}},
+    }
+    if not args.no_cpu:
+        cb = cpu_baseline(with_csr=not args.no_extras and not args.size)
+        detail["cpu_baseline"] = cb
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit", "GFLOP/s"), "cores": cb.get("cores"),
+                                "kind": cb.get("kind", "port"),
+                                "sample": "in-memory MKL, sampled (not the reference's flash path on files): "
+                                          + str(cb.get("sample", ""))[:160]}
+        for q in ("csrmm", "csrgemv_N"):
+            if isinstance(cb.get(q), dict):
+                line["cpu_baseline"][q + "_gflops"] = cb[q].get("value")
+                line["cpu_baseline"][q + "_cores"] = cb[q].get("cores")
+        if cb.get("error"):
+            line["cpu_baseline"]["error"] = str(cb["error"])[:120]
+    if not args.no_extras and not args.size:
+        line["extras"] = extras_single(args, bofhip, torch, dev, st, detail, ksec / args.steps)
+    return line, detail
+
+
+def extras_single(args, bofhip, torch, dev, st, detail, gemm_kernel_s):
+    """The other configurations, each a handful of flat scalars in the line (full records in
+    bench_detail.json): the HBM-resident tile DAG, 65536^3 from files, cfg3 csrmm and cfg5-size
+    csrgemv resident + from files, kmeans."""
+    ex = {}
+    # -- HBM-resident tile DAG of configs[1] (the round 1-3 headline) -------------------------------
+    try:
+        r = resident_gemm_line(bofhip, torch, dev, st, 32768, 32768, 32768, 0, args.blk, 1, 3,
+                               "cfg2 tile DAG, A/B/C resident in HBM (I/O skipped)")
+        detail["resident_cfg2"] = r
+        ex["resident_cfg2_gflops"] = r["gflops"]
+        ex["resident_cfg2_frac_mfma"] = r["frac_of_mfma_peak"]
+        ex["resident_rel_err_vs_f64"] = float(f"{r['first_tile_row_rel_err_vs_float64']:.2e}")
+    except Exception as e:
+        ex["resident_cfg2_error"] = str(e)[:80]
+    sec = {}
+    if not args.no_csr:
+        try:
+            sec = csr_secondary(bofhip, torch, dev, st)
+        except Exception as e:
+            sec = {"error": str(e)[:200]}
+        try:
+            sec["kmeans"] = kmeans_secondary(bofhip, torch, dev, st, args.streams or 1)
+        except Exception as e:
+            sec["kmeans_error"] = str(e)[:200]
+        detail["secondary"] = sec
+        if isinstance(sec.get("csrmm"), dict):
+            r3 = sec["csrmm"]["roofline"]
+            ex["csrmm_kernel_ms"] = sec["csrmm"]["ms"]
+            ex["csrmm_frac_hbm"] = r3["frac"]
+            ex["csrmm_gather_frac_of_8.6TBps"] = r3["gather_frac_of_ceiling"]
+        for tr in "NT":
+            gv = sec.get("csrgemv_" + tr)
+            if isinstance(gv, dict):
+                ex[f"csrgemv_{tr}_kernel_ms"] = gv["ms"]
+                ex[f"csrgemv_{tr}_frac_hbm"] = gv["roofline"]["frac"]
+        if isinstance(sec.get("kmeans"), dict):
+            ex["kmeans_frac_mfma"] = sec["kmeans"]["roofline"]["frac"]
+    if not args.no_e2e:
+        csr_ms = (sec.get("csrmm") or {}).get("ms") if isinstance(sec.get("csrmm"), dict) else None
+        gv_ms = {tr: (sec.get("csrgemv_" + tr) or {}).get("ms") for tr in "NT"} if sec else {}
+        e2e = e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csr_ms * 1e-3 if csr_ms else None,
+                        8.0 * gemm_kernel_s, gv_ms if gv_ms and all(gv_ms.values()) else None,
+                        ceilings=detail.get("ceilings") or {})
+        detail["e2e"] = e2e
+
+        def leg(name, mode, sub=None):
+            d = e2e.get(name)
+            d = d.get(mode) if isinstance(d, dict) else None
+            if sub and isinstance(d, dict):
+                d = d.get(sub)
+            return d if isinstance(d, dict) and "seconds" in d else None
+        for name, mode, tag, sub in (("gemm", "buffered", "cfg2_pagecache", None),
+                                     ("gemm_65536", "odirect", "gemm64k_odirect", None),
+                                     ("csrmm", "odirect", "cfg3_odirect", None),
+                                     ("csrmm", "buffered", "cfg3_pagecache", None),
+                                     ("csrgemv", "odirect", "csrgemvN_odirect", "N"),
+                                     ("csrgemv", "buffered", "csrgemvN_pagecache", "N"),
+                                     ("csrgemv", "buffered", "csrgemvT_pagecache", "T")):
+            d = leg(name, mode, sub)
+            if d:
+                ex[tag + "_s"] = d["seconds"]
+                if "roofline" in d:
+                    ex[tag + "_frac"] = d["roofline"]["frac"]
+                    ex[tag + "_bound"] = d["roofline"]["bound"]
+        g64 = leg("gemm_65536", "odirect")
+        if g64:
+            ex["gemm64k_odirect_gflops"] = g64["gflops"]
+        ok = []
+        for name in ("gemm", "gemm_65536"):
+            for mode in ("odirect", "buffered"):
+                d = leg(name, mode)
+                if d:
+                    ok.append(bool(d.get("whole_C_file_matches_closed_form")))
+        c3 = e2e.get("csrmm") if isinstance(e2e.get("csrmm"), dict) else {}
+        if "sha256_matches_reference_drivers" in c3:
+            ok.append(bool(c3["sha256_matches_reference_drivers"]))
+        for mode in ("odirect", "buffered"):
+            for tr in "NT":
+                d = leg("csrgemv", mode, tr)
+                if d:
+                    ok.append(bool(d.get("sha256_y_matches_reference")))
+        ex["all_outputs_verified"] = bool(ok) and all(ok)
+        if "error" in e2e:
+            ex["e2e_error"] = str(e2e["error"])[:100]
+    return ex
+
+
+def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
+    """N > 1 (BASELINE configs[3] at N = 8): (8192 N) x 65536 x 65536 from ONE set of files on the node's
+    scratch disk, C rows sharded by rank, B read from storage once per node (panel l by rank l % N,
+    passed on through the node-shared staging ring), no data-path collective.  One step = every rank's
+    bof_flash_gemm on its slab between two barriers; value = the flops of all ranks / max-over-ranks time."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch.distributed as dist
+    import bof_dist
+    k = n = args.size or 65536
+    m_local = (args.size or 65536) // 8
+    m = m_local * world
+    blk = args.blk
+    detail = {}
+
+    def phase(fn):
+        err = ""
+        t0 = time.perf_counter()
+        try:
+            fn()
+        except Exception as e:
+            err = f"{type(e).__name__}: {str(e)[:200]}"
+        me = time.perf_counter() - t0
+        v = torch.tensor([0.0 if err else 1.0, -me, me], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(v[0].item() == 1.0), -float(v[1].item()), float(v[2].item()), err
+
+    base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    box = [None]
+    if rank == 0:
+        try:
+            d = tempfile.mkdtemp(prefix="bof_bench_sharded_", dir=base)
+            need = 4 * (m * k + k * n + m * n) + (2 << 30)
+            if shutil.disk_usage(d).free > need:
+                box[0] = d
+                for name, sz in (("A.bin", m * k * 4), ("B.bin", k * n * 4), ("C.bin", m * n * 4)):
+                    with open(os.path.join(d, name), "wb") as f:
+                        f.truncate(sz)
+            else:
+                box[0] = f"!{shutil.disk_usage(d).free / 2**30:.0f} GiB free under {base}, {need / 2**30:.0f} needed"
+                shutil.rmtree(d, ignore_errors=True)
+        except OSError as e:
+            box[0] = f"!{e}"
+    dist.broadcast_object_list(box, src=0)
+    if box[0].startswith("!"):
+        raise SystemExit("bench.py: " + box[0][1:])
+    workdir = box[0]
+    pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
+    r0 = rank * m_local
+    kb = (k + world - 1) // world
+    k0, k1 = min(k, rank * kb), min(k, (rank + 1) * kb)
+    state = {}
+
+    def put(path, off_elems, count, first, mode):
+        if count <= 0:
+            return
+        t = state["t"]
+        bofhip.gen_dense(t.data_ptr(), first, count, mode, 0, st)
+        fd, d = _open(path, True)
+        try:
+            bofhip.device_to_file(bofhip.FPtr(fd, off_elems * 4), count * 4, t.data_ptr(),
+                                  bofhip.default_options(n_io_threads=args.io_threads, use_odirect=1 if d else 0), st)
+            os.fsync(fd)
+        finally:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+
+    def create():
+        state["t"] = torch.empty(max(m_local * max(k, n), (k1 - k0) * n), dtype=torch.float32, device=dev)
+        put(pa, r0 * k, m_local * k, r0 * k, "s")          # dense_create mode s, this rank's rows
+        put(pb, k0 * n, (k1 - k0) * n, k0 * n, "s")        # 1/world of B
+        put(pc, r0 * n, m_local * n, 0, "z")
+        state["rowpat"] = _closed_form_rows(torch, dev, m, k, n)
+    good, create_s, _, err = phase(create)
+    fds = []
+
+    def opening():
+        for p in (pa, pb, pc):
+            fd, d = _open(p, True)
+            fds.append(fd)
+            state["direct"] = state.get("direct", True) and d
+    if good:
+        good, _, _, err = phase(opening)
+    opts = bofhip.default_options(gemm_blk=blk, n_io_threads=args.io_threads, use_odirect=1 if state.get("direct") else 0,
+                                  kernel_timing=1, panel_streams=args.streams)
+    last = {}
+
+    def step():
+        last.clear()
+        last.update(bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], 0, 0, 0, opts, b_once=True))
+    for _ in range(args.warmup if good else 0):
+        if rank == 0:
+            _drop_cache((pa, pb, pc))
+        dist.barrier()
+        good, _, _, err = phase(step)
+        if not good:
+            break
+    per_rank_s, agg_steps = [], []
+    dt = float("nan")
+    if good:
+        if rank == 0:
+            _drop_cache((pa, pb, pc))
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            good, smax, smin, err = phase(step)        # ends in an all-reduce = the barrier between steps
+            per_rank_s.append((smin, smax))
+            agg_steps.append(dict(last))
+            if not good:
+                break
+        dist.barrier()
+        torch.cuda.synchronize()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    keys = ("bytes_read", "bytes_written", "bytes_peer", "bytes_h2d", "bytes_d2h", "kernel_launches", "kernel_seconds", "tasks")
+    agg = torch.tensor([sum(float(s.get(q, 0)) for s in agg_steps) for q in keys], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(agg)
+    agg = dict(zip(keys, [float(v) for v in agg.tolist()]))
+    for fd in fds:
+        bofhip.lib().bof_file_forget(fd)
+        os.close(fd)
+
+    def verify():
+        t = state["t"]
+        fd, _ = _open(pc, False)
+        try:
+            bofhip.file_to_device(bofhip.FPtr(fd, r0 * n * 4), m_local * n * 4, t.data_ptr(),
+                                  bofhip.default_options(use_odirect=0), st)
+        finally:
+            os.close(fd)
+        C = t[:m_local * n].view(m_local, n)
+        rows = max(1, (1 << 27) // n)
+        for q0 in range(0, m_local, rows):
+            q1 = min(m_local, q0 + rows)
+            gi = torch.arange(r0 + q0, r0 + q1, device=dev)
+            if not torch.equal(C[q0:q1], state["rowpat"][gi % 10]):
+                raise AssertionError(f"C rows [{r0 + q0}, {r0 + q1}) differ from the closed form")
+    match, _, _, verr = phase(verify) if good else (False, 0, 0, "")
+    state.clear()
+    torch.cuda.empty_cache()
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(workdir, ignore_errors=True)
+    bofhip.lib().bof_flash_release()
+
+    # csrgemv 'T': the path's one real exchange (partial sums of 200 MB), both algorithms timed
+    red = None
+    if not args.no_csr and not args.size and not args.no_extras:
+        try:
+            red = sharded_csr_extras(bofhip, torch, dev, st, rank, world, red_dev, one_gpu)
+        except Exception as e:
+            red = {"error": str(e)[:120]}
+    if rank != 0:
+        return None, None
+    if not good:
+        raise SystemExit(f"bench.py: the sharded run failed: {err or 'another rank failed'}")
+    flops_step = 2.0 * m * n * k
+    launches, ksec = agg["kernel_launches"], agg["kernel_seconds"]
+    avg_launch_ms = ksec / max(launches, 1) * 1e3
+    achieved = (flops_step * args.steps / max(launches, 1)) / max(avg_launch_ms, 1e-9) / 1e9
+    traffic, traffic_src = pmc_traffic()
+    nk = max(k // blk, 1)
+    line = {
+        "metric": "GFLOP/s, out-of-core GEMM (flash _gemm on SSD-resident A/B/C, wall clock around the call)",
+        "value": round(flops_step * args.steps / dt / 1e9, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic: dense_create mode s A and B, zero C, written to the node's scratch disk by the ranks; "
+                "every rank's C slab checked against the closed form",
+        "config": {"workload": f"flash _gemm fp32 {m}x{k}x{n} row-block sharded over {world}xMI355X ({m_local} C rows "
+                               f"each), {blk}-tile, SSD-resident A/B/C (BASELINE configs[3] at 8 GPUs)",
+                   "what_is_timed": "every rank's bof_flash_gemm on its slab of ONE A/B/C file set between barriers; "
+                                    "B read from storage once per node, no data-path collective",
+                   "parallelism": f"row-block x{world}", "ranks_seen": args.ranks_seen,
+                   "backend": "gloo (one-GPU debug)" if one_gpu else "nccl (RCCL)", "odirect": bool(state.get("direct", True)),
+                   "rank_s_min": round(min(a for a, _ in per_rank_s), 3), "rank_s_max": round(max(b for _, b in per_rank_s), 3),
+                   "read_amplification": round(agg["bytes_read"] / args.steps / (4.0 * (m * k + k * n)), 3),
+                   "write_amplification": round(agg["bytes_written"] / args.steps / (4.0 * m * n), 3),
+                   "B_GiB_from_peers_per_step": round(agg["bytes_peer"] / args.steps / 2**30, 2),
+                   "aggregate_read_GBps": round(agg["bytes_read"] / dt / 1e9, 2),
+                   "aggregate_write_GBps": round(agg["bytes_written"] / dt / 1e9, 2),
+                   "C_verified": bool(match), "create_files_s": round(create_s, 1)},
+        "ranks_seen": args.ranks_seen,
+        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel<NoEpi>", "achieved": round(achieved, 2),
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                     "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(launches),
+                     "timed_with": "HIP events around every tile launch on its compute stream, all ranks",
+                     "algorithmic_bytes_per_launch": int(4 * blk * blk * (3 + (nk - 1) / nk)),
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel_s_per_step_per_rank": round(ksec / args.steps / world, 4)},
+    }
+    if verr:
+        line["config"]["rank0_verify_error"] = verr[:100]
+    if red is not None:
+        line["extras"] = red
+    detail.update({"per_rank_step_seconds_min_max": per_rank_s, "aggregate": agg, "extras": red})
+    return line, detail
+
+
+def sharded_csr_extras(bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
+    """N > 1 extras (strong scaling of the BASELINE CSR matrices, resident shards): max-over-ranks
+    kernel times and the csrgemv 'T' exchange timed as one all-reduce and as reduce-scatter + all-gather."""
+    import torch.distributed as dist
+    import bof_dist
+    keys = ["csrmm_ms", "csrgemv_N_ms", "csrgemv_T_local_ms"]
+    try:
+        mine = csr_secondary_sharded(bofhip, torch, dev, st, rank, world)
+        vec = [float(mine[q]) for q in keys]
+        part = mine["csrgemv_T_partial"]
+    except Exception as e:
+        vec = [-1.0] * len(keys)
+        part = torch.zeros(50_000_000, dtype=torch.float32, device=dev)
+        sys.stderr.write(f"[rank {rank}] sharded CSR extras failed: {e}\n")
+    hi = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+    lo = hi.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    part_r = part.cpu() if one_gpu else part
+    warm = torch.ones(1 << 16, dtype=torch.float32, device=part_r.device)
+    dist.all_reduce(warm)
+    bof_dist.allreduce_partial(warm, algo="rs_ag")
+    red = {}
+    result = None
+    for algo in ("allreduce", "rs_ag"):
+        best = None
+        for _ in range(2):
+            buf = part_r.clone()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_red = time.perf_counter()
+            bof_dist.allreduce_partial(buf, algo=algo)
+            torch.cuda.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t_red) * 1e3], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            best = float(tt.item()) if best is None else min(best, float(tt.item()))
+        red[algo] = round(best, 3)
+        if algo == "allreduce":
+            result = buf
+    ysum = float(result.double().sum().item())
+    ok = bool(lo.min().item() >= 0)
+    out = {"csr_ok": ok, "allreduce_ms": red["allreduce"], "rs_ag_ms": red["rs_ag"],
+           "csrgemv_T_sum_y_ok": bool(ysum == 11249999940.0)}     # SURVEY App. A-3
+    if ok:
+        ms = dict(zip(keys, [float(v) for v in hi.tolist()]))
+        out.update({"csrmm_max_ms": round(ms["csrmm_ms"], 3), "csrgemv_N_max_ms": round(ms["csrgemv_N_ms"], 3),
+                    "csrgemv_T_local_max_ms": round(ms["csrgemv_T_local_ms"], 3),
+                    "csrmm_gflops": round(2.0 * 1e9 * 128 / ms["csrmm_ms"] / 1e6, 1),
+                    "csrgemv_T_gflops": round(2.0 * 5e8 / (ms["csrgemv_T_local_ms"] + min(red.values())) / 1e6, 1)})
+    del part, part_r, result, buf
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=0, help="override problem edge (debug)")
+    ap.add_argument("--size", type=int, default=0, help="override problem edge (debug; skips the extras)")
     ap.add_argument("--blk", type=int, default=4096)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="compute streams for the tile DAG (1 = serialized launches, the "
-                         "configuration the roofline/rocprof numbers are quoted on)")
-    ap.add_argument("--data", default="u", choices=["u", "s"],
-                    help="u: uniform[-1,1) (timing default); s: dense_create mode s")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="compute streams of the row-panel pipeline (0 = the library's default)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--as-shard-of", type=int, default=0,
-                    help="debug: run rank 0's slab of the N-GPU workload on one GPU")
-    ap.add_argument("--no-csr", action="store_true",
-                    help="skip the CSRMM (cfg3) / CSRGEMV (cfg5-size) secondary measurements")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the file-resident (out-of-core) legs")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline (+ cpu_baseline): no resident DAG, CSR, 64k, kmeans legs")
+    ap.add_argument("--no-csr", action="store_true", help="skip the CSRMM (cfg3) / CSRGEMV (cfg5-size) extras")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-resident extras (64k, cfg3, csrgemv from files)")
     ap.add_argument("--e2e-dir", default="", help="directory for the matrix files (default $BOF_BENCH_DIR, $TMPDIR, /tmp)")
-    ap.add_argument("--e2e-size", type=int, default=32768, help="edge of the file-resident GEMM")
-    ap.add_argument("--e2e-reps", type=int, default=3)
+    ap.add_argument("--e2e-size", type=int, default=32768, help=argparse.SUPPRESS)
+    ap.add_argument("--e2e-reps", type=int, default=2)
     ap.add_argument("--no-e2e-64k", action="store_true", help="skip the 65536^3 file-resident leg (48 GiB of files)")
+    ap.add_argument("--more-legs", action="store_true",
+                    help="also the 31000^3 / tile-cache / 8 GiB-budget / two-device file legs (bench_detail.json only)")
     ap.add_argument("--io-threads", type=int, default=8)
     args = ap.parse_args()
 
@@ -1225,288 +1628,23 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     red_dev = torch.device("cpu") if one_gpu else dev     # where cross-rank reductions live
-    ranks_seen = 1
+    args.ranks_seen = 1
     if world > 1:
         # every rank adds a one through the data-path backend (RCCL over xGMI on the GPU box): the sum is
         # the number of ranks that really took part, printed so the driver can check it against --gpus
         ones = torch.ones(1, dtype=torch.float32, device=red_dev)
         dist.all_reduce(ones)
-        ranks_seen = int(ones.item())
-        if ranks_seen != args.gpus:
-            sys.stderr.write(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus says {args.gpus}\n")
+        args.ranks_seen = int(ones.item())
+        if args.ranks_seen != args.gpus:
+            sys.stderr.write(f"bench.py: {args.ranks_seen} ranks answered the all-reduce, --gpus says {args.gpus}\n")
             sys.exit(2)
-
-    n_gpus = max(world, 1)
-    shard_of = args.as_shard_of if world == 1 else 0
-    if shard_of > 1:
-        n_gpus = shard_of
-    if n_gpus == 1:
-        m = n = k = args.size or 32768
-        m_local, row0 = m, 0
-        workload = (f"flash _gemm fp32 {m}x{k}x{n}, {args.blk}-tile, A/B/C resident in HBM, "
-                    f"1xMI355X (BASELINE configs[1])")
-    else:
-        k = n = args.size or 65536
-        m_local = (args.size or 65536) // 8
-        m, row0 = m_local * n_gpus, m_local * rank
-        workload = (f"flash _gemm fp32 {m}x{k}x{n} row-block sharded over {n_gpus} GPUs "
-                    f"({m_local} C rows each), {args.blk}-tile, resident in HBM "
-                    f"(BASELINE configs[3] at 8 GPUs)")
-
-    # ---- inputs generated straight into HBM (no PCIe traffic) --------------------
-    a = torch.empty(m_local * k, dtype=torch.float32, device=dev)
-    b = torch.empty(k * n, dtype=torch.float32, device=dev)
-    c = torch.zeros(m_local * n, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    bofhip.gen_dense(a.data_ptr(), row0 * k, a.numel(), args.data, 1, st)
-    bofhip.gen_dense(b.data_ptr(), 0, b.numel(), args.data, 2, st)
-    torch.cuda.synchronize()
-
-    opts = bofhip.default_options(gemm_blk=args.blk, n_streams=args.streams)
-    tasks, nblk = bofhip.gemm_plan("R", "N", "N", m_local, n, k, 0.0, 0, 0, 0, args.blk)
-    launches_per_step = len(tasks)
-    flops_per_step_rank = 2.0 * m_local * n * k
-
-    def step():
-        bofhip.gemm_resident("R", "N", "N", m_local, n, k, 1.0, 0.0, a.data_ptr(), b.data_ptr(),
-                             c.data_ptr(), 0, 0, 0, opts, st)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()          # torch's current stream == the stream the DAG is forked from/joined to
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # ---- parity check on the timed output: a full tile-row of C against float64 --------------
-    rows = min(m_local, args.blk)
-    rel = check_tile_row_float64(torch, a[:rows * k], b, c[:rows * n], k, n)
-
-    sharded = None
-    if world > 1 and not args.no_csr and not args.size:
-        # every rank runs its shard; failures are turned into -1 so the collectives below always match
-        import torch.distributed as dist
-        del a, b, c
-        torch.cuda.empty_cache()
-        keys = ["csrmm_ms", "csrgemv_N_ms", "csrgemv_T_local_ms"]
-        try:
-            mine = csr_secondary_sharded(bofhip, torch, dev, st, rank, world)
-            vec = [float(mine[q]) for q in keys]
-            part = mine["csrgemv_T_partial"]
-        except Exception as e:
-            vec = [-1.0] * len(keys)
-            part = torch.zeros(50_000_000, dtype=torch.float32, device=dev)
-            sys.stderr.write(f"[rank {rank}] sharded CSR secondary failed: {e}\n")
-        hi = torch.tensor(vec, dtype=torch.float64, device=red_dev)
-        lo = hi.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        # csrgemv 'T': the one real exchange of the path -- sum of the per-rank partial vectors.
-        # Warm-up on a small tensor (communicator set-up is not part of the exchange), then both
-        # forms are timed on copies: one all-reduce, and reduce-scatter + all-gather (7 xGMI links
-        # at once on the fully connected mesh); the result of the faster one is kept.
-        import bof_dist
-        part_r = part.cpu() if one_gpu else part
-        warm = torch.ones(1 << 16, dtype=torch.float32, device=part_r.device)
-        dist.all_reduce(warm)
-        bof_dist.allreduce_partial(warm, algo="rs_ag")
-        red = {}
-        for algo in ("allreduce", "rs_ag"):
-            best = None
-            for _ in range(2):
-                buf = part_r.clone()
-                dist.barrier()
-                torch.cuda.synchronize()
-                t_red = time.perf_counter()
-                bof_dist.allreduce_partial(buf, algo=algo)
-                torch.cuda.synchronize()
-                tt = torch.tensor([(time.perf_counter() - t_red) * 1e3], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                best = float(tt.item()) if best is None else min(best, float(tt.item()))
-            red[algo] = best
-            if algo == "allreduce":
-                result = buf
-        ysum = float(result.double().sum().item())
-        sharded = {"ok": bool(lo.min().item() >= 0), "max_ms": dict(zip(keys, [float(v) for v in hi.tolist()])),
-                   "allreduce_ms": min(red.values()), "reduce_ms_by_algo": red, "y_T_sum": ysum}
-        del part, part_r, result, buf
-        torch.cuda.empty_cache()
-
-    e2e_sharded = None
-    if world > 1 and not args.no_e2e:
-        try:
-            del a, b, c
-        except NameError:
-            pass
-        torch.cuda.empty_cache()
-        e2e_sharded = e2e_gemm_sharded(bofhip, torch, dev, st, args, rank, world, red_dev, m_local, n, k,
-                                       dt / args.steps)
-
+    if world == 1:
+        line, detail = run_single(args, bofhip, torch, dev, st)
+    else:
+        line, detail = run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu)
     if rank == 0:
-        if shard_of > 1:
-            n_gpus = 1          # only this rank's slab actually ran
-        total_flops = flops_per_step_rank * n_gpus * args.steps
-        value = total_flops / dt / 1e9
-        avg_launch_ms = ev_ms / (args.steps * launches_per_step)
-        flops_per_launch = flops_per_step_rank / launches_per_step
-        achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic()
-        pre = os.environ.get("BOF_GEMM_PRETRANSPOSE", "1") != "0" and os.environ.get("BOF_GEMM_VARIANT", "4") in ("3", "4")
-        kname = "sgemm_tile256_dma2_kernel" if os.environ.get("BOF_GEMM_VARIANT", "4") == "4" else "sgemm_tile256_dma_kernel"
-        kernel_label = (kname + " (256x256x32 tile, 1 wave/SIMD, LDS-DMA staging of k-major "
-                        "operands; A is copied k-major once per call, inside the timed region and inside "
-                        "avg_launch_ms)" if pre else
-                        "sgemm_tile256_1w2_kernel<XMAJOR,KMAJOR> (256x256x32 tile, 1 wave/SIMD)")
-        out = {
-            "metric": "GFLOP/s, out-of-core GEMM hot path (tile DAG over HBM-resident tiles)",
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic " + ("uniform[-1,1) fp32 (counter hash)" if args.data == "u"
-                                    else "dense_create mode s (i%10)") + ", generated in HBM",
-            "config": {"workload": workload, "tile": args.blk, "tile_tasks_per_step": launches_per_step,
-                       "compute_streams": args.streams, "parallelism": f"row-block x{n_gpus}",
-                       "ranks_seen": ranks_seen,
-                       "backend": "single process" if world == 1 else ("gloo (one-GPU debug)" if one_gpu else "nccl (RCCL)")},
-            "ranks_seen": ranks_seen,
-            "roofline": {"bound": "mfma", "kernel": kernel_label,
-                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                         "avg_launch_ms": round(avg_launch_ms, 4),
-                         "flops_per_launch": flops_per_launch, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, PMC)",
-                         "traffic_source": traffic_src,
-                         "hbm_GBps": round(traffic / avg_launch_ms / 1e6, 1) if traffic else None,
-                         # A tile + B tile + C written, + C read by the tasks of k-blocks 1.. (beta = 1 there)
-                         "algorithmic_bytes_per_launch": int(4 * args.blk * args.blk *
-                                                             (3 + (max(k // args.blk, 1) - 1) / max(k // args.blk, 1)))},
-            "parity_first_tile_row_rel_err_vs_float64": rel,
-        }
-        if not args.no_cpu and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(with_csr=not args.no_csr and not args.size)
-        if not args.no_csr and n_gpus == 1 and not args.size:
-            del a, b, c
-            torch.cuda.empty_cache()
-            try:
-                out["secondary"] = csr_secondary(bofhip, torch, dev, st)
-            except Exception as e:  # the headline line must still be printed
-                out["secondary"] = {"error": str(e)[:200]}
-            try:
-                out["secondary"]["kmeans"] = kmeans_secondary(bofhip, torch, dev, st, args.streams)
-            except Exception as e:
-                out["secondary"]["kmeans_error"] = str(e)[:200]
-            # north_star's 64k x 64k x 64k at N = 1 (48 GiB resident), and the slab ONE rank of the
-            # 8-GPU run owns (BASELINE configs[3]): the same per-GPU workload the N = 8 line reports
-            try:
-                out["secondary"]["gemm_65536"] = resident_gemm_line(
-                    bofhip, torch, dev, st, 65536, 65536, 65536, 0, args.blk, args.streams, 1,
-                    "flash _gemm fp32 65536^3, 4096-tile, resident in HBM (48 GiB), 1xMI355X: 4096 tile tasks, 562.9 TFLOP")
-                out["secondary"]["gemm_65536_rank0_slab_of_8"] = resident_gemm_line(
-                    bofhip, torch, dev, st, 8192, 65536, 65536, 0, args.blk, args.streams, 2,
-                    "rank 0's row slab of BASELINE configs[3]: 8192 x 65536 x 65536 (512 tile tasks, 70.4 TFLOP), resident")
-            except Exception as e:
-                out["secondary"]["gemm_65536_error"] = str(e)[:200]
-        if not args.no_e2e and n_gpus == 1 and world == 1 and not shard_of:
-            try:
-                del a, b, c
-            except NameError:
-                pass
-            torch.cuda.empty_cache()
-            csr_ms = (out.get("secondary") or {}).get("csrmm", {}).get("ms")
-            sec = out.get("secondary") or {}
-            g64_ms = sec.get("gemm_65536", {}).get("ms_per_step")
-            gv_ms = {tr: sec.get("csrgemv_" + tr, {}).get("ms") for tr in "NT"}
-            out["e2e"] = e2e_block(bofhip, torch, dev, st, args, dt / args.steps if not args.size else None,
-                                   csr_ms * 1e-3 if csr_ms else None, g64_ms * 1e-3 if g64_ms else None,
-                                   gv_ms if all(gv_ms.values()) else None)
-        # ---- the out-of-core numbers where the driver's `parsed` record keeps them: flat scalars inside
-        # `roofline` (e2e_*), plus value_e2e / roofline_e2e at the top level ----------------------------
-        e2e = out.get("e2e") or {}
-        ceil = e2e.get("ceilings") if isinstance(e2e.get("ceilings"), dict) else {}
-        rf = out["roofline"]
-        for key in ("disk_read_GBps", "disk_write_GBps", "disk_read_GBps_while_writing",
-                    "disk_write_GBps_while_reading", "page_cache_read_GBps", "pcie_h2d_GBps", "pcie_d2h_GBps"):
-            if key in ceil:
-                rf["e2e_ceiling_" + key] = ceil[key]
-        for name, tag in (("gemm", "cfg2"), ("gemm_65536", "64k"), ("csrmm", "cfg3"), ("gemm_31000", "31000"),
-                          ("gemm_tile_cache", "cfg2_tilecache"), ("gemm_budget_8GiB", "cfg2_8GiB"),
-                          ("gemm_two_devices_in_process", "cfg2_2dev_1gpu")):
-            for mode, mt in (("odirect", ""), ("buffered", "_pagecache")):
-                leg = (e2e.get(name) or {}).get(mode) if isinstance(e2e.get(name), dict) else None
-                if not isinstance(leg, dict) or "roofline" not in leg:
-                    continue
-                r = leg["roofline"]
-                pre = f"e2e_{tag}{mt}_"
-                rf[pre + "s"] = r["seconds"]
-                rf[pre + "gflops"] = r["gflops"]
-                rf[pre + "bound"] = r["bound"]
-                rf[pre + "tbound_s"] = r["t_bound_s"]
-                rf[pre + "frac"] = r["frac"]
-                rf[pre + "read_amp"] = leg.get("read_amplification")
-                ok = leg.get("whole_C_file_matches_closed_form", leg.get("C_total_matches_reference"))
-                rf[pre + "verified"] = bool(ok)
-        g2 = (e2e.get("gemm") or {}).get("odirect") if isinstance(e2e.get("gemm"), dict) else None
-        if isinstance(g2, dict) and "roofline" in g2:
-            out["value_e2e"] = g2["gflops"]
-            out["roofline_e2e"] = dict(g2["roofline"], workload=e2e["gemm"].get("workload", ""), ceilings=ceil,
-                                       unit_of_value_e2e="GFLOP/s, wall clock around bof_flash_gemm on O_DIRECT files, "
-                                                         "page cache dropped, write-back included")
-        sec0 = out.get("secondary") or {}
-        if isinstance(sec0.get("csrmm"), dict) and "roofline" in sec0["csrmm"]:
-            r3 = sec0["csrmm"]["roofline"]
-            rf["csrmm_kernel_ms"] = sec0["csrmm"]["ms"]
-            rf["csrmm_bytes_frac_of_hbm"] = r3["frac"]
-            rf["csrmm_gather_frac_of_ceiling"] = r3["gather_frac_of_ceiling"]
-            rf["csrmm_traffic_over_algorithmic"] = r3.get("traffic_over_algorithmic")
-        for tr in "NT":
-            gv = sec0.get("csrgemv_" + tr)
-            if isinstance(gv, dict) and "roofline" in gv:
-                rf[f"csrgemv_{tr}_kernel_ms"] = gv["ms"]
-                rf[f"csrgemv_{tr}_bytes_frac_of_hbm"] = gv["roofline"]["frac"]
-        if isinstance(sec0.get("kmeans"), dict) and "roofline" in sec0["kmeans"]:
-            rf["kmeans_frac_of_mfma"] = sec0["kmeans"]["roofline"]["frac"]
-        if sharded is not None:
-            sec = {"scaling": "strong (the BASELINE matrices row-sharded over the ranks; max over ranks)",
-                   "ok": sharded["ok"]}
-            if sharded["ok"]:
-                ms = sharded["max_ms"]
-                nnz3, nnz5 = 10_000_000 * 100, 50_000_000 * 10
-                sec["csrmm"] = {"workload": "flash _csrmm 10M x 1M CSR x 1M x 128, row-sharded, B replicated",
-                                "ms": round(ms["csrmm_ms"], 3),
-                                "gflops": round(2.0 * nnz3 * 128 / ms["csrmm_ms"] / 1e6, 1)}
-                sec["csrgemv_N"] = {"workload": "flash _csrgemv 50M x 50M (5e8 nnz), row-sharded, x replicated",
-                                    "ms": round(ms["csrgemv_N_ms"], 3),
-                                    "gflops": round(2.0 * nnz5 / ms["csrgemv_N_ms"] / 1e6, 1)}
-                t_ms = ms["csrgemv_T_local_ms"] + sharded["allreduce_ms"]
-                sec["csrgemv_T"] = {"workload": "flash _csrgemv 'T': per-rank partial + one all-reduce(sum) of 200 MB",
-                                    "local_ms": round(ms["csrgemv_T_local_ms"], 3),
-                                    "allreduce_ms": round(sharded["allreduce_ms"], 3),
-                                    "reduce_ms_by_algo": sharded["reduce_ms_by_algo"],
-                                    "gflops": round(2.0 * nnz5 / t_ms / 1e6, 1),
-                                    # known answer of the full product: sum(y) = 11249999940
-                                    "sum_y": sharded["y_T_sum"], "sum_y_expected": 11249999940.0}
-            out["secondary"] = sec
-        if e2e_sharded is not None:
-            out["e2e"] = e2e_sharded
-        print(json.dumps(out))
+        emit(line, detail)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -30,7 +30,10 @@ class Options(C.Structure):
                 ("io_request_kib", C.c_int32), ("panel_group", C.c_int32), ("panel_streams", C.c_int32),
                 ("panel_writers", C.c_int32), ("panel_kmajor", C.c_int32),
                 # one process per GPU: the shared operand read once per node (see include/bof_hip.h)
-                ("share_world", C.c_int32), ("share_rank", C.c_int32), ("share_name", C.c_char * 48)]
+                ("share_world", C.c_int32), ("share_rank", C.c_int32), ("share_name", C.c_char * 48),
+                # ABI v4: instrumentation + device-to-device broadcast of a shared operand
+                ("kernel_timing", C.c_int32), ("verify", C.c_int32), ("peer_bcast", C.c_int32),
+                ("reserved_", C.c_int32 * 5)]
 
 
 class GemmTask(C.Structure):
@@ -54,7 +57,9 @@ class PanelPlan(C.Structure):
 class FlashStats(C.Structure):
     _fields_ = [("bytes_read", u64), ("bytes_written", u64), ("bytes_h2d", u64),
                 ("bytes_d2h", u64), ("tasks", u64), ("tile_hits", u64), ("tile_misses", u64),
-                ("seconds", C.c_double), ("read_ops", u64), ("write_ops", u64), ("bytes_peer", u64)]
+                ("seconds", C.c_double), ("read_ops", u64), ("write_ops", u64), ("bytes_peer", u64),
+                ("kernel_launches", u64), ("kernel_seconds", C.c_double), ("bytes_p2p", u64),
+                ("verify_checks", u64)]
 
 
 # every symbol include/bof_hip.h declares: (name, restype, argtypes)

@@ -54,6 +54,9 @@ bof_options resolved(const bof_options *o) {
     memcpy(r.share_name, o->share_name, sizeof(r.share_name));
     r.share_name[sizeof(r.share_name) - 1] = 0;
   }
+  r.kernel_timing = o->kernel_timing > 0 ? 1 : 0;
+  if (o->verify >= 0 && o->verify <= 2) r.verify = o->verify;
+  if (o->peer_bcast >= 0 && o->peer_bcast <= 2) r.peer_bcast = o->peer_bcast;
   return r;
 }
 
@@ -168,6 +171,10 @@ void bof_default_options(bof_options *o) {
   o->share_world = 0;
   o->share_rank = 0;
   memset(o->share_name, 0, sizeof(o->share_name));
+  o->kernel_timing = 0;
+  o->verify = 0;
+  o->peer_bcast = 0;
+  memset(o->reserved_, 0, sizeof(o->reserved_));
 }
 
 int bof_device_count(void) {

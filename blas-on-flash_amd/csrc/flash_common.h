@@ -26,8 +26,63 @@ namespace bof {
 
 struct Counters {
   std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0}, peer{0};
+  std::atomic<uint64_t> klaunch{0}, kns{0};   // KernelTimer: timed tile tasks and their summed durations (ns)
   uint64_t ops0[2];  // file_io_ops() when the call began
   Counters() { file_io_ops(&ops0[0], &ops0[1]); }
+};
+
+// Durations of the compute launches of one level-3 call (bof_options.kernel_timing = 1), measured where
+// the kernels run: a pair of timing events around every tile task / row-block task ON THE STREAM IT IS
+// LAUNCHED ON, read back once the call's streams have drained.  What bof_flash_stats.kernel_seconds /
+// kernel_launches report, and what bench.py's roofline.achieved is computed from (the figure rocprofv3's
+// per-kernel average of the same run must agree with).  Off by default: two markers per launch.
+class KernelTimer {
+  std::vector<hipEvent_t> ev;   // begin / end pairs in launch order
+  std::mutex mu;                // several dispatch streams of one device share a timer
+ public:
+  bool on = false;
+  hipError_t begin(hipStream_t st) {
+    if (!on) return hipSuccess;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&a, hipEventDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDefault);
+    if (e == hipSuccess) e = hipEventRecord(a, st);
+    if (e != hipSuccess) {
+      if (a) (void) hipEventDestroy(a);
+      if (b) (void) hipEventDestroy(b);
+      return e;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    ev.push_back(a);
+    ev.push_back(b);
+    return hipSuccess;
+  }
+  // the end marker of the most recent begin() of this thread's launch (launches of one timer are
+  // issued by one dispatcher thread, so "most recent" is well defined)
+  hipError_t end(hipStream_t st) {
+    if (!on) return hipSuccess;
+    std::lock_guard<std::mutex> lk(mu);
+    return ev.empty() ? hipSuccess : hipEventRecord(ev.back(), st);
+  }
+  // after the streams have been synchronised: adds the pairs that completed to the counters, destroys all
+  void collect(Counters &c) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
+        c.klaunch++;
+        c.kns += (uint64_t) ((double) ms * 1e6);
+      } else {
+        (void) hipGetLastError();
+      }
+      (void) hipEventDestroy(ev[i]);
+      (void) hipEventDestroy(ev[i + 1]);
+    }
+    ev.clear();
+  }
+  ~KernelTimer() {
+    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+  }
 };
 
 // Pinned host blocks are expensive to create and destroy (page pinning: ~0.1 s per GB each way),

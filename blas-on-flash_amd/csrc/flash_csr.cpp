@@ -847,6 +847,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
                    [&R] { return R.cnt.rd.load() + R.cnt.wr.load() + R.cnt.h2d.load() + R.cnt.d2h.load() + R.cnt.tasks.load(); },
                    [&R] { R.fail_io(-ETIMEDOUT); });
   hipError_t herr = hipSuccess;
+  KernelTimer ktimer;
+  ktimer.on = R.o.kernel_timing > 0;
   int fail = 0;
   resident_thread.join();
   if (resident_rc) {
@@ -877,6 +879,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       col = (const int64_t *) (c.d_idx + d0);  // un-shift the sector widening
       val = (const float *) (c.d_val + d1);
     }
+    herr = ktimer.begin(st);
+    if (herr != hipSuccess) break;
     if (is_mm) {
       if (ord_b == 'C' && beta != 0.f)  // C block arrived packed column-major [k][r]
         herr = transpose_f32((const float *) c.d_c, r, k, r, (float *) c.d_c_rm, k, st);
@@ -891,6 +895,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       }
       if (ord_b == 'C' && herr == hipSuccess)  // [r][k] -> packed column-major block [k][r]
         herr = transpose_f32((const float *) c.d_c_rm, k, r, k, (float *) c.d_c, r, st);
+      if (herr == hipSuccess) herr = ktimer.end(st);
       if (herr != hipSuccess) break;
       // C block -> pinned buffer on the D2H stream, after the kernels
       herr = hipEventRecord(c.done, st);
@@ -904,6 +909,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
         herr = scsrgemv('N', r, n, val, d_ia + s, col, (const float *) d_x, (float *) d_y + s, st);
       else
         herr = scsrgemv('T', r, n, val, d_ia + s, col, (const float *) d_x + s, (float *) d_y, st);
+      if (herr == hipSuccess) herr = ktimer.end(st);
       if (herr == hipSuccess) herr = hipEventRecord(c.done, st);
     }
     if (herr != hipSuccess) break;
@@ -916,6 +922,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   R.done_q.close();
   for (auto &th : retirers) th.join();
   (void) hipDeviceSynchronize();
+  ktimer.collect(R.cnt);
   BOF_TRACE_T("csr: drained (C written)");
   if (!is_mm && !ext_y && !fail && herr == hipSuccess) {
     if (device_to_pageable(hc, d_y, (uint64_t) ylen * 4, R.o.n_io_threads)) herr = hipErrorUnknown;
@@ -932,6 +939,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     Counters &o = *ex->out;
     o.rd += R.cnt.rd.load(); o.wr += R.cnt.wr.load(); o.h2d += R.cnt.h2d.load(); o.d2h += R.cnt.d2h.load();
     o.tasks += R.cnt.tasks.load();
+    o.klaunch += R.cnt.klaunch.load(); o.kns += R.cnt.kns.load();
   } else {
     publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   }
@@ -1224,9 +1232,11 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   for (Shard &S : sh) {
     total.rd += S.cnt.rd.load(); total.wr += S.cnt.wr.load(); total.h2d += S.cnt.h2d.load(); total.d2h += S.cnt.d2h.load();
     total.tasks += S.cnt.tasks.load();
+    total.klaunch += S.cnt.klaunch.load(); total.kns += S.cnt.kns.load();
     bof_flash_stats ps{};
     ps.bytes_read = S.cnt.rd; ps.bytes_written = S.cnt.wr; ps.bytes_h2d = S.cnt.h2d; ps.bytes_d2h = S.cnt.d2h;
     ps.tasks = S.cnt.tasks; ps.seconds = S.seconds;
+    ps.kernel_launches = S.cnt.klaunch; ps.kernel_seconds = (double) S.cnt.kns.load() * 1e-9;
     per.push_back(ps);
   }
   publish_stats(total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());

@@ -246,6 +246,7 @@ struct PanelRun {
   KmeansVecs kv{nullptr, nullptr, nullptr};
   bool has_kv = false;
   Counters cnt;                                   // this device's share of the counters
+  KernelTimer ktimer;                             // bof_options.kernel_timing
   hipError_t herr = hipSuccess;
   int fail = 0;
   double seconds = 0;
@@ -808,8 +809,11 @@ void PanelRun::dispatch() {
         }
       }
       float *pcp = (float *) C.panel_ptr(pn[2]) + idx[C.cdim] * C.blk_c;
+      herr = ktimer.begin(st);
+      if (herr != hipSuccess) break;
       herr = tile_sgemm(ord, flag[0], flag[1], tk.M, tk.N, tk.K, alpha, po[0], ldo[0], po[1], ldo[1], tk.beta, pcp, C.ld,
                         has_kv ? &kv : nullptr, row_base + tk.i * g.blk[0], col_base + tk.j * g.blk[2], st);
+      if (herr == hipSuccess) herr = ktimer.end(st);
       if (herr != hipSuccess) break;
       cnt.tasks++;
       H.cnt.tasks++;
@@ -922,6 +926,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     std::unique_ptr<PanelRun> Rp(new PanelRun());
     PanelRun &R = *Rp;
     R.hub = &H; R.di = d; R.dev = used[(size_t) d]; R.o = o;
+    R.ktimer.on = o.kernel_timing > 0;
     R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
     // the slab as a problem of its own: rows [p0 * blk, (p0 + cnt) * blk) of the C panel dimension
     // (the last slab runs to the end: a tail-merged last panel stays merged), explicit leading dims
@@ -1055,6 +1060,9 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   for (auto &R : H.runs) {
     (void) hipSetDevice(R->dev);
     (void) hipDeviceSynchronize();
+    R->ktimer.collect(R->cnt);
+    H.cnt.klaunch += R->cnt.klaunch.load();
+    H.cnt.kns += R->cnt.kns.load();
   }
   (void) hipSetDevice(caller_dev);
   H.trace("drained (writes done)");
@@ -1076,6 +1084,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     bof_flash_stats s{};
     s.bytes_read = R.cnt.rd; s.bytes_written = R.cnt.wr; s.bytes_h2d = R.cnt.h2d; s.bytes_d2h = R.cnt.d2h;
     s.tasks = R.cnt.tasks; s.seconds = R.seconds;
+    s.kernel_launches = R.cnt.klaunch; s.kernel_seconds = (double) R.cnt.kns.load() * 1e-9;
     per[(size_t) d] = s;
   }
   publish_device_stats(per);

@@ -78,6 +78,8 @@ void publish_stats(const Counters &c, double seconds) {
   g_last_stats.tasks = c.tasks; g_last_stats.tile_hits = c.hits;
   g_last_stats.tile_misses = c.misses; g_last_stats.seconds = seconds;
   g_last_stats.bytes_peer = c.peer;
+  g_last_stats.kernel_launches = c.klaunch;
+  g_last_stats.kernel_seconds = (double) c.kns.load() * 1e-9;
   uint64_t r = 0, w = 0;
   file_io_ops(&r, &w);
   g_last_stats.read_ops = r - c.ops0[0]; g_last_stats.write_ops = w - c.ops0[1];
@@ -681,6 +683,8 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   const int lookahead = std::max(2, R.o.pinned_slots) * 2;
   int fetch_pos = 0;
   hipError_t herr = hipSuccess;
+  KernelTimer ktimer;
+  ktimer.on = o.kernel_timing > 0;
   const char *where = "bof_flash_gemm dispatch";   // which step of the loop a HIP error came from
   int fail = 0;
   for (int t = 0; t < T && !fail; t++) {
@@ -743,9 +747,12 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
     DevSlot &sa = R.slots[R.tiles[ids[0]].slot], &sb = R.slots[R.tiles[ids[1]].slot],
             &sc = R.slots[R.tiles[ids[2]].slot];
     // packed tiles: leading dim = stored column count (reference gemm.cpp:117-120)
+    herr = ktimer.begin(st);
+    if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (timing event)"; break; }
     herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
                       (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], kv,
                       tk.i * g.blk[0], tk.j * g.blk[2], st);
+    if (herr == hipSuccess) herr = ktimer.end(st);
     if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (tile kernel launch)"; break; }
     R.cnt.tasks++;
     DevSlot *used[3] = {&sa, &sb, &sc};
@@ -780,6 +787,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   R.write_q.close();
   for (auto &th : writers) th.join();
   (void) hipDeviceSynchronize();
+  ktimer.collect(R.cnt);
   BOF_TRACE_T("drained (writes done)");
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, where);
   if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
@@ -792,6 +800,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   if (out) {
     out->rd += R.cnt.rd.load(); out->wr += R.cnt.wr.load(); out->h2d += R.cnt.h2d.load(); out->d2h += R.cnt.d2h.load();
     out->tasks += R.cnt.tasks.load(); out->hits += R.cnt.hits.load(); out->misses += R.cnt.misses.load();
+    out->klaunch += R.cnt.klaunch.load(); out->kns += R.cnt.kns.load();
   }
   return fail;
 }
@@ -800,6 +809,7 @@ static bof_flash_stats stats_of(const Counters &c, double seconds) {
   bof_flash_stats s{};
   s.bytes_read = c.rd; s.bytes_written = c.wr; s.bytes_h2d = c.h2d; s.bytes_d2h = c.d2h;
   s.tasks = c.tasks; s.tile_hits = c.hits; s.tile_misses = c.misses; s.seconds = seconds;
+  s.kernel_launches = c.klaunch; s.kernel_seconds = (double) c.kns.load() * 1e-9;
   return s;
 }
 

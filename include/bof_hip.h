@@ -54,7 +54,7 @@ extern "C" {
 #define BOF_ENODEV (-4) /* no HIP device */
 #define BOF_ENOMEM (-5)
 
-#define BOF_ABI_VERSION 3
+#define BOF_ABI_VERSION 4
 
 /* ---- library ---------------------------------------------------------------- */
 int bof_abi_version(void);
@@ -118,6 +118,18 @@ typedef struct {
   int32_t share_world;    /* 0 / 1: off */
   int32_t share_rank;
   char share_name[48];    /* e.g. "/bof_29500_7"; at most 40 characters */
+  /* ---- ABI v4 ---------------------------------------------------------------- */
+  int32_t kernel_timing;  /* 1: a pair of HIP timing events around every compute launch of a level-3
+                             call, on the stream it is launched on; summed into
+                             bof_flash_stats.kernel_seconds / kernel_launches.  0 = off           */
+  int32_t verify;         /* hand-over checksums of the level-3 pipelines ($BOF_VERIFY): 0 = the
+                             environment variable, else off; 1 = on; 2 = off whatever the
+                             environment says.  See "Instrumentation" below.                      */
+  int32_t peer_bcast;     /* in-process device list: an operand every device needs is copied over
+                             PCIe to ONE device only and passed on device to device
+                             (hipMemcpyPeerAsync over xGMI); 0 = $BOF_PEER_BCAST, else off; 1 on;
+                             2 off                                                                */
+  int32_t reserved_[5];   /* must be zero */
 } bof_options;
 #define BOF_MAX_DEVICES 16
 void bof_default_options(bof_options *o);
@@ -323,6 +335,12 @@ typedef struct {
                                          (iocbs + pread/pwrite calls)  */
   uint64_t bytes_peer;                /* bytes of a shared operand taken from another rank's
                                          staging ring instead of the file (share_world > 1) */
+  /* ---- ABI v4 ---- */
+  uint64_t kernel_launches;           /* compute launches timed (bof_options.kernel_timing)  */
+  double kernel_seconds;              /* their summed durations, HIP events on their streams */
+  uint64_t bytes_p2p;                 /* bytes of a shared operand that reached a device from
+                                         another device's HBM (bof_options.peer_bcast)       */
+  uint64_t verify_checks;             /* hand-over checksums compared (bof_options.verify)   */
 } bof_flash_stats;
 int bof_flash_last_stats(bof_flash_stats *out);
 /* The same counters per device of the last level-3 call, in the order of the device list

@@ -415,6 +415,18 @@ hipError_t hipEventSynchronize(hipEvent_t e) {
   if (c) c->wait();
   return hipSuccess;
 }
+// KernelTimer (bof_options.kernel_timing): both events must have been recorded and be complete
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+  for (hipEvent_t e : {a, b}) {
+    MockEvent *ev = E(e, "hipEventElapsedTime");
+    std::shared_ptr<Completion> c;
+    { std::lock_guard<std::mutex> lk(ev->m); c = ev->last; }
+    if (!c) violation("R2", "hipEventElapsedTime on an event that was never recorded");
+    else c->wait();
+  }
+  *ms = 0.001f;
+  return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
   if (inject_api(3)) return fail(hipErrorUnknown);
   MockStream *st = S(s, "hipStreamWaitEvent");

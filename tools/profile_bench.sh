@@ -1,20 +1,18 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/rNN (run on the GPU box from the repo root): per-kernel stats
 # of the default bench workload, the three PMC passes of MI355X_MICROARCH.md's HBM recipe, and
-# the kernel trace of one file-resident cfg2 call.  Usage: tools/profile_bench.sh OUTDIR
+# (the bench headline IS the file-resident cfg2 call since round 4).  Usage: tools/profile_bench.sh OUTDIR
 out=$(realpath -m "${1:-gpurun_out/prof}")
 root=$(pwd)
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --no-cpu --no-csr --no-e2e"
+B="python3 $root/bench.py --no-cpu --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- $B --steps 3 --warmup 1 > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o b -- $B --steps 1 --warmup 0 > /dev/null 2> "$out/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o b -- $B --steps 1 --warmup 0 > /dev/null 2> "$out/pmc_write.err"
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$out/pmc_sq" -o b -- $B --steps 1 --warmup 0 > /dev/null 2> "$out/pmc_sq.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e" -o e2e -- python3 $root/tools/flash_e2e.py --n 32768 --path 2 --direct 1 --reps 1 > "$out/e2e_under_rocprof.json" 2> "$out/e2e.err"
 cd "$root"
 python3 tools/pmc_summary.py sgemm_tile256_dma2_kernel "$out/bench_gemm_pmc.json" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq"
 f=$(find "$out/stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/bench_gemm_kernel_stats.csv" && python3 tools/kstats.py "$f" sgemm transpose
-f=$(find "$out/e2e" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/e2e_cfg2_kernel_stats.csv" && python3 tools/kstats.py "$f" sgemm copyBuffer
 # keep only the summaries (the raw traces are tens of MB)
-rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq" "$out/e2e"
+rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq"
