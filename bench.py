@@ -1176,6 +1176,7 @@ def run_single(args, bofhip, torch, dev, st):
                    "what_is_timed": "bof_flash_gemm on O_DIRECT files, page cache dropped, C write-back included "
                                     "(reference: drivers/gemm.cpp:57-62)",
                    "odirect": h["odirect"], "file_system": h["file_system"], "io_threads": args.io_threads,
+                   "compute_streams": args.streams or "library default (2)",
                    "tile_tasks_per_step": int(_mean(p["tasks"] for p in per)),
                    "GiB_read_per_step": round(mean_step["bytes_read"] / 2**30, 3),
                    "GiB_written_per_step": round(mean_step["bytes_written"] / 2**30, 3),
@@ -1566,8 +1567,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=0, help="override problem edge (debug; skips the extras)")
     ap.add_argument("--blk", type=int, default=4096)
-    ap.add_argument("--streams", type=int, default=0,
-                    help="compute streams of the row-panel pipeline (0 = the library's default)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="compute streams of the row-panel pipeline (1: tile launches are serialised, so the "
+                         "event-timed avg_launch_ms is one kernel alone on the chip -- the figure rocprofv3's "
+                         "per-kernel average is compared with; 0 = the library's default of two, whose "
+                         "launches overlap pairwise)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline (+ cpu_baseline): no resident DAG, CSR, 64k, kmeans legs")

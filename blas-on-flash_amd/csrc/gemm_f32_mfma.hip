@@ -1230,6 +1230,15 @@ template <class EP>
 static hipError_t sgemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float *A,
                            int64_t lda, const float *B, int64_t ldb, float beta, float *C,
                            int64_t ldc, hipStream_t st, EP ep) {
+  // cblas_sgemm's quick return (the reference's call site: include/tasks/gemm_task.h:87-90; BLAS: "when
+  // alpha is zero or k is zero, A and B are not referenced"): C = beta*C (+ the epilogue's updates), so
+  // NaN / Inf in A or B must not reach C -- 0 * NaN would.  The guarded kernel over zero k-slabs with
+  // alpha = 0 computes exactly that (acc = 0; c = beta == 0 ? 0 : beta*c) without touching A or B.
+  // MKL's behaviour is pinned by tests/golden/mkl_golden_special.npz.
+  if (alpha == 0.f || K == 0) {
+    K = 0;
+    alpha = 0.f;
+  }
   // A: 'N' stored [M][K] -> XMAJOR; 'T' stored [K][M] -> KMAJOR
   // B: 'N' stored [K][N] -> KMAJOR; 'T' stored [N][K] -> XMAJOR
   if (!ta && !tb) return launch_modes<XMAJOR, KMAJOR>(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st, ep);

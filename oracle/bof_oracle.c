@@ -188,6 +188,15 @@ static inline float epilogue(float alpha, float acc, float beta, float cold) {
 static void sgemm_rm(int ta, int tb, int64_t m, int64_t n, int64_t k, float alpha,
                      const float *a, int64_t lda, const float *b, int64_t ldb,
                      float beta, float *c, int64_t ldc) {
+  /* cblas_sgemm's quick return (BLAS: "when alpha is zero or k is zero, A and B are not
+   * referenced"): C = beta*C, so NaN / Inf in A or B do not reach C.  Pinned by
+   * tests/golden/mkl_golden_special.npz (MKL 2021.4 at the reference's call site,
+   * include/tasks/gemm_task.h:87-90).  mkl_scsrmm has NO such path (same fixture): there
+   * alpha = 0 still multiplies the row sums. */
+  if (alpha == 0.0f || k == 0) {
+    k = 0;
+    alpha = 0.0f;
+  }
   float *acc = (float *) malloc(sizeof(float) * (size_t) (n > 0 ? n : 1));
   for (int64_t i = 0; i < m; i++) {
     for (int64_t j = 0; j < n; j++) acc[j] = 0.0f;
