@@ -20,3 +20,6 @@ def rel_err(got, ref):
     ref = np.asarray(ref, np.float64)
     d = np.abs(ref).max()
     return float(np.abs(got - ref).max() / (d if d > 0 else 1.0))
+
+
+from gpu_util_cpu import bits_equal_nan_aware, rel_err_elementwise, special_mismatch  # noqa: E402,F401

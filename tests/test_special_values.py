@@ -1,0 +1,222 @@
+"""Special values and quick returns at the reference's three MKL call sites (include/tasks/gemm_task.h:87-90,
+csrmm_task.h:226-228, csrgemv_task.h:74,165): NaN / Inf / -0 / denormals in the operands, alpha == 0 with NaN
+in A / B, beta == 0 with NaN in C, k == 0, explicit zero CSR values, empty rows.  Expected results are MKL
+2021.4's own (tests/golden/mkl_golden_special.npz, script make_golden_mkl_special.py).
+
+CPU part (`-m "not gpu"`): the oracle against the fixture.  GPU part: bof_sgemm / bof_scsrmm / bof_scsrgemv
+against the fixture (1e-4) and against the oracle bit for bit, then the same semantics through the tile DAG
+(level 2) and through files (level 3, both paths)."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util_cpu import bits_equal_nan_aware, special_mismatch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def special():
+    return np.load(os.path.join(ROOT, "tests", "golden", "mkl_golden_special.npz"))
+
+
+def gemm_cases(sp):
+    for key in [str(x) for x in sp["names"] if str(x).startswith("gemm_")]:
+        ord_, ta, tb, m, n, k, lda, ldb, ldc = [int(v) for v in sp[key + "_args"]]
+        alpha, beta = [float(v) for v in sp[key + "_ab"]]
+        yield (key, chr(ord_), chr(ta), chr(tb), m, n, k, alpha, beta, sp[key + "_a"], lda, sp[key + "_b"], ldb,
+               sp[key + "_c0"], ldc, sp[key + "_c"])
+
+
+def csrmm_cases(sp):
+    for key in [str(x) for x in sp["names"] if str(x).startswith("csrmm_")]:
+        ord_b, m, n, k = [int(v) for v in sp[key + "_args"]]
+        alpha, beta = [float(v) for v in sp[key + "_ab"]]
+        yield (key, chr(ord_b), m, n, k, alpha, beta, sp[key + "_val"], sp[key + "_ia"], sp[key + "_ja"], sp[key + "_b"],
+               sp[key + "_c0"], sp[key + "_c"])
+
+
+def csrgemv_cases(sp):
+    for key in [str(x) for x in sp["names"] if str(x).startswith("csrgemv_")]:
+        trans, m, n = [int(v) for v in sp[key + "_args"]]
+        yield key, chr(trans), m, n, sp[key + "_val"], sp[key + "_ia"], sp[key + "_ja"], sp[key + "_x"], sp[key + "_y"]
+
+
+def test_fixture_shows_the_semantics(special):
+    """the fixture itself: what MKL does at these edges (so the tests below pin behaviour, not a guess)"""
+    names = [str(x) for x in special["names"]]
+    assert len(names) >= 60
+    # cblas_sgemm, alpha == 0: A and B (with NaN / Inf) are not referenced -> C = beta * C exactly
+    k = "gemm_alpha0_nanAB_beta2_RNN_40"
+    assert np.array_equal(special[k + "_c"], 2.0 * special[k + "_c0"])
+    k = "gemm_alpha0_nanAB_beta0_RNN_40"
+    assert not np.isnan(special[k + "_c"]).any() and not special[k + "_c"].any() and np.isnan(special[k + "_c0"]).any()
+    # beta == 0: NaN / Inf in C do not survive
+    k = "gemm_beta0_nanC_RNN_40"
+    assert np.isnan(special[k + "_c0"]).any() and np.isfinite(special[k + "_c"]).all()
+    # k == 0 = the same quick return
+    k = "gemm_k0_beta2_RNN_40"
+    assert np.array_equal(special[k + "_c"], 2.0 * special[k + "_c0"])
+    # denormals are not flushed
+    k = "gemm_denormal_operand_RNN_40"
+    c = special[k + "_c"]
+    assert (np.abs(c[c != 0]) < np.finfo(np.float32).tiny).any()
+    # mkl_scsrmm has NO alpha == 0 shortcut: 0 * NaN reaches C; explicit zeros are multiplied
+    k = "csrmm_alpha0_nanB_beta2_R_8"
+    assert np.isnan(special[k + "_c"]).any()
+    k = "csrmm_explicit_zero_times_nan_R_8"
+    assert np.isnan(special[k + "_c"]).any()
+    # empty rows (5, 6) with beta == 0: zeros whatever C held
+    k = "csrmm_beta0_nanC_R_8"
+    assert not special[k + "_c"][5:7].any()
+
+
+def test_oracle_sgemm_special_values_vs_mkl(special):
+    n = 0
+    for key, ord_, ta, tb, m, nn, k, alpha, beta, a, lda, b, ldb, c0, ldc, want in gemm_cases(special):
+        got = orc.sgemm(ord_, ta, tb, m, nn, k, alpha, a, lda, b, ldb, beta, c0.copy(), ldc)
+        why = special_mismatch(got, want)
+        assert why is None, (key, why)
+        n += 1
+    assert n >= 30
+
+
+def test_oracle_scsrmm_special_values_vs_mkl(special):
+    for key, ord_b, m, n, k, alpha, beta, val, ia, ja, b, c0, want in csrmm_cases(special):
+        ldb = k if ord_b == "R" else n
+        ldc = k if ord_b == "R" else m
+        got = orc.scsrmm(ord_b, m, k, n, alpha, val, ja, ia, b, ldb, beta, c0.copy(), ldc)
+        why = special_mismatch(got, want)
+        assert why is None, (key, why)
+
+
+def test_oracle_scsrgemv_special_values_vs_mkl(special):
+    for key, trans, m, n, val, ia, ja, x, want in csrgemv_cases(special):
+        y = np.zeros(m if trans == "N" else n, np.float32)
+        got = orc.scsrgemv(trans, m, n, val, ia, ja, x, y)
+        why = special_mismatch(got, want)
+        assert why is None, (key, why)
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_bof_sgemm_special_values(dev, special):
+    import torch
+    import bofhip
+    from gpu_util import ptr, stream, to_dev
+    for key, ord_, ta, tb, m, n, k, alpha, beta, a, lda, b, ldb, c0, ldc, want in gemm_cases(special):
+        da, db, dc = to_dev(a), to_dev(b), to_dev(c0)
+        bofhip.sgemm(ord_, ta, tb, m, n, k, alpha, ptr(da), lda, ptr(db), ldb, beta, ptr(dc), ldc, stream())
+        torch.cuda.synchronize()
+        got = dc.cpu().numpy()
+        why = special_mismatch(got, want)
+        assert why is None, (key, "vs MKL", why)
+        ref = orc.sgemm(ord_, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c0.copy(), ldc)
+        assert bits_equal_nan_aware(got, ref), (key, "vs oracle")
+
+
+@pytest.mark.gpu
+def test_bof_scsrmm_special_values(dev, special):
+    import torch
+    import bofhip
+    from gpu_util import ptr, stream, to_dev
+    for key, ord_b, m, n, k, alpha, beta, val, ia, ja, b, c0, want in csrmm_cases(special):
+        ldb = k if ord_b == "R" else n
+        ldc = k if ord_b == "R" else m
+        dv, dj, di, db, dc = to_dev(val), to_dev(ja), to_dev(ia), to_dev(b), to_dev(c0)
+        bofhip.scsrmm(ord_b, m, k, n, alpha, ptr(dv), ptr(dj), ptr(di), ptr(db), ldb, beta, ptr(dc), ldc, stream())
+        torch.cuda.synchronize()
+        got = dc.cpu().numpy()
+        why = special_mismatch(got, want)
+        assert why is None, (key, "vs MKL", why)
+        ref = orc.scsrmm(ord_b, m, k, n, alpha, val, ja, ia, b, ldb, beta, c0.copy(), ldc)
+        assert bits_equal_nan_aware(got, ref), (key, "vs oracle")
+
+
+@pytest.mark.gpu
+def test_bof_scsrgemv_special_values(dev, special):
+    import torch
+    import bofhip
+    from gpu_util import ptr, stream, to_dev
+    for key, trans, m, n, val, ia, ja, x, want in csrgemv_cases(special):
+        dv, dj, di, dx = to_dev(val), to_dev(ja), to_dev(ia), to_dev(x)
+        dy = torch.zeros(m if trans == "N" else n, dtype=torch.float32, device=dev)
+        bofhip.scsrgemv(trans, m, n, ptr(dv), ptr(di), ptr(dj), ptr(dx), ptr(dy), stream())
+        torch.cuda.synchronize()
+        got = dy.cpu().numpy()
+        why = special_mismatch(got, want)
+        assert why is None, (key, "vs MKL", why)
+        if trans == "N":     # 'T' adds with atomics: order-dependent in the last bit
+            ref = orc.scsrgemv(trans, m, n, val, ia, ja, x, np.zeros(m, np.float32))
+            assert bits_equal_nan_aware(got, ref), (key, "vs oracle")
+
+
+def _poisoned_problem(rng, m, n, k):
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    a[::37, ::11] = np.nan
+    a[5, 7] = np.inf
+    b[::29, ::13] = np.nan
+    b[3, 2] = -np.inf
+    return a, b, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alpha,beta", [(0.0, 2.0), (0.0, 0.0), (0.0, 1.0)])
+def test_gemm_resident_alpha_zero_ignores_nan_operands(dev, alpha, beta):
+    """level 2: the tile DAG with alpha == 0 -- every task's quick return (chains: beta, then 1) -- leaves
+    C = beta * C with NaN / Inf all over A and B (gemm_task.h:87-90 through cblas_sgemm's semantics)."""
+    import torch
+    import bofhip
+    from gpu_util import ptr, stream, to_dev
+    rng = np.random.default_rng(5)
+    m, n, k, blk = 640, 600, 500, 256
+    a, b, c = _poisoned_problem(rng, m, n, k)
+    if beta == 0.0:
+        c[1, 1] = np.nan
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c)
+    bofhip.gemm_resident("R", "N", "N", m, n, k, alpha, beta, ptr(da), ptr(db), ptr(dc), 0, 0, 0,
+                         bofhip.default_options(gemm_blk=blk), stream())
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy()
+    want = orc.flash_gemm("R", "N", "N", m, n, k, alpha, beta, a, b, c.copy(), 0, 0, 0, blk)
+    assert bits_equal_nan_aware(got, want)
+    assert np.array_equal(got, np.float32(beta) * c) if beta != 0 else not got.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("alpha,beta", [(0.0, 2.0), (0.75, 0.0)])
+def test_flash_gemm_files_special_values(dev, tmp_path, path, alpha, beta):
+    """level 3, both paths: alpha == 0 with NaN / Inf in the A and B FILES (C = beta * C), and beta == 0 with
+    NaN in the C file (overwritten); against the oracle's flash::gemm bit for bit."""
+    import bofhip
+    rng = np.random.default_rng(6)
+    m, n, k, blk = 640, 600, 500, 256
+    a, b, c = _poisoned_problem(rng, m, n, k)
+    if alpha != 0.0:          # beta == 0 leg: clean operands, poisoned C
+        a = np.nan_to_num(a, nan=0.5, posinf=1.0, neginf=-1.0)
+        b = np.nan_to_num(b, nan=-0.5, posinf=1.0, neginf=-1.0)
+        c[::7, ::5] = np.nan
+        c[2, 2] = np.inf
+    want = orc.flash_gemm("R", "N", "N", m, n, k, alpha, beta, a, b, c.copy(), 0, 0, 0, blk)
+    paths = [str(tmp_path / x) for x in ("A", "B", "C")]
+    for x, p in zip((a, b, c), paths):
+        x.tofile(p)
+    fds = [os.open(p, os.O_RDWR) for p in paths]
+    try:
+        bofhip.flash_gemm("R", "N", "N", m, n, k, alpha, beta, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                          bofhip.FPtr(fds[2], 0), 0, 0, 0,
+                          bofhip.default_options(gemm_blk=blk, gemm_path=path, use_odirect=0, io_chunk_mib=1))
+    finally:
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+    got = np.fromfile(paths[2], np.float32).reshape(m, n)
+    assert bits_equal_nan_aware(got, want)
+    assert np.isfinite(got).all()
