@@ -117,6 +117,7 @@ SYMBOLS = [
     ("bof_share_selftest", i64, [C.c_char_p, C.c_int, C.c_int, i64, i64, C.c_int, C.c_double]),
     ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
                                           C.c_int32, C.POINTER(FlashStats)]),
+    ("bof_event_dump", u64, [C.c_char_p]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_forget", C.c_int, [C.c_int]),

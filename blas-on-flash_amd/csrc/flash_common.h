@@ -285,6 +285,29 @@ inline std::string io_error_text(int e) {
   return e > -1000 ? std::string(strerror(-e)) : "HIP error " + std::to_string(-1000 - e);
 }
 
+// ---- always-on event ring ------------------------------------------------------------------------------
+// Every hand-over of the level-3 pipelines (call begin / end, chunk read, H2D queued, panel ready, group
+// dispatched, D2H queued, D2H complete, chunk written, share-ring produce / consume, verify mismatch) leaves one
+// 32-byte record -- steady-clock nanoseconds, thread, a static label, three numbers -- in a process-wide ring
+// of the last 4096 events.  Recording is one relaxed fetch_add and four stores, so it is never switched off.
+// The ring is written out (oldest first, times relative to the newest call's begin) by StallWatch when a call
+// stops moving, by the BOF_VERIFY checks on a mismatch, at the end of every level-3 call when
+// $BOF_EVENT_DUMP names a file (appended), and by bof_event_dump(); a stall or a wrong tile therefore comes
+// with the last few thousand things the library did, whichever thread did them.
+struct EventRec {
+  uint64_t t_ns;
+  const char *what;     // string literal
+  uint32_t tid;
+  int32_t a, b;
+  uint32_t c;
+};
+constexpr uint32_t kEventRing = 4096;
+void evt(const char *what, int a = 0, int b = 0, uint64_t c = 0);
+void evt_dump(FILE *f, const char *why);             // whole ring, oldest first
+void evt_dump_env(const char *why);                  // to $BOF_EVENT_DUMP (append) when set
+void evt_mark_call_begin();
+uint64_t evt_count();                          // times in a dump are relative to the last of these
+
 // Watches one level-3 pipeline: `progress` is any number that changes while the call advances (bytes moved +
 // tasks launched).  When it has stood still for $BOF_STALL_TIMEOUT_S seconds (default 600; 0 = off) one line
 // goes to stderr and `on_stall` fails the call (-ETIMEDOUT -> BOF_EIO), so that everything parked on the
@@ -317,6 +340,8 @@ class StallWatch {
         if (idle < (double) limit) continue;
         fprintf(stderr, "[bof] %s: no progress for %.0f s (progress counter at %llu): failing the call\n", what, idle,
                 (unsigned long long) now);
+        evt("stall watchdog fired", 0, 0, now);
+        evt_dump(stderr, what);
         on_stall();
         return;
       }

@@ -411,6 +411,7 @@ void PanelHub::reader_main(int home) {
     } else {
       if (!io_error.load()) {
         TraceRange r("panel chunk read");
+        evt("panel chunk read begin", rq.mat, rq.panel, (uint64_t) rq.c);
         if (M0.widen) rc = file_read_widened(M0.fd, M0.file_off(rq.panel) + rq.off, rq.bytes, slot, &delta, M0.aio);
         else rc = file_sread(M0.fd, M0.file_off(rq.panel) + rq.off, 0, 1, rq.bytes, slot, M0.aio);
       }
@@ -419,6 +420,7 @@ void PanelHub::reader_main(int home) {
         const int prc = sg->ring.produce(ci, ok ? slot + delta : nullptr, rq.bytes, share_world, share_timeout_s, io_error);
         if (prc && prc != -ECANCELED && !rc) rc = prc;
       }
+      evt("panel chunk read end", rq.mat, rq.panel, (uint64_t) rq.c);
       if (rc) fail_io(rc);
       cnt.rd += rq.bytes;
       if (rq.di >= 0) R0.cnt.rd += rq.bytes;
@@ -455,6 +457,7 @@ void PanelHub::reader_main(int home) {
                               P.nr, R.h2d);
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           P.state = 2;
+          evt("panel H2D queued (ready recorded)", rq.mat, rq.panel, (uint64_t) R.di);
           R.trace2("read + H2D queued:", rq.mat, rq.panel);
         }
       }
@@ -474,6 +477,7 @@ void PanelRun::flusher_main() {
     Mat &C = mat[2];
     Panel &P = C.panels[(size_t) pc];
     hipError_t e = hipSuccess;
+    evt("C panel handed to the flusher", pc, di);
     for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
       if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
     const int nc = C.n_chunks(pc, chunk);
@@ -483,6 +487,7 @@ void PanelRun::flusher_main() {
       // a widened C panel lands in the pinned slot at its file offset modulo the page (file_write_split)
       const uint64_t delta = C.widen ? (C.file_off(pc) + off) % Mat::kPage : 0;
       const int ws = res->wring.acquire();
+      evt("C chunk D2H queued", pc, c, (uint64_t) ws);
       e = hipMemcpyAsync((char *) res->wring.ptr(ws) + delta, C.panel_ptr(pc) + off, len, hipMemcpyDeviceToHost, d2h);
       if (e == hipSuccess) e = hipEventRecord(res->wring.event(ws), d2h);
       if (e != hipSuccess) { res->wring.release(ws); break; }
@@ -512,6 +517,7 @@ void PanelHub::writer_main(int home) {
     PanelRun &R = *runs[(size_t) rq.di];
     hipError_t e = hipEventSynchronize(R.res->wring.event(rq.wslot));
     if (e != hipSuccess) fail_io(-1000 - (int) e);
+    evt("C chunk D2H complete, write begin", rq.panel, rq.wslot, rq.file_off >> 20);
     int rc = 0;
     if (!io_error.load()) {
       TraceRange r("panel chunk write");
@@ -520,6 +526,7 @@ void PanelHub::writer_main(int home) {
       else
         rc = file_swrite(R.mat[2].fd, rq.file_off, 0, 1, rq.bytes, R.res->wring.ptr(rq.wslot), R.mat[2].aio);
     }
+    evt("C chunk write end", rq.panel, rq.wslot, rq.file_off >> 20);
     if (rc) fail_io(rc);
     cnt.wr += rq.bytes;
     R.cnt.wr += rq.bytes;
@@ -835,6 +842,7 @@ void PanelRun::dispatch() {
       H.pump_fetches();
     }
     for (int64_t pc = G0; pc < G1; pc++) flush_q.push((int) pc);
+    evt("group dispatched", gi, di, (uint64_t) t);
     if (trace_on()) {
       char lbl[64];
       snprintf(lbl, sizeof(lbl), "group %d dispatched", gi);
@@ -890,6 +898,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
                       const bof_options &o, const std::vector<int> &devs, const KmeansHost *kh) {
   PanelHub H;
   H.t_begin = std::chrono::steady_clock::now();
+  evt_mark_call_begin();
+  evt("bof_flash_gemm (panels) begin", (int) m, (int) n, (uint64_t) k);
   const GemmGeometry gfull = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
   if (gfull.nblk[0] * gfull.nblk[2] == 0 || gfull.nblk[1] == 0) return 1;
   int caller_dev = 0;
@@ -1066,6 +1076,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   }
   (void) hipSetDevice(caller_dev);
   H.trace("drained (writes done)");
+  evt("bof_flash_gemm (panels) drained", nd, 0, H.cnt.tasks.load());
+  evt_dump_env("bof_flash_gemm (panels)");
   int fail = 0;
   for (auto &R : H.runs) {
     if (R->herr != hipSuccess && !fail) fail = hip_fail(R->herr, "bof_flash_gemm (panels) dispatch");

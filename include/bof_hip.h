@@ -394,6 +394,16 @@ int bof_share_cleanup(const char *share_name);
 int64_t bof_share_selftest(const char *share_name, int rank, int world, int64_t n_chunks,
                            int64_t chunk_bytes, int n_slots, double timeout_s);
 
+/* ---- instrumentation --------------------------------------------------------------------------
+ * Event ring: every hand-over inside the level-3 pipelines (chunk read, H2D queued, panel ready,
+ * group dispatched, D2H queued / complete, chunk written, staging-ring produce / consume, watchdog,
+ * verify mismatch) is recorded -- always, it costs one atomic increment -- in a process-wide ring of
+ * the last 4096 events.  bof_event_dump appends the ring to `path` (NULL = stderr), oldest first, times
+ * in ms relative to the newest level-3 call's begin; the library does the same by itself when its
+ * stall watchdog fires, when a BOF_VERIFY check fails, and after every level-3 call when
+ * $BOF_EVENT_DUMP names a file.  Returns the number of events recorded so far. */
+uint64_t bof_event_dump(const char *path);
+
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
  * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided
  * region {stride, n_strides, len_per_stride} in bytes <-> packed host buffer. */

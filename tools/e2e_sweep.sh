@@ -42,6 +42,18 @@ writeback)  # where does the O_DIRECT tail come from: verbose timeline, writer p
   run trace2_buffered BOF_TRACE=2 -- --path 2 --direct 0 --reps 1
   for w in 2 8; do run writers$w BOF_PANEL_WRITERS=$w -- --path 2 --direct 1; done
   run writers8_pinned16 BOF_PANEL_WRITERS=8 -- --path 2 --direct 1 --pinned 16 ;;
+r4)         # round 4: the write-back phase of the O_DIRECT call (reads end at ~0.45 s, writes trail to ~0.8 s)
+  run base X=1 -- --path 2 --direct 1 --reps 3 --streams 1
+  for w in 8 12 16; do run writers$w BOF_PANEL_WRITERS=$w -- --path 2 --direct 1 --reps 3 --streams 1; done
+  run writers8_pinned16 BOF_PANEL_WRITERS=8 -- --path 2 --direct 1 --reps 3 --streams 1 --pinned 16
+  run writers16_pinned16 BOF_PANEL_WRITERS=16 -- --path 2 --direct 1 --reps 3 --streams 1 --pinned 16
+  run thr12_writers8 BOF_PANEL_WRITERS=8 -- --path 2 --direct 1 --reps 3 --streams 1 --io-threads 12 --pinned 12
+  run writers8_req8M BOF_PANEL_WRITERS=8 BOF_IO_REQUEST_KIB=8192 -- --path 2 --direct 1 --reps 3 --streams 1
+  run writers8_req2M BOF_PANEL_WRITERS=8 BOF_IO_REQUEST_KIB=2048 -- --path 2 --direct 1 --reps 3 --streams 1
+  run writers8_uring BOF_PANEL_WRITERS=8 BOF_IO_ENGINE=uring -- --path 2 --direct 1 --reps 3 --streams 1
+  run writers8_group3 BOF_PANEL_WRITERS=8 BOF_PANEL_GROUP=3 -- --path 2 --direct 1 --reps 3 --streams 1
+  run writers8_trace2 BOF_PANEL_WRITERS=8 BOF_TRACE=2 -- --path 2 --direct 1 --reps 2 --streams 1
+  run base_again X=1 -- --path 2 --direct 1 --reps 3 --streams 1 ;;
 engines)    # kernel AIO vs io_uring (contexts / rings pooled), thread counts, request sizes
   for e in aio uring; do
     run ${e} BOF_IO_ENGINE=$e -- --path 2 --reps 3
