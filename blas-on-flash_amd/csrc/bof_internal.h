@@ -82,6 +82,11 @@ hipError_t gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t
 hipError_t gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols, int64_t nnz_per_row,
                            float *csr, int64_t *col, int64_t *off, hipStream_t st);
 
+// BOF_VERIFY (gen_kernels.hip): out2[0] += sum of the 32-bit words of a 2-D region, out2[1] += sum of
+// word * (logical index + 1); t_pitch > 0: the region is the transposed image of the logical object
+hipError_t verify_sum(const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base,
+                      int64_t t_pitch, unsigned long long *out2, hipStream_t st);
+
 // ---- tilers (plan.cpp) ----------------------------------------------------------
 struct GemmGeometry {
   int64_t size[3];  // m, k, n

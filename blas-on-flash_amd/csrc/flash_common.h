@@ -27,6 +27,7 @@ namespace bof {
 struct Counters {
   std::atomic<uint64_t> rd{0}, wr{0}, h2d{0}, d2h{0}, tasks{0}, hits{0}, misses{0}, peer{0};
   std::atomic<uint64_t> klaunch{0}, kns{0};   // KernelTimer: timed tile tasks and their summed durations (ns)
+  std::atomic<uint64_t> p2p{0}, vchecks{0};   // device-to-device bytes of a shared operand; BOF_VERIFY pairs compared
   uint64_t ops0[2];  // file_io_ops() when the call began
   Counters() { file_io_ops(&ops0[0], &ops0[1]); }
 };
@@ -307,6 +308,82 @@ void evt_dump(FILE *f, const char *why);             // whole ring, oldest first
 void evt_dump_env(const char *why);                  // to $BOF_EVENT_DUMP (append) when set
 void evt_mark_call_begin();
 uint64_t evt_count();                          // times in a dump are relative to the last of these
+
+// ---- BOF_VERIFY: hand-over checksums (bof_options.verify / $BOF_VERIFY) ------------------------------------
+// Every object a level-3 GEMM pipeline moves (a row panel; a packed tile) is summed at each hand-over -- in the
+// pinned slot after the file read, in HBM behind the H2D copies, in HBM again behind the last kernel that used
+// it (before its slot is refilled, or at the end of the call), C in HBM behind its last kernel, in the pinned
+// slot behind the D2H copy, and in the file once the call's writes have drained -- as two 64-bit sums (words,
+// and words weighted by their logical position in the object; verify_sum_kernel / host_word_sums).  The sums
+// of one object at two points must agree; the pairs are compared on the host when the call has drained, the
+// first divergence is named (which object, between which two points), the event ring is dumped and the call
+// fails with BOF_EVERIFY.  Off by default: it reads every byte several more times.
+inline void host_word_sums(const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base,
+                           uint64_t out[2]) {
+  uint64_t s1 = 0, s2 = 0;
+  const uint32_t *w = (const uint32_t *) p;
+  for (int64_t r = 0; r < rows; r++) {
+    const uint32_t *row = w + r * pitch_words;
+    uint64_t li = index_base + (uint64_t) (r * row_words) + 1;
+    for (int64_t c = 0; c < row_words; c++, li++) {
+      s1 += row[c];
+      s2 += (uint64_t) row[c] * li;
+    }
+  }
+  out[0] = s1;
+  out[1] = s2;
+}
+inline bool verify_wanted(const bof_options &o) {
+  if (o.verify == 1) return true;
+  if (o.verify == 2) return false;
+  const char *e = getenv("BOF_VERIFY");
+  return e && e[0] && strcmp(e, "0") != 0;
+}
+class Verify {
+  struct Expect { size_t a, b; const char *what; int id0, id1, id2; };
+  unsigned long long *d_tab = nullptr;          // 2 per entry, in the HBM of `dev`
+  std::vector<std::atomic<uint64_t>> h_tab;     // 2 per entry
+  std::vector<std::atomic<uint8_t>> touched;    // bit 0: host side filled, bit 1: device side filled
+  std::atomic<size_t> next{0};
+  size_t cap = 0;
+  std::mutex mu;
+  std::vector<Expect> expects;
+  int dev = 0;
+
+ public:
+  static constexpr size_t kNone = (size_t) -1;
+  bool on = false;
+  ~Verify() { release(); }
+  int init(int device, size_t capacity);        // BOF_OK / BOF_EHIP; the table lives on `device`
+  void release();
+  size_t entry() {
+    if (!on) return kNone;
+    const size_t e = next.fetch_add(1);
+    return e < cap ? e : kNone;
+  }
+  hipError_t on_device(size_t e, const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base,
+                       int64_t t_pitch, hipStream_t st) {
+    if (!on || e == kNone) return hipSuccess;
+    touched[e].fetch_or(2);
+    return verify_sum(p, rows, row_words, pitch_words, index_base, t_pitch, d_tab + 2 * e, st);
+  }
+  void on_host(size_t e, const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base) {
+    if (!on || e == kNone) return;
+    uint64_t s[2];
+    host_word_sums(p, rows, row_words, pitch_words, index_base, s);
+    h_tab[2 * e].fetch_add(s[0], std::memory_order_relaxed);
+    h_tab[2 * e + 1].fetch_add(s[1], std::memory_order_relaxed);
+    touched[e].fetch_or(1);
+  }
+  void expect(size_t a, size_t b, const char *what, int id0 = 0, int id1 = 0, int id2 = 0) {
+    if (!on || a == kNone || b == kNone) return;
+    std::lock_guard<std::mutex> lk(mu);
+    expects.push_back(Expect{a, b, what, id0, id1, id2});
+  }
+  // The device must be idle (the call has drained).  Compares every expected pair both of whose sides were
+  // filled; BOF_OK, or BOF_EVERIFY with the first divergence in bof_last_error() and the event ring on stderr.
+  int finish(Counters &cnt, const char *call);
+};
 
 // Watches one level-3 pipeline: `progress` is any number that changes while the call advances (bytes moved +
 // tasks launched).  When it has stood still for $BOF_STALL_TIMEOUT_S seconds (default 600; 0 = off) one line

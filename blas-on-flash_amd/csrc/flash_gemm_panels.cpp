@@ -99,6 +99,11 @@ struct Panel {
   hipEvent_t ready = nullptr;   // recorded on the H2D stream behind the panel's last copy
   hipEvent_t d2h_done = nullptr;
   std::vector<hipEvent_t> retire_ev;  // what the slot's next occupant must wait for
+  // BOF_VERIFY entries of this panel (Verify::kNone = not checked)
+  enum { VE_HOST_IN, VE_DEV_IN, VE_DEV_LAST, VE_RECT_IN, VE_T_IN, VE_T_LAST, VE_C_DEV, VE_C_HOST, VE_C_FILE, VE_N };
+  size_t ve[VE_N] = {Verify::kNone, Verify::kNone, Verify::kNone, Verify::kNone, Verify::kNone,
+                     Verify::kNone, Verify::kNone, Verify::kNone, Verify::kNone};
+  bool v_last_done = false;     // its HBM image has had its after-last-use sum queued (guarded by PanelRun::vf_mu)
 };
 
 struct Mat {
@@ -247,6 +252,11 @@ struct PanelRun {
   bool has_kv = false;
   Counters cnt;                                   // this device's share of the counters
   KernelTimer ktimer;                             // bof_options.kernel_timing
+  Verify vf;                                      // bof_options.verify: hand-over checksums of this device's panels
+  std::mutex vf_mu;                               // orders "sum the slot's old panel" before the first copy of the new one
+  int verify_setup();
+  hipError_t verify_last_use(int x, int p, hipStream_t st);   // caller holds vf_mu
+  int verify_finish();
   hipError_t herr = hipSuccess;
   int fail = 0;
   double seconds = 0;
@@ -435,8 +445,19 @@ void PanelHub::reader_main(int home) {
       if (prev >= 0)  // WAR: the slot's previous occupant (its events were recorded before it retired)
         for (hipEvent_t w : M.panels[(size_t) prev].retire_ev)
           if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, w, 0);
+      std::unique_lock<std::mutex> vlk(R.vf_mu, std::defer_lock);
+      if (R.vf.on && !rc) {
+        R.vf.on_host(M.panels[(size_t) rq.panel].ve[Panel::VE_HOST_IN], slot + delta, 1, (int64_t) (rq.bytes / 4), 0, rq.off / 4);
+        // self-test of the instrumentation ($BOF_VERIFY_INJECT=1): damage one word between the sum and the copy
+        if (rq.mat == 1 && rq.panel == 0 && rq.c == 0 && env_long("BOF_VERIFY_INJECT", 0) == 1) ((uint32_t *) (slot + delta))[3] ^= 0x00400000u;
+        // the slot's old panel is summed once more behind its last kernel and BEFORE any chunk of the new one
+        // lands (whichever reader comes first queues it; the lock keeps its copy behind the sum)
+        vlk.lock();
+        if (prev >= 0 && e == hipSuccess) e = R.verify_last_use(rq.mat, prev, R.h2d);
+      }
       if (e == hipSuccess && !rc)
         e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, slot + delta, rq.bytes, hipMemcpyHostToDevice, R.h2d);
+      if (vlk.owns_lock()) vlk.unlock();
       if (e == hipSuccess && rring->mark_busy(ps, R.h2d, R.di)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
       cnt.h2d += rq.bytes;
       R.cnt.h2d += rq.bytes;
@@ -452,9 +473,14 @@ void PanelHub::reader_main(int home) {
         Panel &P = M.panels[(size_t) rq.panel];
         if (--P.remaining == 0) {
           if (e == hipSuccess) e = hipSetDevice(R.dev);
+          if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
+          if (e == hipSuccess && M.kmajor_copy)
+            e = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
           if (e == hipSuccess && M.kmajor_copy)
             e = transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
                               P.nr, R.h2d);
+          if (e == hipSuccess && M.kmajor_copy)
+            e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.ld, R.h2d);
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           P.state = 2;
           evt("panel H2D queued (ready recorded)", rq.mat, rq.panel, (uint64_t) R.di);
@@ -480,6 +506,7 @@ void PanelRun::flusher_main() {
     evt("C panel handed to the flusher", pc, di);
     for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
       if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
+    if (e == hipSuccess) e = vf.on_device(P.ve[Panel::VE_C_DEV], C.panel_ptr(pc), 1, (int64_t) (P.bytes / 4), 0, 0, 0, d2h);
     const int nc = C.n_chunks(pc, chunk);
     for (int c = 0; c < nc && e == hipSuccess && !hub->io_error.load(); c++) {
       uint64_t off, len;
@@ -518,6 +545,11 @@ void PanelHub::writer_main(int home) {
     hipError_t e = hipEventSynchronize(R.res->wring.event(rq.wslot));
     if (e != hipSuccess) fail_io(-1000 - (int) e);
     evt("C chunk D2H complete, write begin", rq.panel, rq.wslot, rq.file_off >> 20);
+    if (R.vf.on && e == hipSuccess)
+      R.vf.on_host(R.mat[2].panels[(size_t) rq.panel].ve[Panel::VE_C_HOST], (char *) R.res->wring.ptr(rq.wslot) + rq.delta, 1,
+                   (int64_t) (rq.bytes / 4), 0, (rq.file_off - R.mat[2].file_off(rq.panel)) / 4);
+    if (R.vf.on && rq.panel == 0 && rq.file_off == R.mat[2].file_off(0) && env_long("BOF_VERIFY_INJECT", 0) == 2)
+      ((uint32_t *) ((char *) R.res->wring.ptr(rq.wslot) + rq.delta))[5] ^= 0x00400000u;      // ($BOF_VERIFY_INJECT=2)
     int rc = 0;
     if (!io_error.load()) {
       TraceRange r("panel chunk write");
@@ -754,7 +786,105 @@ int PanelRun::prepare() {
   if (rc) return rc;
   BOF_HIP_TRY(copy_stream_create(&h2d));
   BOF_HIP_TRY(copy_stream_create(&d2h));
+  return verify_setup();
+}
+
+// BOF_VERIFY: one table per device; per panel the hand-over points it passes and which of them must agree
+int PanelRun::verify_setup() {
+  if (!verify_wanted(o)) return BOF_OK;
+  size_t n = 0;
+  for (int x = 0; x < 3; x++) n += mat[x].panels.size();
+  const int rc = vf.init(dev, n * Panel::VE_N + 16);
+  if (rc) return rc;
+  for (int x = 0; x < 3; x++) {
+    Mat &M = mat[x];
+    bool words = (M.f.foffset % 4) == 0;
+    for (size_t p = 0; p < M.panels.size() && words; p++)
+      for (int c = 0; c < M.n_chunks((int) p, chunk); c++) {
+        uint64_t off, len;
+        M.chunk_span((int) p, c, chunk, &off, &len);
+        words = words && off % 4 == 0 && len % 4 == 0;
+      }
+    if (!words) continue;       // byte-granular cuts (never with float matrices at float offsets): not summed
+    for (size_t p = 0; p < M.panels.size(); p++) {
+      Panel &P = M.panels[p];
+      if (x < 2 || c_read) {
+        P.ve[Panel::VE_HOST_IN] = vf.entry();
+        P.ve[Panel::VE_DEV_IN] = vf.entry();
+        vf.expect(P.ve[Panel::VE_HOST_IN], P.ve[Panel::VE_DEV_IN], "panel: pinned slot after the file read vs HBM after H2D (mat, panel, device)",
+                  x, (int) p, di);
+      }
+      if (x < 2) {
+        P.ve[Panel::VE_DEV_LAST] = vf.entry();
+        vf.expect(P.ve[Panel::VE_DEV_IN], P.ve[Panel::VE_DEV_LAST], "panel: HBM after H2D vs HBM after its last use (mat, panel, device)", x,
+                  (int) p, di);
+        if (M.kmajor_copy) {
+          P.ve[Panel::VE_RECT_IN] = vf.entry();
+          P.ve[Panel::VE_T_IN] = vf.entry();
+          P.ve[Panel::VE_T_LAST] = vf.entry();
+          vf.expect(P.ve[Panel::VE_RECT_IN], P.ve[Panel::VE_T_IN], "panel: HBM image vs its k-major copy (mat, panel, device)", x, (int) p, di);
+          vf.expect(P.ve[Panel::VE_T_IN], P.ve[Panel::VE_T_LAST], "panel: k-major copy when made vs after its last use (mat, panel, device)", x,
+                    (int) p, di);
+        }
+      } else {
+        P.ve[Panel::VE_C_DEV] = vf.entry();
+        P.ve[Panel::VE_C_HOST] = vf.entry();
+        P.ve[Panel::VE_C_FILE] = vf.entry();
+        vf.expect(P.ve[Panel::VE_C_DEV], P.ve[Panel::VE_C_HOST], "C panel: HBM after its last kernel vs pinned slot after D2H (panel, device)",
+                  (int) p, di);
+        vf.expect(P.ve[Panel::VE_C_HOST], P.ve[Panel::VE_C_FILE], "C panel: pinned slot after D2H vs the file after the write (panel, device)",
+                  (int) p, di);
+      }
+    }
+  }
   return BOF_OK;
+}
+
+// the HBM image of panel p of operand x has seen its last kernel (st is ordered behind it): sum it once more
+hipError_t PanelRun::verify_last_use(int x, int p, hipStream_t st) {
+  Mat &M = mat[x];
+  Panel &P = M.panels[(size_t) p];
+  if (!vf.on || P.v_last_done || x > 1) return hipSuccess;
+  P.v_last_done = true;
+  hipError_t e = vf.on_device(P.ve[Panel::VE_DEV_LAST], M.panel_ptr(p), 1, (int64_t) (P.bytes / 4), 0, 0, 0, st);
+  if (e == hipSuccess && M.kmajor_copy)
+    e = vf.on_device(P.ve[Panel::VE_T_LAST], M.tpanel_ptr(p), M.cols, P.nr, P.nr, 0, M.ld, st);
+  return e;
+}
+
+// after the call has drained (device idle, writes done): the panels still in HBM, C back from its file, then
+// the comparison.  BOF_OK / BOF_EVERIFY / BOF_EIO.
+int PanelRun::verify_finish() {
+  if (!vf.on) return BOF_OK;
+  DeviceScope scope(dev);
+  {
+    std::lock_guard<std::mutex> lk(vf_mu);
+    for (int x = 0; x < 2; x++)
+      for (size_t p = 0; p < mat[x].panels.size(); p++)
+        if (mat[x].panels[p].state == 2 && mat[x].panel_ptr((int) p) &&
+            (mat[x].natural || p + (size_t) mat[x].n_slots >= mat[x].panels.size()))
+          BOF_HIP_TRY(verify_last_use(x, (int) p, h2d));
+  }
+  BOF_HIP_TRY(hipStreamSynchronize(h2d));
+  Mat &C = mat[2];
+  if (!C.panels.empty() && C.panels[0].ve[Panel::VE_C_FILE] != Verify::kNone) {
+    const int fd = file_is_direct(C.f.fd) ? file_buffered_fd(C.f.fd) : C.f.fd;
+    std::vector<char> buf(8u << 20);
+    for (size_t p = 0; p < C.panels.size() && fd >= 0; p++) {
+      const Panel &P = C.panels[p];
+      for (uint64_t off = 0; off < P.bytes; off += buf.size()) {
+        const size_t len = (size_t) std::min<uint64_t>(buf.size(), P.bytes - off);
+        size_t got = 0;
+        while (got < len) {
+          const ssize_t r = pread(fd, buf.data() + got, len - got, (off_t) (C.file_off((int) p) + off + got));
+          if (r <= 0) { set_error("BOF_VERIFY: re-reading C from its file failed"); return BOF_EIO; }
+          got += (size_t) r;
+        }
+        vf.on_host(P.ve[Panel::VE_C_FILE], buf.data(), 1, (int64_t) (len / 4), 0, off / 4);
+      }
+    }
+  }
+  return vf.finish(cnt, "bof_flash_gemm (panels)");
 }
 
 // the device's tile launches, in schedule order
@@ -1077,8 +1207,16 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   (void) hipSetDevice(caller_dev);
   H.trace("drained (writes done)");
   evt("bof_flash_gemm (panels) drained", nd, 0, H.cnt.tasks.load());
-  evt_dump_env("bof_flash_gemm (panels)");
   int fail = 0;
+  if (!H.io_error.load())
+    for (auto &R : H.runs) {
+      const bool clean = R->herr == hipSuccess && !R->fail;
+      const int vrc = clean ? R->verify_finish() : BOF_OK;
+      H.cnt.vchecks += R->cnt.vchecks.load();
+      if (vrc && !fail) fail = vrc;
+    }
+  (void) hipSetDevice(caller_dev);
+  evt_dump_env("bof_flash_gemm (panels)");
   for (auto &R : H.runs) {
     if (R->herr != hipSuccess && !fail) fail = hip_fail(R->herr, "bof_flash_gemm (panels) dispatch");
     if (R->fail && !fail) fail = R->fail;
@@ -1097,6 +1235,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     s.bytes_read = R.cnt.rd; s.bytes_written = R.cnt.wr; s.bytes_h2d = R.cnt.h2d; s.bytes_d2h = R.cnt.d2h;
     s.tasks = R.cnt.tasks; s.seconds = R.seconds;
     s.kernel_launches = R.cnt.klaunch; s.kernel_seconds = (double) R.cnt.kns.load() * 1e-9;
+    s.verify_checks = R.cnt.vchecks;
     per[(size_t) d] = s;
   }
   publish_device_stats(per);

@@ -39,6 +39,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -80,6 +81,8 @@ void publish_stats(const Counters &c, double seconds) {
   g_last_stats.bytes_peer = c.peer;
   g_last_stats.kernel_launches = c.klaunch;
   g_last_stats.kernel_seconds = (double) c.kns.load() * 1e-9;
+  g_last_stats.bytes_p2p = c.p2p;
+  g_last_stats.verify_checks = c.vchecks;
   uint64_t r = 0, w = 0;
   file_io_ops(&r, &w);
   g_last_stats.read_ops = r - c.ops0[0]; g_last_stats.write_ops = w - c.ops0[1];
@@ -103,6 +106,12 @@ struct Tile {
   bool pinned_c = false;             // C accumulator in the middle of its chain
   std::vector<hipEvent_t> launch_waits;  // events the first kernel must wait for (no-fetch alloc)
   int rb = 0, cb = 0;                // block row / block column of the STORED matrix
+  // BOF_VERIFY entries of the tile's current stay in HBM (Verify::kNone = not checked)
+  size_t ve_host = Verify::kNone, ve_in = Verify::kNone;        // pinned chunk after the read / packed slot after H2D
+  size_t ve_chost = Verify::kNone, ve_cfile = Verify::kNone;    // C: pinned chunk after D2H / file after the write
+  // a slot taken without a fetch (C, beta == 0): what sat there before, summed once more ahead of the first kernel
+  size_t prev_ve_in = Verify::kNone;
+  int64_t prev_rows = 0, prev_cols = 0;
 };
 
 struct DevSlot {
@@ -140,9 +149,14 @@ struct RowGroup {
   int64_t nrows = 0, width = 0, col0 = 0;   // rows of the block row; elements per group row; first stored column
   int64_t rows_per_chunk = 0;
   int remaining = 0;                        // chunks whose copies are not enqueued yet (guarded by mu)
+  // BOF_VERIFY: per tile, the previous occupant of its slot (entry of its after-H2D sum, packed shape)
+  std::vector<size_t> prev_ve_in;
+  std::vector<int64_t> prev_rows, prev_cols;
+  std::vector<char> prev_done;              // its after-last-use sum has been queued (guarded by GemmRun::vf_mu)
 };
 struct FetchReq { RowGroup *grp; int64_t r0, nr; };
-struct WriteReq { int wslot; uint64_t file_off, stride, nrows, len; };
+struct WTile { size_t ve_chost; int64_t col, ncols; };       // BOF_VERIFY: a C tile's columns inside a write-back chunk
+struct WriteReq { int wslot; uint64_t file_off, stride, nrows, len; int64_t r0; std::shared_ptr<std::vector<WTile>> vt; };
 
 // ---- schedule construction and slot replacement: pure host logic, shared by the real
 // ---- pipeline and by bof_flash_gemm_simulate (so the policy is testable without a GPU)
@@ -373,9 +387,23 @@ struct GemmRun {
         for (hipEvent_t w : G.waits[q])  // WAR: previous occupant's kernels / write-back (every chunk: cheap, order-free)
           if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
         const size_t tw = (size_t) t.ncols * 4;
+        std::unique_lock<std::mutex> vlk(vf_mu, std::defer_lock);
+        if (vf.on && !rc) {
+          vf.on_host(t.ve_host, (const char *) res->rring.ptr(ps) + (size_t) col * 4, rq.nr, t.ncols, G.width,
+                     (uint64_t) (rq.r0 * t.ncols));
+          // self-test of the instrumentation ($BOF_VERIFY_INJECT=1): damage one word between the sum and the copy
+          if (t.mat == 1 && rq.r0 == 0 && q == 0 && env_long("BOF_VERIFY_INJECT", 0) == 1)
+            ((uint32_t *) ((char *) res->rring.ptr(ps) + (size_t) col * 4))[1] ^= 0x00400000u;
+          vlk.lock();      // the slot's old tile is summed before ANY chunk of the new one lands
+          if (!G.prev_done[q]) {
+            G.prev_done[q] = 1;
+            if (e == hipSuccess) e = verify_old_tile(G.prev_ve_in[q], s.ptr, G.prev_rows[q], G.prev_cols[q], h2d, G.tiles[q]);
+          }
+        }
         if (e == hipSuccess && !rc)
           e = hipMemcpy2DAsync(s.ptr + (size_t) rq.r0 * tw, tw, (const char *) res->rring.ptr(ps) + (size_t) col * 4,
                                (size_t) row_bytes, tw, (size_t) rq.nr, hipMemcpyHostToDevice, h2d);
+        if (vlk.owns_lock()) vlk.unlock();
         col += t.ncols;
       }
       if (e == hipSuccess && res->rring.mark_busy(ps, h2d)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
@@ -389,6 +417,8 @@ struct GemmRun {
         if (--G.remaining == 0) {
           last = true;
           for (size_t q = 0; q < G.tiles.size(); q++) {
+            const Tile &tq = tiles[G.tiles[q]];
+            if (e == hipSuccess) e = vf.on_device(tq.ve_in, slots[G.slots[q]].ptr, tq.nrows, tq.ncols, tq.ncols, 0, 0, h2d);
             if (e == hipSuccess) e = hipEventRecord(slots[G.slots[q]].ready, h2d);
             tiles[G.tiles[q]].state = 2;
           }
@@ -407,6 +437,12 @@ struct GemmRun {
     while (write_q.pop(rq)) {
       hipError_t e = hipEventSynchronize(res->wring.event(rq.wslot));
       if (e != hipSuccess) fail_io(-1000 - (int) e);
+      if (vf.on && rq.vt && e == hipSuccess)
+        for (const WTile &w : *rq.vt)
+          vf.on_host(w.ve_chost, (const char *) res->wring.ptr(rq.wslot) + (size_t) w.col * 4, (int64_t) rq.nrows, w.ncols,
+                     (int64_t) (rq.len / 4), (uint64_t) (rq.r0 * w.ncols));
+      if (vf.on && rq.vt && rq.r0 == 0 && env_long("BOF_VERIFY_INJECT", 0) == 2)
+        ((uint32_t *) res->wring.ptr(rq.wslot))[2] ^= 0x00400000u;            // ($BOF_VERIFY_INJECT=2)
       int rc = 0;
       if (!io_error.load())
         rc = file_swrite(fd_io[2], rq.file_off, rq.stride, rq.nrows, rq.len, res->wring.ptr(rq.wslot), aio_io[2]);
@@ -422,6 +458,14 @@ struct GemmRun {
     if (sl < 0) return -1;
     cnt.misses++;
     DevSlot &s = slots[sl];
+    // BOF_VERIFY: what the slot held (an A / B tile whose image must still be what its H2D copy delivered)
+    tiles[tid].prev_ve_in = Verify::kNone;
+    if (vf.on && s.tile >= 0 && tiles[s.tile].mat < 2) {
+      tiles[tid].prev_ve_in = tiles[s.tile].ve_in;
+      tiles[tid].prev_rows = tiles[s.tile].nrows;
+      tiles[tid].prev_cols = tiles[s.tile].ncols;
+      tiles[s.tile].ve_in = Verify::kNone;
+    }
     for (int q = 0; q <= kMaxStreams; q++)
       if (s.used[q]) { waits.push_back(s.use[q]); s.used[q] = false; }
     s.tile = tid;
@@ -467,6 +511,15 @@ struct GemmRun {
       tiles[id].state = 1;
       if (tiles[id].mat == 2) tiles[id].pinned_c = true;    // its chain is about to start: not evictable
       G->tiles.push_back(id); G->slots.push_back(tiles[id].slot); G->waits.push_back(w);
+      G->prev_ve_in.push_back(tiles[id].prev_ve_in); G->prev_rows.push_back(tiles[id].prev_rows);
+      G->prev_cols.push_back(tiles[id].prev_cols); G->prev_done.push_back(0);
+      tiles[id].prev_ve_in = Verify::kNone;
+      if (vf.on) {
+        tiles[id].ve_host = vf.entry();
+        tiles[id].ve_in = vf.entry();
+        vf.expect(tiles[id].ve_host, tiles[id].ve_in, "tile: pinned chunk after the file read vs packed slot after H2D (tile id, mat)", id,
+                  tiles[id].mat);
+      }
     };
     for (size_t q = left.size(); q-- > 0;) add(left[q].first, left[q].second);
     add(tid, w0);
@@ -496,6 +549,22 @@ struct GemmRun {
     hipError_t e = hipSuccess;
     for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++)
       e = hipStreamWaitEvent(d2h, slots[tiles[wgroup[q]].slot].use[wgroup_stream[q]], 0);
+    std::shared_ptr<std::vector<WTile>> vt;
+    if (vf.on) {
+      vt = std::make_shared<std::vector<WTile>>();
+      int64_t col = 0;
+      for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++) {
+        Tile &t = tiles[wgroup[q]];
+        const size_t ve_dev = vf.entry();
+        t.ve_chost = vf.entry();
+        t.ve_cfile = vf.entry();
+        vf.expect(ve_dev, t.ve_chost, "C tile: packed slot after its last kernel vs pinned chunk after D2H (tile id)", wgroup[q]);
+        vf.expect(t.ve_chost, t.ve_cfile, "C tile: pinned chunk after D2H vs the file after the write (tile id)", wgroup[q]);
+        e = vf.on_device(ve_dev, slots[t.slot].ptr, t.nrows, t.ncols, t.ncols, 0, 0, d2h);
+        vt->push_back(WTile{t.ve_chost, col, t.ncols});
+        col += t.ncols;
+      }
+    }
     for (int64_t r0 = 0; r0 < nrows && e == hipSuccess; r0 += rpc) {
       const int64_t nr = std::min(rpc, nrows - r0);
       const int ws = res->wring.acquire();
@@ -511,7 +580,7 @@ struct GemmRun {
       if (e != hipSuccess) { res->wring.release(ws); break; }
       cnt.d2h += (uint64_t) nr * (uint64_t) width * 4;
       write_q.push(WriteReq{ws, f[2].foffset + ((uint64_t) first.off + (uint64_t) r0 * (uint64_t) first.ld) * 4,
-                            (uint64_t) first.ld * 4, (uint64_t) nr, (uint64_t) width * 4});
+                            (uint64_t) first.ld * 4, (uint64_t) nr, (uint64_t) width * 4, r0, vt});
     }
     for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++) {
       DevSlot &sc = slots[tiles[wgroup[q]].slot];
@@ -539,6 +608,46 @@ struct GemmRun {
   }
   int group_max = kMaxGroup;
   int64_t group_reach = INT64_MAX;     // how many tasks ahead a neighbour's next use may lie (select_row_group)
+
+  // ---- BOF_VERIFY (flash_common.h) -------------------------------------------------------------------------
+  Verify vf;
+  std::mutex vf_mu;        // orders "sum the slot's old tile" before the first copy of the new one
+  // the packed tile of `rows x cols` in `ptr` has seen its last kernel (st is ordered behind it): sum it once
+  // more and expect the sum it had behind its H2D copy
+  hipError_t verify_old_tile(size_t ve_in, char *ptr, int64_t rows, int64_t cols, hipStream_t st, int tile_id) {
+    if (!vf.on || ve_in == Verify::kNone) return hipSuccess;
+    const size_t e = vf.entry();
+    vf.expect(ve_in, e, "tile: packed slot after H2D vs the same slot after the tile's last use (tile id)", tile_id);
+    return vf.on_device(e, ptr, rows, cols, cols, 0, 0, st);
+  }
+  int verify_finish() {
+    if (!vf.on) return BOF_OK;
+    for (size_t sl = 0; sl < slot_tile.size(); sl++) {      // A / B tiles still resident
+      const int id = slot_tile[sl];
+      if (id < 0 || tiles[id].mat == 2 || tiles[id].state != 2) continue;
+      BOF_HIP_TRY(verify_old_tile(tiles[id].ve_in, slots[sl].ptr, tiles[id].nrows, tiles[id].ncols, h2d, id));
+    }
+    BOF_HIP_TRY(hipStreamSynchronize(h2d));
+    // every C tile back from the file, row by row (the tile's rows lie ld apart)
+    const int fd = file_is_direct(f[2].fd) ? file_buffered_fd(f[2].fd) : f[2].fd;
+    std::vector<char> row;
+    for (size_t id = 0; id < tiles.size() && fd >= 0; id++) {
+      const Tile &t = tiles[id];
+      if (t.mat != 2 || t.ve_cfile == Verify::kNone) continue;
+      row.resize((size_t) t.ncols * 4);
+      for (int64_t r = 0; r < t.nrows; r++) {
+        size_t got = 0;
+        while (got < row.size()) {
+          const ssize_t n = pread(fd, row.data() + got, row.size() - got,
+                                  (off_t) (f[2].foffset + ((uint64_t) t.off + (uint64_t) r * (uint64_t) t.ld) * 4 + got));
+          if (n <= 0) { set_error("BOF_VERIFY: re-reading C from its file failed"); return BOF_EIO; }
+          got += (size_t) n;
+        }
+        vf.on_host(t.ve_cfile, row.data(), 1, t.ncols, 0, (uint64_t) (r * t.ncols));
+      }
+    }
+    return vf.finish(cnt, "bof_flash_gemm (tile cache)");
+  }
 };
 
 }  // namespace
@@ -552,6 +661,8 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
                                 bool check_only = false) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc;
+  evt_mark_call_begin();
+  evt("bof_flash_gemm (tile cache) begin", (int) m, (int) n, (uint64_t) k);
   GemmRun R;
   R.o = o;
   R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
@@ -668,6 +779,10 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   if (rc) return rc;
   BOF_HIP_TRY(copy_stream_create(&R.h2d));
   BOF_HIP_TRY(copy_stream_create(&R.d2h));
+  if (verify_wanted(R.o)) {
+    rc = R.vf.init(R.dev, 16 * R.tiles.size() + 65536);
+    if (rc) return rc;
+  }
   R.ss = stream_set(R.o.n_streams);
   if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
 
@@ -742,6 +857,10 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       for (hipEvent_t w : tl.launch_waits)
         if (herr == hipSuccess) herr = hipStreamWaitEvent(st, w, 0);
       tl.launch_waits.clear();
+      if (tl.prev_ve_in != Verify::kNone && herr == hipSuccess) {   // slot taken without a fetch: its old tile, once more
+        herr = R.verify_old_tile(tl.prev_ve_in, s.ptr, tl.prev_rows, tl.prev_cols, st, ids[x]);
+        tl.prev_ve_in = Verify::kNone;
+      }
     }
     if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (hipStreamWaitEvent)"; break; }
     DevSlot &sa = R.slots[R.tiles[ids[0]].slot], &sb = R.slots[R.tiles[ids[1]].slot],
@@ -789,6 +908,9 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   (void) hipDeviceSynchronize();
   ktimer.collect(R.cnt);
   BOF_TRACE_T("drained (writes done)");
+  evt("bof_flash_gemm (tile cache) drained", R.dev, 0, R.cnt.tasks.load());
+  if (herr == hipSuccess && !fail && !R.io_error.load()) fail = R.verify_finish();
+  evt_dump_env("bof_flash_gemm (tile cache)");
   if (herr != hipSuccess && !fail) fail = hip_fail(herr, where);
   if (R.io_error.load() && (!fail || fail == BOF_EIO)) {
     const int e = R.io_error.load();
@@ -800,7 +922,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   if (out) {
     out->rd += R.cnt.rd.load(); out->wr += R.cnt.wr.load(); out->h2d += R.cnt.h2d.load(); out->d2h += R.cnt.d2h.load();
     out->tasks += R.cnt.tasks.load(); out->hits += R.cnt.hits.load(); out->misses += R.cnt.misses.load();
-    out->klaunch += R.cnt.klaunch.load(); out->kns += R.cnt.kns.load();
+    out->klaunch += R.cnt.klaunch.load(); out->kns += R.cnt.kns.load(); out->vchecks += R.cnt.vchecks.load();
   }
   return fail;
 }
@@ -810,6 +932,7 @@ static bof_flash_stats stats_of(const Counters &c, double seconds) {
   s.bytes_read = c.rd; s.bytes_written = c.wr; s.bytes_h2d = c.h2d; s.bytes_d2h = c.d2h;
   s.tasks = c.tasks; s.tile_hits = c.hits; s.tile_misses = c.misses; s.seconds = seconds;
   s.kernel_launches = c.klaunch; s.kernel_seconds = (double) c.kns.load() * 1e-9;
+  s.verify_checks = c.vchecks;
   return s;
 }
 
@@ -917,6 +1040,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   for (auto &S : slabs) {
     total.rd += S->cnt.rd.load(); total.wr += S->cnt.wr.load(); total.h2d += S->cnt.h2d.load(); total.d2h += S->cnt.d2h.load();
     total.tasks += S->cnt.tasks.load(); total.hits += S->cnt.hits.load(); total.misses += S->cnt.misses.load();
+    total.klaunch += S->cnt.klaunch.load(); total.kns += S->cnt.kns.load(); total.vchecks += S->cnt.vchecks.load();
     per.push_back(stats_of(S->cnt, S->seconds));
     if (S->rc && !rc) { rc = S->rc; set_error(S->err); }
   }

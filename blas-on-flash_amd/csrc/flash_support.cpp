@@ -81,6 +81,72 @@ void evt_dump_env(const char *why) {
 
 uint64_t evt_count() { return g_evt_next.load(); }
 
+// ---- BOF_VERIFY table (flash_common.h) ---------------------------------------------------------------------
+int Verify::init(int device, size_t capacity) {
+  release();
+  dev = device;
+  DeviceScope scope(dev);
+  BOF_HIP_TRY(hipMalloc((void **) &d_tab, capacity * 2 * sizeof(unsigned long long)));
+  BOF_HIP_TRY(hipMemset(d_tab, 0, capacity * 2 * sizeof(unsigned long long)));
+  h_tab = std::vector<std::atomic<uint64_t>>(capacity * 2);
+  touched = std::vector<std::atomic<uint8_t>>(capacity);
+  for (auto &v : h_tab) v.store(0);
+  for (auto &v : touched) v.store(0);
+  cap = capacity;
+  next.store(0);
+  expects.clear();
+  on = true;
+  return BOF_OK;
+}
+void Verify::release() {
+  if (d_tab) {
+    DeviceScope scope(dev);
+    (void) hipFree(d_tab);
+  }
+  d_tab = nullptr;
+  on = false;
+  cap = 0;
+}
+int Verify::finish(Counters &cnt, const char *call) {
+  if (!on) return BOF_OK;
+  const size_t n = std::min(next.load(), cap);
+  std::vector<unsigned long long> d(2 * std::max<size_t>(n, 1), 0);
+  {
+    DeviceScope scope(dev);
+    BOF_HIP_TRY(hipMemcpy(d.data(), d_tab, 2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  auto sums = [&](size_t e, uint64_t out[2]) {
+    // an entry is filled on ONE side (all its contributions come from the host or all from the device)
+    out[0] = h_tab[2 * e].load() + d[2 * e];
+    out[1] = h_tab[2 * e + 1].load() + d[2 * e + 1];
+  };
+  std::lock_guard<std::mutex> lk(mu);
+  uint64_t compared = 0, skipped = 0;
+  for (const Expect &x : expects) {
+    if (x.a >= n || x.b >= n || !touched[x.a].load() || !touched[x.b].load()) { skipped++; continue; }
+    uint64_t sa[2], sb[2];
+    sums(x.a, sa);
+    sums(x.b, sb);
+    compared++;
+    if (sa[0] == sb[0] && sa[1] == sb[1]) continue;
+    char msg[384];
+    snprintf(msg, sizeof(msg),
+             "%s: BOF_VERIFY mismatch -- %s (ids %d %d %d): sums %016llx/%016llx against %016llx/%016llx%s",
+             call, x.what, x.id0, x.id1, x.id2, (unsigned long long) sa[0], (unsigned long long) sa[1],
+             (unsigned long long) sb[0], (unsigned long long) sb[1],
+             sa[0] == sb[0] ? " (same words, different places)" : "");
+    evt("BOF_VERIFY mismatch", x.id0, x.id1, (uint64_t) x.id2);
+    fprintf(stderr, "[bof] %s\n", msg);
+    evt_dump(stderr, "BOF_VERIFY mismatch");
+    set_error(msg);
+    cnt.vchecks += compared;
+    return BOF_EVERIFY;
+  }
+  cnt.vchecks += compared;
+  (void) skipped;
+  return BOF_OK;
+}
+
 long env_long(const char *name, long dflt) {
   const char *v = getenv(name);
   return (v && *v) ? atol(v) : dflt;

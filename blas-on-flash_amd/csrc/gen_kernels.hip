@@ -6,6 +6,8 @@
 // Checked against oracle/bof_oracle.c (itself pinned to the reference tools'
 // known-answer hashes) in tests/test_gpu_generators.py.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "bof_internal.h"
@@ -147,6 +149,50 @@ hipError_t gen_sparse_rows(int64_t row0, int64_t nrows, int64_t ncols, int64_t n
   else if (ndraw <= 1024) BOF_GEN(1024);
   else BOF_GEN(2048);
 #undef BOF_GEN
+  return hipGetLastError();
+}
+
+// ---- BOF_VERIFY: word sums of a 2-D region (instrumentation, bof_options.verify) -----------------------------
+// out[0] += sum of the region's 32-bit words; out[1] += sum of word * (logical index + 1), both modulo 2^64.
+// The region is `rows` rows of `row_words` words, `pitch_words` apart.  Logical index of word (r, c):
+// index_base + r * row_words + c, or -- t_pitch > 0: the region is a TRANSPOSED image of the logical object
+// (the k-major copy of a panel) -- index_base + c * t_pitch + r.  The host computes the same two sums over the
+// same object wherever it sits in a pinned slot or a file (flash_common.h: host_word_sums), so equal sums at two
+// hand-over points mean the words arrived, all of them, each in its place.
+__global__ void __launch_bounds__(256)
+verify_sum_kernel(const uint32_t *__restrict__ p, int64_t rows, int64_t row_words, int64_t pitch_words,
+                  uint64_t index_base, int64_t t_pitch, unsigned long long *__restrict__ out) {
+  const int64_t total = rows * row_words;
+  unsigned long long s1 = 0, s2 = 0;
+  for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t) gridDim.x * 256) {
+    const int64_t r = i / row_words, c = i - r * row_words;
+    const unsigned long long w = p[r * pitch_words + c];
+    const unsigned long long li = index_base + (t_pitch > 0 ? (unsigned long long) (c * t_pitch + r) : (unsigned long long) i);
+    s1 += w;
+    s2 += w * (li + 1ull);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  __shared__ unsigned long long part[2][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[0][wave] = s1; part[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+    atomicAdd(&out[1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+  }
+}
+
+hipError_t verify_sum(const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base,
+                      int64_t t_pitch, unsigned long long *out2, hipStream_t st) {
+  drop_stale_error();
+  if (rows <= 0 || row_words <= 0) return hipSuccess;
+  const int64_t total = rows * row_words;
+  const unsigned blocks = (unsigned) std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(verify_sum_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *) p, rows, row_words, pitch_words,
+                     index_base, t_pitch, out2);
   return hipGetLastError();
 }
 

@@ -53,6 +53,7 @@ extern "C" {
 #define BOF_EIO (-3)    /* file I/O failed */
 #define BOF_ENODEV (-4) /* no HIP device */
 #define BOF_ENOMEM (-5)
+#define BOF_EVERIFY (-6) /* bof_options.verify: a hand-over checksum did not match (bof_last_error names it) */
 
 #define BOF_ABI_VERSION 4
 

@@ -5,6 +5,7 @@
 // row blocks per device, shared operands fanned out, device-to-device segment sums), file engines, budgets --
 // with integer-valued data, so that every result is exact whatever the order of the sums and can be compared
 // with a plain host computation.  Arithmetic parity of the real kernels is the business of the -m gpu suite.
+#include <atomic>
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +39,7 @@ extern "C" long mock_hip_fail_api_pending();
     if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d): %s\n", #c, __LINE__, bof_last_error()); exit(1); } \
   } while (0)
 
+static std::atomic<uint64_t> g_verify_checks{0};
 static std::string g_dir;
 static thread_local std::string t_prefix;      // concurrent callers keep their files apart
 static bool g_truncate_a = false;    // the next gemm_case cuts its A file in half (a reader's request comes back short)
@@ -169,6 +171,12 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   CHECK(fb.read<float>(B.size()) == B);
   bof_flash_stats per[BOF_MAX_DEVICES];
   const int nd = bof_flash_last_device_stats(per, BOF_MAX_DEVICES);
+  if (t_prefix.empty() && getenv("BOF_VERIFY") && atoi(getenv("BOF_VERIFY")) > 0 && m > 0 && n > 0 && k > 0) {
+    // hand-over checksums: at least A, B read -> HBM and C HBM -> pinned -> file were compared
+    bof_flash_stats tot;
+    CHECK(bof_flash_last_stats(&tot) == BOF_OK && tot.verify_checks >= 4);
+    g_verify_checks += tot.verify_checks;
+  }
   if (devs.size() > 1 && nd > 1 && t_prefix.empty()) {   // (a C of one panel is one slab whatever the list; the "last call"
                                                           //  statistics are the process's, so not with concurrent callers)
     uint64_t tasks = 0;
@@ -682,24 +690,28 @@ int main(int argc, char **argv) {
     share_case(8, false);
     CHECK(bof_flash_release() == BOF_OK);
     for (int d = 0; d < 8; d++) CHECK(mock_hip_bytes_in_use(d) == 0);
-    printf("host_pipeline ok: 8 mock devices, %llu kernel stand-in launches\n", (unsigned long long) mock_hip_kernel_launches());
+    if (g_verify_checks.load()) printf("BOF_VERIFY: %llu hand-over sums compared\n", (unsigned long long) g_verify_checks.load());
+  printf("host_pipeline ok: 8 mock devices, %llu kernel stand-in launches\n", (unsigned long long) mock_hip_kernel_launches());
     return 0;
   }
   CHECK(bof_device_count() == 4);
   if (argc > 3 && !strcmp(argv[2], "stress")) {
     g_rng.seed((uint64_t) atol(argv[3]) * 7919 + 1);
     const int n = stress(argc > 4 ? atof(argv[4]) : 60);
-    printf("host_pipeline ok: %d drawn cases, %llu kernel stand-in launches\n", n, (unsigned long long) mock_hip_kernel_launches());
+    if (g_verify_checks.load()) printf("BOF_VERIFY: %llu hand-over sums compared\n", (unsigned long long) g_verify_checks.load());
+  printf("host_pipeline ok: %d drawn cases, %llu kernel stand-in launches\n", n, (unsigned long long) mock_hip_kernel_launches());
     return 0;
   }
   if (argc > 2 && !strcmp(argv[2], "apifail")) {
     api_failure_sweep();
-    printf("host_pipeline ok: API failures\n");
+    if (g_verify_checks.load()) printf("BOF_VERIFY: %llu hand-over sums compared\n", (unsigned long long) g_verify_checks.load());
+  printf("host_pipeline ok: API failures\n");
     return 0;
   }
   if (argc > 2 && !strcmp(argv[2], "allocfail")) {
     alloc_failure_sweep();
-    printf("host_pipeline ok: allocation failures\n");
+    if (g_verify_checks.load()) printf("BOF_VERIFY: %llu hand-over sums compared\n", (unsigned long long) g_verify_checks.load());
+  printf("host_pipeline ok: allocation failures\n");
     return 0;
   }
   const bool brief = argc > 2 && !strcmp(argv[2], "brief");      // the ThreadSanitizer run: two device lists
@@ -708,6 +720,7 @@ int main(int argc, char **argv) {
   const long long s1 = mock_hip_live_streams(), e1 = mock_hip_live_events();
   cases += run_all({{2, 0, 3}});
   CHECK(mock_hip_live_streams() == s1 && mock_hip_live_events() == e1);
+  if (g_verify_checks.load()) printf("BOF_VERIFY: %llu hand-over sums compared\n", (unsigned long long) g_verify_checks.load());
   printf("host_pipeline ok: %d level-3 call groups on 4 mock devices, %llu kernel stand-in launches, %llu bytes of async copies from / to "
          "pageable memory; %lld streams / %lld events stay with the per-device stream sets\n",
          cases, (unsigned long long) mock_hip_kernel_launches(), (unsigned long long) mock_hip_pageable_h2d_bytes(), s1, e1);

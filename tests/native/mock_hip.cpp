@@ -520,6 +520,11 @@ hipError_t hipMemcpyPeerAsync(void *dst, int ddev, const void *src, int sdev, si
   st->enqueue([dst, src, bytes] { memmove(dst, src, bytes); });
   return hipSuccess;
 }
+hipError_t hipMemset(void *dst, int v, size_t bytes) {      // synchronous: BOF_VERIFY's table, before anything is queued
+  need_device_mem(dst, bytes, t_dev, "hipMemset");
+  memset(dst, v, bytes);
+  return hipSuccess;
+}
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s) {
   if (inject_api(6)) return fail(hipErrorUnknown);
   MockStream *st = S(s, "hipMemsetAsync");
@@ -746,6 +751,29 @@ hipError_t scsrgemv_t_partitioned(int64_t m, int64_t n, int64_t, const float *va
   return hipSuccess;
 }
 hipError_t gen_dense(float *, int64_t, int64_t, char, uint64_t, hipStream_t) { return hipErrorUnknown; }
+// BOF_VERIFY's device-side sums (gen_kernels.hip: verify_sum_kernel), same definition
+hipError_t verify_sum(const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base, int64_t t_pitch,
+                      unsigned long long *out2, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "verify_sum");
+  if (rows <= 0 || row_words <= 0) return hipSuccess;
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(p, (size_t) ((rows - 1) * pitch_words + row_words) * 4, dev, "verify_sum");
+    need_device_mem(out2, 16, dev, "verify_sum");
+    const uint32_t *w = (const uint32_t *) p;
+    unsigned long long s1 = 0, s2 = 0;
+    for (int64_t r = 0; r < rows; r++)
+      for (int64_t c = 0; c < row_words; c++) {
+        const unsigned long long v = w[r * pitch_words + c];
+        const unsigned long long li = index_base + (unsigned long long) (t_pitch > 0 ? c * t_pitch + r : r * row_words + c);
+        s1 += v;
+        s2 += v * (li + 1ull);
+      }
+    __atomic_fetch_add(&out2[0], s1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&out2[1], s2, __ATOMIC_RELAXED);
+  });
+  return hipSuccess;
+}
 hipError_t gen_sparse_rows(int64_t, int64_t, int64_t, int64_t, float *, int64_t *, int64_t *, hipStream_t) { return hipErrorUnknown; }
 
 }  // namespace bof

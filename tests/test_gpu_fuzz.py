@@ -26,6 +26,7 @@ pytestmark = pytest.mark.gpu
 
 ENV_KNOBS = ("BOF_TILE_GROUP", "BOF_UNALIGNED_DIRECT", "BOF_MMAP_WRITES")
 LAST = {}      # the parameters of the case being run (printed when it fails)
+VERIFY_SUMS = [0]   # BOF_VERIFY: hand-over sums compared so far
 FORCE_KIND = ""   # --kind: only gemm / kmeans / csr cases
 OVERRIDE = {}  # --set: options forced on top of the drawn ones (bisecting a failing case)
 
@@ -213,6 +214,7 @@ def gemm_case(rng, tmp, kmeans=False):
         files[1].check_against(mats[1])
         st = bofhip.flash_last_stats()
         assert st["bytes_written"] <= mats[2].nbytes, st        # C leaves once, whatever the path
+        VERIFY_SUMS[0] += st["verify_checks"]
     finally:
         for f in files:
             f.close()
@@ -414,7 +416,12 @@ if __name__ == "__main__":
     ap.add_argument("--kind", default="", choices=["", "gemm", "kmeans", "csr", "kernel"])
     ap.add_argument("--repeat", type=int, default=1, help="with --only: run every listed case this many times")
     ap.add_argument("--set", default="", help="with --only: override options of the drawn case, e.g. 'devices=None;n_streams=1'")
+    ap.add_argument("--verify", action="store_true",
+                    help="BOF_VERIFY=1: hand-over checksums inside every level-3 gemm / kmeans call; a mismatch fails the call, names "
+                         "the two hand-over points and dumps the event ring (include/bof_hip.h, Instrumentation)")
     a = ap.parse_args()
+    if a.verify:
+        os.environ["BOF_VERIFY"] = "1"
     if a.range:
         a.only = list(range(a.range[0], a.range[1]))
     quiet = bool(a.range)
@@ -436,5 +443,6 @@ if __name__ == "__main__":
                 print(f"FAIL seed={a.seed} index={idx}: {e}\n     case: {LAST}")
                 traceback.print_exc(limit=3)
             i += 1
-    print(f"fuzz: {i} cases, {fails} failures, seed {a.seed}, {time.time() - t0:.0f} s")
+    print(f"fuzz: {i} cases, {fails} failures, seed {a.seed}, {time.time() - t0:.0f} s"
+          + (f", BOF_VERIFY on: {VERIFY_SUMS[0]} hand-over sums compared" if a.verify else ""))
     sys.exit(1 if fails else 0)

@@ -1,0 +1,79 @@
+"""BOF_VERIFY (hand-over checksums of the level-3 GEMM pipelines, include/bof_hip.h "Instrumentation") on the
+CPU box: the product's host code linked against the mock HIP runtime (tests/native/mock_hip.cpp, asynchronous
+streams).  A clean call compares every panel / tile at every hand-over and passes; a word damaged between two
+hand-over points ($BOF_VERIFY_INJECT) fails the call with BOF_EVERIFY and names the pair of points."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "blas-on-flash_amd"))
+from test_dist_gloo import _use_mock_library
+_use_mock_library(SO)
+import bofhip
+m, n, k, blk = 640, 600, 500, 128
+rng = np.random.default_rng(3)
+a = rng.integers(-3, 4, (m, k)).astype(np.float32); b = rng.integers(-3, 4, (k, n)).astype(np.float32)
+c0 = rng.integers(-3, 4, (m, n)).astype(np.float32)
+for name, x in (("A", a), ("B", b), ("C", c0)): x.tofile(os.path.join(DIR, name))
+fds = [os.open(os.path.join(DIR, x), os.O_RDWR) for x in "ABC"]
+out = {}
+try:
+    bofhip.flash_gemm("R", "N", "N", m, n, k, 1.0, BETA, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0), bofhip.FPtr(fds[2], 0),
+                      0, 0, 0, bofhip.default_options(gemm_blk=blk, gemm_path=PATH, use_odirect=0, io_chunk_mib=1, verify=1,
+                                                      hbm_budget=BUDGET, devices=DEVS))
+    out["rc"] = 0
+except bofhip.BofError as e:
+    out["rc"] = 1; out["err"] = str(e)
+out["stats"] = bofhip.flash_last_stats()
+got = np.fromfile(os.path.join(DIR, "C"), np.float32).reshape(m, n)
+out["exact"] = bool(np.array_equal(got, (a.astype(np.float64) @ b.astype(np.float64) + BETA * c0).astype(np.float32)))
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.fixture(scope="module")
+def mock_lib(tmp_path_factory):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_dist_gloo import _build_mock_library
+    return _build_mock_library(str(tmp_path_factory.mktemp("mocklib_verify")))
+
+
+def run_child(tmp_path, so, path, beta, budget, devs, inject):
+    import json
+    d = tmp_path / f"p{path}_i{inject}_{len(devs)}_{budget}"
+    d.mkdir()
+    code = (f"ROOT={ROOT!r}\nSO={so!r}\nDIR={str(d)!r}\nPATH={path}\nBETA={beta}\nBUDGET={budget}\nDEVS={devs!r}\n" + CHILD)
+    env = dict(os.environ, MOCK_HIP_DEVICES="4", MOCK_HIP_ASYNC="1", MOCK_HIP_JITTER_US="100", BOF_VERIFY_INJECT=str(inject))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(line[-1][7:]), r.stderr
+
+
+@pytest.mark.parametrize("path,budget,devs", [(2, 0, [0]), (2, 0, [0, 1, 2]), (1, 0, [1]), (1, 14 * 256 * 256 * 4, [0]),
+                                              (1, 0, [0, 0, 0])])
+@pytest.mark.parametrize("beta", [0.0, 2.0])
+def test_clean_call_passes_every_hand_over_check(tmp_path, mock_lib, path, budget, devs, beta):
+    out, err = run_child(tmp_path, mock_lib, path, beta, budget, devs, 0)
+    assert out["rc"] == 0, out.get("err", "") + err[-2000:]
+    assert out["exact"]
+    # A and B panels / tiles in (x2 or x3 points each), every C panel / tile out (3 points)
+    assert out["stats"]["verify_checks"] >= 30, out["stats"]
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("inject,needle", [(1, "after the file read vs"), (2, "after D2H vs the file after the write")])
+def test_damaged_word_is_caught_and_named(tmp_path, mock_lib, path, inject, needle):
+    out, err = run_child(tmp_path, mock_lib, path, 0.0, 0, [0], inject)
+    assert out["rc"] == 1, "a damaged word went unnoticed"
+    assert "BOF_VERIFY mismatch" in out["err"] and needle in out["err"], out["err"]
+    assert "[bof events]" in err            # the event ring came with it
