@@ -480,7 +480,7 @@ void PanelHub::reader_main(int home) {
             e = transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
                               P.nr, R.h2d);
           if (e == hipSuccess && M.kmajor_copy)
-            e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.ld, R.h2d);
+            e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           P.state = 2;
           evt("panel H2D queued (ready recorded)", rq.mat, rq.panel, (uint64_t) R.di);
@@ -848,7 +848,7 @@ hipError_t PanelRun::verify_last_use(int x, int p, hipStream_t st) {
   P.v_last_done = true;
   hipError_t e = vf.on_device(P.ve[Panel::VE_DEV_LAST], M.panel_ptr(p), 1, (int64_t) (P.bytes / 4), 0, 0, 0, st);
   if (e == hipSuccess && M.kmajor_copy)
-    e = vf.on_device(P.ve[Panel::VE_T_LAST], M.tpanel_ptr(p), M.cols, P.nr, P.nr, 0, M.ld, st);
+    e = vf.on_device(P.ve[Panel::VE_T_LAST], M.tpanel_ptr(p), M.cols, P.nr, P.nr, 0, M.cols, st);
   return e;
 }
 

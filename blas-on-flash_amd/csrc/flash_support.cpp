@@ -88,6 +88,10 @@ int Verify::init(int device, size_t capacity) {
   DeviceScope scope(dev);
   BOF_HIP_TRY(hipMalloc((void **) &d_tab, capacity * 2 * sizeof(unsigned long long)));
   BOF_HIP_TRY(hipMemset(d_tab, 0, capacity * 2 * sizeof(unsigned long long)));
+  // hipMemset of device memory runs on the null stream and may return before it has executed; the pipelines' streams
+  // are non-blocking (not ordered behind the null stream), so without this the zeroing could land AFTER the first sums
+  // (seen with eight processes sharing the GPU: device-side sums of the first panels read back as zero)
+  BOF_HIP_TRY(hipDeviceSynchronize());
   h_tab = std::vector<std::atomic<uint64_t>>(capacity * 2);
   touched = std::vector<std::atomic<uint8_t>>(capacity);
   for (auto &v : h_tab) v.store(0);

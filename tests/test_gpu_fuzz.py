@@ -420,6 +420,8 @@ if __name__ == "__main__":
                     help="BOF_VERIFY=1: hand-over checksums inside every level-3 gemm / kmeans call; a mismatch fails the call, names "
                          "the two hand-over points and dumps the event ring (include/bof_hip.h, Instrumentation)")
     a = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()          # a crash inside the library leaves the Python stack and the case's index behind
     if a.verify:
         os.environ["BOF_VERIFY"] = "1"
     if a.range:
@@ -434,6 +436,8 @@ if __name__ == "__main__":
     with tempfile.TemporaryDirectory(dir=a.dir) as tmp:
         while (a.only and i < len(a.only)) or (not a.only and time.time() - t0 < a.seconds):
             idx = a.only[i] if a.only else i
+            if i % 2000 == 0:
+                print(f"... case {idx} ({i} done, {fails} failures, {time.time() - t0:.0f} s)", flush=True)
             try:
                 d = one_case(a.seed, idx, tmp)
                 if a.only and not quiet:
