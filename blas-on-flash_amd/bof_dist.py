@@ -114,45 +114,80 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     r0, r1 = row_shard(m, world, rank, tile)
     rows = r1 - r0
     stats = {"rows": rows, "bytes_read": 0, "bytes_written": 0, "bytes_peer": 0, "seconds": 0.0}
-    # the ranks that own rows, in rank order: the share group (the same on every rank)
+    # the ranks that own rows, in rank order (the same list on every rank)
     owners = [g for g in range(world) if row_shard(m, world, g, tile)[1] > row_shard(m, world, g, tile)[0]]
-    name = None
+    name, mates, leader = None, [], None
     if world > 1 and b_once and len(owners) > 1:
         _share_seq += 1                      # every rank makes the same sequence of calls
-        name = f"/bof_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}_{_share_seq}"
-        # the staging ring (64 chunk slots per shared operand, ~2 GiB at the default 32 MiB chunk) lives in
-        # /dev/shm (tmpfs): a store into a tmpfs page that cannot be allocated is a SIGBUS, so the ring is only
-        # used when it fits with room to spare; the first rank decides for everybody (a container's /dev/shm
-        # may be tiny)
-        fits = [True]
-        if rank == 0:
-            bofhip.lib().bof_share_cleanup(name.encode())    # leftovers of a crashed earlier run
-            try:
-                sv = os.statvfs("/dev/shm")
-                ring = 2 * 64 * ((max(int(o.io_chunk_mib), 1) << 20) + 8192)
-                fits[0] = sv.f_bavail * sv.f_frsize > ring * 1.25 + (64 << 20)
-            except OSError:
-                fits[0] = False
-        dist.broadcast_object_list(fits, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        if not fits[0]:
+        # The staging ring is POSIX shared memory: a share group = the row-owning ranks of ONE host.  Every rank
+        # tells the others where it runs (host name + boot id: two containers of one machine with separate /dev/shm
+        # differ in neither, which is why the host's first owner also PROBES the segment below).
+        hosts = [None] * world
+        dist.all_gather_object(hosts, _host_identity(), group=group)
+        mates = [g for g in owners if hosts[g] == hosts[rank]] if rank in owners else []
+        # ... and the host's first owner decides whether its /dev/shm can hold the ring (64 chunk slots per shared
+        # operand, ~2 GiB at the default 32 MiB chunk; a store into a tmpfs page that cannot be allocated is a
+        # SIGBUS, so with room to spare only) and removes leftovers of a crashed earlier run.  The smallest group
+        # rank of the share group is part of the name: disjoint groups never meet in one segment.
+        verdict = None
+        if len(mates) > 1:
+            leader = mates[0]
+            name = f"/bof_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}_{leader}_{_share_seq}"
+            if rank == leader:
+                bofhip.lib().bof_share_cleanup(name.encode())
+                try:
+                    sv = os.statvfs("/dev/shm")
+                    ring = 2 * 64 * ((max(int(o.io_chunk_mib), 1) << 20) + 8192)
+                    verdict = bool(sv.f_bavail * sv.f_frsize > ring * 1.25 + (64 << 20))
+                except OSError:
+                    verdict = False
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, verdict, group=group)
+        if name is not None and not verdicts[leader]:
             name = None
-            stats["b_once"] = "off: /dev/shm cannot hold the staging ring"
+            stats["b_once"] = "off: /dev/shm of this host cannot hold the staging ring"
+        elif name is None and rank in owners:
+            stats["b_once"] = "off: the only row-owning rank of its host"
+    err = None
     if rows > 0:
         import ctypes
         call = bofhip.Options()
         ctypes.memmove(ctypes.byref(call), ctypes.byref(o), ctypes.sizeof(o))
         if name is not None:
-            call.share_world, call.share_rank, call.share_name = len(owners), owners.index(rank), name.encode()
-        bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, r0 * lda * 4),
-                          bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * ldc * 4), lda, ldb, ldc, call)
-        st_ = bofhip.flash_last_stats()
-        for q in ("bytes_read", "bytes_written", "bytes_peer", "seconds"):
-            stats[q] = st_[q]
-    if name is not None:
-        dist.barrier(group)                  # everybody is out of the call: the segment can go
-        if rank == 0:
+            call.share_world, call.share_rank, call.share_name = len(mates), mates.index(rank), name.encode()
+        try:
+            bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, r0 * lda * 4),
+                              bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * ldc * 4), lda, ldb, ldc, call)
+            st_ = bofhip.flash_last_stats()
+            for q in ("bytes_read", "bytes_written", "bytes_peer", "seconds", "kernel_launches", "kernel_seconds", "tasks",
+                      "bytes_h2d", "bytes_d2h"):
+                stats[q] = st_[q]
+        except bofhip.BofError as e:
+            err = str(e)
+    if world > 1 and b_once and len(owners) > 1:
+        # everybody is out of the call -- whether it worked or not: a rank that failed must not leave the others
+        # in a barrier, so the ranks exchange their status (this IS the barrier), the leaders remove the
+        # segments, and only then does a failure become an exception -- on every rank
+        errs = [None] * world
+        dist.all_gather_object(errs, err, group=group)
+        if name is not None and rank == leader:
             bofhip.lib().bof_share_cleanup(name.encode())
+        bad = [(g, e) for g, e in enumerate(errs) if e]
+        if bad:
+            raise bofhip.BofError(err if err else f"flash_gemm_row_sharded: rank {bad[0][0]} failed: {bad[0][1]}")
+    elif err:
+        raise bofhip.BofError(err)
     return stats
+
+
+def _host_identity():
+    import socket
+    boot = ""
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        pass
+    return socket.gethostname() + "/" + boot
 
 
 def flash_kmeans_point_sharded(ncenters, npoints, dim, fd_centers, fd_points, fd_dist, c_l2sq, p_l2sq, opts=None,

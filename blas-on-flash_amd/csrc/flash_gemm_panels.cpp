@@ -1129,7 +1129,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
       // ring depth: what the readers of every rank can have in flight, twice over; 2 GiB at the defaults
       const int n_slots = (int) std::min<size_t>(sg.n_chunks, (size_t) std::max<long>(8, env_long("BOF_SHARE_SLOTS", 64)));
       const std::string base = std::string(o.share_name) + "." + "AB"[x];
-      if (!sg.ring.map(base, H.runs[0]->chunk + 2 * Mat::kPage, n_slots)) {
+      if (!sg.ring.map(base, H.runs[0]->chunk + 2 * Mat::kPage, n_slots, std::string(o.share_name))) {
         set_error(std::string("bof_flash_gemm: cannot map the node-shared staging ring ") + base + ": " + strerror(errno));
         return BOF_EIO;
       }
@@ -1247,6 +1247,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
 extern "C" int bof_share_cleanup(const char *share_name) {
   if (!share_name || !share_name[0]) return BOF_EINVAL;
   for (const char *m : {".A", ".B"}) bof::ShareRing::unlink(std::string(share_name) + m);
+  bof::ShareRing::unlink_group(std::string(share_name));
   return BOF_OK;
 }
 
@@ -1259,7 +1260,7 @@ extern "C" int64_t bof_share_selftest(const char *share_name, int rank, int worl
   if (!share_name || world < 2 || rank < 0 || rank >= world || n_chunks <= 0 || chunk_bytes < 8 || n_slots < 1)
     return -EINVAL;
   bof::ShareRing ring;
-  if (!ring.map(std::string(share_name) + ".A", (size_t) chunk_bytes, n_slots)) return -errno;
+  if (!ring.map(std::string(share_name) + ".A", (size_t) chunk_bytes, n_slots, std::string(share_name))) return -errno;
   std::atomic<int> stop{0};
   std::vector<uint64_t> buf((size_t) chunk_bytes / 8);
   int64_t verified = 0;

@@ -50,6 +50,7 @@
 #include "bof_internal.h"
 #include "fileio.h"
 #include "flash_common.h"
+#include "share_ring.h"
 
 namespace bof {
 
@@ -959,15 +960,32 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   if (g.nblk[1] == 0) { set_error("bof_flash_gemm: k == 0 is not supported on the file path"); return BOF_EINVAL; }
 
   // ---- large working budgets: whole row panels in file layout, big sequential requests ----
+  // One process per GPU with a shared operand (share_world > 1): a rank that cannot do its part -- an error, or a
+  // call the panel path cannot take (eligibility depends on THIS rank's free HBM, gemm_path, ldc) -- must not leave
+  // its peers waiting for panels it will never publish, nor fall back silently to reading B itself: it raises the
+  // ring group's failure word (share_ring.h), which ends every peer's wait at its next check, and reports an error.
+  auto tell_peers = [&o] {
+    if (o.share_world > 1 && o.share_name[0]) ShareRing::mark_group_failed(std::string(o.share_name));
+  };
   if (o.gemm_path != 1) {
     rc = flash_gemm_panels(ord, ta, tb, m, n, k, alpha, beta, fa, fb, fc, lda, ldb, ldc, o, devs, kh);
+    if (rc < 0) tell_peers();
     if (rc <= 0) return rc;
     if (o.gemm_path == 2) {
+      tell_peers();
       set_error("bof_flash_gemm: gemm_path = 2 (panels) but the call is not eligible: C rows must be "
                 "contiguous in the file (ldc = stored width) and B, two A panels and three C panels must "
                 "fit hbm_budget");
       return BOF_ENOMEM;
     }
+  }
+
+  if (o.share_world > 1) {
+    tell_peers();
+    set_error("bof_flash_gemm: share_world > 1 (an operand read once per node) needs the row-panel path, and this rank's "
+              "call is not eligible for it (gemm_path = 1, C rows not contiguous in the file, or B + the panel rings do "
+              "not fit this rank's hbm_budget); the other ranks of the group have been told and fail too");
+    return BOF_EINVAL;
   }
 
   // ---- tile cache ---------------------------------------------------------------------------

@@ -96,7 +96,11 @@ typedef struct {
   int32_t n_devices;
   int32_t devices[16];
   /* per-call forms of what used to be process-wide environment knobs; 0 = the default,
-   * which is the environment variable named, read at every call, else the built-in value */
+   * which is the environment variable named, read at every call, else the built-in value.
+   * io_engine and io_request_kib are applied by setting the file layer's PROCESS-WIDE state at
+   * the start of the call: level-3 calls that run concurrently in one process (allowed on
+   * disjoint device lists) must agree on them, or the later call's values also govern the rest
+   * of the earlier one -- results are unaffected, request sizes / the engine are not. */
   int32_t io_engine;      /* 1 kernel AIO, 2 io_uring      ($BOF_IO_ENGINE=uring)           */
   int32_t io_request_kib; /* O_DIRECT request size         ($BOF_IO_REQUEST_KIB, 4096)      */
   int32_t panel_group;    /* C panels of the ramp group    ($BOF_PANEL_GROUP, computed)     */

@@ -197,9 +197,59 @@ def _file_gemm_worker(rank, world, port, so, out_dir, m, n, k, blk):
     dist.destroy_process_group()
 
 
+def _ineligible_rank_worker(rank, world, port, so, out_dir, m, n, k, blk):
+    """rank 1's call cannot take the row-panel path (gemm_path = 1): every rank must come back with an error, soon"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MOCK_HIP_DEVICES"] = "1"
+    os.environ["MOCK_HIP_ASYNC"] = "1"
+    _use_mock_library(so)
+    import bofhip
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fds = [os.open(os.path.join(out_dir, f"{x}.bin"), os.O_RDWR) for x in "ABC"]
+    t0 = time.time()
+    msg = "no error"
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, io_chunk_mib=1, n_io_threads=3, use_odirect=0,
+                                      gemm_path=1 if rank == 1 else 0)
+        bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], opts=opts)
+    except bofhip.BofError as e:
+        msg = str(e)
+    finally:
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+    with open(os.path.join(out_dir, f"outcome_{rank}.txt"), "w") as f:
+        f.write(f"{time.time() - t0:.1f}\n{msg}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 @pytest.fixture(scope="module")
 def mock_lib(tmp_path_factory):
     return _build_mock_library(str(tmp_path_factory.mktemp("mocklib")))
+
+
+def test_row_sharded_rank_outside_the_panel_path_fails_every_rank_fast(tmp_path, mock_lib):
+    """with B shared through the staging ring, a rank whose call is not eligible for the panel path used to
+    fall back to the tile cache silently, read B itself and succeed, while its peers waited BOF_SHARE_TIMEOUT_S
+    (120 s) for panels it never published and the successful rank then hung in the barrier.  Now that rank raises the
+    ring group's failure word and returns an error, the peers' waits end at once, the ranks exchange their status
+    instead of a bare barrier, and every rank raises."""
+    world, blk, m, n, k = 3, 128, 128 * 6, 300, 128 * 4
+    rng = np.random.default_rng(5)
+    rng.integers(-3, 4, (m, k)).astype(np.float32).tofile(tmp_path / "A.bin")
+    rng.integers(-3, 4, (k, n)).astype(np.float32).tofile(tmp_path / "B.bin")
+    np.zeros((m, n), np.float32).tofile(tmp_path / "C.bin")
+    before = set(os.listdir("/dev/shm"))
+    mp.spawn(_ineligible_rank_worker, args=(world, _free_port(), mock_lib, str(tmp_path), m, n, k, blk), nprocs=world, join=True)
+    for r in range(world):
+        secs, msg = open(tmp_path / f"outcome_{r}.txt").read().split("\n")[:2]
+        assert float(secs) < 30, (r, secs)                       # not the 120 s timeout
+        assert "not eligible" in msg or "failed" in msg, (r, msg)
+    assert "not eligible" in open(tmp_path / "outcome_1.txt").read()
+    assert set(os.listdir("/dev/shm")) - before == set()
 
 
 @pytest.mark.parametrize("world", [2, 3])
