@@ -7,6 +7,9 @@
 #include <errno.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -303,11 +306,56 @@ struct EventRec {
   uint32_t c;
 };
 constexpr uint32_t kEventRing = 4096;
-void evt(const char *what, int a = 0, int b = 0, uint64_t c = 0);
-void evt_dump(FILE *f, const char *why);             // whole ring, oldest first
-void evt_dump_env(const char *why);                  // to $BOF_EVENT_DUMP (append) when set
-void evt_mark_call_begin();
-uint64_t evt_count();                          // times in a dump are relative to the last of these
+// (header-only, C++17 inline variables: the test harnesses link single pieces of the library)
+inline EventRec g_evt[kEventRing];
+inline std::atomic<uint64_t> g_evt_next{0};
+inline std::atomic<uint64_t> g_evt_call_begin_ns{0};
+inline uint64_t evt_now_ns() {
+  return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void evt(const char *what, int a = 0, int b = 0, uint64_t c = 0) {
+  static thread_local const uint32_t tid = (uint32_t) syscall(SYS_gettid);
+  const uint64_t i = g_evt_next.fetch_add(1, std::memory_order_relaxed);
+  EventRec &r = g_evt[i % kEventRing];
+  // relaxed atomic stores, the label last with release: a dump that races with a writer (by design: the ring is
+  // never locked) reads each field whole and sees either the old record's label or the new one's
+  __atomic_store_n(&r.t_ns, evt_now_ns(), __ATOMIC_RELAXED);
+  __atomic_store_n(&r.tid, tid, __ATOMIC_RELAXED);
+  __atomic_store_n(&r.a, a, __ATOMIC_RELAXED);
+  __atomic_store_n(&r.b, b, __ATOMIC_RELAXED);
+  __atomic_store_n(&r.c, (uint32_t) c, __ATOMIC_RELAXED);
+  __atomic_store_n(&r.what, what, __ATOMIC_RELEASE);
+}
+inline void evt_mark_call_begin() { g_evt_call_begin_ns.store(evt_now_ns()); }       // times in a dump are relative to the last of these
+inline uint64_t evt_count() { return g_evt_next.load(); }
+inline void evt_dump(FILE *f, const char *why) {            // whole ring, oldest first
+  const uint64_t end = g_evt_next.load();
+  const uint64_t begin = end > kEventRing ? end - kEventRing : 0;
+  const uint64_t t0 = g_evt_call_begin_ns.load();
+  fprintf(f, "[bof events] %s: last %llu of %llu events (ms relative to the last call's begin; thread; event; a b c)\n",
+          why ? why : "", (unsigned long long) (end - begin), (unsigned long long) end);
+  for (uint64_t i = begin; i < end; i++) {
+    EventRec &src = g_evt[i % kEventRing];
+    const char *w = __atomic_load_n(&src.what, __ATOMIC_ACQUIRE);
+    if (!w) continue;
+    EventRec r;
+    r.t_ns = __atomic_load_n(&src.t_ns, __ATOMIC_RELAXED);
+    r.tid = __atomic_load_n(&src.tid, __ATOMIC_RELAXED);
+    r.a = __atomic_load_n(&src.a, __ATOMIC_RELAXED);
+    r.b = __atomic_load_n(&src.b, __ATOMIC_RELAXED);
+    r.c = __atomic_load_n(&src.c, __ATOMIC_RELAXED);
+    fprintf(f, "[bof events] %12.3f  t%-7u %-34s %d %d %u\n", ((double) r.t_ns - (double) t0) * 1e-6, r.tid, w, r.a, r.b, r.c);
+  }
+  fflush(f);
+}
+inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUMP (append) when set
+  const char *path = getenv("BOF_EVENT_DUMP");
+  if (!path || !path[0]) return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  evt_dump(f, why);
+  fclose(f);
+}                          // times in a dump are relative to the last of these
 
 // ---- BOF_VERIFY: hand-over checksums (bof_options.verify / $BOF_VERIFY) ------------------------------------
 // Every object a level-3 GEMM pipeline moves (a row panel; a packed tile) is summed at each hand-over -- in the

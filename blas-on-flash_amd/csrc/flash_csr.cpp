@@ -49,6 +49,10 @@ namespace {
 struct CsrCtx {
   char *d_idx = nullptr, *d_val = nullptr, *d_c = nullptr, *d_c_rm = nullptr;
   char *h_idx = nullptr, *h_val = nullptr, *h_c = nullptr;
+  // the block's slice of the row offsets (rows + 1 entries) travels with the block instead of the whole array
+  // going to HBM up front (400 MB at the cfg5 size: a staged, synchronous copy out of pageable memory in front
+  // of the first read), and csrgemv 'N' results leave block by block the same way (y slices are disjoint)
+  char *h_ia = nullptr, *d_ia = nullptr, *h_y = nullptr;
   hipEvent_t ready = nullptr, done = nullptr;
   int64_t owner = -1;   // block id this context is reserved for (guarded by mu)
   int state = 0;        // 0 being filled, 1 loaded (H2D enqueued)
@@ -89,6 +93,51 @@ int device_to_pageable(void *dst, const void *src, uint64_t bytes, int n_thr) {
   return fail.load();
 }
 
+// pageable host memory -> HBM through pinned chunks on up to n_thr threads; the copies are queued on streams of
+// their own and `after` (the caller's stream) is ordered behind all of them when this returns.
+int pageable_to_device(void *dst, const void *src, uint64_t bytes, int n_thr, hipStream_t after) {
+  const uint64_t chunk = 8ull << 20;
+  const int64_t nc = (int64_t) ((bytes + chunk - 1) / chunk);
+  if (nc <= 2) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, after) == hipSuccess ? 0 : -1;
+  n_thr = (int) std::max<int64_t>(1, std::min<int64_t>(n_thr, nc));
+  std::atomic<int64_t> next{0};
+  std::atomic<int> fail{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  auto worker = [&, dev] {
+    void *pin[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    if (hipSetDevice(dev) != hipSuccess || copy_stream_create(&st) != hipSuccess) { fail.store(-1); return; }
+    if (pinned_alloc(&pin[0], chunk) != BOF_OK || pinned_alloc(&pin[1], chunk) != BOF_OK) fail.store(-1);
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int q = 0; q < 2 && !fail.load(); q++)
+      if (hipEventCreateWithFlags(&ev[q], hipEventDisableTiming) != hipSuccess) fail.store(-1);
+    bool busy[2] = {false, false};
+    for (int q = 0; !fail.load(); q ^= 1) {
+      const int64_t i = next.fetch_add(1);
+      if (i >= nc) break;
+      const uint64_t o = (uint64_t) i * chunk, len = std::min<uint64_t>(chunk, bytes - o);
+      if (busy[q] && hipEventSynchronize(ev[q]) != hipSuccess) { fail.store(-1); break; }
+      memcpy(pin[q], (const char *) src + o, len);
+      if (hipMemcpyAsync((char *) dst + o, pin[q], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipEventRecord(ev[q], st) != hipSuccess) { fail.store(-1); break; }
+      busy[q] = true;
+    }
+    if (st) (void) hipStreamSynchronize(st);
+    for (int q = 0; q < 2; q++) {
+      if (ev[q]) (void) hipEventDestroy(ev[q]);
+      if (pin[q]) pinned_free(pin[q]);
+    }
+    if (st) (void) hipStreamDestroy(st);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_thr; t++) th.emplace_back(worker);
+  worker();
+  for (auto &x : th) x.join();
+  (void) after;      // every copy has completed (the workers synchronised their streams): nothing left to order
+  return fail.load();
+}
+
 // host arrays that are about to be overwritten whole: no value-initialisation pass
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
@@ -111,6 +160,7 @@ struct CsrRun {
   // A already in HBM (the transposed matrix of csrmm 'T'): 0-based arrays, nothing to read
   const float *res_val = nullptr;
   const int64_t *res_col = nullptr;
+  float *host_y = nullptr;       // csrgemv 'N': the caller's result vector, filled block by block (null: one copy at the end)
   const int64_t *ia = nullptr;   // host offsets of the rows of this call (m + 1 entries, absolute)
   HostI64 ia_store;              // ... when this call read them itself
   std::vector<int64_t> st, sz;
@@ -183,7 +233,13 @@ struct CsrRun {
         cnt.rd += l0 + l1;
       }
       hipError_t e = hipSuccess;
-      if (!rc && !res_val) {
+      if (!rc && c.h_ia) {
+        const size_t ib = (size_t) (sz[b] + 1) * 8;
+        memcpy(c.h_ia, ia + st[b], ib);
+        e = hipMemcpyAsync(c.d_ia, c.h_ia, ib, hipMemcpyHostToDevice, h2d);
+        cnt.h2d += ib;
+      }
+      if (!rc && !res_val && e == hipSuccess) {
         e = hipMemcpyAsync(c.d_idx, c.h_idx, l0, hipMemcpyHostToDevice, h2d);
         if (e == hipSuccess) e = hipMemcpyAsync(c.d_val, c.h_val, l1, hipMemcpyHostToDevice, h2d);
         cnt.h2d += l0 + l1;
@@ -224,7 +280,9 @@ struct CsrRun {
       CsrCtx &c = ctx[b % depth];
       hipError_t e = hipEventSynchronize(c.done);
       if (e != hipSuccess) fail_io(-1000 - (int) e);
-      if (is_mm && !io_error.load() && host_c) {
+      if (!is_mm && host_y && c.h_y && !io_error.load()) {
+        memcpy(host_y + st[b], c.h_y, (size_t) sz[b] * 4);
+      } else if (is_mm && !io_error.load() && host_c) {
         if (ord_b == 'R') memcpy(host_c + (size_t) st[b] * k, c.h_c, c_bytes(b));
         else
           for (int64_t j = 0; j < k; j++)
@@ -659,6 +717,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   R.c_ld = ex && ex->c_ld > 0 ? ex->c_ld : m;
   R.fa = fa; R.fja = fja; R.fb = fb; R.fc = fc;
   if (is_mm && fb.fd < 0) { R.host_b = hb; R.host_c = hc; }
+  if (!is_mm && trans == 'N' && hc && !(ex && ex->partial_y)) R.host_y = hc;
   R.use_aio = R.o.use_odirect != 0;
   BOF_HIP_TRY(hipGetDevice(&R.dev));
   if (m == 0) return BOF_OK;
@@ -688,6 +747,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     if (file_is_direct(fa.fd)) R.sector = std::max(R.sector, file_dio_align(fa.fd));
   }
   size_t max_idx = 0, max_val = 0, max_c = 0;
+  int64_t max_rows = 0;
+  for (int64_t b = 0; b < nb; b++) max_rows = std::max(max_rows, R.sz[b]);
   for (int64_t b = 0; b < nb; b++) {
     uint64_t s, l, d;
     if (!res) {
@@ -727,24 +788,20 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       pinned_free(c.h_idx);
       pinned_free(c.h_val);
       pinned_free(c.h_c);
+      pinned_free(c.h_ia);
+      pinned_free(c.h_y);
+      (void) hipFree(c.d_ia);
       if (c.ready) (void) hipEventDestroy(c.ready);
       if (c.done) (void) hipEventDestroy(c.done);
     }
     if (resident_ev) (void) hipEventDestroy(resident_ev);
-    if (!res) (void) hipFree(d_ia);
     (void) hipFree(own_b); (void) hipFree(own_x); (void) hipFree(own_y);
     if (R.h2d) (void) hipStreamDestroy(R.h2d);
     if (R.d2h) (void) hipStreamDestroy(R.d2h);
   });
   BOF_HIP_TRY(copy_stream_create(&R.h2d));
   BOF_HIP_TRY(copy_stream_create(&R.d2h));
-  if (res) {
-    d_ia = const_cast<int64_t *>(res->ia_dev);
-  } else {
-    BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
-    BOF_HIP_TRY(hipMemcpyAsync(d_ia, R.ia, (size_t) (m + 1) * 8, hipMemcpyHostToDevice, R.h2d));
-    R.cnt.h2d += (uint64_t) (m + 1) * 8;
-  }
+  if (res) d_ia = const_cast<int64_t *>(res->ia_dev);     // else: per block, with the block (CsrCtx::d_ia)
   const int64_t xlen = trans == 'N' ? n : m, ylen = trans == 'N' ? m : n;
   const bool ext_op = ex && ex->shared_op;        // B / x comes from the multi-device caller
   const bool ext_y = ex && ex->partial_y;         // the partial result stays in the caller's vector
@@ -792,7 +849,9 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
         BOF_HIP_TRY(transpose_f32((const float *) tmp, n, k, n, (float *) d_b, k, R.h2d));
       }
     } else {
-      BOF_HIP_TRY(hipMemcpyAsync(d_x, hb, (size_t) xlen * 4, hipMemcpyHostToDevice, R.h2d));
+      // x lives in pageable host memory (include/flash_blas.h:55-57): through pinned chunks on several threads
+      // (a plain copy out of pageable memory is staged by the runtime on the calling thread: 200 MB in 25-40 ms)
+      if (pageable_to_device(d_x, hb, (uint64_t) xlen * 4, std::max(2, R.o.n_io_threads / 2), R.h2d)) return BOF_EHIP;
       if (trans == 'T' && !ext_y) BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
       R.cnt.h2d += (uint64_t) xlen * 4;
     }
@@ -821,6 +880,15 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       BOF_HIP_TRY(hipMalloc((void **) &c.d_val, max_val));
       rc = pinned_alloc((void **) &c.h_idx, max_idx);
       if (!rc) rc = pinned_alloc((void **) &c.h_val, max_val);
+      if (rc) return rc;
+    }
+    if (!res) {
+      BOF_HIP_TRY(hipMalloc((void **) &c.d_ia, (size_t) (max_rows + 1) * 8));
+      rc = pinned_alloc((void **) &c.h_ia, (size_t) (max_rows + 1) * 8);
+      if (rc) return rc;
+    }
+    if (!is_mm && trans == 'N' && !ext_y && hc) {
+      rc = pinned_alloc((void **) &c.h_y, (size_t) std::max<int64_t>(max_rows, 1) * 4);
       if (rc) return rc;
     }
     if (is_mm) {
@@ -867,6 +935,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     herr = hipStreamWaitEvent(st, c.ready, 0);
     if (herr != hipSuccess) break;
     const int64_t s = R.st[b], r = R.sz[b];
+    const int64_t *bia = c.d_ia ? (const int64_t *) c.d_ia : d_ia + s;     // the block's offsets (any base)
     const int64_t *col;
     const float *val;
     if (res) {
@@ -887,10 +956,10 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       for (int64_t j0 = 0; j0 < k && herr == hipSuccess; j0 += R.o.csrmm_cblk) {
         const int64_t w = std::min(k - j0, R.o.csrmm_cblk);
         if (ord_b == 'R')
-          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
+          herr = scsrmm('R', r, w, n, alpha, val, col, bia, (const float *) d_b + j0, k, beta,
                         (float *) c.d_c + j0, k, st);
         else  // 'C': same row-major kernel on the transposed block (d_b is row-major here)
-          herr = scsrmm('R', r, w, n, alpha, val, col, d_ia + s, (const float *) d_b + j0, k, beta,
+          herr = scsrmm('R', r, w, n, alpha, val, col, bia, (const float *) d_b + j0, k, beta,
                         (float *) c.d_c_rm + j0, k, st);
       }
       if (ord_b == 'C' && herr == hipSuccess)  // [r][k] -> packed column-major block [k][r]
@@ -906,11 +975,17 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       R.cnt.d2h += R.c_bytes(b);
     } else {
       if (trans == 'N')
-        herr = scsrgemv('N', r, n, val, d_ia + s, col, (const float *) d_x, (float *) d_y + s, st);
+        herr = scsrgemv('N', r, n, val, bia, col, (const float *) d_x, (float *) d_y + s, st);
       else
-        herr = scsrgemv('T', r, n, val, d_ia + s, col, (const float *) d_x + s, (float *) d_y, st);
+        herr = scsrgemv('T', r, n, val, bia, col, (const float *) d_x + s, (float *) d_y, st);
       if (herr == hipSuccess) herr = ktimer.end(st);
       if (herr == hipSuccess) herr = hipEventRecord(c.done, st);
+      if (herr == hipSuccess && c.h_y) {      // 'N': this block's slice of y leaves now (the retire thread copies it out)
+        herr = hipStreamWaitEvent(R.d2h, c.done, 0);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(c.h_y, (const float *) d_y + s, (size_t) r * 4, hipMemcpyDeviceToHost, R.d2h);
+        if (herr == hipSuccess) herr = hipEventRecord(c.done, R.d2h);
+        R.cnt.d2h += (uint64_t) r * 4;
+      }
     }
     if (herr != hipSuccess) break;
     R.cnt.tasks++;
@@ -924,7 +999,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   (void) hipDeviceSynchronize();
   ktimer.collect(R.cnt);
   BOF_TRACE_T("csr: drained (C written)");
-  if (!is_mm && !ext_y && !fail && herr == hipSuccess) {
+  if (!is_mm && !ext_y && !fail && herr == hipSuccess && !R.host_y) {
     if (device_to_pageable(hc, d_y, (uint64_t) ylen * 4, R.o.n_io_threads)) herr = hipErrorUnknown;
     R.cnt.d2h += (uint64_t) ylen * 4;
     BOF_TRACE_T("csr: y on the host");

@@ -287,6 +287,7 @@ struct PanelHub {
   std::vector<char> issued[2];   // shared operand panels whose read has been queued
   ShareSeg seg[2];               // share_world > 1: the shared operands' node-wide staging
   int share_world = 1, share_rank = 0;
+  bool peer_bcast = false;       // bof_options.peer_bcast: shared panels device to device
   double share_timeout_s = 120;
   std::mutex mu;
   std::condition_variable cv;
@@ -437,7 +438,15 @@ void PanelHub::reader_main(int home) {
     }
     const size_t d0 = rq.di < 0 ? 0 : (size_t) rq.di, d1 = rq.di < 0 ? runs.size() : (size_t) rq.di + 1;
     hipError_t e = hipSuccess;
+    // Shared chunk with bof_options.peer_bcast: over PCIe to ONE device only -- the panel's home, dealt round robin --
+    // and from its HBM to the others device to device (hipMemcpyPeerAsync: xGMI on the 8-GPU node), each on the
+    // receiving device's own copy stream behind the home copy's event.  The host then feeds every shared byte
+    // once instead of once per device.  Resident (never refilled) panels only: the home image is the source.
+    const bool bcast = peer_bcast && rq.di < 0 && runs.size() > 1 && runs[0]->mat[rq.mat].natural;
+    const size_t home = bcast ? (size_t) rq.panel % runs.size() : 0;
+    for (size_t pass = 0; pass < (bcast ? 2u : 1u) && e == hipSuccess; pass++)
     for (size_t d = d0; d < d1 && e == hipSuccess; d++) {
+      if (bcast && ((pass == 0) != (d == home))) continue;       // pass 0: the home device; pass 1: its peers
       PanelRun &R = *runs[d];
       Mat &M = R.mat[rq.mat];
       e = hipSetDevice(R.dev);
@@ -455,12 +464,22 @@ void PanelHub::reader_main(int home) {
         vlk.lock();
         if (prev >= 0 && e == hipSuccess) e = R.verify_last_use(rq.mat, prev, R.h2d);
       }
-      if (e == hipSuccess && !rc)
-        e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, slot + delta, rq.bytes, hipMemcpyHostToDevice, R.h2d);
+      if (bcast && d != home) {
+        PanelRun &Hm = *runs[home];
+        if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, rring->event(ps, Hm.di), 0);     // the home copy of this chunk
+        if (e == hipSuccess && !rc)
+          e = hipMemcpyPeerAsync(M.panel_ptr(rq.panel) + rq.off, R.dev, Hm.mat[rq.mat].panel_ptr(rq.panel) + rq.off, Hm.dev,
+                                 rq.bytes, R.h2d);
+        cnt.p2p += rq.bytes;
+        R.cnt.p2p += rq.bytes;
+      } else {
+        if (e == hipSuccess && !rc)
+          e = hipMemcpyAsync(M.panel_ptr(rq.panel) + rq.off, slot + delta, rq.bytes, hipMemcpyHostToDevice, R.h2d);
+        if (e == hipSuccess && rring->mark_busy(ps, R.h2d, R.di)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
+        cnt.h2d += rq.bytes;
+        R.cnt.h2d += rq.bytes;
+      }
       if (vlk.owns_lock()) vlk.unlock();
-      if (e == hipSuccess && rring->mark_busy(ps, R.h2d, R.di)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
-      cnt.h2d += rq.bytes;
-      R.cnt.h2d += rq.bytes;
     }
     rring->release(ps);
     {
@@ -482,6 +501,9 @@ void PanelHub::reader_main(int home) {
           if (e == hipSuccess && M.kmajor_copy)
             e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
+          // a failed copy / record must be visible BEFORE the panel is: the dispatcher tests io_error right
+          // after it sees state 2, and a `ready` that was never recorded would make its wait a no-op
+          if (e != hipSuccess || rc) { int none = 0; io_error.compare_exchange_strong(none, rc ? rc : -1000 - (int) e); }
           P.state = 2;
           evt("panel H2D queued (ready recorded)", rq.mat, rq.panel, (uint64_t) R.di);
           R.trace2("read + H2D queued:", rq.mat, rq.panel);
@@ -1103,6 +1125,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     }
   }
   for (int x = 0; x < 2; x++) H.issued[x].assign(H.runs[0]->mat[x].panels.size(), 0);
+  H.peer_bcast = H.runs.size() > 1 && (o.peer_bcast == 1 || (o.peer_bcast == 0 && env_long("BOF_PEER_BCAST", 0) > 0));
   guard.add([&H] {
     // a rank that gives up tells the peers so (they would wait for the timeout otherwise)
     for (int x = 0; x < 2; x++) {
@@ -1235,7 +1258,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     s.bytes_read = R.cnt.rd; s.bytes_written = R.cnt.wr; s.bytes_h2d = R.cnt.h2d; s.bytes_d2h = R.cnt.d2h;
     s.tasks = R.cnt.tasks; s.seconds = R.seconds;
     s.kernel_launches = R.cnt.klaunch; s.kernel_seconds = (double) R.cnt.kns.load() * 1e-9;
-    s.verify_checks = R.cnt.vchecks;
+    s.verify_checks = R.cnt.vchecks; s.bytes_p2p = R.cnt.p2p;
     per[(size_t) d] = s;
   }
   publish_device_stats(per);

@@ -421,8 +421,14 @@ struct GemmRun {
             const Tile &tq = tiles[G.tiles[q]];
             if (e == hipSuccess) e = vf.on_device(tq.ve_in, slots[G.slots[q]].ptr, tq.nrows, tq.ncols, tq.ncols, 0, 0, h2d);
             if (e == hipSuccess) e = hipEventRecord(slots[G.slots[q]].ready, h2d);
-            tiles[G.tiles[q]].state = 2;
           }
+          // a failed copy / record must be visible BEFORE the tiles are: the dispatcher tests io_error right
+          // after it sees state 2, and a `ready` that was never recorded would make its wait a no-op
+          if (e != hipSuccess || rc) { int none = 0; io_error.compare_exchange_strong(none, rc ? rc : -1000 - (int) e); }
+          for (size_t q = 0; q < G.tiles.size(); q++) tiles[G.tiles[q]].state = 2;
+        } else if (e != hipSuccess) {
+          int none = 0;
+          io_error.compare_exchange_strong(none, -1000 - (int) e);
         }
       }
       if (e != hipSuccess) fail_io(-1000 - (int) e);

@@ -34,52 +34,7 @@ std::recursive_mutex &device_call_mutex() {
   return g_call_mu[dev & 63];
 }
 
-// ---- the always-on event ring (flash_common.h) ------------------------------------------------------------
-namespace {
-EventRec g_evt[kEventRing];
-std::atomic<uint64_t> g_evt_next{0};
-std::atomic<uint64_t> g_evt_call_begin_ns{0};
-uint64_t now_ns() {
-  return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-}  // namespace
-void evt(const char *what, int a, int b, uint64_t c) {
-  static thread_local const uint32_t tid = (uint32_t) syscall(SYS_gettid);
-  const uint64_t i = g_evt_next.fetch_add(1, std::memory_order_relaxed);
-  EventRec &r = g_evt[i % kEventRing];
-  r.t_ns = now_ns();
-  r.tid = tid;
-  r.a = a;
-  r.b = b;
-  r.c = (uint32_t) c;
-  // the label last: a dump that races with a writer sees either the old record or the new one's label
-  __atomic_store_n(&r.what, what, __ATOMIC_RELEASE);
-}
-void evt_mark_call_begin() { g_evt_call_begin_ns.store(now_ns()); }
-void evt_dump(FILE *f, const char *why) {
-  const uint64_t end = g_evt_next.load();
-  const uint64_t begin = end > kEventRing ? end - kEventRing : 0;
-  const uint64_t t0 = g_evt_call_begin_ns.load();
-  fprintf(f, "[bof events] %s: last %llu of %llu events (ms relative to the last call's begin; thread; event; a b c)\n",
-          why ? why : "", (unsigned long long) (end - begin), (unsigned long long) end);
-  for (uint64_t i = begin; i < end; i++) {
-    const EventRec r = g_evt[i % kEventRing];
-    const char *w = __atomic_load_n(&g_evt[i % kEventRing].what, __ATOMIC_ACQUIRE);
-    if (!w) continue;
-    fprintf(f, "[bof events] %12.3f  t%-7u %-34s %d %d %u\n", ((double) r.t_ns - (double) t0) * 1e-6, r.tid, w, r.a, r.b, r.c);
-  }
-  fflush(f);
-}
-void evt_dump_env(const char *why) {
-  const char *path = getenv("BOF_EVENT_DUMP");
-  if (!path || !path[0]) return;
-  FILE *f = fopen(path, "a");
-  if (!f) return;
-  evt_dump(f, why);
-  fclose(f);
-}
 
-uint64_t evt_count() { return g_evt_next.load(); }
 
 // ---- BOF_VERIFY table (flash_common.h) ---------------------------------------------------------------------
 int Verify::init(int device, size_t capacity) {

@@ -40,6 +40,7 @@ extern "C" long mock_hip_fail_api_pending();
   } while (0)
 
 static std::atomic<uint64_t> g_verify_checks{0};
+static bool g_peer_bcast = false;     // bof_options.peer_bcast for the gemm cases (shared panels device to device)
 static std::string g_dir;
 static thread_local std::string t_prefix;      // concurrent callers keep their files apart
 static bool g_truncate_a = false;    // the next gemm_case cuts its A file in half (a reader's request comes back short)
@@ -141,6 +142,7 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   o.panel_group = g_knobs.group;
   o.use_odirect = direct ? 1 : 0;
   o.hbm_budget = budget;
+  o.peer_bcast = g_peer_bcast ? 1 : 2;
   const uint64_t launches0 = mock_hip_kernel_launches();
   int rc;
   if (kmeans)
@@ -176,6 +178,19 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     bof_flash_stats tot;
     CHECK(bof_flash_last_stats(&tot) == BOF_OK && tot.verify_checks >= 4);
     g_verify_checks += tot.verify_checks;
+  }
+  if (g_peer_bcast && nd > 1 && t_prefix.empty() && path != 1) {
+    // shared panels reach ONE device over PCIe and the others from that device's HBM: every byte read from the files
+    // crosses the host-to-device link exactly once, the rest of the fan-out is device to device
+    bof_flash_stats tot;
+    CHECK(bof_flash_last_stats(&tot) == BOF_OK);
+    if (tot.tile_misses || true) {
+      CHECK(tot.bytes_p2p > 0);
+      CHECK(tot.bytes_h2d == tot.bytes_read);
+      uint64_t p2p = 0;
+      for (int d = 0; d < nd; d++) p2p += per[d].bytes_p2p;
+      CHECK(p2p == tot.bytes_p2p);
+    }
   }
   if (devs.size() > 1 && nd > 1 && t_prefix.empty()) {   // (a C of one panel is one slab whatever the list; the "last call"
                                                           //  statistics are the process's, so not with concurrent callers)
@@ -431,6 +446,15 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
       // panels of several staging chunks each (1.15 MiB panels, 1 MiB chunks; B's rows are unaligned: with O_DIRECT the
       // sector-widened reads cut at page-aligned file positions), shared B fanned out chunk by chunk
       if (devs.size() >= 3) gemm_case('R', 'N', 'N', 256, 2304, 160, 1.f, 0.f, 128, 2, 0, devs, direct, false, 0);
+      // the same with bof_options.peer_bcast: a shared panel over PCIe to its home device only, device to device to the rest
+      if (devs.size() > 1) {
+        g_peer_bcast = true;
+        gemm_case('R', 'N', 'N', 400, 300, 390, 1.f, 0.f, 128, 2, 0, devs, direct, false, 0);
+        gemm_case('C', 'T', 'N', 390, 256, 260, 2.f, 1.f, 128, 2, 0, devs, direct, false, 0);
+        gemm_case('C', 'T', 'N', 256, 520, 200, -2.f, 0.f, 128, 2, 0, devs, direct, true, 0);
+        if (devs.size() >= 3) gemm_case('R', 'N', 'N', 256, 2304, 160, 1.f, 0.f, 128, 2, 0, devs, direct, false, 0);
+        g_peer_bcast = false;
+      }
       // tile cache: forced, and chosen because C's rows have gaps (ldc > stored width)
       gemm_case('R', 'N', 'T', 390, 300, 256, 1.f, 1.f, 128, 1, 0, devs, direct, false, 0);
       gemm_case('C', 'N', 'N', 256, 390, 300, 2.f, 0.f, 128, 0, 8, devs, direct, false, 0);

@@ -43,6 +43,7 @@ hipError_t csc_merge(int, int64_t, const int64_t *, const int64_t *, const int64
 hipError_t scsrcsc(int64_t, int64_t, int64_t, const float *, const int64_t *, const int64_t *, float *,
                    int64_t *, int64_t *, void *, hipStream_t) { return hipErrorUnknown; }
 hipError_t sum_partials(float *, const float *const *, int, int64_t, hipStream_t) { return hipErrorUnknown; }
+hipError_t verify_sum(const void *, int64_t, int64_t, int64_t, uint64_t, int64_t, unsigned long long *, hipStream_t) { return hipErrorUnknown; }
 }  // namespace bof
 extern "C" const char *bof_last_error(void) { return ""; }
 

@@ -234,6 +234,14 @@ def test_cfg4_composition_65536_files(dev, tmp_path, how):
     if free < 14 * 2**30:
         pytest.skip("needs at least 12 GiB of scratch disk")
     n = 65536 if free > 52 * 2**30 else 32768
+    # which size ran is part of the result: printed (pytest -s / the captured log), recorded in
+    # gpurun_out/cfg4_composition_<how>.json when that directory exists, and with BOF_REQUIRE_FULL=1 a short
+    # scratch disk FAILS the test instead of shrinking it
+    if n != 65536 and os.environ.get("BOF_REQUIRE_FULL") == "1":
+        pytest.fail(f"BOF_REQUIRE_FULL=1: the cfg4 composition needs 52 GiB of scratch disk for 3 x 16 GiB files, "
+                    f"{free / 2**30:.0f} GiB free under {tmp_path}")
+    print(f"[cfg4 composition / {how}] running {n} x 65536 x 65536" if n == 65536 else
+          f"[cfg4 composition / {how}] SHRUNK to {n}^3 ({free / 2**30:.0f} GiB of scratch disk free, 52 needed)")
     torch.cuda.empty_cache()
     extra = ["--rank-calls", "8"] if how == "eight_rank_calls" else ["--devices", "0,0,0,0,0,0,0,0"]
     # (a) from the page cache (B is re-read by every call: 8 x 16 GiB would take a minute from the device)
@@ -254,6 +262,13 @@ def test_cfg4_composition_65536_files(dev, tmp_path, how):
         assert st["bytes_read"] == 2 * 4 * n * n                 # A once, B once for all eight devices
         assert st["bytes_h2d"] == 4 * n * n * (1 + 8)            # ... and copied to each of them
         assert len(leg["per_device"]) == 8 and all(p["tasks"] == tiles ** 3 // 8 for p in leg["per_device"])
+    rec = {"how": how, "n": n, "full_size": n == 65536, "scratch_free_GiB": round(free / 2**30, 1), "seconds": leg["seconds"],
+           "bytes_read": st["bytes_read"], "bytes_written": st["bytes_written"], "tasks": st["tasks"], "whole_C_verified": True}
+    print(f"[cfg4 composition / {how}] {json.dumps(rec)}")
+    gout = os.path.join(root, "gpurun_out")
+    if os.path.isdir(gout):
+        with open(os.path.join(gout, f"cfg4_composition_{how}.json"), "w") as f:
+            json.dump(rec, f)
 
 
 def test_cfg5_csrgemv_composition_8_shards(dev):

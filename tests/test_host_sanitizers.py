@@ -86,6 +86,10 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     # library put between them, and ThreadSanitizer follows exactly those edges: a stream-ordering race detector.
     plan = [("asan", [], {}), ("tsan", ["brief"], {"MOCK_HIP_ASYNC": "1", "HOST_PIPELINE_CONCURRENT_ROUNDS": "1"}),
             ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300"}),
+            # BOF_VERIFY on: every panel / tile summed at every hand-over (pinned slot, HBM after H2D, HBM after its last
+            # use, C in HBM -> pinned -> file), with jittered asynchronous streams -- a copy that overtakes a kernel, a slot
+            # refilled too early or a chunk that lands in the wrong place shows up as a named mismatch
+            ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300", "BOF_VERIFY": "1"}),
             # the 8-GPU node's shape: C panels / row blocks over eight devices, eight "ranks" through the staging ring
             ("asan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8"}),
             # every hipMalloc / hipHostMalloc of a gemm call (both paths) and of the CSR calls fails once: an error code
