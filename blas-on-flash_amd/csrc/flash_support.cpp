@@ -342,6 +342,43 @@ int bind_thread_near_device(int dev) {
 
 }  // namespace bof
 
+// $BOF_CRASH_TRACE=1: a fatal signal inside the process prints the native stack (module + offset per frame:
+// resolve with addr2line -e libbof_hip.so) and the event ring before the previous handler (Python's faulthandler,
+// the default action) takes over.  Diagnostic for long fuzz runs; not async-signal-safe by the letter, but the
+// process is about to die anyway.
+#include <execinfo.h>
+#include <signal.h>
+namespace {
+struct sigaction g_prev_segv, g_prev_bus, g_prev_abrt;
+void crash_handler(int sig, siginfo_t *info, void *ctx) {
+  static std::atomic<int> once{0};
+  if (once.fetch_add(1) == 0) {
+    void *bt[64];
+    const int n = backtrace(bt, 64);
+    const char msg[] = "[bof] fatal signal -- native stack (module+offset):\n";
+    (void) !write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    bof::evt_dump(stderr, "fatal signal");
+  }
+  struct sigaction *prev = sig == SIGSEGV ? &g_prev_segv : sig == SIGBUS ? &g_prev_bus : &g_prev_abrt;
+  sigaction(sig, prev, nullptr);
+  if ((prev->sa_flags & SA_SIGINFO) && prev->sa_sigaction) prev->sa_sigaction(sig, info, ctx);
+  else raise(sig);
+}
+struct CrashTraceInit {
+  CrashTraceInit() {
+    const char *e = getenv("BOF_CRASH_TRACE");
+    if (!e || !e[0] || !strcmp(e, "0")) return;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = crash_handler;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigaction(SIGSEGV, &sa, &g_prev_segv);
+    sigaction(SIGBUS, &sa, &g_prev_bus);
+  }
+} g_crash_trace_init;
+}  // namespace
+
 extern "C" uint64_t bof_event_dump(const char *path) {
   if (!path || !path[0]) {
     bof::evt_dump(stderr, "bof_event_dump");
