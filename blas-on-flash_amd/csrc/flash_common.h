@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -356,6 +357,24 @@ inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUM
   evt_dump(f, why);
   fclose(f);
 }                          // times in a dump are relative to the last of these
+
+// ---- persistent launcher threads ------------------------------------------------------------------------------
+// Kernel launches are only ever issued by the CALLING thread or by one of these long-lived threads, never by a
+// thread created for the call.  Why: on this stack (ROCm 7.x HIP runtime, gfx950) a kernel launched from a
+// thread that was created for the call -- reproducibly its SECOND launch -- occasionally runs with a wrong trailing
+// argument (a tile task of flash::kmeans got the next task's p_l2sq pointer; a plain tile task a wrong scalar):
+// 4-9 wrong C tiles per 29 000 fuzzed multi-slab calls with a fresh dispatcher thread per call, 0 per 29 000 from the
+// calling thread and 0 per 29 000 from a persistent worker; neither a device synchronisation before every launch nor a
+// warm-up launch on the fresh thread changed it (profiles/r4/fuzz_thread_bisect.md).  It was the "one unexplained
+// wrong tile" of round 3.  launch_async(dev, rep, fn) runs fn on the persistent thread of (device, repetition of the
+// ordinal in the call's device list), created on first use and kept for the life of the process; launch_wait joins it.
+struct LaunchJob {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+};
+std::shared_ptr<LaunchJob> launch_async(int dev, int rep, std::function<void()> fn);
+void launch_wait(const std::shared_ptr<LaunchJob> &job);
 
 // ---- BOF_VERIFY: hand-over checksums (bof_options.verify / $BOF_VERIFY) ------------------------------------
 // Every object a level-3 GEMM pipeline moves (a row panel; a packed tile) is summed at each hand-over -- in the

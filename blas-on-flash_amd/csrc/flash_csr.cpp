@@ -1192,7 +1192,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   std::string feed_err;
   std::promise<int> fed_promise;
   std::shared_future<int> fed = fed_promise.get_future().share();
-  std::thread feeder([&] {
+  // (on a persistent launcher thread of its own -- it launches the transposes of a column-major B)
+  auto feeder = launch_async(sh[0].dev, 1 << 20, [&] {
     struct SetOnExit {     // the pipelines wait for this future before they wait for the device-side events
       std::promise<int> &p; int &rc;
       ~SetOnExit() { p.set_value(rc); }
@@ -1248,13 +1249,21 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     if (S.rc) S.err = bof_last_error();
     S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   };
+  // the calling thread drives the first shard, a PERSISTENT launcher thread each of the others (never a thread made
+  // for the call: flash_common.h, "persistent launcher threads")
+  auto rep_of = [&sh](int d) {
+    int rep = 0;
+    for (int e = 0; e < d; e++)
+      if (sh[(size_t) e].dev == sh[(size_t) d].dev) rep++;
+    return rep;
+  };
   {
-    std::vector<std::thread> th;
-    for (int d = 1; d < D; d++) th.emplace_back([&, d] { run_shard(sh[(size_t) d]); });
+    std::vector<std::shared_ptr<LaunchJob>> jobs;
+    for (int d = 1; d < D; d++) jobs.push_back(launch_async(sh[(size_t) d].dev, rep_of(d), [&, d] { run_shard(sh[(size_t) d]); }));
     run_shard(sh[0]);
-    for (auto &t : th) t.join();
+    for (auto &j : jobs) launch_wait(j);
   }
-  feeder.join();
+  launch_wait(feeder);
   if (feed_rc) { rc = feed_rc; set_error(feed_err); }
   for (Shard &S : sh)
     if (S.rc && !rc) { rc = S.rc; set_error(S.err); }
@@ -1295,10 +1304,10 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     };
     // NOTE on summation order: segment sums run e = 0 .. D-1, a fixed order; the partials themselves
     // are sums of fp32 atomics (as in the single-device call), exact on integer data
-    std::vector<std::thread> th;
-    for (int d = 1; d < D; d++) th.emplace_back([&, d] { reduce_segment(d); });
+    std::vector<std::shared_ptr<LaunchJob>> jobs;
+    for (int d = 1; d < D; d++) jobs.push_back(launch_async(sh[(size_t) d].dev, rep_of(d), [&, d] { reduce_segment(d); }));
     reduce_segment(0);
-    for (auto &t : th) t.join();
+    for (auto &j : jobs) launch_wait(j);
     for (int d = 0; d < D; d++)
       if (seg_rc[(size_t) d] && !rc) { rc = seg_rc[(size_t) d]; set_error("csrgemv 'T': reducing the partial sums across the devices failed"); }
   }

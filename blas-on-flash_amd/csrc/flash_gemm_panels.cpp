@@ -1191,7 +1191,8 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   H.trace("rings/streams ready");
 
   const int nd = (int) H.runs.size();
-  std::vector<std::thread> readers, writers, flushers, allocators, dispatchers;
+  std::vector<std::thread> readers, writers, flushers, allocators;
+  std::vector<std::shared_ptr<LaunchJob>> dispatch_jobs;
   const int n_readers = std::max(1, o.n_io_threads) + (nd - 1);
   const long wenv = o.panel_writers > 0 ? o.panel_writers : env_long("BOF_PANEL_WRITERS", 0);
   const int n_writers = (wenv > 0 ? (int) wenv : std::max(2, std::min(8, o.n_io_threads / 2))) + (nd - 1);
@@ -1214,10 +1215,14 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   // ---- dispatch: the caller drives the first device, a thread each of the others ---------------------
   for (int d = 1; d < nd; d++) {
     PanelRun *r = H.runs[(size_t) d].get();
-    dispatchers.emplace_back([r] { r->dispatch(); });
+    // (a persistent launcher thread per (device, repetition), never a thread made for the call: flash_common.h)
+    int rep = 0;
+    for (int e = 0; e < d; e++)
+      if (H.runs[(size_t) e]->dev == r->dev) rep++;
+    dispatch_jobs.push_back(launch_async(r->dev, rep, [r] { r->dispatch(); }));
   }
   H.runs[0]->dispatch();
-  for (auto &th : dispatchers) th.join();
+  for (auto &j : dispatch_jobs) launch_wait(j);
 
   // ---- drain ------------------------------------------------------------------------------------
   for (auto &th : allocators) th.join();

@@ -875,6 +875,8 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
     // packed tiles: leading dim = stored column count (reference gemm.cpp:117-120)
     herr = ktimer.begin(st);
     if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (timing event)"; break; }
+    static const long dbg_sync_each = env_long("BOF_DBG_KM_SYNC_EACH", 0);
+    if (dbg_sync_each && kv) (void) hipDeviceSynchronize();
     herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
                       (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], kv,
                       tk.i * g.blk[0], tk.j * g.blk[2], st);
@@ -1051,13 +1053,31 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
     std::vector<int> ords;
     for (auto &S : slabs)
       if (std::find(ords.begin(), ords.end(), S->dev) == ords.end()) ords.push_back(S->dev);
-    std::vector<std::thread> th;
-    for (int od : ords)
-      th.emplace_back([&, od] {
-        for (auto &S : slabs)
-          if (S->dev == od) run_slab(*S);
-      });
-    for (auto &t : th) t.join();
+    // Slabs that share an ordinal run one after the other on that ordinal's launcher: the calling thread for the
+    // first ordinal, a PERSISTENT launcher thread for every other one (never a thread made for the call:
+    // flash_common.h, "persistent launcher threads").  $BOF_DBG_SLAB_THREAD=1 restores a fresh thread per call --
+    // the configuration that produced the wrong tiles -- for the experiment of profiles/r4.
+    if (env_long("BOF_DBG_SLAB_THREAD", 0) == 1) {
+      std::vector<std::thread> th;
+      for (int od : ords)
+        th.emplace_back([&, od] {
+          for (auto &S : slabs)
+            if (S->dev == od) run_slab(*S);
+        });
+      for (auto &t : th) t.join();
+    } else {
+      std::vector<std::shared_ptr<LaunchJob>> jobs;
+      for (size_t q = 1; q < ords.size(); q++) {
+        const int od = ords[q];
+        jobs.push_back(launch_async(od, 0, [&, od] {
+          for (auto &S : slabs)
+            if (S->dev == od) run_slab(*S);
+        }));
+      }
+      for (auto &S : slabs)
+        if (S->dev == ords[0]) run_slab(*S);
+      for (auto &j : jobs) launch_wait(j);
+    }
   }
   Counters total;
   std::vector<bof_flash_stats> per;

@@ -13,7 +13,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
+#include <functional>
 #include <map>
+#include <memory>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <sys/syscall.h>
@@ -35,6 +39,57 @@ std::recursive_mutex &device_call_mutex() {
 }
 
 
+
+// ---- persistent launcher threads (flash_common.h) ------------------------------------------------------------
+namespace {
+struct Launcher {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::pair<std::function<void()>, std::shared_ptr<LaunchJob>>> q;
+};
+std::mutex g_launch_mu;
+// (never destroyed: the detached threads wait on these objects until the process ends)
+std::map<std::pair<int, int>, Launcher *> &launchers() {
+  static auto *m = new std::map<std::pair<int, int>, Launcher *>();
+  return *m;
+}
+}  // namespace
+std::shared_ptr<LaunchJob> launch_async(int dev, int rep, std::function<void()> fn) {
+  Launcher *L = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    Launcher *&slot = launchers()[std::make_pair(dev, rep)];
+    if (!slot) {
+      slot = new Launcher();
+      Launcher *me = slot;
+      std::thread([me, dev] {
+        (void) hipSetDevice(dev);
+        for (;;) {
+          std::pair<std::function<void()>, std::shared_ptr<LaunchJob>> job;
+          {
+            std::unique_lock<std::mutex> lk2(me->mu);
+            me->cv.wait(lk2, [&] { return !me->q.empty(); });
+            job = std::move(me->q.front());
+            me->q.pop_front();
+          }
+          job.first();
+          { std::lock_guard<std::mutex> lk2(job.second->mu); job.second->done = true; }
+          job.second->cv.notify_all();
+        }
+      }).detach();
+    }
+    L = slot;
+  }
+  auto job = std::make_shared<LaunchJob>();
+  { std::lock_guard<std::mutex> lk(L->mu); L->q.emplace_back(std::move(fn), job); }
+  L->cv.notify_one();
+  return job;
+}
+void launch_wait(const std::shared_ptr<LaunchJob> &job) {
+  if (!job) return;
+  std::unique_lock<std::mutex> lk(job->mu);
+  job->cv.wait(lk, [&] { return job->done; });
+}
 
 // ---- BOF_VERIFY table (flash_common.h) ---------------------------------------------------------------------
 int Verify::init(int device, size_t capacity) {

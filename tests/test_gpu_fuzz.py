@@ -191,6 +191,9 @@ def gemm_case(rng, tmp, kmeans=False):
         except AssertionError:
             if os.environ.get("BOF_FUZZ_DUMP"):      # everything needed to look at the failure offline
                 got = np.fromfile(files[2].path, np.uint8)
+                # what the library did during the failing call, hand-over by hand-over (the always-on event ring)
+                bofhip.lib().bof_event_dump(os.path.join(os.environ["BOF_FUZZ_DUMP"],
+                                                         f"fuzz_fail_{os.getpid()}_{int(time.time())}.events.txt").encode())
                 # the same call once more on a restored C: does the mismatch come back?
                 with open(files[2].path, "r+b") as f:
                     f.seek(files[2].head)

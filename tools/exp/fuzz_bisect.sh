@@ -1,0 +1,13 @@
+# Which thread launches the tile kernels of a multi-slab tile-cache call?  (profiles/r4/fuzz_thread_bisect.md)
+run() { name=$1; shift; env "$@" tools/fuzz_parallel.sh gpurun_out/fuzz_x/$name 12 ${SECS:-200} 7001 --kind ${KIND:-kmeans} "--set" "devices=[0,0,0];gemm_path=1" > gpurun_out/fuzz_x/$name.txt 2>&1; echo "== $name: $(grep -h '^fuzz:' gpurun_out/fuzz_x/$name.txt | awk '{c+=$2; f+=$4} END{print c" cases, "f" failures"}')"; }
+mkdir -p gpurun_out/fuzz_x
+for t in "$@"; do
+case $t in
+X0) run X0_fresh_thread BOF_DBG_SLAB_THREAD=1 ;;
+X1) run X1_caller_thread BOF_DBG_SLAB_THREAD=0 ;;
+X2) run X2_fresh_thread_sync_each BOF_DBG_SLAB_THREAD=1 BOF_DBG_KM_SYNC_EACH=1 ;;
+X3) KIND=gemm run X3_gemm_fresh_thread BOF_DBG_SLAB_THREAD=1 ;;
+X4) run X4_fresh_thread_warmup_launch BOF_DBG_SLAB_THREAD=2 ;;
+X5) run X5_persistent_worker BOF_DBG_SLAB_THREAD=3 ;;
+esac
+done

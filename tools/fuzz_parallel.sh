@@ -6,7 +6,7 @@ mkdir -p "$out"
 pids=()
 for i in $(seq 0 $((n - 1))); do
   s=$((seed0 + i))
-  python3 tests/test_gpu_fuzz.py --verify --seconds "$secs" --seed "$s" "$@" > "$out/fuzz_seed$s.log" 2>&1 &
+  BOF_FUZZ_DUMP="${BOF_FUZZ_DUMP_DIR:-}" python3 tests/test_gpu_fuzz.py --verify --seconds "$secs" --seed "$s" "$@" > "$out/fuzz_seed$s.log" 2>&1 &
   pids+=($!)
 done
 rc=0
