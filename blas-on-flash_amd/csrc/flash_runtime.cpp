@@ -775,14 +775,21 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       BOF_HIP_TRY(hipEventCreateWithFlags(&R.slots[s].use[q], hipEventDisableTiming));
     R.free_slots.push_back((int) (n_slots - 1 - s));
   }
-  rc = R.res->rring.init(std::max(2, R.o.pinned_slots), R.slot_bytes);
+  // A staging slot must hold at least ONE row of the widest row group (up to group_max adjacent tiles): with short,
+  // wide tiles (3 x 128 tiles of a 3 x 2000 problem: a group row is 8 KiB, a tile 1.5 KiB) a slot of one tile's size
+  // was overrun by the first chunk -- the segmentation faults of the round-4 fuzz (flush_wgroup -> hipMemcpy2DAsync
+  // past the end of the pinned block; the block cache's slack hid it most of the time).
+  int64_t max_cols = 1;
+  for (const Tile &t : R.tiles) max_cols = std::max(max_cols, t.ncols);
+  const size_t ring_bytes = std::max(R.slot_bytes, (size_t) round_up((uint64_t) R.group_max * (uint64_t) max_cols * 4, 4096));
+  rc = R.res->rring.init(std::max(2, R.o.pinned_slots), ring_bytes);
   if (rc) return rc;
   // write-back ring: a whole C super-block can be in flight, so the dispatcher does not
   // stall at the end of a block while the writers drain the previous one
   // (buffered writes to one file serialise on the inode lock: more than a few writers only
   // add contention -- 4 writers 0.84 s, 8 writers 1.01 s on the cfg2 file run)
   const int n_writers = std::max(2, std::min(4, R.o.n_io_threads / 2));
-  rc = R.res->wring.init((int) std::min<int64_t>(gi * gj, 16) + 2, R.slot_bytes);
+  rc = R.res->wring.init((int) std::min<int64_t>(gi * gj, 16) + 2, ring_bytes);
   if (rc) return rc;
   BOF_HIP_TRY(copy_stream_create(&R.h2d));
   BOF_HIP_TRY(copy_stream_create(&R.d2h));

@@ -458,6 +458,10 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
       // tile cache: forced, and chosen because C's rows have gaps (ldc > stored width)
       gemm_case('R', 'N', 'T', 390, 300, 256, 1.f, 1.f, 128, 1, 0, devs, direct, false, 0);
       gemm_case('C', 'N', 'N', 256, 390, 300, 2.f, 0.f, 128, 0, 8, devs, direct, false, 0);
+      // tile cache with SHORT, WIDE tiles (3 x 128): one row of a 16-tile row group is wider than a whole tile -- the
+      // staging slots must be sized by the group row, not by the tile (round-4 fuzz: pinned block overrun)
+      gemm_case('R', 'N', 'N', 3, 2000, 3, 1.f, 0.f, 128, 1, 0, devs, direct, false, 0);
+      gemm_case('R', 'N', 'T', 5, 1500, 130, 1.f, 1.f, 128, 1, 0, devs, direct, false, 0);
       // tile cache under a budget of a dozen tiles (eviction, write-back of finished row groups)
       gemm_case('R', 'N', 'N', 384, 384, 384, 1.f, 1.f, 128, 1, 0, devs, direct, false, 12 * 128 * 128 * 4);
       // flash::kmeans on both paths

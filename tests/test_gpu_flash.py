@@ -794,3 +794,31 @@ def test_flash_gemm_buffered_descriptors(dev, tmp_path, path):
         assert np.array_equal(F.read("c", np.float32, (m, n)), ref)
     finally:
         F.close()
+
+
+@pytest.mark.parametrize("m,n,k", [(3, 2000, 3), (5, 1500, 130), (2, 4000, 64)])
+def test_flash_gemm_tilecache_short_wide_tiles(dev, tmp_path, m, n, k):
+    """Tile cache with tiles that are short and wide (m of a few rows): one ROW of a 16-tile row group is wider than a
+    whole tile, so the pinned staging slots must be sized by the group row -- sized by the tile they were overrun by the
+    first chunk (the segmentation faults of the round-4 fuzz: flush_wgroup -> hipMemcpy2DAsync past the pinned block)."""
+    rng = np.random.default_rng(m * 1000 + k)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    want = orc.flash_gemm("R", "N", "N", m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, 128)
+    paths = [str(tmp_path / x) for x in "ABC"]
+    for x, p in zip((a, b, c0), paths):
+        x.tofile(p)
+    for rep in range(3):                       # fresh pinned blocks the first time, cached ones later
+        c0.tofile(paths[2])
+        fds = [os.open(p, os.O_RDWR) for p in paths]
+        try:
+            bofhip.lib().bof_flash_release()   # exact-size staging blocks, no slack from the block cache
+            bofhip.flash_gemm("R", "N", "N", m, n, k, 0.5, 2.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                              bofhip.FPtr(fds[2], 0), 0, 0, 0,
+                              bofhip.default_options(gemm_blk=128, gemm_path=1, use_odirect=0, io_chunk_mib=1))
+        finally:
+            for fd in fds:
+                bofhip.lib().bof_file_forget(fd)
+                os.close(fd)
+        assert np.array_equal(np.fromfile(paths[2], np.float32).reshape(m, n), want)

@@ -3,6 +3,7 @@
 # every gemm / kmeans call with BOF_VERIFY=1 hand-over checksums.  Usage: tools/fuzz_parallel.sh OUTDIR N SECONDS FIRST_SEED [extra args]
 out=$1; n=$2; secs=$3; seed0=$4; shift 4
 mkdir -p "$out"
+export BOF_CRASH_TRACE=1      # a crash inside the library leaves its native stack and the event ring behind
 pids=()
 for i in $(seq 0 $((n - 1))); do
   s=$((seed0 + i))
