@@ -368,6 +368,10 @@ inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUM
 // warm-up launch on the fresh thread changed it (profiles/r4/fuzz_thread_bisect.md).  It was the "one unexplained
 // wrong tile" of round 3.  launch_async(dev, rep, fn) runs fn on the persistent thread of (device, repetition of the
 // ordinal in the call's device list), created on first use and kept for the life of the process; launch_wait joins it.
+// what the crash handler ($BOF_CRASH_TRACE=1) prints besides the stack: a callback the running pipeline registers
+extern void (*g_crash_dump_fn)(void *);
+extern void *g_crash_dump_arg;
+
 struct LaunchJob {
   std::mutex mu;
   std::condition_variable cv;

@@ -130,6 +130,28 @@ struct GemmResources {
   PinnedRing rring, wring;
   char *slab = nullptr;
   size_t slab_bytes = 0;
+  // The per-slot events (18 a slot) and the two copy streams are kept between calls too: a small call used to
+  // create and destroy hundreds of events -- per slab -- and under load (16 processes on one GPU) slot tables were
+  // found with the low bytes of an event handle overwritten, as by a late write into an object that had been
+  // freed and whose memory the table had taken over (profiles/r4/fuzz_crash.md).  Steady state: no HIP object is
+  // created or destroyed by a call; bof_flash_release destroys the pool.
+  std::vector<hipEvent_t> ev_pool;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  int events(size_t n) {       // grow the pool to at least n events
+    while (ev_pool.size() < n) {
+      hipEvent_t e = nullptr;
+      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev_pool.push_back(e);
+    }
+    return BOF_OK;
+  }
+  void destroy_hip_objects() {
+    for (hipEvent_t e : ev_pool) (void) hipEventDestroy(e);
+    ev_pool.clear();
+    if (h2d) (void) hipStreamDestroy(h2d);
+    if (d2h) (void) hipStreamDestroy(d2h);
+    h2d = d2h = nullptr;
+  }
 };
 static std::mutex g_res_mu;
 static GemmResources *g_res[64];
@@ -548,8 +570,33 @@ struct GemmRun {
   // ---- write-back of finished C tiles, a row group at a time --------------------------------------------
   std::vector<int> wgroup;              // finished, adjacent C tiles of one block row, not flushed yet
   std::vector<int> wgroup_stream;       // the compute stream each one's last task ran on
+  // every tile waiting in wgroup must still own its slot (it is pinned until its write-back is queued); checked
+  // before each use because a violation used to surface as a crash inside hipEventRecord on a garbage handle
+  bool wgroup_sane(const char *where) {
+    for (size_t q = 0; q < wgroup.size(); q++) {
+      const int id = wgroup[q];
+      const bool ok = id >= 0 && id < (int) tiles.size() && tiles[id].mat == 2 && tiles[id].slot >= 0 &&
+                      tiles[id].slot < (int) slots.size() && slot_tile[(size_t) tiles[id].slot] == id;
+      if (ok) continue;
+      char msg[320];
+      const Tile *t = id >= 0 && id < (int) tiles.size() ? &tiles[id] : nullptr;
+      snprintf(msg, sizeof(msg),
+               "bof_flash_gemm (tile cache): internal error at %s: write-back group entry %zu of %zu is tile %d (mat %d, slot %d of %zu, "
+               "slot holds tile %d, state %d, pinned %d, next use %zu of %zu)", where, q, wgroup.size(), id, t ? t->mat : -1,
+               t ? t->slot : -2, slots.size(),
+               t && t->slot >= 0 && t->slot < (int) slots.size() ? slot_tile[(size_t) t->slot] : -2, t ? t->state : -1,
+               t ? (int) t->pinned_c : -1, t ? t->next_use : (size_t) 0, t ? t->uses.size() : (size_t) 0);
+      fprintf(stderr, "[bof] %s\n", msg);
+      evt("tile cache: write-back group insane", id, t ? t->slot : -2, q);
+      evt_dump(stderr, "tile cache: write-back group");
+      set_error(msg);
+      return false;
+    }
+    return true;
+  }
   hipError_t flush_wgroup() {
     if (wgroup.empty()) return hipSuccess;
+    if (!wgroup_sane("flush_wgroup entry")) return hipErrorUnknown;
     const Tile &first = tiles[wgroup.front()], &lastt = tiles[wgroup.back()];
     const int64_t width = (lastt.off - first.off) + lastt.ncols, nrows = first.nrows;
     const int64_t rpc = std::max<int64_t>(1, (int64_t) (res->wring.bytes / ((size_t) width * 4)));
@@ -589,6 +636,7 @@ struct GemmRun {
       write_q.push(WriteReq{ws, f[2].foffset + ((uint64_t) first.off + (uint64_t) r0 * (uint64_t) first.ld) * 4,
                             (uint64_t) first.ld * 4, (uint64_t) nr, (uint64_t) width * 4, r0, vt});
     }
+    if (e == hipSuccess && !wgroup_sane("flush_wgroup, behind the copies")) e = hipErrorUnknown;
     for (size_t q = 0; q < wgroup.size() && e == hipSuccess; q++) {
       DevSlot &sc = slots[tiles[wgroup[q]].slot];
       e = hipEventRecord(sc.use[kMaxStreams], d2h);
@@ -758,21 +806,14 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   BOF_TRACE_T("device slab allocated");
   R.slots.resize((size_t) n_slots);
   R.slot_tile.assign((size_t) n_slots, -1);
-  Cleanup guard;
-  guard.add([&R] {
-    for (auto &sl : R.slots) {
-      if (sl.ready) (void) hipEventDestroy(sl.ready);
-      for (int q = 0; q <= kMaxStreams; q++)
-        if (sl.use[q]) (void) hipEventDestroy(sl.use[q]);
-    }
-    if (R.h2d) (void) hipStreamDestroy(R.h2d);
-    if (R.d2h) (void) hipStreamDestroy(R.d2h);
-  });
+  // events and copy streams come from the device's pool (GemmResources): nothing is created or destroyed here
+  rc = R.res->events((size_t) n_slots * (kMaxStreams + 2));
+  if (rc) return rc;
   for (int64_t s = 0; s < n_slots; s++) {
     R.slots[s].ptr = R.slab + (size_t) s * R.slot_bytes;
-    BOF_HIP_TRY(hipEventCreateWithFlags(&R.slots[s].ready, hipEventDisableTiming));
-    for (int q = 0; q <= kMaxStreams; q++)
-      BOF_HIP_TRY(hipEventCreateWithFlags(&R.slots[s].use[q], hipEventDisableTiming));
+    hipEvent_t *pool = R.res->ev_pool.data() + (size_t) s * (kMaxStreams + 2);
+    R.slots[s].ready = pool[0];
+    for (int q = 0; q <= kMaxStreams; q++) R.slots[s].use[q] = pool[1 + q];
     R.free_slots.push_back((int) (n_slots - 1 - s));
   }
   // A staging slot must hold at least ONE row of the widest row group (up to group_max adjacent tiles): with short,
@@ -791,8 +832,10 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   const int n_writers = std::max(2, std::min(4, R.o.n_io_threads / 2));
   rc = R.res->wring.init((int) std::min<int64_t>(gi * gj, 16) + 2, ring_bytes);
   if (rc) return rc;
-  BOF_HIP_TRY(copy_stream_create(&R.h2d));
-  BOF_HIP_TRY(copy_stream_create(&R.d2h));
+  if (!R.res->h2d) BOF_HIP_TRY(copy_stream_create(&R.res->h2d));
+  if (!R.res->d2h) BOF_HIP_TRY(copy_stream_create(&R.res->d2h));
+  R.h2d = R.res->h2d;
+  R.d2h = R.res->d2h;
   if (verify_wanted(R.o)) {
     rc = R.vf.init(R.dev, 16 * R.tiles.size() + 65536);
     if (rc) return rc;
@@ -800,6 +843,23 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   R.ss = stream_set(R.o.n_streams);
   if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
 
+  // $BOF_CRASH_TRACE=1: a fatal signal during this call also prints the slot table and the write-back group
+  g_crash_dump_arg = &R;
+  g_crash_dump_fn = [](void *p) {
+    GemmRun &G = *(GemmRun *) p;
+    fprintf(stderr, "[bof] tile cache at the crash: %zu slots, %zu tiles, d2h %p h2d %p, wgroup:", G.slots.size(), G.tiles.size(),
+            (void *) G.d2h, (void *) G.h2d);
+    for (size_t q = 0; q < G.wgroup.size(); q++)
+      fprintf(stderr, " tile %d (slot %d, stream %d)", G.wgroup[q], G.tiles[(size_t) G.wgroup[q]].slot, G.wgroup_stream[q]);
+    fprintf(stderr, "\n");
+    for (size_t sl = 0; sl < G.slots.size() && sl < 40; sl++) {
+      fprintf(stderr, "[bof]   slot %zu: ptr %p tile %d ready %p use:", sl, (void *) G.slots[sl].ptr, G.slots[sl].tile, (void *) G.slots[sl].ready);
+      for (int q = 0; q <= kMaxStreams; q++) fprintf(stderr, " %p%s", (void *) G.slots[sl].use[q], G.slots[sl].used[q] ? "*" : "");
+      fprintf(stderr, "\n");
+    }
+  };
+  Cleanup crash_dump_off;
+  crash_dump_off.add([] { g_crash_dump_fn = nullptr; g_crash_dump_arg = nullptr; });
   BOF_TRACE_T("rings/streams ready");
   std::vector<std::thread> readers, writers;
   for (int i = 0; i < std::max(1, R.o.n_io_threads); i++) readers.emplace_back([&R] { R.reader_main(); });
@@ -1274,9 +1334,13 @@ int bof_flash_release(void) {
   for (int d = 0; d < 64; d++) {
     GemmResources *r = g_res[d];
     if (!r) continue;
-    r->rring.destroy();
-    r->wring.destroy();
-    if (r->slab) (void) hipFree(r->slab);
+    {
+      DeviceScope ds(d);
+      r->rring.destroy();
+      r->wring.destroy();
+      r->destroy_hip_objects();
+      if (r->slab) (void) hipFree(r->slab);
+    }
     delete r;
     g_res[d] = nullptr;
   }

@@ -40,6 +40,9 @@ std::recursive_mutex &device_call_mutex() {
 
 
 
+void (*g_crash_dump_fn)(void *) = nullptr;
+void *g_crash_dump_arg = nullptr;
+
 // ---- persistent launcher threads (flash_common.h) ------------------------------------------------------------
 namespace {
 struct Launcher {
@@ -413,6 +416,7 @@ void crash_handler(int sig, siginfo_t *info, void *ctx) {
     const char msg[] = "[bof] fatal signal -- native stack (module+offset):\n";
     (void) !write(2, msg, sizeof(msg) - 1);
     backtrace_symbols_fd(bt, n, 2);
+    if (bof::g_crash_dump_fn) bof::g_crash_dump_fn(bof::g_crash_dump_arg);
     bof::evt_dump(stderr, "fatal signal");
   }
   struct sigaction *prev = sig == SIGSEGV ? &g_prev_segv : sig == SIGBUS ? &g_prev_bus : &g_prev_abrt;

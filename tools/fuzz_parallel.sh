@@ -7,7 +7,7 @@ export BOF_CRASH_TRACE=1      # a crash inside the library leaves its native sta
 pids=()
 for i in $(seq 0 $((n - 1))); do
   s=$((seed0 + i))
-  BOF_FUZZ_DUMP="${BOF_FUZZ_DUMP_DIR:-}" python3 tests/test_gpu_fuzz.py --verify --seconds "$secs" --seed "$s" "$@" > "$out/fuzz_seed$s.log" 2>&1 &
+  BOF_FUZZ_DUMP="${BOF_FUZZ_DUMP_DIR:-}" python3 tests/test_gpu_fuzz.py ${FUZZ_VERIFY---verify} --seconds "$secs" --seed "$s" "$@" > "$out/fuzz_seed$s.log" 2>&1 &
   pids+=($!)
 done
 rc=0
