@@ -1040,12 +1040,11 @@ int kmeans_upload(const KmeansHost &kh, KmeansVecs *kv) {
   hipError_t e = hipMemcpy(dv, kh.c_l2sq, (size_t) kh.m * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(dv + kh.m, kh.p_l2sq, (size_t) kh.n * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(dv + kh.m + kh.n, kh.ones, (size_t) kh.n_ones * sizeof(float), hipMemcpyHostToDevice);
-  // The caller's vectors are PAGEABLE host memory: a synchronous hipMemcpy returns once they are staged, the transfer
-  // itself may still be in flight on the null stream -- and the pipelines' compute streams are non-blocking, i.e.
-  // not ordered behind the null stream.  The first tile kernels could read a vector before it had landed: the one
-  // wrong C tile in ~10^4-10^5 fuzzed kmeans calls of rounds 3 and 4 (a whole tile off by one k-block's
-  // p_l2sq / c_l2sq term; every hand-over checksum of A, B and C agreed).  Wait for the device before anything is
-  // launched.  ($BOF_KMEANS_UPLOAD_SYNC=0 restores the old behaviour for the A/B experiment of profiles/r4.)
+  // The caller's vectors are PAGEABLE host memory: a synchronous hipMemcpy may return once they are staged, with the
+  // transfer still in flight on the null stream -- and the pipelines' compute streams are non-blocking, i.e. not
+  // ordered behind the null stream.  Wait for the device before anything is launched.  (Not what caused the wrong
+  // kmeans tiles of rounds 3-4 -- that was the launching thread, flash_common.h "persistent launcher threads" --
+  // but the same class of ordering hole; $BOF_KMEANS_UPLOAD_SYNC=0 restores the old behaviour.)
   if (e == hipSuccess && env_long("BOF_KMEANS_UPLOAD_SYNC", 1) != 0) e = hipDeviceSynchronize();
   if (e != hipSuccess) { (void) hipFree(dv); return hip_fail(e, "flash::kmeans: uploading the norm vectors"); }
   *kv = KmeansVecs{dv, dv + kh.m, dv + kh.m + kh.n};
