@@ -141,11 +141,30 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
                     verdict = bool(sv.f_bavail * sv.f_frsize > ring * 1.25 + (64 << 20))
                 except OSError:
                     verdict = False
+        # Can THIS rank's call take the row-panel path?  Layout reasons (C rows with gaps, ...) are the same on every
+        # rank, the HBM budget is not (it is 0.8 of what is free on the rank's own GPU).  The staging ring only works if
+        # every member of the share group is on the panel path, so the ranks agree BEFORE the call: one member that
+        # cannot -> the whole group reads B itself (and that member's call goes to the tile cache).  The library's own
+        # check (BOF_EINVAL + the group's failure word) stays as the safety net behind this.
+        can = None
+        if rows > 0:
+            can = int(o.gemm_path) != 1
+            if can:
+                budget = int(o.hbm_budget)
+                if budget <= 0:
+                    import ctypes
+                    fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
+                    bofhip.check(bofhip.lib().bof_mem_info(ctypes.byref(fr), ctypes.byref(tot)), "bof_mem_info")
+                    budget = int(fr.value * 0.8)
+                can = bool(bofhip.flash_gemm_panel_plan("R", "N", "N", rows, n, k, tile, budget, lda, ldb, ldc, 0)["eligible"])
         verdicts = [None] * world
-        dist.all_gather_object(verdicts, verdict, group=group)
-        if name is not None and not verdicts[leader]:
+        dist.all_gather_object(verdicts, (verdict, can), group=group)
+        if name is not None and not verdicts[leader][0]:
             name = None
             stats["b_once"] = "off: /dev/shm of this host cannot hold the staging ring"
+        elif name is not None and not all(verdicts[g][1] for g in mates):
+            name = None
+            stats["b_once"] = "off: a rank of this host cannot take the row-panel path (layout or its HBM budget)"
         elif name is None and rank in owners:
             stats["b_once"] = "off: the only row-owning rank of its host"
     err = None

@@ -197,8 +197,9 @@ def _file_gemm_worker(rank, world, port, so, out_dir, m, n, k, blk):
     dist.destroy_process_group()
 
 
-def _ineligible_rank_worker(rank, world, port, so, out_dir, m, n, k, blk):
-    """rank 1's call cannot take the row-panel path (gemm_path = 1): every rank must come back with an error, soon"""
+def _ineligible_rank_worker(rank, world, port, so, out_dir, m, n, k, blk, through_bof_dist):
+    """rank 1's call cannot take the row-panel path (gemm_path = 1).  through_bof_dist: the ranks agree beforehand and
+    fall back together; else every rank passes the share options to the library itself and must get an error, soon."""
     import time
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -209,11 +210,18 @@ def _ineligible_rank_worker(rank, world, port, so, out_dir, m, n, k, blk):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     fds = [os.open(os.path.join(out_dir, f"{x}.bin"), os.O_RDWR) for x in "ABC"]
     t0 = time.time()
-    msg = "no error"
+    msg, extra = "no error", ""
     try:
-        opts = bofhip.default_options(gemm_blk=blk, io_chunk_mib=1, n_io_threads=3, use_odirect=0,
-                                      gemm_path=1 if rank == 1 else 0)
-        bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], opts=opts)
+        kw = dict(gemm_blk=blk, io_chunk_mib=1, n_io_threads=3, use_odirect=0, gemm_path=1 if rank == 1 else 0)
+        if through_bof_dist:
+            st = bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], opts=bofhip.default_options(**kw))
+            extra = f"{st['bytes_peer']} {st.get('b_once', '')}"
+        else:
+            r0, r1 = bof_dist.row_shard(m, world, rank, blk)
+            name = f"/bof_test_{port}"
+            bofhip.flash_gemm("R", "N", "N", r1 - r0, n, k, 1.0, 0.0, bofhip.FPtr(fds[0], r0 * k * 4), bofhip.FPtr(fds[1], 0),
+                              bofhip.FPtr(fds[2], r0 * n * 4), k, n, n,
+                              bofhip.default_options(share_world=world, share_rank=rank, share_name=name, **kw))
     except bofhip.BofError as e:
         msg = str(e)
     finally:
@@ -221,8 +229,10 @@ def _ineligible_rank_worker(rank, world, port, so, out_dir, m, n, k, blk):
             bofhip.lib().bof_file_forget(fd)
             os.close(fd)
     with open(os.path.join(out_dir, f"outcome_{rank}.txt"), "w") as f:
-        f.write(f"{time.time() - t0:.1f}\n{msg}\n")
+        f.write(f"{time.time() - t0:.1f}\n{msg}\n{extra}\n")
     dist.barrier()
+    if not through_bof_dist and rank == 0:
+        bofhip.lib().bof_share_cleanup(f"/bof_test_{port}".encode())
     dist.destroy_process_group()
 
 
@@ -231,51 +241,38 @@ def mock_lib(tmp_path_factory):
     return _build_mock_library(str(tmp_path_factory.mktemp("mocklib")))
 
 
-def test_row_sharded_rank_outside_the_panel_path_fails_every_rank_fast(tmp_path, mock_lib):
+@pytest.mark.parametrize("through_bof_dist", [True, False])
+def test_row_sharded_rank_outside_the_panel_path(tmp_path, mock_lib, through_bof_dist):
     """with B shared through the staging ring, a rank whose call is not eligible for the panel path used to
     fall back to the tile cache silently, read B itself and succeed, while its peers waited BOF_SHARE_TIMEOUT_S
-    (120 s) for panels it never published and the successful rank then hung in the barrier.  Now that rank raises the
-    ring group's failure word and returns an error, the peers' waits end at once, the ranks exchange their status
-    instead of a bare barrier, and every rank raises."""
+    (120 s) for panels it never published and the successful rank then hung in the barrier.
+    Through bof_dist the ranks now agree BEFORE the call (every member of a share group must be able to take the
+    panel path, else the whole group reads B itself): every rank succeeds, C is exact, nothing comes from a peer.
+    Handed the share options directly, the library does not fall back: the odd rank raises the ring group's failure
+    word and returns BOF_EINVAL, the peers' waits end at once -- every rank gets an error within seconds."""
     world, blk, m, n, k = 3, 128, 128 * 6, 300, 128 * 4
     rng = np.random.default_rng(5)
-    rng.integers(-3, 4, (m, k)).astype(np.float32).tofile(tmp_path / "A.bin")
-    rng.integers(-3, 4, (k, n)).astype(np.float32).tofile(tmp_path / "B.bin")
-    np.zeros((m, n), np.float32).tofile(tmp_path / "C.bin")
-    before = set(os.listdir("/dev/shm"))
-    mp.spawn(_ineligible_rank_worker, args=(world, _free_port(), mock_lib, str(tmp_path), m, n, k, blk), nprocs=world, join=True)
-    for r in range(world):
-        secs, msg = open(tmp_path / f"outcome_{r}.txt").read().split("\n")[:2]
-        assert float(secs) < 30, (r, secs)                       # not the 120 s timeout
-        assert "not eligible" in msg or "failed" in msg, (r, msg)
-    assert "not eligible" in open(tmp_path / "outcome_1.txt").read()
-    assert set(os.listdir("/dev/shm")) - before == set()
-
-
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_file_gemm_ranks_on_mock_devices(tmp_path, mock_lib, world):
-    """bof_dist.flash_gemm_row_sharded with REAL ranks on the CPU box: every rank is a process whose libbof_hip
-    is the product's host code linked against the mock HIP runtime (asynchronous mock streams).  Rank g runs the
-    level-3 panel pipeline on its C rows; the panels of B are read from the file by one rank each and passed on
-    through the node-shared staging ring (POSIX shared memory between the processes); Python only broadcasts the
-    /dev/shm verdict, barriers and cleans up.  Whole C exact, B read once per node, nothing left in /dev/shm."""
-    so = mock_lib
-    blk, m, n, k = 128, 128 * 2 * world + 128, 300, 128 * 5 + 40        # a rank with one more panel; merged k tail
-    rng = np.random.default_rng(world)
     a = rng.integers(-3, 4, (m, k)).astype(np.float32)
     b = rng.integers(-3, 4, (k, n)).astype(np.float32)
     a.tofile(tmp_path / "A.bin")
     b.tofile(tmp_path / "B.bin")
     np.zeros((m, n), np.float32).tofile(tmp_path / "C.bin")
     before = set(os.listdir("/dev/shm"))
-    mp.spawn(_file_gemm_worker, args=(world, _free_port(), so, str(tmp_path), m, n, k, blk), nprocs=world, join=True)
-    got = np.fromfile(tmp_path / "C.bin", np.float32).reshape(m, n)
-    assert np.array_equal(got, (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32))
-    stats = np.stack([np.load(tmp_path / f"stats_{r}.npy") for r in range(world)])
-    assert stats[:, 0].sum() == m and (stats[:, 0] > 0).all()
-    assert stats[:, 1].sum() == a.nbytes + b.nbytes            # every byte of A and of B read from the files ONCE
-    assert stats[:, 2].sum() == m * n * 4
-    assert stats[:, 3].sum() == (world - 1) * b.nbytes         # ... and B taken from the peers world - 1 times
+    mp.spawn(_ineligible_rank_worker, args=(world, _free_port(), mock_lib, str(tmp_path), m, n, k, blk, through_bof_dist),
+             nprocs=world, join=True)
+    outcomes = [open(tmp_path / f"outcome_{r}.txt").read().split("\n") for r in range(world)]
+    for r, (secs, msg, extra, *_) in enumerate(outcomes):
+        assert float(secs) < 30, (r, secs)                       # not the 120 s timeout
+        if through_bof_dist:
+            assert msg == "no error", (r, msg)
+            assert extra.startswith("0 ") and "cannot take the row-panel path" in extra, (r, extra)
+        else:
+            assert "not eligible" in msg or "failed" in msg or "I/O pipeline" in msg, (r, msg)
+    if through_bof_dist:
+        got = np.fromfile(tmp_path / "C.bin", np.float32).reshape(m, n)
+        assert np.array_equal(got, (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32))
+    else:
+        assert "not eligible" in outcomes[1][1]
     assert set(os.listdir("/dev/shm")) - before == set()
 
 
