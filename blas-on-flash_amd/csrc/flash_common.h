@@ -96,6 +96,13 @@ class KernelTimer {
 int pinned_alloc(void **p, size_t bytes);   // BOF_OK / BOF_EHIP; the block has at least `bytes`
 void pinned_free(void *p);
 void pinned_cache_release();
+// The same for HBM blocks of the CURRENT device that a pipeline needs for the length of one call (CSR row-block
+// contexts, x / y of csrgemv): hipMalloc costs 13-36 ms per GiB and hipFree synchronises the device -- the ~20
+// of each around a cfg5-size csrgemv were 45-60 ms of a 0.24 s call.  A freed block is kept (up to 8 GiB per
+// device) and handed to the next request of a similar size; bof_flash_release empties the cache.
+int dev_cache_alloc(void **p, size_t bytes);   // BOF_OK / BOF_EHIP / BOF_ENOMEM
+void dev_cache_free(void *p);
+void dev_cache_release();
 
 template <class T>
 class WorkQueue {

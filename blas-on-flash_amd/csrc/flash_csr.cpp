@@ -163,6 +163,8 @@ struct CsrRun {
   float *host_y = nullptr;       // csrgemv 'N': the caller's result vector, filled block by block (null: one copy at the end)
   const int64_t *ia = nullptr;   // host offsets of the rows of this call (m + 1 entries, absolute)
   HostI64 ia_store;              // ... when this call read them itself
+  int64_t *ia_pinned = nullptr;  // ... into a block of the pinned cache
+  ~CsrRun() { if (ia_pinned) pinned_free(ia_pinned); }
   std::vector<int64_t> st, sz;
   std::vector<CsrCtx> ctx;
   int depth = 3;
@@ -728,11 +730,14 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   } else if (ex && ex->ia) {
     R.ia = ex->ia;
   } else {
-    R.ia_store.resize((size_t) m + 1);
-    int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia_store.data(), R.use_aio);
-    if (io) { set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
+    // into a block of the pinned cache: its pages exist already (a fresh std::vector is faulted in page by page while
+    // it is filled: the 400 MB of offsets of the cfg5-size matrix took 33 ms from the page cache)
+    rc = pinned_alloc((void **) &R.ia_pinned, (size_t) (m + 1) * 8);
+    if (rc) return rc;
+    int io = read_host(fia, (uint64_t) (m + 1) * 8, R.ia_pinned, R.use_aio);
+    if (io) { pinned_free(R.ia_pinned); R.ia_pinned = nullptr; set_error(std::string("reading ia failed: ") + strerror(-io)); return BOF_EIO; }
     R.cnt.rd += (uint64_t) (m + 1) * 8;
-    R.ia = R.ia_store.data();
+    R.ia = R.ia_pinned;
   }
   BOF_TRACE_T("csr: offsets on the host");
   const int64_t nb = bof_csr_blocks(R.ia, m, 128, R.o.csrmm_rblk, R.o.max_nnzs, nullptr, nullptr, 0);
@@ -784,18 +789,18 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   Cleanup guard;
   guard.add([&] {
     for (auto &c : R.ctx) {
-      (void) hipFree(c.d_idx); (void) hipFree(c.d_val); (void) hipFree(c.d_c); (void) hipFree(c.d_c_rm);
+      dev_cache_free(c.d_idx); dev_cache_free(c.d_val); dev_cache_free(c.d_c); dev_cache_free(c.d_c_rm);
       pinned_free(c.h_idx);
       pinned_free(c.h_val);
       pinned_free(c.h_c);
       pinned_free(c.h_ia);
       pinned_free(c.h_y);
-      (void) hipFree(c.d_ia);
+      dev_cache_free(c.d_ia);
       if (c.ready) (void) hipEventDestroy(c.ready);
       if (c.done) (void) hipEventDestroy(c.done);
     }
     if (resident_ev) (void) hipEventDestroy(resident_ev);
-    (void) hipFree(own_b); (void) hipFree(own_x); (void) hipFree(own_y);
+    dev_cache_free(own_b); dev_cache_free(own_x); dev_cache_free(own_y);
     if (R.h2d) (void) hipStreamDestroy(R.h2d);
     if (R.d2h) (void) hipStreamDestroy(R.d2h);
   });
@@ -806,10 +811,10 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   const bool ext_op = ex && ex->shared_op;        // B / x comes from the multi-device caller
   const bool ext_y = ex && ex->partial_y;         // the partial result stays in the caller's vector
   if (is_mm) {
-    if (!ext_op) BOF_HIP_TRY(hipMalloc((void **) &d_b, (size_t) n * k * 4));
+    if (!ext_op) { rc = dev_cache_alloc((void **) &d_b, (size_t) n * k * 4); if (rc) return rc; }
   } else {
-    if (!ext_op) BOF_HIP_TRY(hipMalloc((void **) &d_x, (size_t) xlen * 4));
-    if (!ext_y) BOF_HIP_TRY(hipMalloc((void **) &d_y, (size_t) ylen * 4));
+    if (!ext_op) { rc = dev_cache_alloc((void **) &d_x, (size_t) xlen * 4); if (rc) return rc; }
+    if (!ext_y) { rc = dev_cache_alloc((void **) &d_y, (size_t) ylen * 4); if (rc) return rc; }
   }
   own_b = d_b; own_x = d_x; own_y = d_y;
   if (ext_op) (is_mm ? d_b : d_x) = ex->shared_op;
@@ -876,14 +881,16 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   for (int i = 0; i < R.depth; i++) {
     CsrCtx &c = R.ctx[i];
     if (!res) {
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_idx, max_idx));
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_val, max_val));
+      rc = dev_cache_alloc((void **) &c.d_idx, max_idx);
+      if (!rc) rc = dev_cache_alloc((void **) &c.d_val, max_val);
+      if (rc) return rc;
       rc = pinned_alloc((void **) &c.h_idx, max_idx);
       if (!rc) rc = pinned_alloc((void **) &c.h_val, max_val);
       if (rc) return rc;
     }
     if (!res) {
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_ia, (size_t) (max_rows + 1) * 8));
+      rc = dev_cache_alloc((void **) &c.d_ia, (size_t) (max_rows + 1) * 8);
+      if (rc) return rc;
       rc = pinned_alloc((void **) &c.h_ia, (size_t) (max_rows + 1) * 8);
       if (rc) return rc;
     }
@@ -892,8 +899,9 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       if (rc) return rc;
     }
     if (is_mm) {
-      BOF_HIP_TRY(hipMalloc((void **) &c.d_c, max_c));
-      if (ord_b == 'C') BOF_HIP_TRY(hipMalloc((void **) &c.d_c_rm, max_c));
+      rc = dev_cache_alloc((void **) &c.d_c, max_c);
+      if (!rc && ord_b == 'C') rc = dev_cache_alloc((void **) &c.d_c_rm, max_c);
+      if (rc) return rc;
       rc = pinned_alloc((void **) &c.h_c, max_c);
       if (rc) return rc;
     }

@@ -1345,6 +1345,7 @@ int bof_flash_release(void) {
     g_res[d] = nullptr;
   }
   uring_release_buffers();
+  dev_cache_release();
   pinned_cache_release();
   file_unmap_all();
   return BOF_OK;

@@ -43,6 +43,85 @@ std::recursive_mutex &device_call_mutex() {
 void (*g_crash_dump_fn)(void *) = nullptr;
 void *g_crash_dump_arg = nullptr;
 
+// ---- per-device cache of call-lifetime HBM blocks (flash_common.h) -----------------------------------------
+namespace {
+struct DevCache {
+  std::mutex mu;
+  std::multimap<size_t, void *> free_[64];
+  std::unordered_map<void *, std::pair<int, size_t>> live;
+  size_t cached[64] = {};
+} g_devc;
+constexpr size_t kDevCacheCap = 8ull << 30;
+}  // namespace
+int dev_cache_alloc(void **p, size_t bytes) {
+  int dev = 0;
+  BOF_HIP_TRY(hipGetDevice(&dev));
+  dev &= 63;
+  if (bytes == 0) bytes = 4;
+  {
+    std::lock_guard<std::mutex> lk(g_devc.mu);
+    auto it = g_devc.free_[dev].lower_bound(bytes);
+    if (it != g_devc.free_[dev].end() && it->first <= std::max(2 * bytes, bytes + (8u << 20))) {
+      *p = it->second;
+      g_devc.live[*p] = std::make_pair(dev, it->first);
+      g_devc.cached[dev] -= it->first;
+      g_devc.free_[dev].erase(it);
+      return BOF_OK;
+    }
+  }
+  const size_t rounded = (bytes + 4095) / 4096 * 4096;
+  hipError_t e = hipMalloc(p, rounded);
+  if (e != hipSuccess) {          // the cache may be what is in the way
+    (void) hipGetLastError();
+    dev_cache_release();
+    e = hipMalloc(p, rounded);
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc (call-lifetime block)");
+  std::lock_guard<std::mutex> lk(g_devc.mu);
+  g_devc.live[*p] = std::make_pair(dev, rounded);
+  return BOF_OK;
+}
+void dev_cache_free(void *p) {
+  if (!p) return;
+  int dev = -1;
+  size_t sz = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_devc.mu);
+    auto it = g_devc.live.find(p);
+    if (it != g_devc.live.end()) {
+      dev = it->second.first;
+      sz = it->second.second;
+      g_devc.live.erase(it);
+      if (g_devc.cached[dev] + sz <= kDevCacheCap) {
+        g_devc.free_[dev].emplace(sz, p);
+        g_devc.cached[dev] += sz;
+        return;
+      }
+    }
+  }
+  if (dev >= 0) {
+    DeviceScope ds(dev);
+    (void) hipFree(p);
+  } else {
+    (void) hipFree(p);
+  }
+}
+void dev_cache_release() {
+  std::vector<std::pair<int, void *>> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_devc.mu);
+    for (int d = 0; d < 64; d++) {
+      for (auto &kv : g_devc.free_[d]) drop.emplace_back(d, kv.second);
+      g_devc.free_[d].clear();
+      g_devc.cached[d] = 0;
+    }
+  }
+  for (auto &x : drop) {
+    DeviceScope ds(x.first);
+    (void) hipFree(x.second);
+  }
+}
+
 // ---- persistent launcher threads (flash_common.h) ------------------------------------------------------------
 namespace {
 struct Launcher {
