@@ -1445,6 +1445,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
             if not torch.equal(C[q0:q1], state["rowpat"][gi % 10]):
                 raise AssertionError(f"C rows [{r0 + q0}, {r0 + q1}) differ from the closed form")
     match, _, _, verr = phase(verify) if good else (False, 0, 0, "")
+    was_direct = bool(state.get("direct", False))
     state.clear()
     torch.cuda.empty_cache()
     dist.barrier()
@@ -1481,7 +1482,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
                    "what_is_timed": "every rank's bof_flash_gemm on its slab of ONE A/B/C file set between barriers; "
                                     "B read from storage once per node, no data-path collective",
                    "parallelism": f"row-block x{world}", "ranks_seen": args.ranks_seen,
-                   "backend": "gloo (one-GPU debug)" if one_gpu else "nccl (RCCL)", "odirect": bool(state.get("direct", True)),
+                   "backend": "gloo (one-GPU debug)" if one_gpu else "nccl (RCCL)", "odirect": was_direct,
                    "rank_s_min": round(min(a for a, _ in per_rank_s), 3), "rank_s_max": round(max(b for _, b in per_rank_s), 3),
                    "read_amplification": round(agg["bytes_read"] / args.steps / (4.0 * (m * k + k * n)), 3),
                    "write_amplification": round(agg["bytes_written"] / args.steps / (4.0 * m * n), 3),
@@ -1561,6 +1562,10 @@ def sharded_csr_extras(bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
 
 
 def main():
+    # a stalled run leaves the Python stacks of every thread on stderr every 15 minutes (the library's own stall
+    # watchdog fails the call and dumps its event ring after BOF_STALL_TIMEOUT_S)
+    import faulthandler
+    faulthandler.dump_traceback_later(900, repeat=True, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

@@ -376,8 +376,8 @@ inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUM
 // wrong tile" of round 3.  launch_async(dev, rep, fn) runs fn on the persistent thread of (device, repetition of the
 // ordinal in the call's device list), created on first use and kept for the life of the process; launch_wait joins it.
 // what the crash handler ($BOF_CRASH_TRACE=1) prints besides the stack: a callback the running pipeline registers
-extern void (*g_crash_dump_fn)(void *);
-extern void *g_crash_dump_arg;
+extern std::atomic<void (*)(void *)> g_crash_dump_fn;      // (the last pipeline to register wins: a diagnostic)
+extern std::atomic<void *> g_crash_dump_arg;
 
 struct LaunchJob {
   std::mutex mu;

@@ -190,8 +190,28 @@ struct PanelResources {
       if (tslot[x][i]) (void) hipFree(tslot[x][i]);
     tslot[x].resize(keep);
   }
+  // events and copy streams are kept between calls like the slots (a call creates and destroys no HIP object in
+  // the steady state: see GemmResources in flash_runtime.cpp and profiles/r4/fuzz_crash.md)
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  int take_event(hipEvent_t *e) {
+    if (ev_next == ev_pool.size()) {
+      hipEvent_t n = nullptr;
+      BOF_HIP_TRY(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+      ev_pool.push_back(n);
+    }
+    *e = ev_pool[ev_next++];
+    return BOF_OK;
+  }
   void drop_all() {
     DeviceScope ds(dev);
+    for (hipEvent_t e : ev_pool) (void) hipEventDestroy(e);
+    ev_pool.clear();
+    ev_next = 0;
+    if (h2d) (void) hipStreamDestroy(h2d);
+    if (d2h) (void) hipStreamDestroy(d2h);
+    h2d = d2h = nullptr;
     wring.destroy();
     for (int x = 0; x < 3; x++) drop(x, 0);
     for (int x = 0; x < 2; x++) drop_t(x, 0);
@@ -492,14 +512,27 @@ void PanelHub::reader_main(int home) {
         Panel &P = M.panels[(size_t) rq.panel];
         if (--P.remaining == 0) {
           if (e == hipSuccess) e = hipSetDevice(R.dev);
-          if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
-          if (e == hipSuccess && M.kmajor_copy)
-            e = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
-          if (e == hipSuccess && M.kmajor_copy)
-            e = transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
-                              P.nr, R.h2d);
-          if (e == hipSuccess && M.kmajor_copy)
-            e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
+          // kernels behind the panel's last copy (the k-major copy; BOF_VERIFY's sums): launched by a PERSISTENT
+          // launcher thread, not by this reader, which was created for the call (flash_common.h, "persistent
+          // launcher threads"); this thread waits for the launches to be queued, then records `ready` behind them
+          if (e == hipSuccess && (M.kmajor_copy || R.vf.on)) {
+            int rep = 0;
+            for (size_t q = 0; q < d; q++)
+              if (runs[q]->dev == R.dev) rep++;
+            hipError_t le = hipSuccess;
+            launch_wait(launch_async(R.dev, (2 << 20) + rep, [&] {   // (1 << 20 is the CSR feeder's)
+              le = hipSetDevice(R.dev);
+              if (le == hipSuccess) le = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
+              if (le == hipSuccess && M.kmajor_copy)
+                le = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
+              if (le == hipSuccess && M.kmajor_copy)
+                le = transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
+                                   P.nr, R.h2d);
+              if (le == hipSuccess && M.kmajor_copy)
+                le = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
+            }));
+            e = le;
+          }
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           // a failed copy / record must be visible BEFORE the panel is: the dispatcher tests io_error right
           // after it sees state 2, and a `ready` that was never recorded would make its wait a no-op
@@ -785,10 +818,12 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
 
 // events, streams, the write ring (the device is current)
 int PanelRun::prepare() {
+  res->ev_next = 0;       // this call's events come out of the resources' pool, from its start
   for (int x = 0; x < 3; x++)
     for (auto &P : mat[x].panels) {
-      BOF_HIP_TRY(hipEventCreateWithFlags(&P.ready, hipEventDisableTiming));
-      if (x == 2) BOF_HIP_TRY(hipEventCreateWithFlags(&P.d2h_done, hipEventDisableTiming));
+      int rc0 = res->take_event(&P.ready);
+      if (!rc0 && x == 2) rc0 = res->take_event(&P.d2h_done);
+      if (rc0) return rc0;
     }
   // A 4096^2 tile launch is 256 workgroups = the whole chip, so more than two compute streams only
   // interleave whole-chip kernels of different chains and starve the copy queues: measured on
@@ -801,13 +836,16 @@ int PanelRun::prepare() {
   for (auto &v : group_ev)
     for (int s = 0; s < ss->n; s++) {
       hipEvent_t e;
-      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      const int rc0 = res->take_event(&e);
+      if (rc0) return rc0;
       v.push_back(e);
     }
   const int rc = res->wring.init(std::max(2, o.pinned_slots), chunk + 2 * Mat::kPage);   // slack: widened / page-congruent placement
   if (rc) return rc;
-  BOF_HIP_TRY(copy_stream_create(&h2d));
-  BOF_HIP_TRY(copy_stream_create(&d2h));
+  if (!res->h2d) BOF_HIP_TRY(copy_stream_create(&res->h2d));
+  if (!res->d2h) BOF_HIP_TRY(copy_stream_create(&res->d2h));
+  h2d = res->h2d;
+  d2h = res->d2h;
   return verify_setup();
 }
 
@@ -1075,15 +1113,6 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     for (auto &Rp : H.runs) {
       PanelRun &R = *Rp;
       DeviceScope ds(R.dev);
-      for (auto &M : R.mat)
-        for (auto &P : M.panels) {
-          if (P.ready) (void) hipEventDestroy(P.ready);
-          if (P.d2h_done) (void) hipEventDestroy(P.d2h_done);
-        }
-      for (auto &v : R.group_ev)
-        for (hipEvent_t e : v) (void) hipEventDestroy(e);
-      if (R.h2d) (void) hipStreamDestroy(R.h2d);
-      if (R.d2h) (void) hipStreamDestroy(R.d2h);
       if (R.has_kv) (void) hipFree(const_cast<float *>(R.kv.c_l2sq));
     }
   });

@@ -844,8 +844,8 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   if (!R.ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
 
   // $BOF_CRASH_TRACE=1: a fatal signal during this call also prints the slot table and the write-back group
-  g_crash_dump_arg = &R;
-  g_crash_dump_fn = [](void *p) {
+  g_crash_dump_arg.store(&R);
+  g_crash_dump_fn.store([](void *p) {
     GemmRun &G = *(GemmRun *) p;
     fprintf(stderr, "[bof] tile cache at the crash: %zu slots, %zu tiles, d2h %p h2d %p, wgroup:", G.slots.size(), G.tiles.size(),
             (void *) G.d2h, (void *) G.h2d);
@@ -857,9 +857,12 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       for (int q = 0; q <= kMaxStreams; q++) fprintf(stderr, " %p%s", (void *) G.slots[sl].use[q], G.slots[sl].used[q] ? "*" : "");
       fprintf(stderr, "\n");
     }
-  };
+  });
   Cleanup crash_dump_off;
-  crash_dump_off.add([] { g_crash_dump_fn = nullptr; g_crash_dump_arg = nullptr; });
+  crash_dump_off.add([&R] {
+    void *me = &R;
+    if (g_crash_dump_arg.compare_exchange_strong(me, nullptr)) g_crash_dump_fn.store(nullptr);
+  });
   BOF_TRACE_T("rings/streams ready");
   std::vector<std::thread> readers, writers;
   for (int i = 0; i < std::max(1, R.o.n_io_threads); i++) readers.emplace_back([&R] { R.reader_main(); });

@@ -40,8 +40,8 @@ std::recursive_mutex &device_call_mutex() {
 
 
 
-void (*g_crash_dump_fn)(void *) = nullptr;
-void *g_crash_dump_arg = nullptr;
+std::atomic<void (*)(void *)> g_crash_dump_fn{nullptr};
+std::atomic<void *> g_crash_dump_arg{nullptr};
 
 // ---- per-device cache of call-lifetime HBM blocks (flash_common.h) -----------------------------------------
 namespace {
@@ -495,7 +495,7 @@ void crash_handler(int sig, siginfo_t *info, void *ctx) {
     const char msg[] = "[bof] fatal signal -- native stack (module+offset):\n";
     (void) !write(2, msg, sizeof(msg) - 1);
     backtrace_symbols_fd(bt, n, 2);
-    if (bof::g_crash_dump_fn) bof::g_crash_dump_fn(bof::g_crash_dump_arg);
+    if (auto fn = bof::g_crash_dump_fn.load()) fn(bof::g_crash_dump_arg.load());
     bof::evt_dump(stderr, "fatal signal");
   }
   struct sigaction *prev = sig == SIGSEGV ? &g_prev_segv : sig == SIGBUS ? &g_prev_bus : &g_prev_abrt;
