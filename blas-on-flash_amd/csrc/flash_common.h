@@ -386,6 +386,21 @@ struct LaunchJob {
 };
 std::shared_ptr<LaunchJob> launch_async(int dev, int rep, std::function<void()> fn);
 void launch_wait(const std::shared_ptr<LaunchJob> &job);
+bool on_launcher_thread();      // (the mock runtime's rule R6: kernels are launched by the caller or by these threads)
+// The kernels a thread CREATED FOR THE CALL needs behind its copies (a reader's k-major copy, BOF_VERIFY's sums, the
+// transposition of a resident operand): fn runs on the device's auxiliary launcher thread and this thread waits until
+// it has returned (the launches are queued, nothing is waited for on the GPU).  Jobs of this lane only enqueue work.
+constexpr int kAuxLane = 2 << 20;        // (lanes below 1 << 20: repetitions of an ordinal; 1 << 20: the CSR feeder)
+template <class F>
+inline hipError_t launch_from_persistent(int dev, F &&fn) {
+  if (on_launcher_thread()) return fn();
+  hipError_t e = hipSuccess;
+  launch_wait(launch_async(dev, kAuxLane, [&] {
+    e = hipSetDevice(dev);
+    if (e == hipSuccess) e = fn();
+  }));
+  return e;
+}
 
 // ---- BOF_VERIFY: hand-over checksums (bof_options.verify / $BOF_VERIFY) ------------------------------------
 // Every object a level-3 GEMM pipeline moves (a row panel; a packed tile) is summed at each hand-over -- in the
@@ -443,7 +458,7 @@ class Verify {
                        int64_t t_pitch, hipStream_t st) {
     if (!on || e == kNone) return hipSuccess;
     touched[e].fetch_or(2);
-    return verify_sum(p, rows, row_words, pitch_words, index_base, t_pitch, d_tab + 2 * e, st);
+    return launch_from_persistent(dev, [&] { return verify_sum(p, rows, row_words, pitch_words, index_base, t_pitch, d_tab + 2 * e, st); });
   }
   void on_host(size_t e, const void *p, int64_t rows, int64_t row_words, int64_t pitch_words, uint64_t index_base) {
     if (!on || e == kNone) return;

@@ -851,7 +851,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
         const int rc2 = scratch_get(SCR_B_RM, (size_t) n * k * 4, &tmp);
         if (rc2) return rc2;
         BOF_HIP_TRY(hipMemcpyAsync(tmp, d_b, (size_t) n * k * 4, hipMemcpyDeviceToDevice, R.h2d));
-        BOF_HIP_TRY(transpose_f32((const float *) tmp, n, k, n, (float *) d_b, k, R.h2d));
+        // (this is a thread created for the call: the kernel goes through the device's persistent launcher)
+        BOF_HIP_TRY(launch_from_persistent(R.dev, [&] { return transpose_f32((const float *) tmp, n, k, n, (float *) d_b, k, R.h2d); }));
       }
     } else {
       // x lives in pageable host memory (include/flash_blas.h:55-57): through pinned chunks on several threads

@@ -515,23 +515,15 @@ void PanelHub::reader_main(int home) {
           // kernels behind the panel's last copy (the k-major copy; BOF_VERIFY's sums): launched by a PERSISTENT
           // launcher thread, not by this reader, which was created for the call (flash_common.h, "persistent
           // launcher threads"); this thread waits for the launches to be queued, then records `ready` behind them
-          if (e == hipSuccess && (M.kmajor_copy || R.vf.on)) {
-            int rep = 0;
-            for (size_t q = 0; q < d; q++)
-              if (runs[q]->dev == R.dev) rep++;
-            hipError_t le = hipSuccess;
-            launch_wait(launch_async(R.dev, (2 << 20) + rep, [&] {   // (1 << 20 is the CSR feeder's)
-              le = hipSetDevice(R.dev);
-              if (le == hipSuccess) le = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
-              if (le == hipSuccess && M.kmajor_copy)
-                le = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
-              if (le == hipSuccess && M.kmajor_copy)
-                le = transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
-                                   P.nr, R.h2d);
-              if (le == hipSuccess && M.kmajor_copy)
-                le = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
-            }));
-            e = le;
+          if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
+          if (e == hipSuccess && M.kmajor_copy) {
+            e = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
+            if (e == hipSuccess)
+              e = launch_from_persistent(R.dev, [&] {
+                return transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel), P.nr,
+                                     R.h2d);
+              });
+            if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
           }
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           // a failed copy / record must be visible BEFORE the panel is: the dispatcher tests io_error right

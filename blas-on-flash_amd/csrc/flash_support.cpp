@@ -130,6 +130,7 @@ struct Launcher {
   std::deque<std::pair<std::function<void()>, std::shared_ptr<LaunchJob>>> q;
 };
 std::mutex g_launch_mu;
+thread_local bool t_launcher = false;
 // (never destroyed: the detached threads wait on these objects until the process ends)
 std::map<std::pair<int, int>, Launcher *> &launchers() {
   static auto *m = new std::map<std::pair<int, int>, Launcher *>();
@@ -145,6 +146,7 @@ std::shared_ptr<LaunchJob> launch_async(int dev, int rep, std::function<void()> 
       slot = new Launcher();
       Launcher *me = slot;
       std::thread([me, dev] {
+        t_launcher = true;
         (void) hipSetDevice(dev);
         for (;;) {
           std::pair<std::function<void()>, std::shared_ptr<LaunchJob>> job;
@@ -167,6 +169,7 @@ std::shared_ptr<LaunchJob> launch_async(int dev, int rep, std::function<void()> 
   L->cv.notify_one();
   return job;
 }
+bool on_launcher_thread() { return t_launcher; }
 void launch_wait(const std::shared_ptr<LaunchJob> &job) {
   if (!job) return;
   std::unique_lock<std::mutex> lk(job->mu);

@@ -24,6 +24,7 @@
 #include "bof_hip.h"
 
 extern "C" uint64_t mock_hip_kernel_launches();
+extern "C" void mock_hip_mark_caller_thread();      // arms rule R6 and marks this thread as a caller of the library
 extern "C" size_t mock_hip_bytes_in_use(int dev);
 extern "C" uint64_t mock_hip_pageable_h2d_bytes();
 extern "C" int64_t mock_hip_live_streams();
@@ -327,6 +328,7 @@ static void share_case(int world, bool direct) {
   std::vector<bof_flash_stats> st((size_t) world);
   for (int r = 0; r < world; r++)
     th.emplace_back([&, r] {
+      mock_hip_mark_caller_thread();
       bof_options o = options({r});
       o.gemm_blk = blk;
       o.gemm_path = 2;
@@ -481,6 +483,7 @@ static int run_all(const std::vector<std::vector<int>> &lists) {
     std::vector<std::thread> th;
     for (int t = 0; t < 2; t++)
       th.emplace_back([t] {
+        mock_hip_mark_caller_thread();
         t_prefix = "t" + std::to_string(t) + "_";
         const std::vector<int> mine = t == 0 ? std::vector<int>{0, 1} : std::vector<int>{2, 3};
         for (int rep = 0; rep < 2; rep++) {
@@ -705,6 +708,7 @@ static void api_failure_sweep() {
 int main(int argc, char **argv) {
   CHECK(argc > 1);
   g_dir = argv[1];
+  mock_hip_mark_caller_thread();
   if (bof_device_count() == 8) {       // MOCK_HIP_DEVICES=8: the shape of the 8-GPU node, C panels / row blocks over all eight
     const std::vector<int> all = {0, 1, 2, 3, 4, 5, 6, 7};
     for (int direct = 0; direct < 2; direct++) {

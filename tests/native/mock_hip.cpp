@@ -27,7 +27,11 @@
 //       ranges lie inside their allocations;
 //   R4  kernel stand-ins: the calling thread's current device is the stream's device and every pointer is that
 //       device's memory -- except the sources of sum_partials, which need peer access;
-//   R5  streams / events are not used after they were destroyed; nothing is freed twice.
+//   R5  streams / events are not used after they were destroyed; nothing is freed twice;
+//   R6  (armed by the harness, mock_hip_mark_caller_thread) a kernel is launched by a thread that called the library
+//       or by one of its persistent launcher threads, never by a thread created for the call: on the real runtime
+//       the launches of such a thread were seen to carry a stale trailing argument (the wrong C tile of round 3,
+//       profiles/r4/fuzz_thread_bisect.md) -- this rule is the regression test of that fix.
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,6 +55,8 @@
 
 #include "bof_hip.h"
 #include "bof_internal.h"
+
+namespace bof { bool on_launcher_thread(); }   // flash_support.cpp
 
 namespace {
 
@@ -81,6 +87,11 @@ std::vector<struct MockStream *> &g_streams = *new std::vector<struct MockStream
 // here (a vector that is itself never destroyed), so LeakSanitizer does not count them
 std::vector<void *> &g_created = *new std::vector<void *>();
 thread_local int t_dev = 0;
+// R6 (armed by the first mock_hip_mark_caller_thread()): a kernel is launched by a thread that CALLED the library or by
+// one of its persistent launcher threads, never by a thread the library created for the call (flash_common.h,
+// "persistent launcher threads": on the real runtime such a thread's launches were seen to carry a stale argument)
+thread_local bool t_caller = false;
+std::atomic<bool> g_r6{false};
 thread_local hipError_t t_last = hipSuccess;
 
 int n_devices() {
@@ -226,6 +237,9 @@ MockStream *kernel_stream(hipStream_t st, const char *who) {
   if (s->dev != t_dev)
     violation("R4", std::string(who) + ": launched with current device " + std::to_string(t_dev) + " on a stream of device " +
                         std::to_string(s->dev));
+  if (g_r6.load() && !t_caller && !bof::on_launcher_thread())
+    violation("R6", std::string(who) + ": launched by a thread created for the call (neither a caller of the library nor a "
+                                       "persistent launcher thread)");
   g_kernel_launches++;
   g_launches_on[s->dev & 63]++;
   return s;
@@ -253,6 +267,10 @@ extern "C" void mock_hip_fail_api_after(int kind, long n) { g_fail_api_kind.stor
 extern "C" long mock_hip_fail_api_pending() { return g_fail_api_in.load(); }
 static bool inject_api(int kind) { return g_fail_api_kind.load() == kind && inject(g_fail_api_in); }
 extern "C" uint64_t mock_hip_kernel_launches() { return g_kernel_launches.load(); }
+extern "C" void mock_hip_mark_caller_thread() {
+  t_caller = true;
+  g_r6.store(true);
+}
 extern "C" uint64_t mock_hip_pageable_h2d_bytes();
 extern "C" int64_t mock_hip_live_streams() { return g_live_streams.load(); }
 extern "C" int64_t mock_hip_live_events() { return g_live_events.load(); }

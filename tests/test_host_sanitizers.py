@@ -63,7 +63,8 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
     """The C ABI's level-3 entry points end to end on tests/native/mock_hip.cpp -- a stand-in HIP runtime with FOUR
     DISTINCT mock devices whose rules (an event recorded on its own device's stream, no wait on a never-recorded
     event, copies and kernel stand-ins only on memory of the stream's device or an enabled peer, pinned host sides,
-    nothing used after destruction) are fatal -- under ASan + UBSan + LeakSanitizer (all device lists; then with
+    nothing used after destruction, every kernel launched by a caller of the library or by one of its persistent
+    launcher threads -- rule R6, the regression test of round 3's wrong C tile) are fatal -- under ASan + UBSan + LeakSanitizer (all device lists; then with
     asynchronous, jittered mock streams) and under ThreadSanitizer with asynchronous streams, where a buffer touched
     by two streams without an event between them is a reported race.  The pool's GPU boxes have one GPU: this is where the in-process multi-device
     code meets more than one ordinal.  Test infrastructure only; the product refuses to run without a GPU."""
