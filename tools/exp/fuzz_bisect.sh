@@ -9,5 +9,9 @@ X2) run X2_fresh_thread_sync_each BOF_DBG_SLAB_THREAD=1 BOF_DBG_KM_SYNC_EACH=1 ;
 X3) KIND=gemm run X3_gemm_fresh_thread BOF_DBG_SLAB_THREAD=1 ;;
 X4) run X4_fresh_thread_warmup_launch BOF_DBG_SLAB_THREAD=2 ;;
 X5) run X5_persistent_worker BOF_DBG_SLAB_THREAD=3 ;;
+# where the runtime puts kernel arguments (fresh launching threads, the reproducer): in device memory through the PCIe
+# BAR (the default on this part) or in host memory; and the runtime's own HDP-flush workaround for the device placement
+K0) run K0_fresh_thread_host_kernarg BOF_DBG_SLAB_THREAD=1 HIP_FORCE_DEV_KERNARG=0 ;;
+K1) run K1_fresh_thread_hdp_flush_wa BOF_DBG_SLAB_THREAD=1 DEBUG_CLR_KERNARG_HDP_FLUSH_WA=1 ;;
 esac
 done
