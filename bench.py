@@ -489,10 +489,15 @@ def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
                 for cidx in range(i, nchunks, nthr):
                     L.bof_file_swrite(fd_, cidx * slot, 0, 1, slot, hbuf[base + i], 1)
             # a ceiling must not be lower than what a pipeline can get: best over two queue depths
+            # (all read passes before the first write pass: right behind 4 GiB of writes the device reads slower than
+            # the pipelines, whose inputs were written long before, ever see -- round 4's probes read 14 GB/s where
+            # the csrgemv run of the same process then read 19)
             best_r = best_w = 0.0
-            for nthr in (io_threads, 2 * io_threads):
+            time.sleep(1.0)
+            for nthr in (io_threads, 2 * io_threads, io_threads):
                 os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
                 best_r = max(best_r, run(nthr, rd))
+            for nthr in (io_threads, 2 * io_threads):
                 best_w = max(best_w, run(nthr, wr))
             out["disk_read_GBps"] = round(best_r, 2)
             out["disk_write_GBps"] = round(best_w, 2)
