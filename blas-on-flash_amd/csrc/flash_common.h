@@ -386,6 +386,12 @@ struct LaunchJob {
 };
 std::shared_ptr<LaunchJob> launch_async(int dev, int rep, std::function<void()> fn);
 void launch_wait(const std::shared_ptr<LaunchJob> &job);
+// flags of the POOLED events of the two GEMM paths: hipEventDisableTiming, or -- $BOF_EVENT_TIMING=1, an experiment switch
+// for the crash site of profiles/r4/fuzz_crash.md (a different record path inside the runtime) -- hipEventDefault
+inline unsigned pooled_event_flags() {
+  static const unsigned f = env_long("BOF_EVENT_TIMING", 0) ? (unsigned) hipEventDefault : (unsigned) hipEventDisableTiming;
+  return f;
+}
 bool on_launcher_thread();      // (the mock runtime's rule R6: kernels are launched by the caller or by these threads)
 // The kernels a thread CREATED FOR THE CALL needs behind its copies (a reader's k-major copy, BOF_VERIFY's sums, the
 // transposition of a resident operand): fn runs on the device's auxiliary launcher thread and this thread waits until

@@ -198,7 +198,7 @@ struct PanelResources {
   int take_event(hipEvent_t *e) {
     if (ev_next == ev_pool.size()) {
       hipEvent_t n = nullptr;
-      BOF_HIP_TRY(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+      BOF_HIP_TRY(hipEventCreateWithFlags(&n, pooled_event_flags()));
       ev_pool.push_back(n);
     }
     *e = ev_pool[ev_next++];

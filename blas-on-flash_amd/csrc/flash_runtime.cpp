@@ -140,7 +140,7 @@ struct GemmResources {
   int events(size_t n) {       // grow the pool to at least n events
     while (ev_pool.size() < n) {
       hipEvent_t e = nullptr;
-      BOF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      BOF_HIP_TRY(hipEventCreateWithFlags(&e, pooled_event_flags()));
       ev_pool.push_back(e);
     }
     return BOF_OK;
