@@ -13,5 +13,9 @@ X5) run X5_persistent_worker BOF_DBG_SLAB_THREAD=3 ;;
 # BAR (the default on this part) or in host memory; and the runtime's own HDP-flush workaround for the device placement
 K0) run K0_fresh_thread_host_kernarg BOF_DBG_SLAB_THREAD=1 HIP_FORCE_DEV_KERNARG=0 ;;
 K1) run K1_fresh_thread_hdp_flush_wa BOF_DBG_SLAB_THREAD=1 DEBUG_CLR_KERNARG_HDP_FLUSH_WA=1 ;;
+# the crash site of profiles/r4/fuzz_crash.md (hipEventRecord in flush_wgroup, 1 in ~300 000 under 16 processes): pooled
+# events with timing disabled (default) against timing enabled; needs long runs (SECS=1800, 16 processes) to say anything
+T0) run T0_events_timing_disabled BOF_EVENT_TIMING=0 ;;
+T1) run T1_events_timing_enabled BOF_EVENT_TIMING=1 ;;
 esac
 done
