@@ -366,7 +366,8 @@ def one_case(seed, index, tmp):
     for k in ENV_KNOBS:
         os.environ.pop(k, None)
     for f in os.listdir(tmp):
-        os.unlink(os.path.join(tmp, f))
+        if f.endswith(".bin"):          # the previous case's files, nothing else (tmp may be a directory the caller shares)
+            os.unlink(os.path.join(tmp, f))
     if FORCE_KIND:
         kind = {"gemm": 0, "kmeans": 5, "csr": 9, "kernel": -1}[FORCE_KIND]
     try:
