@@ -116,6 +116,10 @@ struct StreamSet {
   int join(hipStream_t parent);  // parent waits for every stream
 };
 StreamSet *stream_set(int n_streams);  // per-device singleton
+// $BOF_STREAMS_PER_REP=1 (experiment switch, profiles/r4/fuzz_thread_bisect.md section 6): the pipelines of a REPEATED
+// ordinal of the device list ([0,0,0]: the one-GPU stand-in for three devices) get compute streams of their own instead
+// of feeding the ordinal's shared set from several dispatcher threads; the repetition is announced per thread
+extern thread_local int t_ordinal_rep;
 
 bof_options resolved(const bof_options *o);
 

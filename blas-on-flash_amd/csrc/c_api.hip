@@ -64,14 +64,20 @@ bof_options resolved(const bof_options *o) {
 // them.  (One private group of streams per n left up to 1 + 2 + 4 + ... streams alive; HIP maps
 // streams onto a handful of hardware queues, so every extra live stream makes it likelier that
 // two streams that should overlap end up in one queue.)
-static hipStream_t g_compute_stream[64][16];
+static constexpr int kStreamReps = 8;
+static hipStream_t g_compute_stream[64][kStreamReps][16];
+thread_local int t_ordinal_rep = 0;
+static int stream_rep() {
+  static const bool on = getenv("BOF_STREAMS_PER_REP") && atoi(getenv("BOF_STREAMS_PER_REP")) != 0;
+  return on && t_ordinal_rep > 0 && t_ordinal_rep < kStreamReps ? t_ordinal_rep : 0;
+}
 int StreamSet::init(int n_streams) {
   n = n_streams;
   int dev = 0;
   BOF_HIP_TRY(hipGetDevice(&dev));
   BOF_HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
   for (int i = 0; i < n; i++) {
-    hipStream_t &shared = g_compute_stream[dev & 63][i];
+    hipStream_t &shared = g_compute_stream[dev & 63][stream_rep()][i];
     if (!shared) BOF_HIP_TRY(hipStreamCreateWithFlags(&shared, hipStreamNonBlocking));
     s[i] = shared;
     BOF_HIP_TRY(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
@@ -92,12 +98,12 @@ int StreamSet::join(hipStream_t parent) {
 }
 
 static std::mutex g_ss_mu;
-static StreamSet *g_ss[64][17];
+static StreamSet *g_ss[64][kStreamReps][17];
 StreamSet *stream_set(int n_streams) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lk(g_ss_mu);
-  StreamSet *&p = g_ss[dev][n_streams];
+  StreamSet *&p = g_ss[dev][stream_rep()][n_streams];
   if (!p) {
     p = new StreamSet();
     if (p->init(n_streams) != BOF_OK) { delete p; p = nullptr; }

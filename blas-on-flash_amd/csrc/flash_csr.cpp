@@ -1235,6 +1235,10 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   // ---- one pipeline per device on its rows ------------------------------------------------------------
   auto run_shard = [&](Shard &S) {
     DeviceScope ds(S.dev);
+    struct RepScope {        // which repetition of its ordinal this shard is ($BOF_STREAMS_PER_REP)
+      explicit RepScope(int r) { t_ordinal_rep = r; }
+      ~RepScope() { t_ordinal_rep = 0; }
+    } rep_scope((int) std::count_if(sh.begin(), sh.begin() + (&S - sh.data()), [&](const Shard &E) { return E.dev == S.dev; }));
     CsrExtra ex;
     ex.ia = ia.data() + S.row0;
     ex.out = &S.cnt;

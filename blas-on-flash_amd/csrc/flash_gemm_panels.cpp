@@ -1190,7 +1190,13 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   // ---- per-device events, streams, write rings; the shared read ring --------------------------------
   for (auto &R : H.runs) {
     BOF_HIP_TRY(hipSetDevice(R->dev));
+    t_ordinal_rep = 0;       // which repetition of its ordinal this run is ($BOF_STREAMS_PER_REP: stream sets per repetition)
+    for (auto &E : H.runs) {
+      if (E.get() == R.get()) break;
+      if (E->dev == R->dev) t_ordinal_rep++;
+    }
     int rc = R->prepare();
+    t_ordinal_rep = 0;
     if (rc) return rc;
     if (kh) {
       rc = kmeans_upload(*kh, &R->kv);

@@ -22,6 +22,7 @@ namespace bof {
 void set_error(const std::string &msg) { fprintf(stderr, "set_error: %s\n", msg.c_str()); }
 int hip_fail(hipError_t, const char *) { return BOF_EHIP; }
 StreamSet *stream_set(int) { return nullptr; }
+thread_local int t_ordinal_rep = 0;
 int scratch_get(int, size_t, void **) { return BOF_ENODEV; }
 void scratch_release_all() {}
 bof_options resolved(const bof_options *o) { return o ? *o : bof_options{}; }

@@ -17,5 +17,8 @@ K1) run K1_fresh_thread_hdp_flush_wa BOF_DBG_SLAB_THREAD=1 DEBUG_CLR_KERNARG_HDP
 # events with timing disabled (default) against timing enabled; needs long runs (SECS=1800, 16 processes) to say anything
 T0) run T0_events_timing_disabled BOF_EVENT_TIMING=0 ;;
 T1) run T1_events_timing_enabled BOF_EVENT_TIMING=1 ;;
+# compute streams per repetition of an ordinal instead of one set per ordinal fed by several dispatcher threads (section 6 of
+# profiles/r4/fuzz_thread_bisect.md); KIND=gemm and --set 'devices=[0,0,0];gemm_path=2' is the configuration of the open mismatch
+S1) run S1_streams_per_repetition BOF_STREAMS_PER_REP=1 ;;
 esac
 done
