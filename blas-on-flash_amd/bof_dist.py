@@ -48,7 +48,7 @@ def gemm_shard_args(m, n, k, lda, ldc, world, rank, tile):
     return r1 - r0, r0 * (lda or k), r0 * (ldc or n)
 
 
-def allreduce_partial(y, group=None, algo="allreduce"):
+def allreduce_partial(y, group=None, algo="allreduce", force=False):
     """Sum the per-rank partial vectors of CSRGEMV 'T' in place (RCCL over xGMI for device tensors).
     fp32; exact for the integer-valued generator data.
 
@@ -56,10 +56,11 @@ def allreduce_partial(y, group=None, algo="allreduce"):
     all-gather -- on the fully connected xGMI mesh (7 point-to-point links per GPU) every rank sends
     its 7 foreign chunks of S/8 over 7 different links at once, so the step is bound by S/8 per
     link instead of a ring's 2 (N-1)/N S over one.  The vector length is padded
-    to a multiple of the world size in a scratch tensor when needed."""
+    to a multiple of the world size in a scratch tensor when needed.
+    force=True issues the collectives even in a world of one rank (the GPU smoke test of the RCCL path)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return y
     world = dist.get_world_size(group)
     if algo != "rs_ag":
@@ -122,8 +123,7 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
         # The staging ring is POSIX shared memory: a share group = the row-owning ranks of ONE host.  Every rank
         # tells the others where it runs (host name + boot id: two containers of one machine with separate /dev/shm
         # differ in neither, which is why the host's first owner also PROBES the segment below).
-        hosts = [None] * world
-        dist.all_gather_object(hosts, _host_identity(), group=group)
+        hosts = _hosts_of(group, world)
         mates = [g for g in owners if hosts[g] == hosts[rank]] if rank in owners else []
         # ... and the host's first owner decides whether its /dev/shm can hold the ring (64 chunk slots per shared
         # operand, ~2 GiB at the default 32 MiB chunk; a store into a tmpfs page that cannot be allocated is a
@@ -146,19 +146,27 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
         # every member of the share group is on the panel path, so the ranks agree BEFORE the call: one member that
         # cannot -> the whole group reads B itself (and that member's call goes to the tile cache).  The library's own
         # check (BOF_EINVAL + the group's failure word) stays as the safety net behind this.
-        can = None
+        can, pre_err = None, None
         if rows > 0:
-            can = int(o.gemm_path) != 1
-            if can:
-                budget = int(o.hbm_budget)
-                if budget <= 0:
-                    import ctypes
-                    fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
-                    bofhip.check(bofhip.lib().bof_mem_info(ctypes.byref(fr), ctypes.byref(tot)), "bof_mem_info")
-                    budget = int(fr.value * 0.8)
-                can = bool(bofhip.flash_gemm_panel_plan("R", "N", "N", rows, n, k, tile, budget, lda, ldb, ldc, 0)["eligible"])
+            # (an exception here would leave the other ranks blocked in the gather below: it travels WITH the verdict
+            #  and is raised on every rank afterwards, like the post-call errors)
+            try:
+                can = int(o.gemm_path) != 1
+                if can:
+                    budget = int(o.hbm_budget)
+                    if budget <= 0:
+                        import ctypes
+                        fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
+                        bofhip.check(bofhip.lib().bof_mem_info(ctypes.byref(fr), ctypes.byref(tot)), "bof_mem_info")
+                        budget = int(fr.value * 0.8)
+                    can = bool(bofhip.flash_gemm_panel_plan("R", "N", "N", rows, n, k, tile, budget, lda, ldb, ldc, 0)["eligible"])
+            except Exception as e:      # noqa: BLE001 -- whatever it is, every rank must hear of it
+                can, pre_err = False, f"{type(e).__name__}: {e}"
         verdicts = [None] * world
-        dist.all_gather_object(verdicts, (verdict, can), group=group)
+        dist.all_gather_object(verdicts, (verdict, can, pre_err), group=group)
+        bad_pre = [(g, v[2]) for g, v in enumerate(verdicts) if v is not None and v[2]]
+        if bad_pre:
+            raise bofhip.BofError(f"flash_gemm_row_sharded: rank {bad_pre[0][0]} failed its eligibility check: {bad_pre[0][1]}")
         if name is not None and not verdicts[leader][0]:
             name = None
             stats["b_once"] = "off: /dev/shm of this host cannot hold the staging ring"
@@ -199,14 +207,32 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     return stats
 
 
+_host_id = None
+_hosts_cache = {}
+
+
 def _host_identity():
-    import socket
-    boot = ""
-    try:
-        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
-    except OSError:
-        pass
-    return socket.gethostname() + "/" + boot
+    global _host_id
+    if _host_id is None:
+        import socket
+        boot = ""
+        try:
+            boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            pass
+        _host_id = socket.gethostname() + "/" + boot
+    return _host_id
+
+
+def _hosts_of(group, world):
+    """Where every rank of the group runs; gathered once per (group, world), not per call."""
+    import torch.distributed as dist
+    key = (id(group) if group is not None else None, world)
+    if key not in _hosts_cache:
+        hosts = [None] * world
+        dist.all_gather_object(hosts, _host_identity(), group=group)
+        _hosts_cache[key] = hosts
+    return _hosts_cache[key]
 
 
 def flash_kmeans_point_sharded(ncenters, npoints, dim, fd_centers, fd_points, fd_dist, c_l2sq, p_l2sq, opts=None,

@@ -33,7 +33,8 @@ class Options(C.Structure):
                 ("share_world", C.c_int32), ("share_rank", C.c_int32), ("share_name", C.c_char * 48),
                 # ABI v4: instrumentation + device-to-device broadcast of a shared operand
                 ("kernel_timing", C.c_int32), ("verify", C.c_int32), ("peer_bcast", C.c_int32),
-                ("reserved_", C.c_int32 * 5)]
+                # ABI v5: how the k-blocks of a C tile are combined (0 / 2: one chain over the whole K; 1: the reference's)
+                ("gemm_chain", C.c_int32), ("reserved_", C.c_int32 * 4)]
 
 
 class GemmTask(C.Structure):

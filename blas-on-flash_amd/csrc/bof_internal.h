@@ -32,6 +32,41 @@ hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64
                          const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                          int64_t ldc, const float *u1, const float *v1, const float *u2, const float *v2,
                          hipStream_t st);
+// One k-range of an ACCUMULATE CHAIN (gemm_f32_mfma.hip, ChainEpi): the chain carries its raw fp32 accumulators from
+// launch to launch -- raw_out stores them unscaled into c, acc_in starts the next range from them -- and only the final
+// launch (raw_out = false) applies  c = beta == 0 ? alpha*acc : fmaf(alpha, acc, beta*c_in)  (c_in == nullptr: c itself).
+// A chain cut at any k positions therefore equals ONE sgemm over the whole K bit for bit.
+struct GemmChain {
+  const float *acc_in = nullptr;   // laid out like C, leading dimension ld_acc
+  int64_t ld_acc = 0;
+  const float *c_in = nullptr;     // laid out like C, leading dimension ld_cin
+  int64_t ld_cin = 0;
+  bool raw_out = false;
+};
+hipError_t sgemm_chain(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a,
+                       int64_t lda, const float *b, int64_t ldb, float beta, float *c, int64_t ldc, const GemmChain &ch,
+                       hipStream_t st);
+// BOF_VERIFY: spot check of one launch (gemm_f32_mfma.hip): 64 sampled outputs recomputed in the kernels' arithmetic.
+// The arguments are the launch's own (sgemm / sgemm_chain / sgemm_rank1x2 terms); capture runs in FRONT of the launch
+// (it saves the values the launch overwrites), check behind it; exp2 / got2: two 64-bit sums each (Verify entries).
+struct SpotArgs {
+  char ord, ta, tb;
+  int64_t m, n, k;
+  float alpha;
+  const float *a;
+  int64_t lda;
+  const float *b;
+  int64_t ldb;
+  float beta;
+  float *c;
+  int64_t ldc;
+  GemmChain ch;
+  const float *u1 = nullptr, *v1 = nullptr, *u2 = nullptr, *v2 = nullptr;
+  uint64_t seed = 0;
+};
+hipError_t sgemm_spot_capture(const SpotArgs &s, float *save128, hipStream_t st);
+hipError_t sgemm_spot_check(const SpotArgs &s, const float *save128, unsigned long long *exp2, unsigned long long *got2,
+                            hipStream_t st);
 // dst[i] = src[i - min(i / blk, nblk - 1) * blk]: a vector indexed inside a tile (the tiler's blocks, last one
 // tail-merged) unrolled over the whole dimension
 hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t blk, int64_t nblk, hipStream_t st);
@@ -116,9 +151,10 @@ struct StreamSet {
   int join(hipStream_t parent);  // parent waits for every stream
 };
 StreamSet *stream_set(int n_streams);  // per-device singleton
-// $BOF_STREAMS_PER_REP=1 (experiment switch, profiles/r4/fuzz_thread_bisect.md section 6): the pipelines of a REPEATED
-// ordinal of the device list ([0,0,0]: the one-GPU stand-in for three devices) get compute streams of their own instead
-// of feeding the ordinal's shared set from several dispatcher threads; the repetition is announced per thread
+// The pipelines of a REPEATED ordinal of the device list ([0,0,0]: the one-GPU stand-in for three devices) get compute
+// streams of their own instead of feeding the ordinal's shared set from several dispatcher threads (default since
+// round 5; $BOF_STREAMS_PER_REP=0 shares them again: profiles/r4/fuzz_thread_bisect.md section 6); the repetition is
+// announced per thread
 extern thread_local int t_ordinal_rep;
 
 bof_options resolved(const bof_options *o);

@@ -57,6 +57,7 @@ bof_options resolved(const bof_options *o) {
   r.kernel_timing = o->kernel_timing > 0 ? 1 : 0;
   if (o->verify >= 0 && o->verify <= 2) r.verify = o->verify;
   if (o->peer_bcast >= 0 && o->peer_bcast <= 2) r.peer_bcast = o->peer_bcast;
+  if (o->gemm_chain >= 0 && o->gemm_chain <= 2) r.gemm_chain = o->gemm_chain;
   return r;
 }
 
@@ -64,12 +65,16 @@ bof_options resolved(const bof_options *o) {
 // them.  (One private group of streams per n left up to 1 + 2 + 4 + ... streams alive; HIP maps
 // streams onto a handful of hardware queues, so every extra live stream makes it likelier that
 // two streams that should overlap end up in one queue.)
-static constexpr int kStreamReps = 8;
+static constexpr int kStreamReps = BOF_MAX_DEVICES;
 static hipStream_t g_compute_stream[64][kStreamReps][16];
 thread_local int t_ordinal_rep = 0;
+// Every repetition of an ordinal in a device list ([0,0,0]: one GPU standing in for three) has compute streams of its
+// own: dispatchers of a repeated ordinal run on different host threads, and every wrong result of rounds 3-4 involved
+// two host threads feeding ONE stream (profiles/r4/fuzz_thread_bisect.md section 6; correlated, not proven).
+// $BOF_STREAMS_PER_REP=0 restores the shared set (the A/B switch of tools/exp/fuzz_bisect.sh).
 static int stream_rep() {
-  static const bool on = getenv("BOF_STREAMS_PER_REP") && atoi(getenv("BOF_STREAMS_PER_REP")) != 0;
-  return on && t_ordinal_rep > 0 && t_ordinal_rep < kStreamReps ? t_ordinal_rep : 0;
+  static const bool on = !getenv("BOF_STREAMS_PER_REP") || atoi(getenv("BOF_STREAMS_PER_REP")) != 0;
+  return on && t_ordinal_rep > 0 ? t_ordinal_rep % kStreamReps : 0;
 }
 int StreamSet::init(int n_streams) {
   n = n_streams;
@@ -180,6 +185,7 @@ void bof_default_options(bof_options *o) {
   o->kernel_timing = 0;
   o->verify = 0;
   o->peer_bcast = 0;
+  o->gemm_chain = 0;
   memset(o->reserved_, 0, sizeof(o->reserved_));
 }
 
@@ -345,6 +351,15 @@ static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, 
       a = repl[0]; b = repl[1]; ta = flag[0]; tb = flag[1];
       g = gemm_geometry(ord, ta, tb, m, n, k, ld_new[0], ld_new[1], ldc, o.gemm_blk);
     }
+  }
+  // flash::gemm's default arithmetic (bof_options.gemm_chain 0 / 2): ONE k-ordered chain per element over the whole K.
+  // With everything resident that is one launch over the whole matrices -- what drivers/in_mem_gemm.cpp:63-70 does with
+  // its one cblas_sgemm call; the tiler's blocks (src/blas/gemm.cpp:39-129) would only cut it into launches whose
+  // raw accumulators travel through C (gemm_f32_mfma.hip, ChainEpi), same bits.  alpha == 0 keeps the task loop below:
+  // cblas_sgemm's quick return per task.
+  if (!kv && o.gemm_chain != 1 && alpha != 0.f && g.nblk[1] > 0 && m <= INT32_MAX && n <= INT32_MAX && k <= INT32_MAX) {
+    BOF_HIP_TRY(sgemm(ord, ta, tb, m, n, k, alpha, a, g.ld[0], b, g.ld[1], beta, c, g.ld[2], parent));
+    return BOF_OK;
   }
   rc = ss->fork(parent);
   if (rc) return rc;

@@ -438,9 +438,21 @@ inline bool verify_wanted(const bof_options &o) {
   const char *e = getenv("BOF_VERIFY");
   return e && e[0] && strcmp(e, "0") != 0;
 }
+// Round 5, what the hand-over sums could not see (profiles/r4/fuzz_thread_bisect.md section 6: a k-block that did not
+// add to C although every operand sum agreed):
+//  * CONSUMER-side sums: every operand panel / tile is summed once more ON THE COMPUTE STREAM in front of each launch
+//    that reads it (and a chain's partial sums behind one launch and in front of the next): a missing or mis-targeted
+//    cross-stream wait shows as a launch-side sum that differs from the producer-side one;
+//  * SPOT CHECKS: 64 outputs of every launch recomputed from its own arguments (bof_internal.h: SpotArgs) -- a
+//    launch that ran with other arguments, too early, twice or not at all is named by its (panel, k-range);
+//  * POISON: every HBM image is filled with 0xFF words (NaN) before its first byte of the call arrives, so a read
+//    ahead of the fill gives NaN instead of a plausible old number.
 class Verify {
   struct Expect { size_t a, b; const char *what; int id0, id1, id2; };
   unsigned long long *d_tab = nullptr;          // 2 per entry, in the HBM of `dev`
+  float *d_spot = nullptr;                      // 128 saved values per spot check
+  std::atomic<size_t> spot_next{0};
+  size_t spot_cap = 0;
   std::vector<std::atomic<uint64_t>> h_tab;     // 2 per entry
   std::vector<std::atomic<uint8_t>> touched;    // bit 0: host side filled, bit 1: device side filled
   std::atomic<size_t> next{0};
@@ -453,7 +465,32 @@ class Verify {
   static constexpr size_t kNone = (size_t) -1;
   bool on = false;
   ~Verify() { release(); }
-  int init(int device, size_t capacity);        // BOF_OK / BOF_EHIP; the table lives on `device`
+  int init(int device, size_t capacity, size_t spots = 0);   // BOF_OK / BOF_EHIP; the table lives on `device`
+  // spot check of one launch: before() in front of it on its stream, after() behind it (flash_common.h header above)
+  struct Spot { float *save = nullptr; size_t e_exp = kNone, e_got = kNone; };
+  hipError_t spot_before(const SpotArgs &a, hipStream_t st, Spot *sp, const char *what, int id0, int id1, int id2) {
+    *sp = Spot();
+    if (!on || !d_spot) return hipSuccess;
+    const size_t i = spot_next.fetch_add(1);
+    if (i >= spot_cap) return hipSuccess;
+    sp->save = d_spot + 128 * i;
+    sp->e_exp = entry();
+    sp->e_got = entry();
+    if (sp->e_exp == kNone || sp->e_got == kNone) { sp->save = nullptr; return hipSuccess; }
+    expect(sp->e_exp, sp->e_got, what, id0, id1, id2);
+    return sgemm_spot_capture(a, sp->save, st);
+  }
+  hipError_t spot_after(const SpotArgs &a, const Spot &sp, hipStream_t st) {
+    if (!on || !sp.save) return hipSuccess;
+    touched[sp.e_exp].fetch_or(2);
+    touched[sp.e_got].fetch_or(2);
+    return sgemm_spot_check(a, sp.save, d_tab + 2 * sp.e_exp, d_tab + 2 * sp.e_got, st);
+  }
+  // fills an HBM range with 0xFF words on `st` (NaN: a read ahead of the fill cannot pass for data)
+  hipError_t poison(void *p, size_t bytes, hipStream_t st) {
+    if (!on || !p || !bytes) return hipSuccess;
+    return launch_from_persistent(dev, [&] { return hipMemsetAsync(p, 0xFF, bytes, st); });
+  }
   void release();
   size_t entry() {
     if (!on) return kNone;

@@ -104,6 +104,7 @@ struct Panel {
   size_t ve[VE_N] = {Verify::kNone, Verify::kNone, Verify::kNone, Verify::kNone, Verify::kNone,
                      Verify::kNone, Verify::kNone, Verify::kNone, Verify::kNone};
   bool v_last_done = false;     // its HBM image has had its after-last-use sum queued (guarded by PanelRun::vf_mu)
+  bool poisoned = false;        // BOF_VERIFY: its HBM image was filled with NaN ahead of its first chunk (guarded by vf_mu)
 };
 
 struct Mat {
@@ -125,7 +126,16 @@ struct Mat {
   // entry = not allocated yet; entries are written under PanelHub::mu.
   std::vector<char *> *slots = nullptr;
   int slot_of(int p) const { return natural ? p : p % n_slots; }
-  char *panel_ptr(int p) const { return (*slots)[(size_t) slot_of(p)]; }
+  // A RESIDENT OPERAND (A or B kept whole) is ONE allocation holding the matrix in file layout, panel p at its file
+  // offset: a launch may then run over any range of its rows -- the whole K of a k-paneled operand, the whole width of
+  // a C panel -- with one pointer and the file's leading dimension (round 5; C and the streamed operand keep one
+  // allocation per slot).  Allocated like a slot: by alloc_main, in first-use order, kept between calls.
+  bool whole = false;
+  char **whole_ptr = nullptr, **twhole_ptr = nullptr;
+  char *panel_ptr(int p) const {
+    if (whole) return *whole_ptr ? *whole_ptr + (uint64_t) panels[(size_t) p].r0 * (uint64_t) ld * 4 : nullptr;
+    return (*slots)[(size_t) slot_of(p)];
+  }
   // k-major copy of a k-contiguous operand panel ([rows][k] -> [k][rows], one per slot), made on
   // the H2D stream behind the panel's last copy: the tile tasks then take the LDS-DMA kernel
   // (148.6 instead of 145.7 TFLOP/s at 4096^3) exactly as bof_gemm_resident arranges it for
@@ -133,7 +143,12 @@ struct Mat {
   bool kmajor_copy = false;
   size_t tslot_bytes = 0;
   std::vector<char *> *tslots = nullptr;
-  char *tpanel_ptr(int p) const { return (*tslots)[(size_t) slot_of(p)]; }
+  // (a resident operand's copy is ONE [cols][rows] image, panel p in its columns r0 .. r0 + nr - 1)
+  char *tpanel_ptr(int p) const {
+    if (whole) return *twhole_ptr ? *twhole_ptr + (uint64_t) panels[(size_t) p].r0 * 4 : nullptr;
+    return (*tslots)[(size_t) slot_of(p)];
+  }
+  int64_t t_ld(int p) const { return whole ? rows : panels[(size_t) p].nr; }
   bool slot_ready(int p) const { return panel_ptr(p) && (!kmajor_copy || tpanel_ptr(p)); }
   uint64_t file_off(int p) const { return f.foffset + (uint64_t) panels[(size_t) p].r0 * (uint64_t) ld * 4; }
   // O_DIRECT kept although some request of the call is not sector aligned (an unaligned leading dimension
@@ -159,6 +174,10 @@ struct Mat {
 };
 
 struct ChunkReq { int di, mat, panel, c; uint64_t off, bytes; };   // di < 0: a shared panel (every device)
+// One kernel launch of the schedule: C panel pc, its tiles [q0, q1) along C's other dimension, the k-blocks [l0, l1).
+// flash::gemm: a whole C panel per launch -- one k-block at a time while the resident operand streams in (the ramp
+// group), the whole K afterwards; flash::kmeans: one tile task per launch, as the reference has them.
+struct Launch { int pc; int64_t q0, q1, l0, l1; };
 struct WriteReq { int di, wslot; uint64_t file_off, bytes, delta; int panel; bool last; };
 
 // Per device (and per repetition of one ordinal in the device list): the HBM panel slots and the
@@ -170,8 +189,32 @@ struct PanelResources {
   size_t slot_bytes[3] = {0, 0, 0};
   std::vector<char *> tslot[2];           // k-major copies of operand panels (A, B)
   size_t tslot_bytes[2] = {0, 0};
+  char *whole[2] = {nullptr, nullptr};    // resident operands: the whole matrix in file layout, and its k-major copy
+  size_t whole_bytes[2] = {0, 0};
+  char *twhole[2] = {nullptr, nullptr};
+  size_t twhole_bytes[2] = {0, 0};
+  std::vector<char *> acc;                // raw accumulator panels of the ramp group's chains (beta != 0), C slot size
+  size_t acc_bytes = 0;
+  void drop_whole(int x) {
+    if (whole[x]) (void) hipFree(whole[x]);
+    whole[x] = nullptr;
+    whole_bytes[x] = 0;
+  }
+  void drop_twhole(int x) {
+    if (twhole[x]) (void) hipFree(twhole[x]);
+    twhole[x] = nullptr;
+    twhole_bytes[x] = 0;
+  }
+  void drop_acc(size_t keep) {
+    for (size_t i = keep; i < acc.size(); i++)
+      if (acc[i]) (void) hipFree(acc[i]);
+    acc.resize(keep);
+  }
   size_t held_bytes() const {
     size_t tot = 0;
+    for (int x = 0; x < 2; x++) tot += (whole[x] ? whole_bytes[x] : 0) + (twhole[x] ? twhole_bytes[x] : 0);
+    for (char *p : acc)
+      if (p) tot += acc_bytes;
     for (int x = 0; x < 3; x++)
       for (char *p : slot[x])
         if (p) tot += slot_bytes[x];
@@ -214,7 +257,8 @@ struct PanelResources {
     h2d = d2h = nullptr;
     wring.destroy();
     for (int x = 0; x < 3; x++) drop(x, 0);
-    for (int x = 0; x < 2; x++) drop_t(x, 0);
+    for (int x = 0; x < 2; x++) { drop_t(x, 0); drop_whole(x); drop_twhole(x); }
+    drop_acc(0);
   }
 };
 std::mutex g_pres_mu;
@@ -262,14 +306,23 @@ struct PanelRun {
   std::vector<std::pair<int, int>> order;        // (mat, panel) in order of first use
   std::vector<std::pair<int, int>> alloc_order;  // (mat, slot) still to be allocated, in order of first use
   size_t next_fetch = 0;
-  std::vector<bof_gemm_task> tasks;               // execution order
-  std::vector<size_t> group_end;                  // task index one past each group
+  std::vector<Launch> launches;                   // execution order
+  std::vector<size_t> group_end;                  // launch index one past each group
+  // How a C tile's k-blocks are combined (bof_options.gemm_chain).  false (default): the chain carries its raw
+  // accumulators from launch to launch and scales once at the end -- ONE k-ordered fmaf chain per element however K is
+  // cut (gemm_f32_mfma.hip, ChainEpi), which is also what lets a C panel whose operands are complete run as a single
+  // launch over the whole K.  true: the reference's task arithmetic, C = alpha*A_l*B_l + (l ? 1 : beta)*C per k-block
+  // (src/blas/gemm.cpp:122-127, include/tasks/gemm_task.h:87-90) -- also taken for alpha == 0 (cblas_sgemm's quick
+  // return: neither operand may be looked at) and by flash::kmeans, whose tasks add their rank-1 terms per block.
+  bool ref_chain = false;
+  bool need_acc = false;                          // beta != 0 and a chain of several launches: raw sums in res->acc
   std::vector<int64_t> gb;                        // first C panel of each group, then NpC
   int n_groups = 0;
   std::vector<std::vector<hipEvent_t>> group_ev;  // per group: one event per compute stream
   std::vector<int> group_of;                      // C panel -> group
   KmeansVecs kv{nullptr, nullptr, nullptr};
   bool has_kv = false;
+  bool kmeans = false;                            // the call is flash::kmeans (known before the vectors are uploaded)
   Counters cnt;                                   // this device's share of the counters
   KernelTimer ktimer;                             // bof_options.kernel_timing
   Verify vf;                                      // bof_options.verify: hand-over checksums of this device's panels
@@ -400,13 +453,29 @@ void PanelRun::alloc_main() {
     char *p = nullptr, *tp = nullptr;
     Mat &M = mat[as.first];
     hipError_t e = hipSuccess;
-    if (!(*M.slots)[(size_t) as.second]) e = hipMalloc((void **) &p, M.slot_bytes);
-    if (e == hipSuccess && M.kmajor_copy && !(*M.tslots)[(size_t) as.second]) e = hipMalloc((void **) &tp, M.tslot_bytes);
-    if (e != hipSuccess) { (void) hipGetLastError(); hub->fail_io(e == hipErrorOutOfMemory ? -ENOMEM : -1000 - (int) e); break; }
+    if (M.whole) {     // (as.second = -1) the resident operand's one image, and its k-major copy
+      if (!*M.whole_ptr) e = hipMalloc((void **) &p, res->whole_bytes[as.first]);
+      if (e == hipSuccess && M.kmajor_copy && !*M.twhole_ptr) e = hipMalloc((void **) &tp, res->twhole_bytes[as.first]);
+    } else {
+      if (!(*M.slots)[(size_t) as.second]) e = hipMalloc((void **) &p, M.slot_bytes);
+      if (e == hipSuccess && M.kmajor_copy && !(*M.tslots)[(size_t) as.second]) e = hipMalloc((void **) &tp, M.tslot_bytes);
+    }
+    if (e != hipSuccess) {
+      (void) hipGetLastError();
+      if (p) (void) hipFree(p);
+      hub->fail_io(e == hipErrorOutOfMemory ? -ENOMEM : -1000 - (int) e);
+      break;
+    }
     {
       std::lock_guard<std::mutex> lk(hub->mu);
-      if (tp) (*M.tslots)[(size_t) as.second] = tp;   // before the raw slot: a usable raw slot implies its copy's
-      if (p) (*M.slots)[(size_t) as.second] = p;
+      // (the copy before the raw image: a usable raw image implies its copy's)
+      if (M.whole) {
+        if (tp) *M.twhole_ptr = tp;
+        if (p) *M.whole_ptr = p;
+      } else {
+        if (tp) (*M.tslots)[(size_t) as.second] = tp;
+        if (p) (*M.slots)[(size_t) as.second] = p;
+      }
       hub->pump_fetches();
     }
     hub->cv.notify_all();
@@ -483,6 +552,14 @@ void PanelHub::reader_main(int home) {
         // lands (whichever reader comes first queues it; the lock keeps its copy behind the sum)
         vlk.lock();
         if (prev >= 0 && e == hipSuccess) e = R.verify_last_use(rq.mat, prev, R.h2d);
+        // ... and the image is poisoned (0xFF words: NaN) before the first byte of the new panel: whoever reads it
+        // ahead of its fill -- a missing wait, a stale pointer -- gets NaN instead of a plausible old number
+        Panel &PN = M.panels[(size_t) rq.panel];
+        if (!PN.poisoned && e == hipSuccess) {
+          PN.poisoned = true;
+          e = R.vf.poison(M.panel_ptr(rq.panel), PN.bytes, R.h2d);
+          if (e == hipSuccess && M.kmajor_copy && !M.whole) e = R.vf.poison(M.tpanel_ptr(rq.panel), (size_t) PN.nr * (size_t) M.cols * 4, R.h2d);
+        }
       }
       if (bcast && d != home) {
         PanelRun &Hm = *runs[home];
@@ -520,10 +597,11 @@ void PanelHub::reader_main(int home) {
             e = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
             if (e == hipSuccess)
               e = launch_from_persistent(R.dev, [&] {
-                return transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel), P.nr,
-                                     R.h2d);
+                return transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
+                                     M.t_ld(rq.panel), R.h2d);
               });
-            if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, P.nr, 0, M.cols, R.h2d);
+            if (e == hipSuccess)
+              e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, M.t_ld(rq.panel), 0, M.cols, R.h2d);
           }
           if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
           // a failed copy / record must be visible BEFORE the panel is: the dispatcher tests io_error right
@@ -659,8 +737,16 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
   ymat = 1 - xmat;
   NpC = g.nblk[dC];
   Nq = dC == 0 ? g.nblk[2] : g.nblk[0];        // C tiles per panel
+  // (bof_options.gemm_chain / PanelRun::ref_chain: see the struct)
+  ref_chain = kmeans || o.gemm_chain == 1 || alpha == 0.0f;
+  // raw accumulator panels: only a chain of several launches on a C that is read (beta != 0) needs them -- one per C
+  // panel of the ramp group, of a C slot's size
+  need_acc = !ref_chain && c_read && Nk > 1;
+  auto fits = [&](const bof_panel_plan &p2) {
+    return p2.eligible && (!need_acc || p2.need_bytes + (uint64_t) p2.first_group * p2.slot_bytes[2] <= budget);
+  };
   bof_panel_plan pl = plan_panels(g, budget, 1, full_dC);
-  if (!pl.eligible) return 1;
+  if (!fits(pl)) return 1;
   {
     // size of the ramp group (see the header): read time of one panel of the resident operand
     // over the time of the tile tasks one C panel contributes per such panel.  The rates are
@@ -679,7 +765,7 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     }
     for (int64_t G = std::min(want, NpC); G > 1; G--) {
       const bof_panel_plan p2 = plan_panels(g, budget, G, full_dC);
-      if (p2.eligible) { pl = p2; break; }
+      if (fits(p2)) { pl = p2; break; }
     }
   }
   const int64_t group = pl.first_group;
@@ -716,40 +802,66 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     M.n_slots = (int) pl.n_slots[x];
   }
 
-  // ---- task list in execution order, panels in first-use order ------------------------------
-  tasks.reserve((size_t) (g.nblk[0] * Nk * g.nblk[2]));
+  // ---- launch list in execution order, panels in first-use order ------------------------------
   group_of.assign((size_t) NpC, 0);
   std::vector<std::vector<char>> seen(3);
   for (int x = 0; x < 3; x++) seen[x].assign(mat[x].panels.size(), 0);
   gb.push_back(0);
   for (int64_t pc = group; pc < NpC; pc++) gb.push_back(pc);
   gb.push_back(NpC);
+  auto add_launch = [&](int64_t pc, int64_t q0, int64_t q1, int64_t l0, int64_t l1) {
+    launches.push_back(Launch{(int) pc, q0, q1, l0, l1});
+    // the panels it touches, in the order A, B, C: a matrix paneled along k contributes l0 .. l1-1, one paneled
+    // along C's other dimension q0 .. q1-1, one paneled along the C panel dimension the panel pc
+    for (int x = 0; x < 3; x++) {
+      const int rd = mat[x].rdim;
+      const int64_t p0 = rd == dC ? pc : (rd == 1 ? l0 : q0), p1 = rd == dC ? pc + 1 : (rd == 1 ? l1 : q1);
+      for (int64_t pp = p0; pp < p1; pp++) {
+        if (seen[x][(size_t) pp]) continue;
+        seen[x][(size_t) pp] = 1;
+        if (x < 2 || c_read) order.emplace_back(x, (int) pp);
+      }
+    }
+  };
   for (size_t gx = 0; gx + 1 < gb.size(); gx++, n_groups++) {
     const int64_t G0 = gb[gx], G1 = gb[gx + 1];
-    for (int64_t l = 0; l < Nk; l++)
-      for (int64_t pc = G0; pc < G1; pc++) {
-        group_of[(size_t) pc] = n_groups;
-        for (int64_t q = 0; q < Nq; q++) {
-          const int64_t i = dC == 0 ? pc : q, j = dC == 0 ? q : pc;
-          bof_gemm_task t;
-          gemm_task_at(g, l, i, j, beta, &t);
-          tasks.push_back(t);
-          const int64_t idx[3] = {i, l, j};
-          for (int x = 0; x < 3; x++) {
-            const int p = (int) idx[mat[x].rdim];
-            if (seen[x][(size_t) p]) continue;
-            seen[x][(size_t) p] = 1;
-            if (x < 2 || c_read) order.emplace_back(x, p);
-          }
-        }
-      }
-    group_end.push_back(tasks.size());
+    for (int64_t pc = G0; pc < G1; pc++) group_of[(size_t) pc] = n_groups;
+    if (kmeans) {
+      // flash::kmeans: the reference's tile tasks, l-major inside the group
+      for (int64_t l = 0; l < Nk; l++)
+        for (int64_t pc = G0; pc < G1; pc++)
+          for (int64_t q = 0; q < Nq; q++) add_launch(pc, q, q + 1, l, l + 1);
+    } else if (gx == 0 || ref_chain) {
+      // the ramp group (the resident operand is still streaming in): k-block by k-block, l-major, so that panel l of
+      // it unlocks work on every C panel of the group; the reference's chain keeps that cut for all groups
+      for (int64_t l = 0; l < Nk; l++)
+        for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, l + 1);
+    } else {
+      // behind the ramp everything a C panel needs but its own streamed panel is resident: ONE launch over the
+      // whole K -- no C round trip between the k-blocks, an eighth of the launch boundaries
+      for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, 0, Nk);
+    }
+    group_end.push_back(launches.size());
   }
 
-  // ---- HBM slots: kept from an earlier call when they have this call's size; the missing ones
-  // are allocated by alloc_main in first-use order while the pipeline already runs
+  // ---- HBM: kept from an earlier call when it has this call's size; what is missing is allocated by alloc_main
+  // in first-use order while the pipeline already runs.  A resident operand is ONE allocation (Mat::whole).
   for (int x = 0; x < 3; x++) {
     Mat &M = mat[x];
+    M.whole = x < 2 && M.natural;
+    M.whole_ptr = x < 2 ? &res->whole[x] : nullptr;
+    M.twhole_ptr = x < 2 ? &res->twhole[x] : nullptr;
+    if (M.whole) {
+      res->drop(x, 0);
+      const size_t want_b = round_up(M.total_bytes, 2u << 20);
+      if (res->whole_bytes[x] != want_b) {
+        res->drop_whole(x);
+        res->whole_bytes[x] = want_b;
+      }
+      M.slots = &res->slot[x];
+      continue;
+    }
+    if (x < 2) res->drop_whole(x);
     if (res->slot_bytes[x] != M.slot_bytes) {
       res->drop(x, 0);
       res->slot_bytes[x] = M.slot_bytes;
@@ -760,12 +872,12 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     M.slots = &res->slot[x];
   }
   {
-    // k-major copies (see Mat::kmajor_copy): for an operand stored k-contiguous whose panels'
-    // row counts keep the copy's leading dimension a multiple of 4 (vector loads), whose tiles
-    // are each used by >= 4 tasks, and whose copies still fit the budget.  bof_options.panel_kmajor
-    // (1 off, 2 on, 3 on without the reuse condition: tests) / BOF_PANEL_KMAJOR (0, 1, 2).
+    // k-major copies (see Mat::kmajor_copy): for an operand stored k-contiguous whose panels' row counts keep the
+    // copy's leading dimension a multiple of 4 (vector loads), whose tiles are each used by >= 4 tile tasks, and
+    // whose copies still fit the budget.  bof_options.panel_kmajor (1 off, 2 on, 3 on without the reuse
+    // condition: tests) / BOF_PANEL_KMAJOR (0, 1, 2).
     const int kmode = o.panel_kmajor > 0 ? o.panel_kmajor - 1 : (int) env_long("BOF_PANEL_KMAJOR", 1);
-    size_t extra = 0;
+    size_t extra = need_acc ? (size_t) group * mat[2].slot_bytes : 0;
     for (int x = 0; x < 2; x++) {
       Mat &M = mat[x];
       const int64_t reuse = x == xmat ? Nq : NpC;
@@ -775,6 +887,21 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
         ok = ok && P.nr % 4 == 0;
         max_nr = std::max(max_nr, P.nr);
       }
+      if (M.whole) {
+        const size_t tb = round_up((size_t) M.rows * (size_t) M.cols * 4, 2u << 20);
+        if (ok && pl.need_bytes + extra + tb > budget) ok = false;
+        M.kmajor_copy = ok;
+        res->drop_t(x, 0);
+        res->tslot_bytes[x] = 0;
+        if (!ok || res->twhole_bytes[x] != tb) {
+          res->drop_twhole(x);
+          res->twhole_bytes[x] = ok ? tb : 0;
+        }
+        if (ok) extra += tb;
+        M.tslots = &res->tslot[x];
+        continue;
+      }
+      res->drop_twhole(x);
       M.tslot_bytes = round_up((size_t) max_nr * (size_t) M.cols * 4, 2u << 20);
       const size_t n = (size_t) (M.natural ? (int) M.panels.size() : M.n_slots);
       if (ok && pl.need_bytes + extra + n * M.tslot_bytes > budget) ok = false;
@@ -792,18 +919,28 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     }
   }
   {
+    // what alloc_main has to provide, in order of first use ((x, -1): a resident operand's one image)
     std::vector<std::vector<char>> listed(3);
-    for (int x = 0; x < 3; x++) listed[x].assign(res->slot[x].size(), 0);
-    for (const bof_gemm_task &tk : tasks) {
-      const int64_t idx[3] = {tk.i, tk.l, tk.j};
-      for (int x = 0; x < 3; x++) {
-        const int sl = mat[x].slot_of((int) idx[mat[x].rdim]);
-        if (listed[x][(size_t) sl]) continue;
-        listed[x][(size_t) sl] = 1;
-        if (!(*mat[x].slots)[(size_t) sl] || (mat[x].kmajor_copy && !(*mat[x].tslots)[(size_t) sl]))
-          alloc_order.emplace_back(x, sl);
+    for (int x = 0; x < 3; x++) listed[x].assign(std::max<size_t>(1, res->slot[x].size()), 0);
+    auto want_panel = [&](int x, int64_t pp) {
+      Mat &M = mat[x];
+      if (M.whole) {
+        if (listed[x][0]) return;
+        listed[x][0] = 1;
+        if (!*M.whole_ptr || (M.kmajor_copy && !*M.twhole_ptr)) alloc_order.emplace_back(x, -1);
+        return;
       }
-    }
+      const int sl = M.slot_of((int) pp);
+      if (listed[x][(size_t) sl]) return;
+      listed[x][(size_t) sl] = 1;
+      if (!(*M.slots)[(size_t) sl] || (M.kmajor_copy && !(*M.tslots)[(size_t) sl])) alloc_order.emplace_back(x, sl);
+    };
+    for (const Launch &L : launches)
+      for (int x = 0; x < 3; x++) {
+        const int rd = mat[x].rdim;
+        const int64_t p0 = rd == dC ? L.pc : (rd == 1 ? L.l0 : L.q0), p1 = rd == dC ? L.pc + 1 : (rd == 1 ? L.l1 : L.q1);
+        for (int64_t pp = p0; pp < p1; pp++) want_panel(x, pp);
+      }
   }
   return BOF_OK;
 }
@@ -834,6 +971,23 @@ int PanelRun::prepare() {
     }
   const int rc = res->wring.init(std::max(2, o.pinned_slots), chunk + 2 * Mat::kPage);   // slack: widened / page-congruent placement
   if (rc) return rc;
+  // raw accumulator panels of the ramp group's chains (beta != 0 only: else the C slot itself carries the sums)
+  {
+    const size_t nacc = need_acc ? (size_t) (gb[1] - gb[0]) : 0;
+    if (res->acc_bytes != mat[2].slot_bytes) { res->drop_acc(0); res->acc_bytes = mat[2].slot_bytes; }
+    if (res->acc.size() > nacc) res->drop_acc(nacc);
+    res->acc.resize(nacc, nullptr);
+    for (char *&p : res->acc)
+      if (!p) {
+        const hipError_t e = hipMalloc((void **) &p, res->acc_bytes);
+        if (e != hipSuccess) {
+          (void) hipGetLastError();
+          p = nullptr;
+          set_error("bof_flash_gemm: no HBM for the accumulator panels of the ramp group");
+          return e == hipErrorOutOfMemory ? BOF_ENOMEM : BOF_EHIP;
+        }
+      }
+  }
   if (!res->h2d) BOF_HIP_TRY(copy_stream_create(&res->h2d));
   if (!res->d2h) BOF_HIP_TRY(copy_stream_create(&res->d2h));
   h2d = res->h2d;
@@ -846,7 +1000,11 @@ int PanelRun::verify_setup() {
   if (!verify_wanted(o)) return BOF_OK;
   size_t n = 0;
   for (int x = 0; x < 3; x++) n += mat[x].panels.size();
-  const int rc = vf.init(dev, n * Panel::VE_N + 16);
+  // per launch: a consumer-side sum (two with a k-major copy) of every operand panel it reads, one of its C panel,
+  // the chain's partial sums behind it and in front of the next one; one spot check
+  size_t per_launch = 0;
+  for (const Launch &L : launches) per_launch += 2 * (size_t) ((L.l1 - L.l0) + (L.q1 - L.q0) + 1) * 2 + 4;
+  const int rc = vf.init(dev, n * Panel::VE_N + 16 + per_launch, launches.size());
   if (rc) return rc;
   for (int x = 0; x < 3; x++) {
     Mat &M = mat[x];
@@ -900,7 +1058,7 @@ hipError_t PanelRun::verify_last_use(int x, int p, hipStream_t st) {
   P.v_last_done = true;
   hipError_t e = vf.on_device(P.ve[Panel::VE_DEV_LAST], M.panel_ptr(p), 1, (int64_t) (P.bytes / 4), 0, 0, 0, st);
   if (e == hipSuccess && M.kmajor_copy)
-    e = vf.on_device(P.ve[Panel::VE_T_LAST], M.tpanel_ptr(p), M.cols, P.nr, P.nr, 0, M.cols, st);
+    e = vf.on_device(P.ve[Panel::VE_T_LAST], M.tpanel_ptr(p), M.cols, P.nr, M.t_ld(p), 0, M.cols, st);
   return e;
 }
 
@@ -939,73 +1097,194 @@ int PanelRun::verify_finish() {
   return vf.finish(cnt, "bof_flash_gemm (panels)");
 }
 
-// the device's tile launches, in schedule order
+// the device's launches, in schedule order
 void PanelRun::dispatch() {
   (void) hipSetDevice(dev);
   PanelHub &H = *hub;
   Mat &X = mat[xmat], &C = mat[2];
-  // per (matrix, stream): the panel whose events that stream has already been told to wait for
-  std::vector<int> waited((size_t) 3 * (size_t) ss->n, -1);
+  const int64_t Nk = g.nblk[1];
+  const int qdim = dC == 0 ? 2 : 0;            // C's other dimension (its stored columns)
+  // per (matrix, stream): the panels whose `ready` (C without a read: whose slot's previous write-back) that
+  // stream has already been told to wait for
+  std::vector<std::vector<char>> waited((size_t) 3 * (size_t) ss->n);
+  std::map<std::pair<int, int64_t>, size_t> chain_post;     // BOF_VERIFY: (C panel, first tile) -> sum behind the chain's last launch
+  for (int x = 0; x < 3; x++)
+    for (int q = 0; q < ss->n; q++) waited[(size_t) x * (size_t) ss->n + (size_t) q].assign(mat[x].panels.size(), 0);
+  // first stored row / column of a launch's part of matrix x along logical dimension d (0 m, 1 k, 2 n)
+  auto start_of = [&](const Launch &L, int d) -> int64_t {
+    return d == dC ? (int64_t) L.pc * g.blk[dC] : (d == 1 ? L.l0 * g.blk[1] : L.q0 * g.blk[qdim]);
+  };
+  auto range_of = [&](const Launch &L, int x, int64_t *p0, int64_t *p1) {
+    const int rd = mat[x].rdim;
+    *p0 = rd == dC ? L.pc : (rd == 1 ? L.l0 : L.q0);
+    *p1 = rd == dC ? L.pc + 1 : (rd == 1 ? L.l1 : L.q1);
+  };
   size_t t = 0;
   for (int gi = 0; gi < n_groups && !fail && herr == hipSuccess; gi++) {
     TraceRange grange("panel group dispatch");
     for (; t < group_end[(size_t) gi]; t++) {
-      const bof_gemm_task &tk = tasks[t];
-      const int64_t idx[3] = {tk.i, tk.l, tk.j};
-      int pn[3];
-      for (int x = 0; x < 3; x++) pn[x] = (int) idx[mat[x].rdim];
-      const int cprev = C.natural ? -1 : pn[2] - C.n_slots;
+      const Launch &L = launches[t];
+      const bool first = L.l0 == 0, last = L.l1 == Nk;
+      // does this launch read the caller's C?  (reference chain: its first k-block scales it; one chain over K: the
+      // final launch does; beta == 0: nobody)
+      const bool reads_c = c_read && (ref_chain ? first : last);
+      // does it store into the C panel's slot?  (a chain with raw accumulator panels only at its end)
+      const bool writes_c = !need_acc || ref_chain || last;
+      const int cprev = C.natural ? -1 : L.pc - C.n_slots;
+      int64_t p0[3], p1[3];
+      for (int x = 0; x < 3; x++) range_of(L, x, &p0[x], &p1[x]);
       {
         std::unique_lock<std::mutex> lk(H.mu);
         H.cv.wait(lk, [&] {
           if (H.io_error.load()) return true;
-          if (mat[0].panels[(size_t) pn[0]].state != 2 || mat[1].panels[(size_t) pn[1]].state != 2) return false;
-          if (c_read) return C.panels[(size_t) pn[2]].state == 2;
-          if (!C.panel_ptr(pn[2])) return false;                  // its HBM slot is still being allocated
+          for (int x = 0; x < 2; x++)
+            for (int64_t pp = p0[x]; pp < p1[x]; pp++)
+              if (mat[x].panels[(size_t) pp].state != 2) return false;
+          if (reads_c) return C.panels[(size_t) L.pc].state == 2;
+          if (c_read || !writes_c) return true;               // its C panel comes in through the readers, later
+          if (!C.panel_ptr(L.pc)) return false;               // its HBM slot is still being allocated
           return cprev < 0 || C.panels[(size_t) cprev].retired;   // the slot's write-back is on its way
         });
       }
       if (H.io_error.load()) { fail = BOF_EIO; break; }
-      const int64_t q = dC == 0 ? tk.j : tk.i;
-      const int sidx = (int) (((int64_t) pn[2] * Nq + q) % ss->n);   // chain -> stream: FIFO = parent dependency
+      // chain -> stream: FIFO = the parent dependency of src/blas/gemm.cpp:122-127
+      const int sidx = (int) ((kmeans ? (int64_t) L.pc * Nq + L.q0 : (int64_t) L.pc) % ss->n);
       hipStream_t st = ss->s[sidx];
-      for (int x = 0; x < 3 && herr == hipSuccess; x++) {
-        int &w = waited[(size_t) x * (size_t) ss->n + (size_t) sidx];
-        if (w == pn[x]) continue;
-        w = pn[x];
-        if (x < 2 || c_read) herr = hipStreamWaitEvent(st, mat[x].panels[(size_t) pn[x]].ready, 0);
-        else if (cprev >= 0)
-          for (hipEvent_t e : C.panels[(size_t) cprev].retire_ev)
-            if (herr == hipSuccess) herr = hipStreamWaitEvent(st, e, 0);
+      for (int x = 0; x < 2 && herr == hipSuccess; x++)
+        for (int64_t pp = p0[x]; pp < p1[x] && herr == hipSuccess; pp++) {
+          char &w = waited[(size_t) x * (size_t) ss->n + (size_t) sidx][(size_t) pp];
+          if (w) continue;
+          w = 1;
+          herr = hipStreamWaitEvent(st, mat[x].panels[(size_t) pp].ready, 0);
+        }
+      if (herr == hipSuccess && (reads_c || (writes_c && !c_read))) {
+        char &w = waited[(size_t) 2 * (size_t) ss->n + (size_t) sidx][(size_t) L.pc];
+        if (!w) {
+          w = 1;
+          if (reads_c) herr = hipStreamWaitEvent(st, C.panels[(size_t) L.pc].ready, 0);
+          else if (cprev >= 0)
+            for (hipEvent_t e : C.panels[(size_t) cprev].retire_ev)
+              if (herr == hipSuccess) herr = hipStreamWaitEvent(st, e, 0);
+        }
       }
       if (herr != hipSuccess) break;
-      // operand tile: pointer into the panel + the file's leading dimension, or -- with a k-major
-      // copy -- into the copy ([k][panel rows]: the tile starts at row k0 of it), the flag flipped
+      // operands: pointer into the image (a resident operand: the whole matrix; else the panel) + the file's leading
+      // dimension, or -- with a k-major copy -- into the copy ([k][rows]), the flag flipped
       const float *po[2];
       int64_t ldo[2];
       char flag[2] = {ta, tb};
       for (int x = 0; x < 2; x++) {
         const Mat &M = mat[x];
-        const int64_t k0 = M.col_base + idx[M.cdim] * M.blk_c;   // first stored column of the tile
+        const int64_t R0 = start_of(L, M.rdim);
+        const int64_t C0 = start_of(L, M.cdim) + (M.cdim == dC ? M.col_base : 0);
+        const int pp = (int) p0[x];
+        const int64_t rb = M.whole ? 0 : M.panels[(size_t) pp].r0;      // rows count from the image's first row
         if (M.kmajor_copy) {
-          const int64_t nr = M.panels[(size_t) pn[x]].nr;
-          po[x] = (const float *) M.tpanel_ptr(pn[x]) + k0 * nr;
-          ldo[x] = nr;
+          const float *T = (const float *) (M.whole ? *M.twhole_ptr : M.tpanel_ptr(pp));
+          po[x] = T + C0 * M.t_ld(pp) + (R0 - rb);
+          ldo[x] = M.t_ld(pp);
           flag[x] = flag[x] == 'N' ? 'T' : 'N';
         } else {
-          po[x] = (const float *) M.panel_ptr(pn[x]) + k0;
+          const float *B = (const float *) (M.whole ? *M.whole_ptr : M.panel_ptr(pp));
+          po[x] = B + (R0 - rb) * M.ld + C0;
           ldo[x] = M.ld;
         }
       }
-      float *pcp = (float *) C.panel_ptr(pn[2]) + idx[C.cdim] * C.blk_c;
+      int64_t ext[3];
+      ext[dC] = C.panels[(size_t) L.pc].nr;
+      ext[1] = last ? g.size[1] - L.l0 * g.blk[1] : (L.l1 - L.l0) * g.blk[1];
+      ext[qdim] = L.q1 == Nq ? g.size[qdim] - L.q0 * g.blk[qdim] : (L.q1 - L.q0) * g.blk[qdim];
+      float *pcp = (float *) C.panel_ptr(L.pc) + L.q0 * C.blk_c;
+      // what the launch is, in the terms of its kernel entry point
+      const bool chain_step = !ref_chain && !(first && last);   // one k-range of a chain that carries raw sums
+      float *accp = chain_step && need_acc ? (float *) res->acc[(size_t) (L.pc - gb[0])] + L.q0 * C.blk_c : pcp;
+      SpotArgs sa{ord, flag[0], flag[1], ext[0], ext[2], ext[1], alpha, po[0], ldo[0], po[1], ldo[1],
+                  ref_chain ? (first ? beta : 1.0f) : beta, chain_step && !last ? accp : pcp, C.ld};
+      if (chain_step) {
+        if (!first) { sa.ch.acc_in = accp; sa.ch.ld_acc = C.ld; }
+        sa.ch.raw_out = !last;
+      }
+      const int64_t ti = dC == 0 ? L.pc : L.q0, tj = dC == 0 ? L.q0 : L.pc;
+      if (has_kv) {
+        sa.u1 = kv.c_l2sq + row_base + ti * g.blk[0]; sa.v1 = kv.ones;
+        sa.u2 = kv.ones; sa.v2 = kv.p_l2sq + col_base + tj * g.blk[2];
+      }
+      sa.seed = ((uint64_t) L.pc << 40) ^ ((uint64_t) L.l0 << 20) ^ (uint64_t) L.q0 ^ ((uint64_t) di << 56);
+      evt("launch", L.pc, (int) (L.l0 * 1024 + L.l1), (uint64_t) (((uint64_t) di << 24) | ((uint64_t) sidx << 16) | (uint64_t) L.q0));
+      Verify::Spot spot;
+      // the rectangle of C (or of the raw accumulator panel) the launch stores into; the same one it starts from
+      const int64_t c_rows = C.panels[(size_t) L.pc].nr, c_cols = ext[qdim];
+      if (vf.on) {
+        // CONSUMER-side sums, on the compute stream in front of the launch: every operand panel it reads (and the
+        // panel's k-major copy), the C panel its beta applies to, the raw sums it continues -- against what the
+        // producers summed when they handed the objects over (flash_common.h, "Round 5")
+        for (int x = 0; x < 2 && herr == hipSuccess; x++)
+          for (int64_t pp = p0[x]; pp < p1[x] && herr == hipSuccess; pp++) {
+            const Mat &M = mat[x];
+            const Panel &P = M.panels[(size_t) pp];
+            if (P.ve[Panel::VE_DEV_IN] == Verify::kNone) continue;
+            const size_t e1 = vf.entry();
+            vf.expect(P.ve[Panel::VE_DEV_IN], e1, "panel: HBM after H2D vs on the COMPUTE stream in front of a launch (mat, panel, C panel)",
+                      x, (int) pp, L.pc);
+            herr = vf.on_device(e1, M.panel_ptr((int) pp), 1, (int64_t) (P.bytes / 4), 0, 0, 0, st);
+            if (herr == hipSuccess && M.kmajor_copy && P.ve[Panel::VE_T_IN] != Verify::kNone) {
+              const size_t e2 = vf.entry();
+              vf.expect(P.ve[Panel::VE_T_IN], e2, "panel: k-major copy when made vs on the COMPUTE stream in front of a launch (mat, panel, C panel)",
+                        x, (int) pp, L.pc);
+              herr = vf.on_device(e2, M.tpanel_ptr((int) pp), M.cols, P.nr, M.t_ld((int) pp), 0, M.cols, st);
+            }
+          }
+        if (herr == hipSuccess && reads_c && C.panels[(size_t) L.pc].ve[Panel::VE_DEV_IN] != Verify::kNone) {
+          const size_t e1 = vf.entry();
+          vf.expect(C.panels[(size_t) L.pc].ve[Panel::VE_DEV_IN], e1, "C panel: HBM after H2D vs on the COMPUTE stream in front of the launch that reads it (panel, device)",
+                    L.pc, di);
+          herr = vf.on_device(e1, C.panel_ptr(L.pc), 1, (int64_t) (C.panels[(size_t) L.pc].bytes / 4), 0, 0, 0, st);
+        }
+        const auto key = std::make_pair(L.pc, L.q0);
+        if (herr == hipSuccess && !first) {       // the chain's partial result as the launch before left it
+          auto it = chain_post.find(key);
+          if (it != chain_post.end()) {
+            const size_t e1 = vf.entry();
+            vf.expect(it->second, e1, "chain: partial result behind a launch vs in front of the next launch of the chain (C panel, first k-block, first tile)",
+                      L.pc, (int) L.l0, (int) L.q0);
+            herr = vf.on_device(e1, accp, c_rows, c_cols, C.ld, 0, 0, st);
+          }
+        }
+        // a launch that starts its rectangle from nothing: poison it first (a first k-range that did not store shows)
+        if (herr == hipSuccess && first && !reads_c && (chain_step || !c_read))
+          herr = launch_from_persistent(dev, [&] {
+            return hipMemset2DAsync(chain_step && !last ? (void *) accp : (void *) pcp, (size_t) C.ld * 4, 0xFF, (size_t) c_cols * 4, (size_t) c_rows, st);
+          });
+        if (herr == hipSuccess)
+          herr = vf.spot_before(sa, st, &spot, "launch: 64 sampled outputs recomputed vs stored (C panel, l0 * 1024 + l1, first tile)", L.pc,
+                                (int) (L.l0 * 1024 + L.l1), (int) L.q0);
+        if (herr != hipSuccess) break;
+      }
       herr = ktimer.begin(st);
       if (herr != hipSuccess) break;
-      herr = tile_sgemm(ord, flag[0], flag[1], tk.M, tk.N, tk.K, alpha, po[0], ldo[0], po[1], ldo[1], tk.beta, pcp, C.ld,
-                        has_kv ? &kv : nullptr, row_base + tk.i * g.blk[0], col_base + tk.j * g.blk[2], st);
+      // self-test of the instrumentation ($BOF_VERIFY_INJECT=3): the second launch of the call is dropped
+      if (vf.on && t == 1 && env_long("BOF_VERIFY_INJECT", 0) == 3) {
+      } else
+      if (ref_chain)
+        herr = tile_sgemm(ord, flag[0], flag[1], ext[0], ext[2], ext[1], alpha, po[0], ldo[0], po[1], ldo[1], sa.beta, pcp, C.ld,
+                          has_kv ? &kv : nullptr, row_base + ti * g.blk[0], col_base + tj * g.blk[2], st);
+      else if (!chain_step)
+        herr = sgemm(ord, flag[0], flag[1], ext[0], ext[2], ext[1], alpha, po[0], ldo[0], po[1], ldo[1], beta, pcp, C.ld, st);
+      else   // one k-range of the chain: raw sums in, raw sums out; the caller's alpha and beta at the end
+        herr = sgemm_chain(ord, flag[0], flag[1], ext[0], ext[2], ext[1], alpha, po[0], ldo[0], po[1], ldo[1], beta, sa.c, C.ld, sa.ch, st);
       if (herr == hipSuccess) herr = ktimer.end(st);
+      if (herr == hipSuccess && vf.on) {
+        herr = vf.spot_after(sa, spot, st);
+        if (herr == hipSuccess && !last) {        // what the next launch of the chain must find
+          const size_t e1 = vf.entry();
+          chain_post[std::make_pair(L.pc, L.q0)] = e1;
+          herr = vf.on_device(e1, sa.c, c_rows, c_cols, C.ld, 0, 0, st);
+        }
+      }
       if (herr != hipSuccess) break;
-      cnt.tasks++;
-      H.cnt.tasks++;
+      const uint64_t n_tasks = (uint64_t) ((L.q1 - L.q0) * (L.l1 - L.l0));     // in the reference's tile tasks
+      cnt.tasks += n_tasks;
+      H.cnt.tasks += n_tasks;
     }
     if (fail || herr != hipSuccess) break;
     // group finished on the host side: mark where every stream stands, hand its C panels to the
@@ -1117,6 +1396,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     R.hub = &H; R.di = d; R.dev = used[(size_t) d]; R.o = o;
     R.ktimer.on = o.kernel_timing > 0;
     R.ord = ord; R.ta = ta; R.tb = tb; R.alpha = alpha; R.beta = beta;
+    R.kmeans = kh != nullptr;
     // the slab as a problem of its own: rows [p0 * blk, (p0 + cnt) * blk) of the C panel dimension
     // (the last slab runs to the end: a tail-merged last panel stays merged), explicit leading dims
     const int64_t e0 = p0 * gfull.blk[dC];

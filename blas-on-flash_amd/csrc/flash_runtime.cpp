@@ -97,8 +97,12 @@ namespace {
 
 constexpr int kMaxStreams = 16;
 
+// (bof_options.gemm_chain, default) One chain over the whole K: the C tile's slot carries the chain's RAW accumulators
+// from task to task (gemm_f32_mfma.hip, ChainEpi) and the last task scales.  With beta != 0 the caller's C is then an
+// operand of the LAST task only: it is fetched as a tile of its own kind (mat 3, "C-in": the file region of the C
+// tile, read-only, one use) into any free slot shortly before that task, instead of at the chain's start.
 struct Tile {
-  int mat = 0;                       // 0 A, 1 B, 2 C
+  int mat = 0;                       // 0 A, 1 B, 2 C, 3 C-in (the caller's C, read by the chain's last task)
   int64_t off = 0, nrows = 0, ncols = 0, ld = 0;  // file region in elements
   std::vector<int> uses;             // task positions (execution order) touching this tile
   size_t next_use = 0;               // index into uses of the first not-yet-launched use
@@ -185,9 +189,9 @@ struct WriteReq { int wslot; uint64_t file_off, stride, nrows, len; int64_t r0; 
 // ---- pipeline and by bof_flash_gemm_simulate (so the policy is testable without a GPU)
 static size_t tile_bytes_of(const Tile &t) { return (size_t) t.nrows * t.ncols * sizeof(float); }
 
-static void build_tiles(const GemmGeometry &g, float beta, std::vector<Tile> &tiles, size_t &max_tile) {
+static void build_tiles(const GemmGeometry &g, float beta, bool cin, std::vector<Tile> &tiles, size_t &max_tile) {
   const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
-  tiles.assign((size_t) (Nm * Nk + Nk * Nn + Nm * Nn), Tile());
+  tiles.assign((size_t) (Nm * Nk + Nk * Nn + Nm * Nn * (cin ? 2 : 1)), Tile());
   max_tile = 0;
   bof_gemm_task t;
   for (int64_t l = 0; l < Nk; l++)
@@ -204,13 +208,21 @@ static void build_tiles(const GemmGeometry &g, float beta, std::vector<Tile> &ti
           T.rb = (int) idx[g.rdim[x]]; T.cb = (int) idx[g.cdim[x]];
           max_tile = std::max(max_tile, tile_bytes_of(T));
         }
+        if (cin && l == 0) {          // the same file region once more, as the last task's read-only operand
+          Tile &T = tiles[(size_t) (ids[2] + Nm * Nn)];
+          T = tiles[(size_t) ids[2]];
+          T.mat = 3;
+        }
       }
 }
+// with C-in tiles a chain reads the caller's C at its END: beta != 0, several k-blocks, one chain over the whole K
+static bool cin_wanted(const GemmGeometry &g, float beta, bool ref_chain) { return !ref_chain && beta != 0.0f && g.nblk[1] > 1; }
 
 // C super-blocks of gi x gj accumulate chains sized so that the block's C tiles plus two
 // generations of its A/B panels fit the slot budget; inside a block tasks go l-major so all
 // its chains advance together.  With everything resident this is the reference's order.
-static void build_order(const GemmGeometry &g, float beta, int64_t n_slots, std::vector<Tile> &tiles,
+// task_tiles: 4 per task -- A, B, C tile ids, then the C-in tile of a chain's last task (or -1)
+static void build_order(const GemmGeometry &g, float beta, bool cin, int64_t n_slots, std::vector<Tile> &tiles,
                         std::vector<bof_gemm_task> &tasks, std::vector<int> &task_tiles,
                         int64_t &gi, int64_t &gj) {
   const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
@@ -241,11 +253,12 @@ static void build_order(const GemmGeometry &g, float beta, int64_t n_slots, std:
           gemm_task_at(g, l, i, j, beta, &t);
           const int pos = (int) tasks.size();
           tasks.push_back(t);
-          const int ids[3] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
-                              (int) (Nm * Nk + Nk * Nn + i * Nn + j)};
-          for (int x = 0; x < 3; x++) {
+          const int ids[4] = {(int) (i * Nk + l), (int) (Nm * Nk + l * Nn + j),
+                              (int) (Nm * Nk + Nk * Nn + i * Nn + j),
+                              cin && l == Nk - 1 ? (int) (Nm * Nk + Nk * Nn + Nm * Nn + i * Nn + j) : -1};
+          for (int x = 0; x < 4; x++) {
             task_tiles.push_back(ids[x]);
-            tiles[ids[x]].uses.push_back(pos);
+            if (ids[x] >= 0) tiles[ids[x]].uses.push_back(pos);
           }
         }
       }
@@ -285,12 +298,13 @@ static int claim_slot(std::vector<Tile> &tiles, std::vector<int> &slot_tile, std
 static int tile_at(const GemmGeometry &g, int mat, int rb, int cb) {
   const int64_t Nm = g.nblk[0], Nk = g.nblk[1], Nn = g.nblk[2];
   int64_t idx[3] = {0, 0, 0};
-  if (rb < 0 || cb < 0 || rb >= g.nblk[g.rdim[mat]] || cb >= g.nblk[g.cdim[mat]]) return -1;
-  idx[g.rdim[mat]] = rb;
-  idx[g.cdim[mat]] = cb;
+  const int gm = mat == 3 ? 2 : mat;       // a C-in tile lies where its C tile lies
+  if (rb < 0 || cb < 0 || rb >= g.nblk[g.rdim[gm]] || cb >= g.nblk[g.cdim[gm]]) return -1;
+  idx[g.rdim[gm]] = rb;
+  idx[g.cdim[gm]] = cb;
   if (mat == 0) return (int) (idx[0] * Nk + idx[1]);
   if (mat == 1) return (int) (Nm * Nk + idx[1] * Nn + idx[2]);
-  return (int) (Nm * Nk + Nk * Nn + idx[0] * Nn + idx[2]);
+  return (int) (Nm * Nk + Nk * Nn + (mat == 3 ? Nm * Nn : 0) + idx[0] * Nn + idx[2]);
 }
 
 // The row group fetched together with tile `tid`: its absent, still-needed neighbours in the same block
@@ -346,10 +360,12 @@ struct GemmRun {
   GemmGeometry g;
   char ord, ta, tb;
   float alpha, beta;
+  bool ref_chain = false;                    // the reference's per-block rounding (bof_options.gemm_chain = 1, kmeans, alpha == 0)
+  bool cin = false;                          // C-in tiles: the caller's C is an operand of every chain's last task
   bof_fptr f[3];
   std::vector<Tile> tiles;
   std::vector<bof_gemm_task> tasks;          // execution order
-  std::vector<int> task_tiles;               // 3 per task: A, B, C tile ids
+  std::vector<int> task_tiles;               // 4 per task: A, B, C tile ids, the last task's C-in tile or -1
   std::vector<DevSlot> slots;
   std::vector<int> slot_tile;                // tile id per device slot (-1 = empty)
   std::vector<int> free_slots;
@@ -397,9 +413,10 @@ struct GemmRun {
       const int ps = res->rring.acquire();
       const uint64_t row_bytes = (uint64_t) G.width * 4, bytes = row_bytes * (uint64_t) rq.nr;
       int rc = 0;
+      const int fm = G.mat == 3 ? 2 : G.mat;       // a C-in tile is read from the C file
       if (!io_error.load())
-        rc = file_sread(fd_io[G.mat], f[G.mat].foffset + ((uint64_t) t0.off + (uint64_t) rq.r0 * (uint64_t) t0.ld) * 4,
-                        (uint64_t) t0.ld * 4, (uint64_t) rq.nr, row_bytes, res->rring.ptr(ps), aio_io[G.mat]);
+        rc = file_sread(fd_io[fm], f[fm].foffset + ((uint64_t) t0.off + (uint64_t) rq.r0 * (uint64_t) t0.ld) * 4,
+                        (uint64_t) t0.ld * 4, (uint64_t) rq.nr, row_bytes, res->rring.ptr(ps), aio_io[fm]);
       if (rc) fail_io(rc);
       cnt.rd += bytes;
       hipError_t e = hipSuccess;
@@ -421,6 +438,8 @@ struct GemmRun {
           if (!G.prev_done[q]) {
             G.prev_done[q] = 1;
             if (e == hipSuccess) e = verify_old_tile(G.prev_ve_in[q], s.ptr, G.prev_rows[q], G.prev_cols[q], h2d, G.tiles[q]);
+            // ... and the slot is poisoned (NaN) before the first byte of the new tile: a read ahead of the fill shows
+            if (e == hipSuccess) e = vf.poison(s.ptr, tile_bytes(t), h2d);
           }
         }
         if (e == hipSuccess && !rc)
@@ -489,7 +508,7 @@ struct GemmRun {
     DevSlot &s = slots[sl];
     // BOF_VERIFY: what the slot held (an A / B tile whose image must still be what its H2D copy delivered)
     tiles[tid].prev_ve_in = Verify::kNone;
-    if (vf.on && s.tile >= 0 && tiles[s.tile].mat < 2) {
+    if (vf.on && s.tile >= 0 && tiles[s.tile].mat != 2) {
       tiles[tid].prev_ve_in = tiles[s.tile].ve_in;
       tiles[tid].prev_rows = tiles[s.tile].nrows;
       tiles[tid].prev_cols = tiles[s.tile].ncols;
@@ -741,13 +760,15 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
 
   // ---- tiles ------------------------------------------------------------------------
   size_t max_tile = 0;
-  build_tiles(g, beta, R.tiles, max_tile);
+  R.ref_chain = kh != nullptr || R.o.gemm_chain == 1 || alpha == 0.0f;
+  R.cin = cin_wanted(g, beta, R.ref_chain);
+  build_tiles(g, beta, R.cin, R.tiles, max_tile);
   R.slot_bytes = round_up(max_tile, 4096);
   for (int x = 0; x < 3; x++) {
     const uint64_t A = file_is_direct(R.f[x].fd) ? file_dio_align(R.f[x].fd) : 512;
     bool aligned = (R.f[x].foffset % A) == 0;
     for (const Tile &t : R.tiles)
-      if (t.mat == x)
+      if ((t.mat == 3 ? 2 : t.mat) == x)
         aligned = aligned && ((uint64_t) t.off * 4) % A == 0 && ((uint64_t) t.ncols * 4) % A == 0 &&
                   (t.nrows <= 1 || ((uint64_t) t.ld * 4) % A == 0);
     R.fd_io[x] = R.f[x].fd;
@@ -772,15 +793,15 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   size_t budget = R.o.hbm_budget > 0 ? (size_t) R.o.hbm_budget : (size_t) (free_b * 0.8);
   budget = std::min(budget, (size_t) (free_b * 0.95));
   int64_t n_slots = (int64_t) (budget / R.slot_bytes);
-  // six slots (two tasks' worth) or, for problems of fewer tiles than that, all of them
-  if (n_slots < std::min<int64_t>(6, (int64_t) R.tiles.size())) {
+  // six slots (two tasks' worth; eight with C-in tiles) or, for problems of fewer tiles than that, all of them
+  if (n_slots < std::min<int64_t>(R.cin ? 8 : 6, (int64_t) R.tiles.size())) {
     set_error("bof_flash_gemm: HBM budget below 6 tile slots");
     return BOF_ENOMEM;
   }
   if (check_only) return BOF_OK;
   n_slots = std::min<int64_t>(n_slots, (int64_t) R.tiles.size());
   int64_t gi, gj;
-  build_order(g, beta, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
+  build_order(g, beta, R.cin, n_slots, R.tiles, R.tasks, R.task_tiles, gi, gj);
   // everything resident: read ahead freely; else at most two k steps of the current C block
   // (with B resident beside a row block of C -- build_order's second branch -- the A tiles of the block's
   //  rows are all used within the block: the whole block is within reach)
@@ -837,7 +858,8 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   R.h2d = R.res->h2d;
   R.d2h = R.res->d2h;
   if (verify_wanted(R.o)) {
-    rc = R.vf.init(R.dev, 16 * R.tiles.size() + 65536);
+    // (per task: consumer-side sums of its tiles, the chain's partial sums behind it and in front of the next; a spot check)
+    rc = R.vf.init(R.dev, 16 * R.tiles.size() + 65536 + 10 * R.tasks.size(), R.tasks.size());
     if (rc) return rc;
   }
   R.ss = stream_set(R.o.n_streams);
@@ -879,21 +901,25 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
   ktimer.on = o.kernel_timing > 0;
   const char *where = "bof_flash_gemm dispatch";   // which step of the loop a HIP error came from
   int fail = 0;
+  std::map<int, size_t> chain_post;      // BOF_VERIFY: C tile -> sum behind the last task of its chain so far
   for (int t = 0; t < T && !fail; t++) {
     {
       std::lock_guard<std::mutex> lk(R.mu);
       while (fetch_pos < T && fetch_pos <= t + lookahead) {
         const bof_gemm_task &ft = R.tasks[fetch_pos];
-        const int *ids = &R.task_tiles[(size_t) fetch_pos * 3];
+        const int *ids = &R.task_tiles[(size_t) fetch_pos * 4];
         bool ok = R.make_resident(ids[0], fetch_pos, true) &&
                   R.make_resident(ids[1], fetch_pos, true);
         if (ok) {
           Tile &C = R.tiles[ids[2]];
           if (C.slot < 0) {
-            ok = R.make_resident(ids[2], fetch_pos, ft.beta != 0.0f);
+            // the C tile is READ at the chain's start only when its slot is where beta is applied from: the
+            // reference's chain, or a chain of one task; with C-in tiles its slot just carries the raw sums
+            ok = R.make_resident(ids[2], fetch_pos, ft.beta != 0.0f && !R.cin);
             if (ok) C.pinned_c = true;
           }
         }
+        if (ok && ids[3] >= 0) ok = R.make_resident(ids[3], fetch_pos, true);     // the caller's C, for the chain's last task
         if (!ok) break;
         fetch_pos++;
       }
@@ -911,7 +937,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       break;
     }
     const bof_gemm_task &tk = R.tasks[t];
-    const int *ids = &R.task_tiles[(size_t) t * 3];
+    const int *ids = &R.task_tiles[(size_t) t * 4];
     if (trace_enabled() && (t == 0 || tk.l != R.tasks[t - 1].l)) {
       char lbl[64];
       snprintf(lbl, sizeof(lbl), "task %d (l=%d) next", t, (int) tk.l);
@@ -921,16 +947,17 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       std::unique_lock<std::mutex> lk(R.mu);
       R.cv.wait(lk, [&] {
         return R.io_error.load() || (R.tiles[ids[0]].state == 2 && R.tiles[ids[1]].state == 2 &&
-                                     R.tiles[ids[2]].state == 2);
+                                     R.tiles[ids[2]].state == 2 && (ids[3] < 0 || R.tiles[ids[3]].state == 2));
       });
     }
     if (R.io_error.load()) { fail = BOF_EIO; break; }
     const int sidx = (int) ((tk.i * Nn + tk.j) % R.ss->n);
     hipStream_t st = R.ss->s[sidx];
-    for (int x = 0; x < 3 && herr == hipSuccess; x++) {
+    for (int x = 0; x < 4 && herr == hipSuccess; x++) {
+      if (ids[x] < 0) continue;
       Tile &tl = R.tiles[ids[x]];
       DevSlot &s = R.slots[tl.slot];
-      if (x < 2 || (tk.l == 0 && tk.beta != 0.0f)) herr = hipStreamWaitEvent(st, s.ready, 0);
+      if (x != 2 || (tk.l == 0 && tk.beta != 0.0f && !R.cin)) herr = hipStreamWaitEvent(st, s.ready, 0);
       for (hipEvent_t w : tl.launch_waits)
         if (herr == hipSuccess) herr = hipStreamWaitEvent(st, w, 0);
       tl.launch_waits.clear();
@@ -947,28 +974,89 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
     if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (timing event)"; break; }
     static const long dbg_sync_each = env_long("BOF_DBG_KM_SYNC_EACH", 0);
     if (dbg_sync_each && kv) (void) hipDeviceSynchronize();
-    herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
-                      (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], kv,
-                      tk.i * g.blk[0], tk.j * g.blk[2], st);
+    DevSlot *sin = ids[3] >= 0 ? &R.slots[R.tiles[ids[3]].slot] : nullptr;
+    // the reference's task (kmeans; gemm_chain = 1; alpha == 0) or a chain of one: scaled into the C tile's slot; else
+    // one k-block of ONE chain over the whole K: the C tile's slot carries the raw sums, the last task scales them and
+    // adds beta times the caller's C (its C-in tile)
+    const bool chain_step = !(R.ref_chain || Nk == 1);
+    SpotArgs spa{ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0], (const float *) sb.ptr, tk.ncols[1],
+                 chain_step ? beta : tk.beta, (float *) sc.ptr, tk.ncols[2]};
+    if (chain_step) {
+      if (tk.l > 0) { spa.ch.acc_in = (const float *) sc.ptr; spa.ch.ld_acc = tk.ncols[2]; }
+      spa.ch.raw_out = tk.l < Nk - 1;
+      if (sin) { spa.ch.c_in = (const float *) sin->ptr; spa.ch.ld_cin = tk.ncols[2]; }
+    }
+    if (kv) {
+      spa.u1 = kv->c_l2sq + tk.i * g.blk[0]; spa.v1 = kv->ones;
+      spa.u2 = kv->ones; spa.v2 = kv->p_l2sq + tk.j * g.blk[2];
+    }
+    spa.seed = ((uint64_t) t << 20) ^ (uint64_t) R.dev;
+    Verify::Spot spot;
+    const bool c_fetched = tk.l == 0 && tk.beta != 0.0f && !R.cin;     // the C slot holds the caller's C (read from the file)
+    if (R.vf.on) {
+      // CONSUMER-side sums on the compute stream in front of the launch (flash_common.h, "Round 5")
+      DevSlot *opnd[4] = {&sa, &sb, c_fetched ? &sc : nullptr, sin};
+      for (int x = 0; x < 4 && herr == hipSuccess; x++) {
+        if (!opnd[x] || ids[x] < 0) continue;
+        const Tile &tl = R.tiles[ids[x]];
+        if (tl.ve_in == Verify::kNone) continue;
+        const size_t e1 = R.vf.entry();
+        R.vf.expect(tl.ve_in, e1, "tile: packed slot after H2D vs on the COMPUTE stream in front of a task (tile id, task)", ids[x], t);
+        herr = R.vf.on_device(e1, opnd[x]->ptr, tl.nrows, tl.ncols, tl.ncols, 0, 0, st);
+      }
+      if (herr == hipSuccess && tk.l > 0) {
+        auto it = chain_post.find(ids[2]);
+        if (it != chain_post.end()) {
+          const size_t e1 = R.vf.entry();
+          R.vf.expect(it->second, e1, "chain: C tile behind a task vs in front of the next task of its chain (tile id, task)", ids[2], t);
+          herr = R.vf.on_device(e1, sc.ptr, tk.nrows[2], tk.ncols[2], tk.ncols[2], 0, 0, st);
+        }
+      }
+      if (herr == hipSuccess && tk.l == 0 && !c_fetched)      // a chain that starts from nothing: poison its slot first
+        herr = R.vf.poison(sc.ptr, (size_t) tk.nrows[2] * (size_t) tk.ncols[2] * 4, st);
+      if (herr == hipSuccess)
+        herr = R.vf.spot_before(spa, st, &spot, "task: 64 sampled outputs recomputed vs stored (task, l, C tile id)", t, (int) tk.l, ids[2]);
+      if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (BOF_VERIFY in front of the launch)"; break; }
+    }
+    // self-test of the instrumentation ($BOF_VERIFY_INJECT=3): the second task of the call is dropped
+    if (R.vf.on && t == 1 && env_long("BOF_VERIFY_INJECT", 0) == 3) {
+    } else
+    if (!chain_step)
+      herr = tile_sgemm(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0],
+                        (const float *) sb.ptr, tk.ncols[1], tk.beta, (float *) sc.ptr, tk.ncols[2], kv,
+                        tk.i * g.blk[0], tk.j * g.blk[2], st);
+    else
+      herr = sgemm_chain(ord, ta, tb, tk.M, tk.N, tk.K, alpha, (const float *) sa.ptr, tk.ncols[0], (const float *) sb.ptr,
+                         tk.ncols[1], beta, (float *) sc.ptr, tk.ncols[2], spa.ch, st);
     if (herr == hipSuccess) herr = ktimer.end(st);
+    if (herr == hipSuccess && R.vf.on) {
+      herr = R.vf.spot_after(spa, spot, st);
+      if (herr == hipSuccess && tk.l < Nk - 1) {
+        const size_t e1 = R.vf.entry();
+        chain_post[ids[2]] = e1;
+        herr = R.vf.on_device(e1, sc.ptr, tk.nrows[2], tk.ncols[2], tk.ncols[2], 0, 0, st);
+      }
+    }
     if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (tile kernel launch)"; break; }
     R.cnt.tasks++;
-    DevSlot *used[3] = {&sa, &sb, &sc};
-    for (int x = 0; x < 3 && herr == hipSuccess; x++) {
+    DevSlot *used[4] = {&sa, &sb, &sc, sin};
+    for (int x = 0; x < 4 && herr == hipSuccess; x++) {
+      if (!used[x]) continue;
       herr = hipEventRecord(used[x]->use[sidx], st);
       used[x]->used[sidx] = true;
     }
     if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (hipEventRecord)"; break; }
     {
       std::lock_guard<std::mutex> lk(R.mu);
-      for (int x = 0; x < 3; x++) R.tiles[ids[x]].next_use++;
+      for (int x = 0; x < 4; x++)
+        if (ids[x] >= 0) R.tiles[ids[x]].next_use++;
     }
     if (tk.l == Nk - 1) {  // chain finished: the C tile joins its row group; written back, it becomes evictable
       herr = R.finish_c_tile(ids[2], sidx);
       if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (C tile hand-over)"; break; }
       // the last chain of this block row in the current super-block: nothing more will join
       const bool row_done = t + 1 >= T || R.tasks[t + 1].l != Nk - 1 ||
-                            R.tiles[R.task_tiles[(size_t) (t + 1) * 3 + 2]].rb != R.tiles[ids[2]].rb;
+                            R.tiles[R.task_tiles[(size_t) (t + 1) * 4 + 2]].rb != R.tiles[ids[2]].rb;
       if (row_done) herr = R.flush_wgroup();
       if (herr != hipSuccess) { where = "bof_flash_gemm dispatch (row-group write-back)"; break; }
     }
@@ -1226,10 +1314,11 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
   std::vector<bof_gemm_task> tasks;
   std::vector<int> task_tiles;
   size_t max_tile = 0;
-  build_tiles(g, beta, tiles, max_tile);
+  const bool cin = cin_wanted(g, beta, false);      // the default arithmetic (bof_options.gemm_chain = 0)
+  build_tiles(g, beta, cin, tiles, max_tile);
   n_slots = std::min<int64_t>(n_slots, (int64_t) tiles.size());
   int64_t gi, gj;
-  build_order(g, beta, n_slots, tiles, tasks, task_tiles, gi, gj);
+  build_order(g, beta, cin, n_slots, tiles, tasks, task_tiles, gi, gj);
   const int64_t group_reach = group_reach_of(g, n_slots, (int64_t) tiles.size(), gi, gj);
   std::vector<int> slot_tile((size_t) n_slots, -1), free_slots;
   for (int64_t s = 0; s < n_slots; s++) free_slots.push_back((int) (n_slots - 1 - s));
@@ -1266,18 +1355,20 @@ int bof_flash_gemm_simulate(char ord, char ta, char tb, uint64_t m, uint64_t n, 
   };
   for (int t = 0; t < T; t++) {
     while (fetch_pos < T && fetch_pos <= t + std::max(lookahead, 0)) {
-      const int *ids = &task_tiles[(size_t) fetch_pos * 3];
+      const int *ids = &task_tiles[(size_t) fetch_pos * 4];
       bool ok = resident(ids[0], fetch_pos, true) && resident(ids[1], fetch_pos, true);
       if (ok && tiles[ids[2]].slot < 0) {
-        ok = resident(ids[2], fetch_pos, tasks[fetch_pos].beta != 0.0f);
+        ok = resident(ids[2], fetch_pos, tasks[fetch_pos].beta != 0.0f && !cin);
         if (ok) tiles[ids[2]].pinned_c = true;
       }
+      if (ok && ids[3] >= 0) ok = resident(ids[3], fetch_pos, true);
       if (!ok) break;
       fetch_pos++;
     }
     if (fetch_pos <= t) { set_error("simulate: tile budget too small"); return BOF_ENOMEM; }
-    const int *ids = &task_tiles[(size_t) t * 3];
-    for (int x = 0; x < 3; x++) tiles[ids[x]].next_use++;
+    const int *ids = &task_tiles[(size_t) t * 4];
+    for (int x = 0; x < 4; x++)
+      if (ids[x] >= 0) tiles[ids[x]].next_use++;
     out->tasks++;
     if (tasks[t].l == g.nblk[1] - 1) {
       out->bytes_written += tile_bytes_of(tiles[ids[2]]);

@@ -177,12 +177,16 @@ void launch_wait(const std::shared_ptr<LaunchJob> &job) {
 }
 
 // ---- BOF_VERIFY table (flash_common.h) ---------------------------------------------------------------------
-int Verify::init(int device, size_t capacity) {
+int Verify::init(int device, size_t capacity, size_t spots) {
   release();
   dev = device;
   DeviceScope scope(dev);
+  capacity += 2 * spots;
   BOF_HIP_TRY(hipMalloc((void **) &d_tab, capacity * 2 * sizeof(unsigned long long)));
   BOF_HIP_TRY(hipMemset(d_tab, 0, capacity * 2 * sizeof(unsigned long long)));
+  if (spots) BOF_HIP_TRY(hipMalloc((void **) &d_spot, spots * 128 * sizeof(float)));
+  spot_cap = spots;
+  spot_next.store(0);
   // hipMemset of device memory runs on the null stream and may return before it has executed; the pipelines' streams
   // are non-blocking (not ordered behind the null stream), so without this the zeroing could land AFTER the first sums
   // (seen with eight processes sharing the GPU: device-side sums of the first panels read back as zero)
@@ -198,11 +202,14 @@ int Verify::init(int device, size_t capacity) {
   return BOF_OK;
 }
 void Verify::release() {
-  if (d_tab) {
+  if (d_tab || d_spot) {
     DeviceScope scope(dev);
-    (void) hipFree(d_tab);
+    if (d_tab) (void) hipFree(d_tab);
+    if (d_spot) (void) hipFree(d_spot);
   }
   d_tab = nullptr;
+  d_spot = nullptr;
+  spot_cap = 0;
   on = false;
   cap = 0;
 }

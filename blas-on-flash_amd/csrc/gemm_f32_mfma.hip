@@ -40,16 +40,41 @@ enum { XMAJOR = 0, KMAJOR = 1 };
 //   c = c + round(u1[row]*v1[col]);  c = c + round(u2[row]*v2[col])
 // (row, col: element of the row-major C this launch produces), so the fused tile equals the
 // three-call sequence bit for bit while C crosses HBM once instead of five times.
+//
+// ChainEpi: one k-range of an ACCUMULATE CHAIN (flash::gemm's k-blocks, src/blas/gemm.cpp:122-127: task (l, i, j) runs
+// behind (l-1, i, j) and adds to the same C tile).  The reference rounds once per block (C = alpha*A_l*B_l + 1*C);
+// here the chain carries the RAW accumulators from launch to launch instead -- the fp32 partial sums leave the
+// registers unscaled (raw_out), the next k-range starts from them (acc_in) and only the last launch applies
+//   c = beta == 0 ? alpha*acc : fmaf(alpha, acc, beta*c_in)
+// -- so a chain cut at ANY k positions produces exactly the bits of ONE launch over the whole K (fp32 values
+// survive the round trip through HBM unchanged, and an MFMA accumulator started from a value continues the same
+// k-ordered fmaf chain): the result of flash::gemm no longer depends on the tile size, the HBM budget or the
+// schedule, and equals what drivers/in_mem_gemm.cpp:63-70 computes with one call.
 struct NoEpi {
   static constexpr bool active = false;
+  static constexpr bool chain = false;
 };
 struct Rank1x2 {
   static constexpr bool active = true;
+  static constexpr bool chain = false;
   const float *u1, *v1, *u2, *v2;
   __host__ __device__ Rank1x2 shifted(int64_t dr, int64_t dc) const { return Rank1x2{u1 + dr, v1 + dc, u2 + dr, v2 + dc}; }
 };
+struct ChainEpi {
+  static constexpr bool active = false;
+  static constexpr bool chain = true;
+  const float *acc_in;   // raw partial sums of the k-ranges before this one, laid out like C with ld_acc; nullptr: start at 0
+  int64_t ld_acc;
+  const float *c_in;     // final store: the matrix the caller's beta applies to, laid out like C with ld_cin; nullptr: C itself
+  int64_t ld_cin;
+  int raw_out;           // 1: store the accumulators unscaled (the chain goes on); 0: final store
+  __host__ __device__ ChainEpi shifted(int64_t dr, int64_t dc) const {
+    return ChainEpi{acc_in ? acc_in + dr * ld_acc + dc : nullptr, ld_acc, c_in ? c_in + dr * ld_cin + dc : nullptr, ld_cin, raw_out};
+  }
+};
 inline NoEpi epi_shift(const NoEpi &e, int64_t, int64_t) { return e; }
 inline Rank1x2 epi_shift(const Rank1x2 &e, int64_t dr, int64_t dc) { return e.shifted(dr, dc); }
+inline ChainEpi epi_shift(const ChainEpi &e, int64_t dr, int64_t dc) { return e.shifted(dr, dc); }
 
 // ---- global -> registers ---------------------------------------------------
 // One K-slab of one operand of extent BX is BX*8 float4; thread t owns float4
@@ -175,12 +200,29 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
   const int wm = wave / WN, wn = wave % WN;
 
   f32x16 acc[MT][NT];
+  bool acc_from_mem = false;
+  if constexpr (EP::chain) acc_from_mem = ep.acc_in != nullptr;
+  if (!acc_from_mem) {
 #pragma unroll
-  for (int a = 0; a < MT; a++)
+    for (int a = 0; a < MT; a++)
 #pragma unroll
-    for (int b = 0; b < NT; b++)
+      for (int b = 0; b < NT; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  } else if constexpr (EP::chain) {   // the chain's partial sums so far (same element map as the store below)
+    const float *atile = ep.acc_in + (int64_t) m0 * ep.ld_acc + n0;
+    const int a_lane = (wm * WTM + 4 * h) * (int) ep.ld_acc + wn * WTN + i;
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int b = 0; b < NT; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int dr = a * 32 + (r & 3) + 8 * (r >> 2), dc = b * 32;
+          const bool ok = !GUARD || (m0 + wm * WTM + 4 * h + dr < M && n0 + wn * WTN + i + dc < N);
+          acc[a][b][r] = ok ? (atile + ((int64_t) dr * ep.ld_acc + dc))[a_lane] : 0.f;
+        }
+  }
 
   const int nkt = (K + BK - 1) / BK;
   auto ra = g2r<AMODE, BM, NTHR, GUARD>(A, lda, m0, 0, M, K, t);
@@ -240,6 +282,19 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
   float *ctile = C + (int64_t) m0 * ldc + n0;
   const int lrow = wm * WTM + 4 * h, lcol = wn * WTN + i;
   const int lane_off = lrow * (int) ldc + lcol;
+  // ChainEpi: the final store may take the caller's C from another matrix; a raw store takes none
+  const float *itile = ctile;
+  int64_t ldi = ldc;
+  int lane_in = lane_off;
+  bool raw = false;
+  if constexpr (EP::chain) {
+    raw = ep.raw_out != 0;
+    if (ep.c_in) {
+      itile = ep.c_in + (int64_t) m0 * ep.ld_cin + n0;
+      ldi = ep.ld_cin;
+      lane_in = lrow * (int) ep.ld_cin + lcol;
+    }
+  }
   // Rank1x2: this lane's column factors once, the 16 row factors of an accumulator row block once
   // per mt (fetched per element they doubled the instruction count of the store loop, and the
   // stores to C keep the compiler from hoisting them)
@@ -268,12 +323,12 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       f32x16 old;
-      if (beta != 0.f) {
+      if (beta != 0.f && !raw) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int dr = mt * 32 + (r & 3) + 8 * (r >> 2), dc = nt * 32;
-          const float *src = ctile + ((int64_t) dr * ldc + dc);
-          old[r] = (!GUARD || (m0 + lrow + dr < M && n0 + lcol + dc < N)) ? src[lane_off] : 0.f;
+          const float *src = itile + ((int64_t) dr * ldi + dc);
+          old[r] = (!GUARD || (m0 + lrow + dr < M && n0 + lcol + dc < N)) ? src[lane_in] : 0.f;
         }
       }
 #pragma unroll
@@ -281,7 +336,8 @@ sgemm_tile_kernel(const float *__restrict__ A, int64_t lda, const float *__restr
         const int dr = mt * 32 + (r & 3) + 8 * (r >> 2), dc = nt * 32;
         float *dst = ctile + ((int64_t) dr * ldc + dc);
         if (!GUARD || (m0 + lrow + dr < M && n0 + lcol + dc < N)) {
-          float t = (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+          float t = raw ? acc[mt][nt][r]
+                        : (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
           if constexpr (EP::active) {
             t = __fadd_rn(t, __fmul_rn(u1r[r], v1c[nt]));
             t = __fadd_rn(t, __fmul_rn(u2r[r], v2c[nt]));
@@ -302,6 +358,19 @@ __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64
                                                     float beta, const EP &ep) {
   float *ctile = C + (int64_t) m0 * ldc + n0;
   const int lane_off = (wm * 128 + 4 * h) * (int) ldc + wn * 128 + i;
+  // ChainEpi: the final store may take the caller's C from another matrix; a raw store takes none
+  const float *itile = ctile;
+  int64_t ldi = ldc;
+  int lane_in = lane_off;
+  bool raw = false;
+  if constexpr (EP::chain) {
+    raw = ep.raw_out != 0;
+    if (ep.c_in) {
+      itile = ep.c_in + (int64_t) m0 * ep.ld_cin + n0;
+      ldi = ep.ld_cin;
+      lane_in = (wm * 128 + 4 * h) * (int) ep.ld_cin + wn * 128 + i;
+    }
+  }
   float v1c[4], v2c[4];
   if constexpr (EP::active) {
 #pragma unroll
@@ -323,15 +392,16 @@ __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) {
       f32x16 old;
-      if (beta != 0.f) {
+      if (beta != 0.f && !raw) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
-          old[r] = (ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32))[lane_off];
+          old[r] = (itile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldi + nt * 32))[lane_in];
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         float *dst = ctile + ((int64_t) (mt * 32 + (r & 3) + 8 * (r >> 2)) * ldc + nt * 32);
-        float t = (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
+        float t = raw ? acc[mt][nt][r]
+                      : (beta == 0.f) ? alpha * acc[mt][nt][r] : __builtin_fmaf(alpha, acc[mt][nt][r], beta * old[r]);
         if constexpr (EP::active) {
           t = __fadd_rn(t, __fmul_rn(u1r[r], v1c[nt]));
           t = __fadd_rn(t, __fmul_rn(u2r[r], v2c[nt]));
@@ -339,6 +409,35 @@ __device__ __forceinline__ void store_wave_tile_128(float *__restrict__ C, int64
         dst[lane_off] = t;
       }
     }
+  }
+}
+
+// The accumulators of a wave's 128 x 128 tile at the start of a launch: zero, or -- ChainEpi with acc_in -- the
+// chain's raw partial sums, fetched with the element map of the store above.
+template <class EP>
+__device__ __forceinline__ void init_wave_tile_128(f32x16 (&acc)[4][4], const EP &ep, int m0, int n0, int wm, int wn,
+                                                   int h, int i) {
+  bool from_mem = false;
+  if constexpr (EP::chain) from_mem = ep.acc_in != nullptr;
+  if (!from_mem) {
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+    return;
+  }
+  if constexpr (EP::chain) {
+    const float *atile = ep.acc_in + (int64_t) m0 * ep.ld_acc + n0;
+    const int lane_off = (wm * 128 + 4 * h) * (int) ep.ld_acc + wn * 128 + i;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          acc[a][b][r] = (atile + ((int64_t) (a * 32 + (r & 3) + 8 * (r >> 2)) * ep.ld_acc + b * 32))[lane_off];
   }
 }
 
@@ -511,12 +610,7 @@ sgemm_tile256_1w2_kernel(const float *__restrict__ A, int64_t lda, const float *
   b1.a_wr = lds + a_wr;            b1.b_wr = lds + b_wr;
 
   f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  init_wave_tile_128(acc, ep, m0, n0, wm, wn, h, i);
 
   // caller guarantees at least two full slabs before a partial one (K >= 64; K >= 96 if K % 32);
   // KTAIL instantiation <=> K % 32 != 0: its last slab is fetched with guarded loads
@@ -706,12 +800,6 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
   const uint64_t a_slab = a_step4 * 8, b_slab = b_step4 * 8;                     // 32 k-rows
 
   f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   const int nkt = K / BK;
 #pragma unroll
@@ -719,6 +807,7 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
     dma16(a_goff, a_org + (uint64_t) p * a_step4, a_dst0 + p * 4096);
     dma16(b_goff, b_org + (uint64_t) p * b_step4, b_dst0 + p * 4096);
   }
+  init_wave_tile_128(acc, ep, m0, n0, wm, wn, h, i);   // (a chain's partial sums arrive under the first slab's DMA)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x4 fa[2][4], fb[2][4];
@@ -914,12 +1003,7 @@ sgemm_tile256_1w3_kernel(const float *__restrict__ A, int64_t lda, const float *
   const uint64_t b_slab = (BMODE == XMAJOR) ? 128 : (uint64_t) ldb * 128;
 
   f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+  init_wave_tile_128(acc, ep, m0, n0, wm, wn, h, i);
 
   const int nkt = K / BK;   // even, >= 2 (launch_modes)
   f32x4 ra[8], rb[8];
@@ -1208,7 +1292,7 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   // one-wave-per-SIMD kernel (BOF_GEMM_PERSIST=0: off)
   // (BOF_GEMM_PERSIST_MIN_TILES lowers the tile count for tests)
   const bool persist_on = knob("BOF_GEMM_PERSIST", 1) != 0;
-  if (persist_on && vec_ld && K % (2 * BK) == 0 && K >= 4 * BK && K < short_k && M % 256 == 0 && N % 256 == 0 &&
+  if (!EP::chain && persist_on && vec_ld && K % (2 * BK) == 0 && K >= 4 * BK && K < short_k && M % 256 == 0 && N % 256 == 0 &&
       (int64_t) (M / 256) * (N / 256) >= knob("BOF_GEMM_PERSIST_MIN_TILES", 1024) && lda < (1 << 22) && ldb < (1 << 22)) {
     // one workgroup per CU; BOF_GEMM_PERSIST_WGS (a multiple of 8) makes the runs longer on small test problems
     const int wgs = std::max(8, knob("BOF_GEMM_PERSIST_WGS", 256) / 8 * 8);
@@ -1235,7 +1319,14 @@ static hipError_t sgemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, c
   // NaN / Inf in A or B must not reach C -- 0 * NaN would.  The guarded kernel over zero k-slabs with
   // alpha = 0 computes exactly that (acc = 0; c = beta == 0 ? 0 : beta*c) without touching A or B.
   // MKL's behaviour is pinned by tests/golden/mkl_golden_special.npz.
-  if (alpha == 0.f || K == 0) {
+  // An accumulate chain (ChainEpi): the quick return belongs to the FINAL launch, which then also ignores the partial
+  // sums (they may hold the 0 * NaN the rule exists to keep out); a raw launch just accumulates.
+  bool quick = alpha == 0.f || K == 0;
+  if constexpr (EP::chain) {
+    if (ep.raw_out) quick = false;
+    else if (alpha == 0.f) ep.acc_in = nullptr;
+  }
+  if (quick) {
     K = 0;
     alpha = 0.f;
   }
@@ -1275,6 +1366,19 @@ hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, fl
                   ldc, st, NoEpi{});
 }
 
+// One k-range of an accumulate chain (ChainEpi above; GemmChain in bof_internal.h).  acc_in / c_in are stored like C
+// (same order, their own leading dimensions), so the column-major swap applies to them unchanged.
+hipError_t sgemm_chain(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a,
+                       int64_t lda, const float *b, int64_t ldb, float beta, float *c, int64_t ldc, const GemmChain &ch,
+                       hipStream_t st) {
+  drop_stale_error();
+  if (m == 0 || n == 0) return hipSuccess;
+  const ChainEpi ep{ch.acc_in, ch.ld_acc, ch.c_in, ch.ld_cin, ch.raw_out ? 1 : 0};
+  if (ord == 'C')
+    return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta, c, ldc, st, ep);
+  return sgemm_rm(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c, ldc, st, ep);
+}
+
 // KMeansTask::execute on one tile (reference include/tasks/kmeans_task.h:53-82):
 //   C = alpha*op(A)*op(B) + beta*C;  C[r][c] += u1[r]*v1[c];  C[r][c] += u2[r]*v2[c]
 // with r along m and c along n whatever the storage order (the reference passes
@@ -1291,6 +1395,105 @@ hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64
                     c, ldc, st, Rank1x2{v1, u1, v2, u2});
   return sgemm_rm(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c,
                   ldc, st, Rank1x2{u1, v1, u2, v2});
+}
+
+// ---- BOF_VERIFY: spot check of one launch ---------------------------------------------------------------------------
+// 64 output elements of a launch (the corners + pseudo-random positions drawn from `seed`) are recomputed by one wave,
+// element by element, in the kernels' own arithmetic -- the k-ordered fmaf chain from 0 or from the chain's raw sums,
+// then the launch's store rule -- from the operands as they stand behind the launch, and compared bit for bit with what
+// the launch stored.  What it sees and the hand-over sums cannot: a launch that ran with another launch's arguments,
+// ran too early (operands that landed later no longer reproduce what it stored), ran twice, or not at all.  The values
+// the launch overwrites (raw sums it started from, the C its beta applies to) are captured in front of it.
+// Both results go to the verify table as word sums (plain, and weighted by the sample index).
+struct SpotView {
+  const float *A, *B;
+  int64_t lda, ldb;
+  int ta, tb;             // row-major core terms: a(r,k) = ta ? A[k*lda + r] : A[r*lda + k]; b(k,c) = tb ? B[c*ldb + k] : B[k*ldb + c]
+  int M, N, K;
+  float alpha, beta;
+  float *C;
+  int64_t ldc;
+  const float *acc_in, *c_in;
+  int64_t ld_acc, ld_cin;
+  int raw_out;
+  const float *u1, *v1, *u2, *v2;   // Rank1x2 (nullptr: none), indexed by the row-major core's row / column
+  uint64_t seed;
+};
+__device__ __forceinline__ void spot_position(const SpotView &v, int t, int *r, int *c) {
+  uint64_t h = v.seed * 0x9E3779B97F4A7C15ull + (uint64_t) (t + 1) * 0xD1B54A32D192ED03ull;
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  *r = (int) ((h & 0xFFFFFFFFu) % (uint32_t) v.M);
+  *c = (int) ((h >> 32) % (uint32_t) v.N);
+  if (t == 0) { *r = 0; *c = 0; }
+  if (t == 1) { *r = v.M - 1; *c = v.N - 1; }
+  if (t == 2) { *r = 0; *c = v.N - 1; }
+  if (t == 3) { *r = v.M - 1; *c = 0; }
+}
+__global__ void __launch_bounds__(64) spot_capture_kernel(SpotView v, float *save) {
+  int r, c;
+  spot_position(v, (int) threadIdx.x, &r, &c);
+  save[threadIdx.x] = v.acc_in ? v.acc_in[(int64_t) r * v.ld_acc + c] : 0.f;
+  const float *ci = v.c_in ? v.c_in + (int64_t) r * v.ld_cin + c : v.C + (int64_t) r * v.ldc + c;
+  save[64 + threadIdx.x] = (v.beta != 0.f && !v.raw_out) ? *ci : 0.f;
+}
+__global__ void __launch_bounds__(64) spot_check_kernel(SpotView v, const float *save, unsigned long long *exp2,
+                                                        unsigned long long *got2) {
+  const int t = (int) threadIdx.x;
+  int r, c;
+  spot_position(v, t, &r, &c);
+  float acc = v.acc_in ? save[t] : 0.f;
+  const bool quick = !v.raw_out && v.alpha == 0.f;      // cblas_sgemm's quick return: A, B and the sums are not looked at
+  if (quick) acc = 0.f;
+  else
+    for (int k = 0; k < v.K; k++) {
+      const float a = v.ta ? v.A[(int64_t) k * v.lda + r] : v.A[(int64_t) r * v.lda + k];
+      const float b = v.tb ? v.B[(int64_t) c * v.ldb + k] : v.B[(int64_t) k * v.ldb + c];
+      acc = __builtin_fmaf(a, b, acc);
+    }
+  float want = v.raw_out ? acc : (v.beta == 0.f ? v.alpha * acc : __builtin_fmaf(v.alpha, acc, v.beta * save[64 + t]));
+  if (v.u1) {
+    want = __fadd_rn(want, __fmul_rn(v.u1[r], v.v1[c]));
+    want = __fadd_rn(want, __fmul_rn(v.u2[r], v.v2[c]));
+  }
+  const float got = v.C[(int64_t) r * v.ldc + c];
+  unsigned long long we = __float_as_uint(want), wg = __float_as_uint(got);
+  unsigned long long e1 = we, e2 = we * (unsigned long long) (t + 1), g1 = wg, g2 = wg * (unsigned long long) (t + 1);
+  for (int off = 32; off > 0; off >>= 1) {
+    e1 += __shfl_down(e1, off, 64); e2 += __shfl_down(e2, off, 64);
+    g1 += __shfl_down(g1, off, 64); g2 += __shfl_down(g2, off, 64);
+  }
+  if (t == 0) {
+    atomicAdd(&exp2[0], e1); atomicAdd(&exp2[1], e2);
+    atomicAdd(&got2[0], g1); atomicAdd(&got2[1], g2);
+  }
+}
+static SpotView spot_view(const SpotArgs &s) {
+  SpotView v{};
+  const bool cm = s.ord == 'C';
+  // column-major: C^T = op(B)^T * op(A)^T, the row-major core sees the operands swapped (as sgemm does)
+  v.A = cm ? s.b : s.a; v.lda = cm ? s.ldb : s.lda; v.ta = cm ? s.tb == 'T' : s.ta == 'T';
+  v.B = cm ? s.a : s.b; v.ldb = cm ? s.lda : s.ldb; v.tb = cm ? s.ta == 'T' : s.tb == 'T';
+  v.M = (int) (cm ? s.n : s.m); v.N = (int) (cm ? s.m : s.n); v.K = (int) s.k;
+  v.alpha = s.alpha; v.beta = s.beta; v.C = s.c; v.ldc = s.ldc;
+  v.acc_in = s.ch.acc_in; v.ld_acc = s.ch.ld_acc; v.c_in = s.ch.c_in; v.ld_cin = s.ch.ld_cin; v.raw_out = s.ch.raw_out ? 1 : 0;
+  if (s.u1) {   // (u by C row, v by C column in the caller's terms; swapped with the operands)
+    v.u1 = cm ? s.v1 : s.u1; v.v1 = cm ? s.u1 : s.v1; v.u2 = cm ? s.v2 : s.u2; v.v2 = cm ? s.u2 : s.v2;
+  }
+  v.seed = s.seed;
+  return v;
+}
+hipError_t sgemm_spot_capture(const SpotArgs &s, float *save128, hipStream_t st) {
+  drop_stale_error();
+  if (s.m <= 0 || s.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(spot_capture_kernel, dim3(1), dim3(64), 0, st, spot_view(s), save128);
+  return hipGetLastError();
+}
+hipError_t sgemm_spot_check(const SpotArgs &s, const float *save128, unsigned long long *exp2, unsigned long long *got2,
+                            hipStream_t st) {
+  drop_stale_error();
+  if (s.m <= 0 || s.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(spot_check_kernel, dim3(1), dim3(64), 0, st, spot_view(s), save128, exp2, got2);
+  return hipGetLastError();
 }
 
 }  // namespace bof

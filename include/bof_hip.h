@@ -55,7 +55,7 @@ extern "C" {
 #define BOF_ENOMEM (-5)
 #define BOF_EVERIFY (-6) /* bof_options.verify: a hand-over checksum did not match (bof_last_error names it) */
 
-#define BOF_ABI_VERSION 4
+#define BOF_ABI_VERSION 5
 
 /* ---- library ---------------------------------------------------------------- */
 int bof_abi_version(void);
@@ -134,7 +134,20 @@ typedef struct {
                              PCIe to ONE device only and passed on device to device
                              (hipMemcpyPeerAsync over xGMI); 0 = $BOF_PEER_BCAST, else off; 1 on;
                              2 off                                                                */
-  int32_t reserved_[5];   /* must be zero */
+  /* ---- ABI v5 ---------------------------------------------------------------- */
+  int32_t gemm_chain;     /* how the k-blocks of a C tile are combined by flash::gemm (levels 2 and 3):
+                             0 / 2 (default): ONE k-ordered fmaf chain per output element over the whole K, scaled once
+                                at the end -- c = beta == 0 ? alpha*acc : fmaf(alpha, acc, beta*c) -- however the tiler,
+                                the HBM budget or the schedule cut K: k-ranges that run as separate launches hand their
+                                raw fp32 accumulators on, and a C panel whose operands are complete runs as a single
+                                launch over the whole K.  The result equals bof_sgemm on the whole matrices bit for
+                                bit, i.e. what drivers/in_mem_gemm.cpp:63-70 computes with its one cblas_sgemm call.
+                             1: the reference's task arithmetic, one rounding per k-block: C = alpha*A_l*B_l + C for
+                                l > 0 (src/blas/gemm.cpp:122-127, include/tasks/gemm_task.h:87-90) -- bit-identical to
+                                the tile-by-tile oracle (oracle/bof_oracle.c: orc_flash_gemm).
+                             flash::kmeans always runs its tasks the reference's way (every k-block's task adds the
+                             rank-1 terms).  The two differ by rounding only (~1e-7 relative; the bar is 1e-4).      */
+  int32_t reserved_[4];   /* must be zero */
 } bof_options;
 #define BOF_MAX_DEVICES 16
 void bof_default_options(bof_options *o);

@@ -263,6 +263,24 @@ void orc_flash_gemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
   free(tasks);
 }
 
+/* drivers/in_mem_gemm.cpp:63-70: the whole product as ONE cblas_sgemm call on the in-memory images of the three
+ * files (leading dimension 0 = the stored width, the flash API's default: include/flash_blas.h:14-18).  Per output
+ * element one k-ordered fmaf chain over the WHOLE K -- no rounding at the tiler's k-block boundaries, which is where
+ * it differs (by ~1e-7 relative) from orc_flash_gemm's chain of per-tile calls.  The north-star bar is stated
+ * against this driver ("outputs match drivers/in_mem_gemm"), and the product's default arithmetic
+ * (bof_options.gemm_chain = 0) reproduces it bit for bit whatever the tile size. */
+void orc_in_mem_gemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                     float alpha, float beta, const float *a, const float *b,
+                     float *c, int64_t lda, int64_t ldb, int64_t ldc) {
+  const int colmajor = ord == 'C';
+  /* stored width of A, B, C (src/blas/gemm.cpp:39-60: a matrix stored as the transpose of its logical shape
+   * swaps its dimensions) */
+  if (!lda) lda = ((ta == 'T') != colmajor) ? m : k;
+  if (!ldb) ldb = ((tb == 'T') != colmajor) ? k : n;
+  if (!ldc) ldc = colmajor ? m : n;
+  orc_sgemm(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}
+
 /* KMeansTask::execute (include/tasks/kmeans_task.h:53-82): the tile product, then two K = 1
  * products with alpha = beta = 1:
  *   mkl_gemm(ord, NoTrans, Trans, a_nrows, b_ncols, 1, 1.0, c_l2sq, a_nrows, ones, b_ncols, 1.0, C, ldc)

@@ -85,6 +85,10 @@ void orc_flash_gemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
                     float alpha, float beta, const float *a, const float *b,
                     float *c, int64_t lda, int64_t ldb, int64_t ldc,
                     int64_t blk);
+/* drivers/in_mem_gemm.cpp:63-70 restated: ONE sgemm over the whole matrices (ld 0 = stored width). */
+void orc_in_mem_gemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,
+                     float alpha, float beta, const float *a, const float *b,
+                     float *c, int64_t lda, int64_t ldb, int64_t ldc);
 /* KMeansTask::execute (include/tasks/kmeans_task.h:53-82) and flash::kmeans
  * (src/blas/kmeans.cpp:27-198); see the notes in bof_oracle.c about row-major. */
 void orc_skmeans_task(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k,

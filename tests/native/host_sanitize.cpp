@@ -29,6 +29,12 @@ bof_options resolved(const bof_options *o) { return o ? *o : bof_options{}; }
 size_t csrcsc_workspace_bytes(int64_t, int64_t) { return 0; }
 hipError_t sgemm(char, char, char, int64_t, int64_t, int64_t, float, const float *, int64_t, const float *,
                  int64_t, float, float *, int64_t, hipStream_t) { return hipErrorUnknown; }
+hipError_t sgemm_spot_capture(const SpotArgs &, float *, hipStream_t) { return hipErrorUnknown; }
+hipError_t sgemm_spot_check(const SpotArgs &, const float *, unsigned long long *, unsigned long long *, hipStream_t) {
+  return hipErrorUnknown;
+}
+hipError_t sgemm_chain(char, char, char, int64_t, int64_t, int64_t, float, const float *, int64_t, const float *,
+                       int64_t, float, float *, int64_t, const GemmChain &, hipStream_t) { return hipErrorUnknown; }
 hipError_t sgemm_rank1x2(char, char, char, int64_t, int64_t, int64_t, float, const float *, int64_t, const float *,
                          int64_t, float, float *, int64_t, const float *, const float *, const float *, const float *,
                          hipStream_t) { return hipErrorUnknown; }

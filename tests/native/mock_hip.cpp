@@ -543,6 +543,16 @@ hipError_t hipMemset(void *dst, int v, size_t bytes) {      // synchronous: BOF_
   memset(dst, v, bytes);
   return hipSuccess;
 }
+hipError_t hipMemset2DAsync(void *dst, size_t pitch, int v, size_t width, size_t height, hipStream_t s) {
+  if (inject_api(6)) return fail(hipErrorUnknown);
+  MockStream *st = S(s, "hipMemset2DAsync");
+  if (!width || !height) return hipSuccess;
+  need_device_mem(dst, (height - 1) * pitch + width, st->dev, "hipMemset2DAsync");
+  st->enqueue([dst, pitch, v, width, height] {
+    for (size_t r = 0; r < height; r++) memset((char *) dst + r * pitch, v, width);
+  });
+  return hipSuccess;
+}
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s) {
   if (inject_api(6)) return fail(hipErrorUnknown);
   MockStream *st = S(s, "hipMemsetAsync");
@@ -561,7 +571,7 @@ namespace bof {
 
 static hipError_t gemm_any(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a, int64_t lda,
                            const float *b, int64_t ldb, float beta, float *c, int64_t ldc, const float *u1, const float *v1,
-                           const float *u2, const float *v2, hipStream_t st, const char *who) {
+                           const float *u2, const float *v2, hipStream_t st, const char *who, GemmChain ch = GemmChain()) {
   MockStream *ms = kernel_stream(st, who);
   if (m <= 0 || n <= 0) return hipSuccess;
   const int dev = ms->dev;
@@ -580,13 +590,18 @@ static hipError_t gemm_any(char ord, char ta, char tb, int64_t m, int64_t n, int
       need_device_mem(u1, (size_t) m * 4, dev, who); need_device_mem(v1, (size_t) n * 4, dev, who);
       need_device_mem(u2, (size_t) m * 4, dev, who); need_device_mem(v2, (size_t) n * 4, dev, who);
     }
+    if (ch.acc_in) need_device_mem(ch.acc_in, (size_t) ((c_rows - 1) * ch.ld_acc + c_cols) * 4, dev, who);
+    if (ch.c_in) need_device_mem(ch.c_in, (size_t) ((c_rows - 1) * ch.ld_cin + c_cols) * 4, dev, who);
     for (int64_t i = 0; i < m; i++)
       for (int64_t j = 0; j < n; j++) {
-        float acc = 0.f;
+        // (an accumulate chain: the raw sums of the k-ranges before this one come in, and go out unscaled)
+        float acc = ch.acc_in ? (ord == 'R' ? ch.acc_in[i * ch.ld_acc + j] : ch.acc_in[j * ch.ld_acc + i]) : 0.f;
         for (int64_t l = 0; l < k; l++)
           acc = fmaf(a_mk ? a[i * lda + l] : a[l * lda + i], b_kn ? b[l * ldb + j] : b[j * ldb + l], acc);
         float *cp = ord == 'R' ? c + i * ldc + j : c + j * ldc + i;
-        float r = beta == 0.f ? alpha * acc : fmaf(alpha, acc, beta * *cp);
+        if (ch.raw_out) { *cp = acc; continue; }
+        const float cin = ch.c_in ? (ord == 'R' ? ch.c_in[i * ch.ld_cin + j] : ch.c_in[j * ch.ld_cin + i]) : *cp;
+        float r = beta == 0.f ? alpha * acc : fmaf(alpha, acc, beta * cin);
         if (u1) r = fmaf(u2[i], v2[j], fmaf(u1[i], v1[j], r));
         *cp = r;
       }
@@ -597,10 +612,77 @@ hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, fl
                  const float *b, int64_t ldb, float beta, float *c, int64_t ldc, hipStream_t st) {
   return gemm_any(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, nullptr, nullptr, nullptr, nullptr, st, "sgemm");
 }
+hipError_t sgemm_chain(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a, int64_t lda,
+                       const float *b, int64_t ldb, float beta, float *c, int64_t ldc, const GemmChain &ch, hipStream_t st) {
+  GemmChain c2 = ch;
+  if (alpha == 0.f && !ch.raw_out) { c2.acc_in = nullptr; k = 0; }      // the quick return belongs to the final launch
+  return gemm_any(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, nullptr, nullptr, nullptr, nullptr, st, "sgemm_chain", c2);
+}
 hipError_t sgemm_rank1x2(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float *a, int64_t lda,
                          const float *b, int64_t ldb, float beta, float *c, int64_t ldc, const float *u1, const float *v1,
                          const float *u2, const float *v2, hipStream_t st) {
   return gemm_any(ord, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, u1, v1, u2, v2, st, "sgemm_rank1x2");
+}
+// BOF_VERIFY's spot check of a launch (gemm_f32_mfma.hip: spot_capture_kernel / spot_check_kernel), same definition:
+// 64 sampled outputs recomputed in the kernels' arithmetic, word sums of wanted and stored values
+namespace {
+struct SpotPos { int64_t r, c; };
+SpotPos spot_position(uint64_t seed, int t, int64_t M, int64_t N) {
+  uint64_t h = seed * 0x9E3779B97F4A7C15ull + (uint64_t) (t + 1) * 0xD1B54A32D192ED03ull;
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+  SpotPos p{(int64_t) ((h & 0xFFFFFFFFu) % (uint32_t) M), (int64_t) ((h >> 32) % (uint32_t) N)};
+  if (t == 0) p = {0, 0};
+  if (t == 1) p = {M - 1, N - 1};
+  if (t == 2) p = {0, N - 1};
+  if (t == 3) p = {M - 1, 0};
+  return p;
+}
+// element (i along m, j along n) of a matrix stored like C
+inline int64_t c_at(char ord, int64_t i, int64_t j, int64_t ld) { return ord == 'R' ? i * ld + j : j * ld + i; }
+}  // namespace
+hipError_t sgemm_spot_capture(const SpotArgs &s, float *save, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "sgemm_spot_capture");
+  if (s.m <= 0 || s.n <= 0) return hipSuccess;
+  const SpotArgs a = s;
+  ms->enqueue([a, save] {
+    // (positions are drawn in the row-major core's terms: rows of the stored C)
+    const int64_t M = a.ord == 'C' ? a.n : a.m, N = a.ord == 'C' ? a.m : a.n;
+    for (int t = 0; t < 64; t++) {
+      const SpotPos p = spot_position(a.seed, t, M, N);
+      save[t] = a.ch.acc_in ? a.ch.acc_in[p.r * a.ch.ld_acc + p.c] : 0.f;
+      const float *ci = a.ch.c_in ? a.ch.c_in + p.r * a.ch.ld_cin + p.c : a.c + p.r * a.ldc + p.c;
+      save[64 + t] = (a.beta != 0.f && !a.ch.raw_out) ? *ci : 0.f;
+    }
+  });
+  return hipSuccess;
+}
+hipError_t sgemm_spot_check(const SpotArgs &s, const float *save, unsigned long long *exp2, unsigned long long *got2, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "sgemm_spot_check");
+  if (s.m <= 0 || s.n <= 0) return hipSuccess;
+  const SpotArgs a = s;
+  ms->enqueue([a, save, exp2, got2] {
+    const bool cm = a.ord == 'C';
+    const int64_t M = cm ? a.n : a.m, N = cm ? a.m : a.n;
+    const bool a_mk = (a.ta == 'N') == (a.ord == 'R'), b_kn = (a.tb == 'N') == (a.ord == 'R');
+    for (int t = 0; t < 64; t++) {
+      const SpotPos p = spot_position(a.seed, t, M, N);
+      const int64_t i = cm ? p.c : p.r, j = cm ? p.r : p.c;       // along m, along n
+      float acc = a.ch.acc_in ? save[t] : 0.f;
+      if (!a.ch.raw_out && a.alpha == 0.f) acc = 0.f;
+      else
+        for (int64_t l = 0; l < a.k; l++)
+          acc = fmaf(a_mk ? a.a[i * a.lda + l] : a.a[l * a.lda + i], b_kn ? a.b[l * a.ldb + j] : a.b[j * a.ldb + l], acc);
+      float want = a.ch.raw_out ? acc : (a.beta == 0.f ? a.alpha * acc : fmaf(a.alpha, acc, a.beta * save[64 + t]));
+      if (a.u1) want = fmaf(a.u2[i], a.v2[j], fmaf(a.u1[i], a.v1[j], want));      // (as this file's gemm_any adds them)
+      const float got = a.c[p.r * a.ldc + p.c];
+      uint32_t we, wg;
+      memcpy(&we, &want, 4);
+      memcpy(&wg, &got, 4);
+      exp2[0] += we; exp2[1] += (unsigned long long) we * (unsigned long long) (t + 1);
+      got2[0] += wg; got2[1] += (unsigned long long) wg * (unsigned long long) (t + 1);
+    }
+  });
+  return hipSuccess;
 }
 hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t blk, int64_t nblk, hipStream_t st) {
   MockStream *ms = kernel_stream(st, "expand_tile_local");

@@ -49,6 +49,7 @@ def lib():
         L.orc_sgemm.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64]
         L.orc_flash_gemm.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P,
                                      i64, i64, i64, i64]
+        L.orc_in_mem_gemm.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P, i64, i64, i64]
         L.orc_skmeans_task.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, P, i64, P, i64, f32, P, i64,
                                        P, P, P]
         L.orc_flash_kmeans.argtypes = [chr_, chr_, chr_, i64, i64, i64, f32, f32, P, P, P,
@@ -126,10 +127,27 @@ def sgemm(ord_, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
     return c
 
 
-def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, blk):
+def flash_gemm_tiles(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, blk):
+    """The reference's flash::gemm restated task by task (src/blas/gemm.cpp:83-129): per-tile sgemm on packed
+    tiles, accumulate chains with one rounding per k-block.  What the product computes with gemm_chain=1."""
     lib().orc_flash_gemm(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, _p(a), _p(b), _p(c),
                          lda, ldb, ldc, blk)
     return c
+
+
+def in_mem_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda=0, ldb=0, ldc=0):
+    """drivers/in_mem_gemm.cpp:63-70 restated: ONE sgemm over the whole matrices, in place on c."""
+    lib().orc_in_mem_gemm(_c(ord_), _c(ta), _c(tb), m, n, k, alpha, beta, _p(a), _p(b), _p(c), lda, ldb, ldc)
+    return c
+
+
+def flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, blk=0, chain=0):
+    """What the product's flash::gemm must produce bit for bit.  chain = 0 (bof_options.gemm_chain default): one
+    k-ordered chain per element over the whole K, independent of the tile size `blk` -- the in-memory driver's
+    result; chain = 1: the reference's task-by-task arithmetic (needs blk)."""
+    if chain == 1:
+        return flash_gemm_tiles(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc, blk)
+    return in_mem_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c, lda, ldb, ldc)
 
 
 def skmeans_task(ord_, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, c_l2sq, p_l2sq, ones):

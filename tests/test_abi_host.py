@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in bof_hip.h but not exported"
         assert n in bound, f"{n} has no ctypes signature in bofhip.SYMBOLS"
-    assert L.bof_abi_version() == 4
+    assert L.bof_abi_version() == 5
 
 
 def test_header_cites_reference_for_each_level():

@@ -84,6 +84,80 @@ def test_flash_gemm_layouts_unaligned(dev, tmp_path, monkeypatch, ord_, ta, tb, 
         F.close()
 
 
+@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_flash_gemm_reference_chain(dev, tmp_path, ord_, ta, tb, path):
+    """bof_options.gemm_chain = 1: the reference's task arithmetic, one rounding per k-block -- C = alpha*A_l*B_l + C
+    for l > 0 (src/blas/gemm.cpp:122-127, include/tasks/gemm_task.h:87-90) -- bit for bit what the tile-by-tile
+    restatement of flash::gemm computes (oracle/bof_oracle.c: orc_flash_gemm).  640 x 600 x 500 with 128-tiles
+    (chains of 4 with a merged k tail), beta != 0, all 8 layouts, tile cache / row panels / row panels with
+    k-major copies."""
+    m, k, n, blk = 640, 600, 500, 128
+    rng = np.random.default_rng(23)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk, chain=1)
+    whole = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk)
+    assert not np.array_equal(ref, whole)           # the two arithmetics do differ on random data (by rounding) ...
+    assert np.abs(ref - whole).max() / np.abs(whole).max() < 1e-5     # ... and only by rounding
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=3, pinned_slots=4, gemm_path=min(path, 2),
+                                      io_chunk_mib=1, panel_kmajor=3 if path == 3 else 1, gemm_chain=1, verify=1)
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+        st = bofhip.flash_last_stats()
+        assert st["tasks"] == 5 * 4 * 4 and st["bytes_read"] == 4 * (a.size + b.size + c0.size)
+    finally:
+        F.close()
+
+
+@pytest.mark.parametrize("ord_,ta,tb,beta", [("R", "N", "N", 0.0), ("R", "N", "N", 2.0), ("R", "T", "T", 2.0),
+                                             ("C", "N", "T", 0.0), ("C", "T", "N", 2.0)])
+def test_flash_gemm_result_does_not_depend_on_the_cut(dev, tmp_path, ord_, ta, tb, beta):
+    """The default arithmetic (bof_options.gemm_chain = 0): ONE k-ordered chain per output element over the whole K,
+    whatever the tiler, the path, the budget or the device list cut the product into -- k-ranges that run as
+    separate launches hand their raw accumulators on (gemm_f32_mfma.hip, ChainEpi).  So every configuration writes
+    the SAME C file, the one drivers/in_mem_gemm.cpp:63-70 computes with its single cblas_sgemm call: equal to the
+    oracle's in-memory gemm AND to one bof_sgemm over the whole resident matrices, bit for bit."""
+    import torch
+    m, k, n = 1100, 1500, 900
+    rng = np.random.default_rng(29)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.in_mem_gemm(ord_, ta, tb, m, n, k, 0.5, beta, a, b, c0.copy())
+    da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c0))
+    bofhip.sgemm(ord_, ta, tb, m, n, k, 0.5, da.data_ptr(), sa[1], db.data_ptr(), sb[1], beta, dc.data_ptr(), sc[1],
+                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        tile = 256 * 256 * 4
+        for kw in (dict(gemm_blk=128, gemm_path=1), dict(gemm_blk=256, gemm_path=1, hbm_budget=14 * tile),
+                   dict(gemm_blk=512, gemm_path=1), dict(gemm_blk=128, gemm_path=2, panel_group=1),
+                   dict(gemm_blk=256, gemm_path=2, panel_group=3, panel_kmajor=3), dict(gemm_blk=4096, gemm_path=2),
+                   dict(gemm_blk=256, gemm_path=2, devices=[0, 0, 0]), dict(gemm_blk=128, gemm_path=1, devices=[0, 0])):
+            bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              bofhip.default_options(n_io_threads=3, pinned_slots=4, io_chunk_mib=1, verify=1, **kw))
+            assert np.array_equal(F.read("c", np.float32, sc), ref), kw
+            assert bofhip.flash_last_stats()["bytes_read"] == 4 * (a.size + b.size + (c0.size if beta else 0)), kw
+            c0.tofile(F.paths["c"])
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+        # level 2: the tile DAG over resident matrices is the same single chain
+        dc2 = torch.from_numpy(c0).cuda()
+        bofhip.gemm_resident(ord_, ta, tb, m, n, k, 0.5, beta, da.data_ptr(), db.data_ptr(), dc2.data_ptr(), 0, 0, 0,
+                             bofhip.default_options(gemm_blk=256), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(dc2.cpu().numpy(), ref)
+    finally:
+        F.close()
+
+
 @pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
 def test_flash_gemm_mixed_alignment_stress(dev, tmp_path, ord_, ta, tb):
     """Aligned leading dimension (640 floats = 5 sectors) + a tail-merged tile whose width is not a

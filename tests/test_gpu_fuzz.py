@@ -92,6 +92,8 @@ def common_opts(rng, kw):
     dev = pick(rng, [None, None, [0, 0], [0, 0, 0], [0]])
     if dev is not None:
         kw["devices"] = dev
+        if len(dev) > 1:       # the shared operand device to device (row panels; ignored elsewhere)
+            kw["peer_bcast"] = pick(rng, [0, 1, 1, 2])
     for k, v in OVERRIDE.items():
         if v is None:
             kw.pop(k, None)
@@ -153,6 +155,8 @@ def gemm_case(rng, tmp, kmeans=False):
           "panel_streams": pick(rng, [0, 0, 1, 3]), "panel_writers": pick(rng, [0, 0, 1, 3])}
     if int(rng.integers(0, 4)) == 0:     # a budget of a few tiles: the tile cache under pressure / small panel rings
         kw["hbm_budget"] = int(rng.integers(6, 40)) * blk * blk * 4
+    if not kmeans:       # the default arithmetic (one chain over the whole K) or the reference's (one rounding per k-block)
+        kw["gemm_chain"] = pick(rng, [0, 0, 1])
     env = common_opts(rng, kw)
     desc = dict(kind="kmeans" if kmeans else "gemm", ord=ord_, ta=ta, tb=tb, m=m, n=n, k=k, alpha=alpha, beta=beta,
                 lds=lds, heads=heads, opts=kw, env=env)
@@ -164,7 +168,8 @@ def gemm_case(rng, tmp, kmeans=False):
         ones = np.ones(max(m, n), np.float32)
         orc.flash_kmeans(ord_, ta, tb, m, n, k, alpha, beta, mats[0], mats[1], ref, lds[0], lds[1], lds[2], blk, cl, pl, ones)
     else:
-        orc.flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, mats[0], mats[1], ref, lds[0], lds[1], lds[2], blk)
+        orc.flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, mats[0], mats[1], ref, lds[0], lds[1], lds[2], blk,
+                       chain=kw.get("gemm_chain", 0))
     direct = bool(rng.integers(0, 4))
     files = [BinFile(os.path.join(tmp, f"{nm}.bin"), x, rng, head=h, tail=int(pick(rng, [0, 0, 777, 4096])), direct=direct)
              for nm, x, h in zip("abc", mats, heads)]

@@ -65,6 +65,78 @@ def test_flash_gemm_devices_all_layouts(dev, tmp_path, ord_, ta, tb, path, ndev)
         F.close()
 
 
+@pytest.mark.parametrize("ndev", [2, 3])
+@pytest.mark.parametrize("path", [0, 2])
+@pytest.mark.parametrize("ord_,ta,tb", list(itertools.product("RC", "NT", "NT")))
+def test_flash_gemm_peer_bcast(dev, tmp_path, ord_, ta, tb, path, ndev):
+    """SURVEY 8f-4, B-panel broadcast device to device (bof_options.peer_bcast; no analogue in the reference, which
+    reads every shared key once per process: include/tasks/csrmm_task.h:129-235).  A panel every device needs
+    crosses PCIe ONCE, to its home device (panel p -> device p % ndev), and reaches the others from the home's
+    HBM with hipMemcpyPeerAsync behind the home copy's event.  640 x 600 x 500, 128-tiles, beta != 0, all 8
+    layouts, auto path and forced row panels: C bit-equal to the oracle; every shared byte is counted once in
+    bytes_h2d and (ndev - 1) times in bytes_p2p, on the devices that are NOT its home."""
+    m, k, n, blk = 640, 600, 500, 128
+    rng = np.random.default_rng(41)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    ref = orc.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, a, b, c0.copy(), 0, 0, 0, blk)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        opts = bofhip.default_options(gemm_blk=blk, n_streams=3, n_io_threads=3, pinned_slots=4, gemm_path=path,
+                                      io_chunk_mib=1, devices=[0] * ndev, peer_bcast=1, verify=1)
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+        st = bofhip.flash_last_stats()
+        per = bofhip.flash_last_device_stats()
+        assert len(per) == ndev and st["verify_checks"] > 0
+        shared = b.size if ord_ == "R" else a.size        # the operand without the C panel dimension
+        shared += (a.size if ord_ == "R" and ta == "T" else 0) + (b.size if ord_ == "C" and tb == "T" else 0)
+        assert st["bytes_read"] == 4 * (a.size + b.size + c0.size)
+        assert st["bytes_h2d"] == st["bytes_read"]                      # the host feeds every byte once ...
+        assert st["bytes_p2p"] == 4 * shared * (ndev - 1)               # ... the peers get theirs device to device
+        assert sum(p["bytes_p2p"] for p in per) == st["bytes_p2p"] and all(p["bytes_p2p"] > 0 for p in per)
+        # the same call without the broadcast: same bits, no device-to-device byte
+        c0.tofile(F.paths["c"])
+        os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+        opts.peer_bcast = 2
+        bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, 2.0, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0, opts)
+        assert np.array_equal(F.read("c", np.float32, sc), ref)
+        assert bofhip.flash_last_stats()["bytes_p2p"] == 0
+    finally:
+        F.close()
+
+
+def test_flash_gemm_peer_bcast_at_scale(dev, tmp_path):
+    """6144 x 5120 x 4096 with 1024-tiles from O_DIRECT files, three devices, several 4 MiB chunks per shared panel
+    (each chunk: home copy, event, two peer copies): C equals the single-device call bit for bit."""
+    m, n, k, blk = 6144, 5120, 4096, 1024
+    rng = np.random.default_rng(43)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        res = []
+        for devices, bc in ((None, 0), ([0, 0, 0], 1)):
+            kw = dict(gemm_blk=blk, n_io_threads=6, pinned_slots=6, gemm_path=2, io_chunk_mib=4, peer_bcast=bc)
+            if devices:
+                kw["devices"] = devices
+            bofhip.flash_gemm("R", "N", "N", m, n, k, 0.5, 1.5, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              bofhip.default_options(**kw))
+            st = bofhip.flash_last_stats()
+            assert st["bytes_read"] == 4 * (a.size + b.size + c0.size) and st["bytes_written"] == 4 * c0.size
+            if devices:
+                assert st["bytes_p2p"] == 4 * b.size * 2 and st["bytes_h2d"] == st["bytes_read"]
+            res.append(F.read("c", np.float32, (m, n)).copy())
+            c0.tofile(F.paths["c"])
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+        assert np.array_equal(res[0], res[1])
+    finally:
+        F.close()
+
+
 @pytest.mark.parametrize("ord_,ta,tb,beta", [("R", "N", "N", 0.0), ("R", "T", "N", 1.5), ("C", "N", "T", 0.0),
                                              ("C", "T", "T", 1.5)])
 def test_flash_gemm_devices_ring_reuse(dev, tmp_path, ord_, ta, tb, beta):

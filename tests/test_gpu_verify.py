@@ -59,7 +59,8 @@ def test_verify_clean_call_odirect(dev, tmp_path):
 
 
 @pytest.mark.parametrize("path", [1, 2])
-@pytest.mark.parametrize("inject,needle", [(1, "after the file read vs"), (2, "after D2H vs the file after the write")])
+@pytest.mark.parametrize("inject,needle", [(1, "after the file read vs"), (2, "after D2H vs the file after the write"),
+                                           (3, "64 sampled outputs recomputed vs stored")])
 def test_verify_names_a_damaged_word(dev, tmp_path, path, inject, needle, capfd):
     err, st, exact = run(tmp_path, path, 0.0, inject=inject)
     assert err is not None and "BOF_VERIFY mismatch" in err and needle in err, err

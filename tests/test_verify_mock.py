@@ -71,9 +71,10 @@ def test_clean_call_passes_every_hand_over_check(tmp_path, mock_lib, path, budge
 
 
 @pytest.mark.parametrize("path", [1, 2])
-@pytest.mark.parametrize("inject,needle", [(1, "after the file read vs"), (2, "after D2H vs the file after the write")])
+@pytest.mark.parametrize("inject,needle", [(1, "after the file read vs"), (2, "after D2H vs the file after the write"),
+                                           (3, "64 sampled outputs recomputed vs stored")])
 def test_damaged_word_is_caught_and_named(tmp_path, mock_lib, path, inject, needle):
     out, err = run_child(tmp_path, mock_lib, path, 0.0, 0, [0], inject)
-    assert out["rc"] == 1, "a damaged word went unnoticed"
+    assert out["rc"] == 1, "a damaged word / a dropped launch went unnoticed"
     assert "BOF_VERIFY mismatch" in out["err"] and needle in out["err"], out["err"]
     assert "[bof events]" in err            # the event ring came with it
