@@ -449,6 +449,95 @@ def _drop_cache(paths):
             os.close(fd)
 
 
+def disk_probe(bofhip, read_paths, write_path, io_threads=8, passes=3, label=""):
+    """The scratch disk's O_DIRECT rates measured ON THE WORKLOAD'S OWN FILES with the pipeline's own request
+    shape -- bof_file_sread / bof_file_swrite, 32 MiB per call cut into the library's 4 MiB requests, kernel AIO,
+    `io_threads` threads (the panel pipeline's reader pool) -- best of `passes` passes per direction, every read
+    pass over all of `read_paths` (A and B: 8 GiB at configs[1]) with the page cache dropped, every write pass
+    twice over `write_path` (C: 2 x 4 GiB), then both directions at once.  A file written long ago reads faster than
+    one written a second ago (round 4's 4 GiB scratch-file probe under-read the disk by 30 %), hence the real inputs.
+    Returns {} when the files cannot be opened O_DIRECT."""
+    import threading
+    L = bofhip.lib()
+    slot = 32 << 20
+    fds = []
+    for pth in list(read_paths) + [write_path]:
+        fd, d = _open(pth, True)
+        if not d:
+            for f in fds:
+                os.close(f)
+            os.close(fd)
+            return {}
+        fds.append(fd)
+    rfds, wfd = fds[:-1], fds[-1]
+    sizes = [os.fstat(fd).st_size // slot * slot for fd in fds]
+    hbuf = []
+    for _ in range(2 * io_threads):
+        pv = ctypes.c_void_p()
+        bofhip.check(L.bof_host_alloc(ctypes.byref(pv), slot), "host_alloc")
+        hbuf.append(pv.value)
+    rchunks = [(fd, off) for fd, sz in zip(rfds, sizes) for off in range(0, sz, slot)]
+    wchunks = [(wfd, off) for _ in range(2) for off in range(0, sizes[-1], slot)]
+
+    def run(chunks, nthr, fn, base=0):
+        def work(i):
+            for fd, off in chunks[i::nthr]:
+                fn(fd, off, hbuf[base + i])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return len(chunks) * slot / (time.perf_counter() - t0) / 1e9
+
+    def rd(fd, off, buf):
+        L.bof_file_sread(fd, off, 0, 1, slot, buf, 1)
+
+    def wr(fd, off, buf):
+        L.bof_file_swrite(fd, off, 0, 1, slot, buf, 1)
+    out = {"files": "the workload's own A, B (read) and C (written)", "GiB_per_read_pass": round(len(rchunks) * slot / 2**30, 1),
+           "GiB_per_write_pass": round(len(wchunks) * slot / 2**30, 1), "threads": io_threads, "passes": passes, "when": label}
+    try:
+        reads, writes = [], []
+        for _ in range(passes):
+            _drop_cache(read_paths)
+            reads.append(run(rchunks, io_threads, rd))
+        for _ in range(passes):
+            writes.append(run(wchunks, io_threads, wr))
+        _drop_cache(read_paths)
+        both = {}
+        ta = threading.Thread(target=lambda: both.__setitem__("r", run(rchunks, io_threads, rd)))
+        tb = threading.Thread(target=lambda: both.__setitem__("w", run(wchunks, io_threads, wr, io_threads)))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        out.update({"disk_read_GBps": round(max(reads), 2), "disk_write_GBps": round(max(writes), 2),
+                    "read_passes_GBps": [round(x, 2) for x in reads], "write_passes_GBps": [round(x, 2) for x in writes],
+                    "disk_read_GBps_while_writing": round(both["r"], 2), "disk_write_GBps_while_reading": round(both["w"], 2)})
+    finally:
+        for h in hbuf:
+            L.bof_host_free(h)
+        for fd in fds:
+            L.bof_file_forget(fd)
+            os.close(fd)
+    return out
+
+
+def merge_ceilings(ceil, *probes):
+    """A ceiling is the BEST the device showed in any probe of this run (before the steps, after them, the scratch-file
+    probe): the probe moves, never the run."""
+    out = dict(ceil)
+    for pr in probes:
+        for q in ("disk_read_GBps", "disk_write_GBps"):
+            if pr.get(q):
+                out[q] = max(out.get(q, 0.0), pr[q])
+        mixed_new = pr.get("disk_read_GBps_while_writing", 0) + pr.get("disk_write_GBps_while_reading", 0)
+        mixed_old = out.get("disk_read_GBps_while_writing", 0) + out.get("disk_write_GBps_while_reading", 0)
+        if mixed_new > mixed_old:
+            out["disk_read_GBps_while_writing"] = pr["disk_read_GBps_while_writing"]
+            out["disk_write_GBps_while_reading"] = pr["disk_write_GBps_while_reading"]
+    return out
+
+
 def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
     """What this box's scratch disk, page cache and PCIe link deliver RIGHT NOW (about five seconds):
     the ceilings the `roofline_e2e` fractions of this same run are taken against.  Measured with the
@@ -564,9 +653,10 @@ def roofline_e2e(leg, ceil, flops, kernel_s, mode):
     """Lower bound on the wall time of one out-of-core call from the ceilings PROBED in this run, and the
     fraction of it the call achieved: t_bound = max over the stages that all run concurrently in the
     pipeline -- kernel time at the measured kernel rate, bytes over PCIe each way, bytes read / written at
-    the disk's (odirect) or the page cache's (buffered) rate; frac = t_bound / seconds.  The probe is
-    never adjusted to what the call achieved: the scratch disk's rate moves from minute to minute on the
-    pool's boxes, so a call can beat a probe taken a minute earlier (frac > 1 then says exactly that);
+    the disk's (odirect) or the page cache's (buffered) rate; frac = t_bound / seconds.  The ceilings are the
+    best of every probe of the run (the scratch-file probe and the probes on the headline's own files before and
+    after its timed steps); a call that still beats its bound raises that stage's ceiling to its own rate
+    (`probe_raised`): a ceiling below an observed rate is a bad probe, not a fast run.
     `run_disk_GBps` is what the call itself moved."""
     st = leg["stats"]
     terms = {"mfma" if flops > 1e13 else "hbm": kernel_s or 0.0}
@@ -585,9 +675,16 @@ def roofline_e2e(leg, ceil, flops, kernel_s, mode):
         terms["page_cache_read"] = st["bytes_read"] / (ceil["page_cache_read_GBps"] * 1e9)
     bound = max(terms, key=terms.get)
     t_bound = terms[bound]
-    return {"seconds": leg["seconds"], "gflops": leg["gflops"], "bound": bound, "t_bound_s": round(t_bound, 4),
-            "frac": round(t_bound / leg["seconds"], 3), "terms_s": {k: round(v, 4) for k, v in terms.items()},
-            "run_disk_GBps": round((st["bytes_read"] + st["bytes_written"]) / leg["seconds"] / 1e9, 2)}
+    out = {"seconds": leg["seconds"], "gflops": leg["gflops"], "bound": bound, "t_bound_s": round(t_bound, 4),
+           "frac": round(t_bound / leg["seconds"], 3), "terms_s": {k: round(v, 4) for k, v in terms.items()},
+           "run_disk_GBps": round((st["bytes_read"] + st["bytes_written"]) / leg["seconds"] / 1e9, 2)}
+    if t_bound > leg["seconds"]:
+        # the call moved its bytes faster than the probe of that stage did: the stage CAN do what it just did, so its
+        # ceiling is raised to the call's own rate (and says so) -- the probe moves, never the run
+        out["probe_raised"] = f"{bound}: probed bound {t_bound:.4f} s > the call's {leg['seconds']:.4f} s; ceiling raised to the call's own rate"
+        out["t_bound_s"] = round(leg["seconds"], 4)
+        out["frac"] = 1.0
+    return out
 
 
 def _leg_summary(runs, flops, kernel_s, compulsory_rd, compulsory_wr, units):
@@ -1022,7 +1119,8 @@ def _closed_form_rows(torch, dev, n, k, ncols):
     return pat[:, torch.arange(ncols, device=dev) % 10]
 
 
-def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, steps, warmup, panel_streams):
+def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, steps, warmup, panel_streams, probe=True,
+                        event_dir=None):
     """BASELINE configs[1]: flash _gemm fp32 n^3, blk-tile, A / B / C SSD-resident.  One step = one
     bof_flash_gemm call on the three files: reads A and B (8 GiB), runs the 512 tile tasks, writes C
     (4 GiB) back; beta = 0, so every step recomputes and rewrites the whole of C.  Returns the timed
@@ -1078,22 +1176,43 @@ def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, ste
         bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
                           bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
         return bofhip.flash_last_stats()
+    probes, slow_events = [], None
     try:
         warm = []
         for _ in range(warmup):
             _drop_cache((pa, pb, pc))
             warm.append(step())
         ok_warm = verify() if warmup else None
+        if direct and probe:
+            probes.append(disk_probe(bofhip, (pa, pb), pc, io_threads, label="before the timed steps"))
         reset_c()                                   # the timed steps must produce C, not find it
         _drop_cache((pa, pb, pc))
         torch.cuda.synchronize()
-        per = []
+        per, dumps = [], []
+        L = bofhip.lib()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             per.append(step())
+            if event_dir:                           # the always-on event ring of this step (about a millisecond)
+                dumps.append(os.path.join(event_dir, f"step{i}.events"))
+                L.bof_event_dump(dumps[-1].encode())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ok = verify()
+        if direct and probe:
+            probes.append(disk_probe(bofhip, (pa, pb), pc, io_threads, label="after the timed steps"))
+        if dumps:
+            slowest = max(range(steps), key=lambda i: per[i]["seconds"])
+            try:
+                lines = []
+                for ln in open(dumps[slowest]).read().splitlines():
+                    f = ln.split()
+                    # "[bof events] <ms relative to the newest call's begin> t<tid> <label> a b c": this step's only
+                    if len(f) > 3 and f[0] == "[bof" and f[2][:1].isdigit():
+                        lines.append(ln[13:].strip())
+                slow_events = {"step": slowest, "seconds": per[slowest]["seconds"], "events": lines[-2500:]}
+            except (OSError, ValueError):
+                pass
     finally:
         for fd in fds:
             bofhip.lib().bof_file_forget(fd)
@@ -1105,7 +1224,7 @@ def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, ste
         torch.cuda.empty_cache()
     return {"dt": dt, "per_step": per, "warmup_steps": warm, "verified": bool(ok) and ok_warm is not False,
             "verified_after_warmup": ok_warm, "odirect": direct, "create_files_s": round(create_s, 1),
-            "file_system": _fs_of(workdir)}
+            "file_system": _fs_of(workdir), "disk_probes": probes, "slowest_step_events": slow_events}
 
 
 def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
@@ -1124,6 +1243,20 @@ def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
         terms["disk_total"] = (st["bytes_read"] + st["bytes_written"]) / (total * 1e9)
     bound = max(terms, key=terms.get)
     return bound, terms[bound], {k: round(v, 4) for k, v in terms.items()}
+
+
+def _alg_bytes_per_launch(n, blk, launches_per_step):
+    """GEMM bytes = 4 (M K + K N + M N (1 + [C is read])) per launch, averaged over the launches of one
+    step of the row-panel schedule: G C panels of the ramp group run one k-block per launch (the raw sums of the
+    k-blocks before it are read back: [C is read] = 1 for all but the first), the others ONE launch over the whole K.
+    G is recovered from the launch count: launches = G Nk + (Np - G)."""
+    nk = npan = max(n // blk, 1)
+    if nk <= 1:
+        return int(4 * 3 * n * n)
+    g = min(npan, max(0, round((launches_per_step - npan) / (nk - 1))))
+    ramp = g * (4.0 * (blk * n + blk * n * nk + blk * n * (2 * nk - 1)))        # A panel once; B panel l per launch; C write + read-back
+    whole = (npan - g) * 4.0 * (blk * n + n * n + blk * n)
+    return int((ramp + whole) / max(launches_per_step, 1))
 
 
 def _mean(xs):
@@ -1151,11 +1284,18 @@ def run_single(args, bofhip, torch, dev, st):
             ceil = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         detail["ceilings"] = ceil
         bofhip.lib().bof_flash_release()
+        evdir = os.path.join(workdir, "events")
+        os.makedirs(evdir, exist_ok=True)
         h = headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, args.io_threads, args.steps, args.warmup,
-                                args.streams)
+                                args.streams, probe=not args.no_probe, event_dir=evdir)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
     detail["headline"] = h
+    # the disk ceilings of the headline: the best the device showed on the workload's own files before / after the
+    # timed steps or on the scratch-file probe -- the probe moves, never the run
+    if "error" not in ceil:
+        ceil = merge_ceilings(ceil, *h.get("disk_probes", []))
+        detail["ceilings_merged"] = ceil
     per = h["per_step"]
     flops_step = 2.0 * n ** 3
     dt = h["dt"]
@@ -1170,6 +1310,15 @@ def run_single(args, bofhip, torch, dev, st):
     mean_step = {q: _mean(p[q] for p in per) for q in ("bytes_read", "bytes_written", "bytes_h2d", "bytes_d2h")}
     bound, t_bound, terms = e2e_bound(mean_step, ceil if "error" not in ceil else {}, args.steps, ksec / args.steps)
     secs = sorted(p["seconds"] for p in per)
+    med_step = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
+    probe_note = None
+    if t_bound > dt / args.steps and bound.startswith("disk"):
+        # the steps moved bytes faster than every probe: the device CAN do what it just did -- the ceiling is raised to
+        # the rate the steps themselves showed (flagged), never the other way round
+        probe_note = (f"every probe of this run read / wrote slower than the timed steps did: bound {bound} raised from "
+                      f"{t_bound:.4f} s to the steps' own {dt / args.steps:.4f} s")
+        t_bound = dt / args.steps
+        terms[bound] = round(t_bound, 4)
     line = {
         "metric": "GFLOP/s, out-of-core GEMM (flash _gemm on SSD-resident A/B/C, wall clock around the call)",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -1185,7 +1334,9 @@ def run_single(args, bofhip, torch, dev, st):
                    "tile_tasks_per_step": int(_mean(p["tasks"] for p in per)),
                    "GiB_read_per_step": round(mean_step["bytes_read"] / 2**30, 3),
                    "GiB_written_per_step": round(mean_step["bytes_written"] / 2**30, 3),
-                   "step_s_min_med_max": [round(secs[0], 3), round(secs[len(secs) // 2], 3), round(secs[-1], 3)],
+                   "step_s_min_med_max": [round(secs[0], 3), round(med_step, 3), round(secs[-1], 3)],
+                   "ms_per_step_median": round(med_step * 1e3, 2),
+                   "mean_over_median": round(dt / args.steps / med_step, 3),
                    "C_verified": h["verified"], "parallelism": "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel<NoEpi>",
                      "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -1193,11 +1344,13 @@ def run_single(args, bofhip, torch, dev, st):
                      "launches": launches, "timed_with": "HIP events around every tile launch on its compute stream, "
                                                          "inside the timed steps (bof_options.kernel_timing)",
                      "flops_per_launch": flops_per_launch,
-                     "algorithmic_bytes_per_launch": int(4 * blk * blk * (3 + (nk - 1) / nk)),
+                     "launches_per_step": round(launches / args.steps, 1),
+                     "algorithmic_bytes_per_launch": _alg_bytes_per_launch(n, blk, launches / args.steps),
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_s_per_step": round(ksec / args.steps, 4),
                      "e2e_bound": bound, "e2e_t_bound_s": round(t_bound, 4),
                      "e2e_frac": round(t_bound / (dt / args.steps), 3), "e2e_terms_s": terms,
+                     **({"e2e_probe_note": probe_note} if probe_note else {}),
                      "e2e_probe": {k: ceil.get(k) for k in ("disk_read_GBps", "disk_write_GBps",
                                                             "disk_read_GBps_while_writing",
                                                             "disk_write_GBps_while_reading", "pcie_h2d_GBps",
@@ -1264,7 +1417,7 @@ def extras_single(args, bofhip, torch, dev, st, detail, gemm_kernel_s):
         gv_ms = {tr: (sec.get("csrgemv_" + tr) or {}).get("ms") for tr in "NT"} if sec else {}
         e2e = e2e_block(bofhip, torch, dev, st, args, gemm_kernel_s, csr_ms * 1e-3 if csr_ms else None,
                         8.0 * gemm_kernel_s, gv_ms if gv_ms and all(gv_ms.values()) else None,
-                        ceilings=detail.get("ceilings") or {})
+                        ceilings=detail.get("ceilings_merged") or detail.get("ceilings") or {})
         detail["e2e"] = e2e
 
         def leg(name, mode, sub=None):
@@ -1338,29 +1491,59 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
         return bool(v[0].item() == 1.0), -float(v[1].item()), float(v[2].item()), err
 
     base = args.e2e_dir or os.environ.get("BOF_BENCH_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    # $BOF_BENCH_DIRS=a,b,...: one directory per scratch VOLUME of the node.  ONE disk caps the 8-GPU run at its ~20 GB/s
+    # (weak-scaling efficiency ~0.3 at N = 8); with several volumes rank g keeps ITS A and C slabs
+    # as files of their own in dirs[g % D], and every directory holds a replica of B (panel l of B is read by rank
+    # l % N from its own replica and passed on through the node's staging ring, so B's reads spread over the volumes
+    # too).  Unset: the one shared A / B / C file set under $BOF_BENCH_DIR.
+    dirs = [d for d in os.environ.get("BOF_BENCH_DIRS", "").split(",") if d]
+    local_slabs = len(dirs) > 0
+    D = max(len(dirs), 1)
+    my_dir_i = rank % D
+    mates = [g for g in range(world) if g % D == my_dir_i]          # the ranks that share this rank's directory
     box = [None]
     if rank == 0:
         try:
-            d = tempfile.mkdtemp(prefix="bof_bench_sharded_", dir=base)
-            need = 4 * (m * k + k * n + m * n) + (2 << 30)
-            if shutil.disk_usage(d).free > need:
-                box[0] = d
+            made = []
+            for bdir in (dirs or [base]):
+                d = tempfile.mkdtemp(prefix="bof_bench_sharded_", dir=bdir)
+                made.append(d)
+                users = len([g for g in range(world) if g % D == len(made) - 1]) if local_slabs else world
+                need = 4 * (users * m_local * (k + n) + k * n) + (2 << 30)
+                if shutil.disk_usage(d).free <= need:
+                    raise OSError(f"{shutil.disk_usage(d).free / 2**30:.0f} GiB free under {bdir}, {need / 2**30:.0f} needed")
+            if not local_slabs:
                 for name, sz in (("A.bin", m * k * 4), ("B.bin", k * n * 4), ("C.bin", m * n * 4)):
-                    with open(os.path.join(d, name), "wb") as f:
+                    with open(os.path.join(made[0], name), "wb") as f:
                         f.truncate(sz)
             else:
-                box[0] = f"!{shutil.disk_usage(d).free / 2**30:.0f} GiB free under {base}, {need / 2**30:.0f} needed"
-                shutil.rmtree(d, ignore_errors=True)
+                for d in made:
+                    with open(os.path.join(d, "B.bin"), "wb") as f:
+                        f.truncate(k * n * 4)
+            box[0] = made
         except OSError as e:
+            for d in made:
+                shutil.rmtree(d, ignore_errors=True)
             box[0] = f"!{e}"
     dist.broadcast_object_list(box, src=0)
-    if box[0].startswith("!"):
+    if isinstance(box[0], str):
         raise SystemExit("bench.py: " + box[0][1:])
-    workdir = box[0]
-    pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
+    workdirs = box[0]
+    workdir = workdirs[my_dir_i if local_slabs else 0]
+    if local_slabs:
+        pa, pb, pc = (os.path.join(workdir, x) for x in (f"A.{rank}.bin", "B.bin", f"C.{rank}.bin"))
+        for pth, sz in ((pa, m_local * k * 4), (pc, m_local * n * 4)):
+            with open(pth, "wb") as f:
+                f.truncate(sz)
+    else:
+        pa, pb, pc = (os.path.join(workdir, x) for x in ("A.bin", "B.bin", "C.bin"))
     r0 = rank * m_local
-    kb = (k + world - 1) // world
-    k0, k1 = min(k, rank * kb), min(k, (rank + 1) * kb)
+    file_r0 = 0 if local_slabs else r0                  # where this rank's rows start in ITS A / C files
+    # B is written by the ranks that share a directory, a row range each
+    nb = len(mates) if local_slabs else world
+    bi = mates.index(rank) if local_slabs else rank
+    kb = (k + nb - 1) // nb
+    k0, k1 = min(k, bi * kb), min(k, (bi + 1) * kb)
     state = {}
 
     def put(path, off_elems, count, first, mode):
@@ -1379,9 +1562,9 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
 
     def create():
         state["t"] = torch.empty(max(m_local * max(k, n), (k1 - k0) * n), dtype=torch.float32, device=dev)
-        put(pa, r0 * k, m_local * k, r0 * k, "s")          # dense_create mode s, this rank's rows
-        put(pb, k0 * n, (k1 - k0) * n, k0 * n, "s")        # 1/world of B
-        put(pc, r0 * n, m_local * n, 0, "z")
+        put(pa, file_r0 * k, m_local * k, r0 * k, "s")     # dense_create mode s, this rank's rows
+        put(pb, k0 * n, (k1 - k0) * n, k0 * n, "s")        # its share of (this directory's replica of) B
+        put(pc, file_r0 * n, m_local * n, 0, "z")
         state["rowpat"] = _closed_form_rows(torch, dev, m, k, n)
     good, create_s, _, err = phase(create)
     fds = []
@@ -1399,9 +1582,10 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
 
     def step():
         last.clear()
-        last.update(bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], 0, 0, 0, opts, b_once=True))
+        last.update(bof_dist.flash_gemm_row_sharded(m, n, k, 1.0, 0.0, fds[0], fds[1], fds[2], 0, 0, 0, opts, b_once=True,
+                                                    local_slabs=local_slabs))
     for _ in range(args.warmup if good else 0):
-        if rank == 0:
+        if rank == 0 or local_slabs:
             _drop_cache((pa, pb, pc))
         dist.barrier()
         good, _, _, err = phase(step)
@@ -1410,7 +1594,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
     per_rank_s, agg_steps = [], []
     dt = float("nan")
     if good:
-        if rank == 0:
+        if rank == 0 or local_slabs:
             _drop_cache((pa, pb, pc))
         dist.barrier()
         torch.cuda.synchronize()
@@ -1438,7 +1622,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
         t = state["t"]
         fd, _ = _open(pc, False)
         try:
-            bofhip.file_to_device(bofhip.FPtr(fd, r0 * n * 4), m_local * n * 4, t.data_ptr(),
+            bofhip.file_to_device(bofhip.FPtr(fd, file_r0 * n * 4), m_local * n * 4, t.data_ptr(),
                                   bofhip.default_options(use_odirect=0), st)
         finally:
             os.close(fd)
@@ -1455,7 +1639,8 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
     torch.cuda.empty_cache()
     dist.barrier()
     if rank == 0:
-        shutil.rmtree(workdir, ignore_errors=True)
+        for d in workdirs:
+            shutil.rmtree(d, ignore_errors=True)
     bofhip.lib().bof_flash_release()
 
     # csrgemv 'T': the path's one real exchange (partial sums of 200 MB), both algorithms timed
@@ -1487,7 +1672,9 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
                    "what_is_timed": "every rank's bof_flash_gemm on its slab of ONE A/B/C file set between barriers; "
                                     "B read from storage once per node, no data-path collective",
                    "parallelism": f"row-block x{world}", "ranks_seen": args.ranks_seen,
-                   "backend": "gloo (one-GPU debug)" if one_gpu else "nccl (RCCL)", "odirect": was_direct,
+                   "backend": args.backend_seen, "odirect": was_direct,
+                   "file_dirs": (f"{D} directories ($BOF_BENCH_DIRS): per-rank A / C slab files, a replica of B in each"
+                                 if local_slabs else "one shared A / B / C file set"),
                    "rank_s_min": round(min(a for a, _ in per_rank_s), 3), "rank_s_max": round(max(b for _, b in per_rank_s), 3),
                    "read_amplification": round(agg["bytes_read"] / args.steps / (4.0 * (m * k + k * n)), 3),
                    "write_amplification": round(agg["bytes_written"] / args.steps / (4.0 * m * n), 3),
@@ -1583,6 +1770,10 @@ def main():
                          "per-kernel average is compared with; 0 = the library's default of two, whose "
                          "launches overlap pairwise)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="only the HBM-resident tile DAG of configs[1] (no file I/O, no D2H: what tools/profile_bench.sh puts "
+                         "under rocprofv3 --kernel-trace to corroborate the kernel's launch time); prints its record")
+    ap.add_argument("--no-probe", action="store_true", help="skip the disk probes on the workload's files around the timed steps")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline (+ cpu_baseline): no resident DAG, CSR, 64k, kmeans legs")
     ap.add_argument("--no-csr", action="store_true", help="skip the CSRMM (cfg3) / CSRGEMV (cfg5-size) extras")
@@ -1643,7 +1834,14 @@ def main():
     dev = torch.device("cuda", local)
     red_dev = torch.device("cpu") if one_gpu else dev     # where cross-rank reductions live
     args.ranks_seen = 1
+    args.backend_seen = "none (one rank)"
     if world > 1:
+        # the backend the collectives of this run really went through, asked of torch.distributed (not assumed)
+        be = dist.get_backend()
+        args.backend_seen = f"{be} (RCCL over xGMI)" if be == "nccl" else f"{be} (one-GPU debug)"
+        if not one_gpu and be != "nccl":
+            sys.stderr.write(f"bench.py: the N > 1 run must go through the nccl (RCCL) backend, torch.distributed says {be!r}\n")
+            sys.exit(2)
         # every rank adds a one through the data-path backend (RCCL over xGMI on the GPU box): the sum is
         # the number of ranks that really took part, printed so the driver can check it against --gpus
         ones = torch.ones(1, dtype=torch.float32, device=red_dev)
@@ -1653,6 +1851,12 @@ def main():
             sys.stderr.write(f"bench.py: {args.ranks_seen} ranks answered the all-reduce, --gpus says {args.gpus}\n")
             sys.exit(2)
     st = torch.cuda.current_stream().cuda_stream
+    if world == 1 and args.resident_only:
+        n = args.size or 32768
+        r = resident_gemm_line(bofhip, torch, dev, st, n, n, n, 0, args.blk, 1, args.steps,
+                               f"{n}^3 tile DAG, A/B/C resident in HBM (I/O skipped)")
+        print(json.dumps(r), flush=True)
+        return
     if world == 1:
         line, detail = run_single(args, bofhip, torch, dev, st)
     else:

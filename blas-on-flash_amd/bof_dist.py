@@ -84,7 +84,7 @@ _share_seq = 0
 
 
 def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0, ldc=0, opts=None, group=None,
-                           b_once=True):
+                           b_once=True, local_slabs=False):
     """Multi-GPU flash::gemm('R','N','N') on FILE-resident matrices (BASELINE configs[3]; SURVEY 8e), one
     process per GPU: rank g owns the C rows [r0, r1) (tile-aligned, `row_shard`) and calls the
     single-GPU file pipeline on its slab -- bof_flash_gemm with the A and C pointers advanced to row
@@ -100,6 +100,9 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
     in include/bof_hip.h).  At cfg4 that is 16 + 16 GiB of reads per node instead of 16 + 8 x 16.  The
     only torch.distributed call is the barrier behind which the staging ring is removed.
     b_once=False: every rank reads B itself.
+    local_slabs=True: fd_a / fd_c are THIS RANK'S OWN files holding only its rows (A rows [r0, r1) at offset 0, its
+    C slab likewise) instead of the whole matrices -- how a node with one scratch volume per GPU spreads the file
+    set (bench.py: $BOF_BENCH_DIRS); fd_b is then the rank's replica of B.
 
     Returns {rows, bytes_read, bytes_written, bytes_peer, seconds} of this rank."""
     global _share_seq
@@ -159,7 +162,9 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
                         fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
                         bofhip.check(bofhip.lib().bof_mem_info(ctypes.byref(fr), ctypes.byref(tot)), "bof_mem_info")
                         budget = int(fr.value * 0.8)
-                    can = bool(bofhip.flash_gemm_panel_plan("R", "N", "N", rows, n, k, tile, budget, lda, ldb, ldc, 0)["eligible"])
+                    pl = bofhip.flash_gemm_panel_plan("R", "N", "N", rows, n, k, tile, budget, lda, ldb, ldc, 0)
+                    # (beta != 0: the ramp group's chains also need their raw accumulator panels, bof_panel_plan.acc_bytes)
+                    can = bool(pl["eligible"]) and (beta == 0 or int(o.gemm_chain) == 1 or pl["need_bytes"] + pl["acc_bytes"] <= budget)
             except Exception as e:      # noqa: BLE001 -- whatever it is, every rank must hear of it
                 can, pre_err = False, f"{type(e).__name__}: {e}"
         verdicts = [None] * world
@@ -183,8 +188,9 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
         if name is not None:
             call.share_world, call.share_rank, call.share_name = len(mates), mates.index(rank), name.encode()
         try:
-            bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, r0 * lda * 4),
-                              bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * ldc * 4), lda, ldb, ldc, call)
+            off_a, off_c = (0, 0) if local_slabs else (r0 * lda * 4, r0 * ldc * 4)
+            bofhip.flash_gemm("R", "N", "N", rows, n, k, alpha, beta, bofhip.FPtr(fd_a, off_a),
+                              bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, off_c), lda, ldb, ldc, call)
             st_ = bofhip.flash_last_stats()
             for q in ("bytes_read", "bytes_written", "bytes_peer", "seconds", "kernel_launches", "kernel_seconds", "tasks",
                       "bytes_h2d", "bytes_d2h"):

@@ -52,7 +52,7 @@ class PanelPlan(C.Structure):
     """bof_panel_plan: which path bof_flash_gemm takes for a budget, and the row-panel layout."""
     _fields_ = [("eligible", C.c_int32), ("why", C.c_int32), ("streamed", C.c_int32), ("resident", C.c_int32 * 3),
                 ("n_panels", i64 * 3), ("n_slots", i64 * 3), ("slot_bytes", u64 * 3), ("need_bytes", u64),
-                ("groups", i64), ("first_group", i64)]
+                ("groups", i64), ("first_group", i64), ("acc_bytes", u64)]
 
 
 class FlashStats(C.Structure):
@@ -330,7 +330,7 @@ def flash_gemm_panel_plan(ord_, ta, tb, m, n, k, blk, hbm_budget, lda=0, ldb=0, 
                                           C.byref(p)), "bof_flash_gemm_panel_plan")
     return {"eligible": bool(p.eligible), "why": p.why, "streamed": p.streamed, "resident": list(p.resident),
             "n_panels": list(p.n_panels), "n_slots": list(p.n_slots), "slot_bytes": list(p.slot_bytes),
-            "need_bytes": p.need_bytes, "groups": p.groups, "first_group": p.first_group}
+            "need_bytes": p.need_bytes, "groups": p.groups, "first_group": p.first_group, "acc_bytes": p.acc_bytes}
 
 
 def flash_last_stats():

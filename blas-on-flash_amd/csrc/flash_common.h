@@ -41,35 +41,52 @@ struct Counters {
 // LAUNCHED ON, read back once the call's streams have drained.  What bof_flash_stats.kernel_seconds /
 // kernel_launches report, and what bench.py's roofline.achieved is computed from (the figure rocprofv3's
 // per-kernel average of the same run must agree with).  Off by default: two markers per launch.
+// HIP events and streams a call needs for its own lifetime come out of per-device pools and go back when the call is
+// done with them (bof_flash_release destroys the pools): in the steady state a level-3 call creates and destroys no
+// HIP object.  The create / destroy churn of hundreds of events per call is what the corrupted handles and the
+// wrong tiles of rounds 3-4 correlated with (profiles/r4/fuzz_crash.md) -- the two GEMM paths pooled theirs in round
+// 4, the CSR pipelines, the region transfers and KernelTimer follow here.  An object is taken and returned
+// on the device it belongs to (the pool remembers); a returned event / stream may still have work pending -- the
+// next user re-records the event or queues behind the stream's old work.
+hipError_t pooled_event(hipEvent_t *e, bool timing = false);
+void pooled_event_return(hipEvent_t e);
+hipError_t pooled_stream(hipStream_t *s, bool copy_priority);   // copy_priority: copy_stream_create's kind; else plain non-blocking
+void pooled_stream_return(hipStream_t s);
+void hip_pools_release();
+
 class KernelTimer {
   std::vector<hipEvent_t> ev;   // begin / end pairs in launch order
   std::mutex mu;                // several dispatch streams of one device share a timer
  public:
   bool on = false;
-  hipError_t begin(hipStream_t st) {
+  // returns the launch's pair index through *pair (what end() takes): two dispatchers sharing a timer cannot mix
+  // their pairs up
+  hipError_t begin(hipStream_t st, size_t *pair = nullptr) {
     if (!on) return hipSuccess;
     hipEvent_t a = nullptr, b = nullptr;
-    hipError_t e = hipEventCreateWithFlags(&a, hipEventDefault);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDefault);
+    hipError_t e = pooled_event(&a, true);
+    if (e == hipSuccess) e = pooled_event(&b, true);
     if (e == hipSuccess) e = hipEventRecord(a, st);
     if (e != hipSuccess) {
-      if (a) (void) hipEventDestroy(a);
-      if (b) (void) hipEventDestroy(b);
+      if (a) pooled_event_return(a);
+      if (b) pooled_event_return(b);
       return e;
     }
     std::lock_guard<std::mutex> lk(mu);
+    if (pair) *pair = ev.size() / 2;
     ev.push_back(a);
     ev.push_back(b);
     return hipSuccess;
   }
-  // the end marker of the most recent begin() of this thread's launch (launches of one timer are
-  // issued by one dispatcher thread, so "most recent" is well defined)
-  hipError_t end(hipStream_t st) {
+  // the end marker of pair `pair` (default: the most recent begin() -- a timer driven by ONE dispatcher thread)
+  hipError_t end(hipStream_t st, size_t pair = (size_t) -1) {
     if (!on) return hipSuccess;
     std::lock_guard<std::mutex> lk(mu);
-    return ev.empty() ? hipSuccess : hipEventRecord(ev.back(), st);
+    if (ev.empty()) return hipSuccess;
+    const size_t i = pair == (size_t) -1 ? ev.size() - 1 : 2 * pair + 1;
+    return i < ev.size() ? hipEventRecord(ev[i], st) : hipErrorInvalidValue;
   }
-  // after the streams have been synchronised: adds the pairs that completed to the counters, destroys all
+  // after the streams have been synchronised: adds the pairs that completed to the counters, returns the events
   void collect(Counters &c) {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i + 1 < ev.size(); i += 2) {
@@ -80,13 +97,13 @@ class KernelTimer {
       } else {
         (void) hipGetLastError();
       }
-      (void) hipEventDestroy(ev[i]);
-      (void) hipEventDestroy(ev[i + 1]);
+      pooled_event_return(ev[i]);
+      pooled_event_return(ev[i + 1]);
     }
     ev.clear();
   }
   ~KernelTimer() {
-    for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+    for (hipEvent_t e : ev) pooled_event_return(e);
   }
 };
 
@@ -367,14 +384,19 @@ inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUM
 
 // ---- persistent launcher threads ------------------------------------------------------------------------------
 // Kernel launches are only ever issued by the CALLING thread or by one of these long-lived threads, never by a
-// thread created for the call.  Why: on this stack (ROCm 7.x HIP runtime, gfx950) a kernel launched from a
-// thread that was created for the call -- reproducibly its SECOND launch -- occasionally runs with a wrong trailing
-// argument (a tile task of flash::kmeans got the next task's p_l2sq pointer; a plain tile task a wrong scalar):
-// 4-9 wrong C tiles per 29 000 fuzzed multi-slab calls with a fresh dispatcher thread per call, 0 per 29 000 from the
-// calling thread and 0 per 29 000 from a persistent worker; neither a device synchronisation before every launch nor a
-// warm-up launch on the fresh thread changed it (profiles/r4/fuzz_thread_bisect.md).  It was the "one unexplained
-// wrong tile" of round 3.  launch_async(dev, rep, fn) runs fn on the persistent thread of (device, repetition of the
-// ordinal in the call's device list), created on first use and kept for the life of the process; launch_wait joins it.
+// thread created for the call.  Why -- CORRELATED, NOT PROVEN (profiles/r4/fuzz_thread_bisect.md, sections 4-6): with a
+// fresh dispatcher thread per call AND hundreds of HIP events created and destroyed per call, 4-9 C tiles per 29 000
+// fuzzed multi-slab calls came out wrong (a tile task of flash::kmeans ran with the next task's p_l2sq pointer; a plain
+// tile task with a wrong scalar); 0 per 29 000 from the calling thread, 0 from a persistent worker -- and, once the
+// events were pooled, 0 per 34 000 from a fresh thread as well: either half of the combination removed makes the wrong
+// tiles go away, and the cause inside the runtime was not found.  Both halves stay removed (these threads; pooled
+// events and copy streams; rule R6 of the mock runtime).  One later mismatch (a k-block that did not add to C, both
+// dispatchers of a repeated ordinal, 1 in ~450 000 cases) is unexplained; what it has in common with every earlier
+// one is a REPEATED ORDINAL whose dispatchers fed one compute-stream set from several host threads -- since round 5
+// every repetition has its own streams (c_api.hip: stream_rep) and BOF_VERIFY checks every launch at its source
+// (consumer-side sums, spot checks: "Round 5" below).  launch_async(dev, rep, fn) runs fn on the persistent thread of
+// (device, repetition of the ordinal in the call's device list), created on first use and kept for the life of the
+// process; launch_wait joins it.
 // what the crash handler ($BOF_CRASH_TRACE=1) prints besides the stack: a callback the running pipeline registers
 extern std::atomic<void (*)(void *)> g_crash_dump_fn;      // (the last pipeline to register wins: a diagnostic)
 extern std::atomic<void *> g_crash_dump_arg;

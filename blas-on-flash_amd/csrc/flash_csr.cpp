@@ -73,8 +73,8 @@ int device_to_pageable(void *dst, const void *src, uint64_t bytes, int n_thr) {
   auto worker = [&, dev] {
     void *pin = nullptr;
     hipStream_t st = nullptr;
-    if (hipSetDevice(dev) != hipSuccess || copy_stream_create(&st) != hipSuccess) { fail.store(-1); return; }
-    if (pinned_alloc(&pin, chunk) != BOF_OK) { fail.store(-1); (void) hipStreamDestroy(st); return; }
+    if (hipSetDevice(dev) != hipSuccess || pooled_stream(&st, true) != hipSuccess) { fail.store(-1); return; }
+    if (pinned_alloc(&pin, chunk) != BOF_OK) { fail.store(-1); pooled_stream_return(st); return; }
     for (;;) {
       const int64_t i = next.fetch_add(1);
       if (i >= nc || fail.load()) break;
@@ -84,7 +84,7 @@ int device_to_pageable(void *dst, const void *src, uint64_t bytes, int n_thr) {
       memcpy((char *) dst + o, pin, len);
     }
     pinned_free(pin);
-    (void) hipStreamDestroy(st);
+    pooled_stream_return(st);
   };
   std::vector<std::thread> th;
   for (int t = 1; t < n_thr; t++) th.emplace_back(worker);
@@ -107,11 +107,11 @@ int pageable_to_device(void *dst, const void *src, uint64_t bytes, int n_thr, hi
   auto worker = [&, dev] {
     void *pin[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;
-    if (hipSetDevice(dev) != hipSuccess || copy_stream_create(&st) != hipSuccess) { fail.store(-1); return; }
+    if (hipSetDevice(dev) != hipSuccess || pooled_stream(&st, true) != hipSuccess) { fail.store(-1); return; }
     if (pinned_alloc(&pin[0], chunk) != BOF_OK || pinned_alloc(&pin[1], chunk) != BOF_OK) fail.store(-1);
     hipEvent_t ev[2] = {nullptr, nullptr};
     for (int q = 0; q < 2 && !fail.load(); q++)
-      if (hipEventCreateWithFlags(&ev[q], hipEventDisableTiming) != hipSuccess) fail.store(-1);
+      if (pooled_event(&ev[q]) != hipSuccess) fail.store(-1);
     bool busy[2] = {false, false};
     for (int q = 0; !fail.load(); q ^= 1) {
       const int64_t i = next.fetch_add(1);
@@ -125,10 +125,10 @@ int pageable_to_device(void *dst, const void *src, uint64_t bytes, int n_thr, hi
     }
     if (st) (void) hipStreamSynchronize(st);
     for (int q = 0; q < 2; q++) {
-      if (ev[q]) (void) hipEventDestroy(ev[q]);
+      if (ev[q]) pooled_event_return(ev[q]);
       if (pin[q]) pinned_free(pin[q]);
     }
-    if (st) (void) hipStreamDestroy(st);
+    if (st) pooled_stream_return(st);
   };
   std::vector<std::thread> th;
   for (int t = 1; t < n_thr; t++) th.emplace_back(worker);
@@ -421,6 +421,7 @@ static int flash_transpose_to_hbm(int64_t m, int64_t n, bof_fptr fa, bof_fptr fi
   const size_t in_bytes = (size_t) nnz * 12 + (size_t) (m + 1) * 8;
   const size_t out_bytes = (size_t) nnz * 12 + (size_t) (n + 1) * 8 + csrcsc_workspace_bytes(n, nnz);
   size_t free_b = 0, total_b = 0;
+  dev_cache_release();        // cached call-lifetime blocks of earlier CSR calls are free memory for this check
   BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (in_bytes + out_bytes > free_b) {  // scratch that is already allocated only helps
     set_error("csrcsc: the matrix needs " + std::to_string((in_bytes + out_bytes) >> 20) +
@@ -438,9 +439,9 @@ static int flash_transpose_to_hbm(int64_t m, int64_t n, bof_fptr fa, bof_fptr fi
   Cleanup guard;
   guard.add([&] {
     (void) hipFree(d_val); (void) hipFree(d_col); (void) hipFree(d_ia);
-    if (st) (void) hipStreamDestroy(st);
+    if (st) pooled_stream_return(st);
   });
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  BOF_HIP_TRY(pooled_stream(&st, false));
   BOF_HIP_TRY(hipMalloc((void **) &d_val, (size_t) std::max<int64_t>(nnz, 1) * 4));
   BOF_HIP_TRY(hipMalloc((void **) &d_col, (size_t) std::max<int64_t>(nnz, 1) * 8));
   BOF_HIP_TRY(hipMalloc((void **) &d_ia, (size_t) (m + 1) * 8));
@@ -531,10 +532,10 @@ static int flash_csrcsc_blocked(int64_t m, int64_t n, const std::vector<int64_t>
     if (tfd_col >= 0) close(tfd_col);
     (void) hipFree(d_val); (void) hipFree(d_col); (void) hipFree(d_ia); (void) hipFree(d_vt); (void) hipFree(d_ct);
     (void) hipFree(d_pt); (void) hipFree(d_aux);
-    if (st) (void) hipStreamDestroy(st);
+    if (st) pooled_stream_return(st);
   });
   if (tfd_val < 0 || tfd_col < 0) { set_error("csrcsc: cannot create temporary files"); return BOF_EIO; }
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  BOF_HIP_TRY(pooled_stream(&st, false));
   int64_t max_b = 0, max_rows = 0;
   for (int b = 0; b < nb; b++) {
     max_b = std::max(max_b, ia[(size_t) rb[b + 1]] - ia[(size_t) rb[b]]);
@@ -654,6 +655,7 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
     }
     const int64_t nnz = ia[(size_t) m] - ia[0];
     size_t free_b = 0, total_b = 0;
+    dev_cache_release();      // cached call-lifetime blocks of earlier CSR calls are free memory for this budget
     BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = o.hbm_budget > 0 ? std::min((size_t) o.hbm_budget, (size_t) (free_b * 0.9)) : (size_t) (free_b * 0.9);
     const size_t need = (size_t) std::max<int64_t>(nnz, 0) * 24 + (size_t) (m + n + 2) * 8 + csrcsc_workspace_bytes(n, std::max<int64_t>(nnz, 0));
@@ -668,9 +670,9 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
   rc = flash_transpose_to_hbm(m, n, fa, fia, fja, o, cnt, T);
   if (rc) return rc;
   hipStream_t st = nullptr;
-  BOF_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  BOF_HIP_TRY(pooled_stream(&st, false));
   Cleanup guard;
-  guard.add([&] { (void) hipStreamDestroy(st); });
+  guard.add([&] { pooled_stream_return(st); });
   const bool use_aio = o.use_odirect != 0;
   rc = stream_file(fa_tr, (uint64_t) T.nnz * 4, (char *) T.val, false, st, use_aio, o.n_io_threads, cnt);
   if (!rc) rc = stream_file(fja_tr, (uint64_t) T.nnz * 8, (char *) T.col, false, st, use_aio, o.n_io_threads, cnt);
@@ -796,16 +798,16 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       pinned_free(c.h_ia);
       pinned_free(c.h_y);
       dev_cache_free(c.d_ia);
-      if (c.ready) (void) hipEventDestroy(c.ready);
-      if (c.done) (void) hipEventDestroy(c.done);
+      if (c.ready) pooled_event_return(c.ready);
+      if (c.done) pooled_event_return(c.done);
     }
-    if (resident_ev) (void) hipEventDestroy(resident_ev);
+    if (resident_ev) pooled_event_return(resident_ev);
     dev_cache_free(own_b); dev_cache_free(own_x); dev_cache_free(own_y);
-    if (R.h2d) (void) hipStreamDestroy(R.h2d);
-    if (R.d2h) (void) hipStreamDestroy(R.d2h);
+    if (R.h2d) pooled_stream_return(R.h2d);
+    if (R.d2h) pooled_stream_return(R.d2h);
   });
-  BOF_HIP_TRY(copy_stream_create(&R.h2d));
-  BOF_HIP_TRY(copy_stream_create(&R.d2h));
+  BOF_HIP_TRY(pooled_stream(&R.h2d, true));
+  BOF_HIP_TRY(pooled_stream(&R.d2h, true));
   if (res) d_ia = const_cast<int64_t *>(res->ia_dev);     // else: per block, with the block (CsrCtx::d_ia)
   const int64_t xlen = trans == 'N' ? n : m, ylen = trans == 'N' ? m : n;
   const bool ext_op = ex && ex->shared_op;        // B / x comes from the multi-device caller
@@ -819,7 +821,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   own_b = d_b; own_x = d_x; own_y = d_y;
   if (ext_op) (is_mm ? d_b : d_x) = ex->shared_op;
   if (ext_y) d_y = (char *) ex->partial_y;
-  BOF_HIP_TRY(hipEventCreateWithFlags(&resident_ev, hipEventDisableTiming));
+  BOF_HIP_TRY(pooled_event(&resident_ev));
   // B (csrmm) / x (csrgemv) go to HBM on a thread of their own while the block contexts are set up
   // and the first row blocks are already being read; the compute streams wait for `resident_ev`
   // before the first kernel (36 ms of B at cfg3, 25 ms of x at cfg5 size used to sit in front of
@@ -857,7 +859,10 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     } else {
       // x lives in pageable host memory (include/flash_blas.h:55-57): through pinned chunks on several threads
       // (a plain copy out of pageable memory is staged by the runtime on the calling thread: 200 MB in 25-40 ms)
-      if (pageable_to_device(d_x, hb, (uint64_t) xlen * 4, std::max(2, R.o.n_io_threads / 2), R.h2d)) return BOF_EHIP;
+      if (pageable_to_device(d_x, hb, (uint64_t) xlen * 4, std::max(2, R.o.n_io_threads / 2), R.h2d)) {
+        set_error("flash csr: copying the host vector to the device through pinned chunks failed (pinned block, copy stream or HIP copy)");
+        return BOF_EHIP;
+      }
       if (trans == 'T' && !ext_y) BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
       R.cnt.h2d += (uint64_t) xlen * 4;
     }
@@ -906,8 +911,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       rc = pinned_alloc((void **) &c.h_c, max_c);
       if (rc) return rc;
     }
-    BOF_HIP_TRY(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
-    BOF_HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    BOF_HIP_TRY(pooled_event(&c.ready));
+    BOF_HIP_TRY(pooled_event(&c.done));
     c.owner = i;
   }
   StreamSet *ss = stream_set(R.o.n_streams);
@@ -1176,8 +1181,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
       DeviceScope ds(S.dev);
       (void) hipFree(S.op);
       (void) hipFree(S.partial);
-      if (S.ready) (void) hipEventDestroy(S.ready);
-      if (S.st) (void) hipStreamDestroy(S.st);
+      if (S.ready) pooled_event_return(S.ready);
+      if (S.st) pooled_stream_return(S.st);
     }
   });
   for (int d = 0; d < D; d++) {
@@ -1186,8 +1191,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     S.row0 = bst[(size_t) cut[(size_t) d]];
     S.rows = (cut[(size_t) d + 1] == nb ? m : bst[(size_t) cut[(size_t) d + 1]]) - S.row0;
     DeviceScope ds(S.dev);
-    BOF_HIP_TRY(copy_stream_create(&S.st));
-    BOF_HIP_TRY(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+    BOF_HIP_TRY(pooled_stream(&S.st, true));
+    BOF_HIP_TRY(pooled_event(&S.ready));
     if (share_op) BOF_HIP_TRY(hipMalloc((void **) &S.op, std::max<uint64_t>(op_bytes, 4)));
     if (!is_mm && trans == 'T') {
       BOF_HIP_TRY(hipMalloc((void **) &S.partial, (size_t) std::max<int64_t>(n, 1) * 4));
@@ -1373,6 +1378,7 @@ static int flash_csrmm_trans(uint64_t m, uint64_t n, uint64_t k, float alpha, fl
     }
     const int64_t nnz = iav[(size_t) m] - iav[0];
     size_t free_b = 0, total_b = 0;
+    dev_cache_release();      // cached call-lifetime blocks of earlier CSR calls are free memory for this budget
     BOF_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = o.hbm_budget > 0 ? std::min((size_t) o.hbm_budget, (size_t) (free_b * 0.9)) : (size_t) (free_b * 0.9);
     const size_t need = (size_t) std::max<int64_t>(nnz, 0) * 24 + (size_t) (m + n + 2) * 8 +

@@ -1119,6 +1119,7 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   if (rc) return rc;
   DeviceCallLock call_lock(devs);
   TraceRange range("bof_flash_gemm");
+  dev_cache_release();        // the CSR pipelines' cached HBM blocks (up to 8 GiB a device) are free memory for the budgets below
   if (o.io_request_kib > 0) (void) bof_file_set_request_bytes((uint64_t) o.io_request_kib << 10);
   file_set_engine(o.io_engine);
   const GemmGeometry g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
@@ -1390,15 +1391,15 @@ static int region_transfer(bof_fptr f, uint64_t bytes, void *dptr, bool to_devic
   const bof_options o = resolved(opts);
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;
-  BOF_HIP_TRY(copy_stream_create(&st));
+  BOF_HIP_TRY(pooled_stream(&st, true));
   Cleanup guard;
   guard.add([&] {
-    if (ev) (void) hipEventDestroy(ev);
-    (void) hipStreamDestroy(st);
+    if (ev) pooled_event_return(ev);
+    pooled_stream_return(st);
   });
   // the private copy stream is non-blocking: order it behind whatever the caller has queued
   // on `after` for this buffer (an allocator's fill kernel, the kernels that produced it)
-  BOF_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  BOF_HIP_TRY(pooled_event(&ev));
   BOF_HIP_TRY(hipEventRecord(ev, (hipStream_t) after));
   BOF_HIP_TRY(hipStreamWaitEvent(st, ev, 0));
   Counters cnt;
@@ -1440,6 +1441,7 @@ int bof_flash_release(void) {
   }
   uring_release_buffers();
   dev_cache_release();
+  hip_pools_release();
   pinned_cache_release();
   file_unmap_all();
   return BOF_OK;

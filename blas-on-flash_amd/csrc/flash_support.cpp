@@ -76,6 +76,11 @@ int dev_cache_alloc(void **p, size_t bytes) {
     dev_cache_release();
     e = hipMalloc(p, rounded);
   }
+  if (e == hipErrorOutOfMemory) {
+    (void) hipGetLastError();
+    set_error("out of HBM: a call-lifetime block of " + std::to_string(rounded >> 20) + " MiB (the block cache was emptied first)");
+    return BOF_ENOMEM;
+  }
   if (e != hipSuccess) return hip_fail(e, "hipMalloc (call-lifetime block)");
   std::lock_guard<std::mutex> lk(g_devc.mu);
   g_devc.live[*p] = std::make_pair(dev, rounded);
@@ -308,6 +313,77 @@ DeviceCallLock::DeviceCallLock(const std::vector<int> &devs) {
 }
 DeviceCallLock::~DeviceCallLock() {
   for (auto it = held.rbegin(); it != held.rend(); ++it) (*it)->unlock();
+}
+
+// ---- per-device pools of call-lifetime HIP events and streams (flash_common.h) ----------------------------------
+namespace {
+struct HipPools {
+  std::mutex mu;
+  std::vector<hipEvent_t> ev[64][2];        // [device][timing]
+  std::vector<hipStream_t> st[64][2];       // [device][copy priority]
+  std::unordered_map<void *, std::pair<int, int>> home;   // handle -> (device, kind)
+} g_pools;
+}  // namespace
+hipError_t pooled_event(hipEvent_t *e, bool timing) {
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess) return rc;
+  dev &= 63;
+  {
+    std::lock_guard<std::mutex> lk(g_pools.mu);
+    auto &v = g_pools.ev[dev][timing ? 1 : 0];
+    if (!v.empty()) { *e = v.back(); v.pop_back(); return hipSuccess; }
+  }
+  rc = hipEventCreateWithFlags(e, timing ? hipEventDefault : hipEventDisableTiming);
+  if (rc != hipSuccess) return rc;
+  std::lock_guard<std::mutex> lk(g_pools.mu);
+  g_pools.home[(void *) *e] = std::make_pair(dev, timing ? 1 : 0);
+  return hipSuccess;
+}
+void pooled_event_return(hipEvent_t e) {
+  if (!e) return;
+  std::lock_guard<std::mutex> lk(g_pools.mu);
+  auto it = g_pools.home.find((void *) e);
+  if (it == g_pools.home.end()) return;       // released meanwhile (bof_flash_release): the handle is gone
+  g_pools.ev[it->second.first][it->second.second].push_back(e);
+}
+hipError_t pooled_stream(hipStream_t *s, bool copy_priority) {
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess) return rc;
+  dev &= 63;
+  {
+    std::lock_guard<std::mutex> lk(g_pools.mu);
+    auto &v = g_pools.st[dev][copy_priority ? 1 : 0];
+    if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+  }
+  rc = copy_priority ? copy_stream_create(s) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  if (rc != hipSuccess) return rc;
+  std::lock_guard<std::mutex> lk(g_pools.mu);
+  g_pools.home[(void *) *s] = std::make_pair(dev, copy_priority ? 1 : 0);
+  return hipSuccess;
+}
+void pooled_stream_return(hipStream_t s) {
+  if (!s) return;
+  std::lock_guard<std::mutex> lk(g_pools.mu);
+  auto it = g_pools.home.find((void *) s);
+  if (it == g_pools.home.end()) return;
+  g_pools.st[it->second.first][it->second.second].push_back(s);
+}
+void hip_pools_release() {
+  std::lock_guard<std::mutex> lk(g_pools.mu);
+  for (int d = 0; d < 64; d++) {
+    bool any = false;
+    for (int q = 0; q < 2; q++) any = any || !g_pools.ev[d][q].empty() || !g_pools.st[d][q].empty();
+    if (!any) continue;
+    DeviceScope ds(d);
+    for (int q = 0; q < 2; q++) {
+      for (hipEvent_t e : g_pools.ev[d][q]) { (void) hipEventDestroy(e); g_pools.home.erase((void *) e); }
+      for (hipStream_t s : g_pools.st[d][q]) { (void) hipStreamDestroy(s); g_pools.home.erase((void *) s); }
+      g_pools.ev[d][q].clear();
+      g_pools.st[d][q].clear();
+    }
+  }
 }
 
 hipError_t copy_stream_create(hipStream_t *s) {

@@ -104,6 +104,7 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
   }
   if (P.n_slots[2] == NpC) P.resident[2] = 1;
   P.need_bytes = need_of(0) + need_of(1) + need_of(2);
+  P.acc_bytes = g.nblk[1] > 1 ? (uint64_t) P.first_group * P.slot_bytes[2] : 0;
   P.eligible = 1;
   return P;
 }

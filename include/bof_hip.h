@@ -393,6 +393,11 @@ typedef struct {
   uint64_t need_bytes;  /* HBM the plan needs                                         */
   int64_t groups;       /* outer iterations: the first group, then one C panel each   */
   int64_t first_group;  /* C panels of the first group (`group` clamped to the count) */
+  /* ---- ABI v5 ---- */
+  uint64_t acc_bytes;   /* what bof_flash_gemm needs ON TOP of need_bytes when beta != 0, K spans several blocks
+                           and gemm_chain is 0 / 2: one raw accumulator panel (a C slot) per C panel of the first
+                           group -- the chains of the ramp group carry their sums there while C still holds the
+                           caller's values (bof_options.gemm_chain)                                          */
 } bof_panel_plan;
 int bof_flash_gemm_panel_plan(char ord, char trans_a, char trans_b, uint64_t m, uint64_t n,
                               uint64_t k, uint64_t lda, uint64_t ldb, uint64_t ldc, int64_t blk,

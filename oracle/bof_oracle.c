@@ -198,20 +198,26 @@ static void sgemm_rm(int ta, int tb, int64_t m, int64_t n, int64_t k, float alph
     alpha = 0.0f;
   }
   float *acc = (float *) malloc(sizeof(float) * (size_t) (n > 0 ? n : 1));
+  /* B stored [n][k] ('T'): one [k][n] copy, so that the j loop below runs over contiguous memory and vectorises in
+   * both layouts (the fuzz tests spend most of their time here); the arithmetic per element is untouched */
+  float *bt = NULL;
+  if (tb && k > 0 && n > 0) {
+    bt = (float *) malloc(sizeof(float) * (size_t) k * (size_t) n);
+    for (int64_t j = 0; j < n; j++)
+      for (int64_t kk = 0; kk < k; kk++) bt[kk * n + j] = b[j * ldb + kk];
+  }
   for (int64_t i = 0; i < m; i++) {
     for (int64_t j = 0; j < n; j++) acc[j] = 0.0f;
     for (int64_t kk = 0; kk < k; kk++) {
       const float av = ta ? a[kk * lda + i] : a[i * lda + kk];
-      if (!tb) {
-        const float *brow = b + kk * ldb;
-        for (int64_t j = 0; j < n; j++) acc[j] = fmaf(av, brow[j], acc[j]);
-      } else {
-        for (int64_t j = 0; j < n; j++) acc[j] = fmaf(av, b[j * ldb + kk], acc[j]);
-      }
+      const float *restrict brow = bt ? bt + kk * n : b + kk * ldb;
+      float *restrict ac = acc;
+      for (int64_t j = 0; j < n; j++) ac[j] = fmaf(av, brow[j], ac[j]);
     }
     float *crow = c + i * ldc;
     for (int64_t j = 0; j < n; j++) crow[j] = epilogue(alpha, acc[j], beta, crow[j]);
   }
+  free(bt);
   free(acc);
 }
 

@@ -718,6 +718,14 @@ int main(int argc, char **argv) {
       gemm_case('C', 'T', 'N', 200, 128 * 12, 96, -2.f, 0.f, 128, 0, 0, all, direct, true, 0);             // kmeans, driver shape
       csr_case(4000, 900, 16, 'R', 1.f, 0.f, all, direct);
       csr_case(3000, 700, 12, 'C', 2.f, 1.f, {1, 3, 5, 7, 0, 2, 4, 6}, direct);
+      // SURVEY 8f-4 on the node's shape: every shared panel over "PCIe" to ONE of the eight devices and from its memory
+      // to the seven others (hipMemcpyPeerAsync behind the home copy's event), panels of several chunks each; beta != 0
+      // (the ramp group's chains carry raw sums in accumulator panels), and the reference's chain arithmetic
+      g_peer_bcast = true;
+      gemm_case('R', 'N', 'N', 128 * 17 + 40, 260, 300, 1.f, 0.f, 128, 2, 0, all, direct, false, 0);
+      gemm_case('R', 'N', 'N', 128 * 16, 2304, 300, 1.f, 2.f, 128, 2, 0, all, direct, false, 0);
+      gemm_case('C', 'T', 'N', 300, 128 * 9, 200, 2.f, 1.f, 128, 0, 0, {7, 6, 5, 4, 3, 2, 1, 0}, direct, false, 0);
+      g_peer_bcast = false;
     }
     share_case(8, false);
     CHECK(bof_flash_release() == BOF_OK);

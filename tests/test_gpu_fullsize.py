@@ -217,7 +217,7 @@ def test_cfg4_rank0_slab_8192x65536x65536_closed_form(dev):
 
 
 @pytest.mark.parametrize("how", ["eight_rank_calls", "eight_devices_in_process"])
-def test_cfg4_composition_65536_files(dev, tmp_path, how):
+def test_cfg4_composition_65536_files(dev, tmp_path, how, request):
     """BASELINE configs[3] as a COMPOSITION on one GPU, on one shared A / B / C file set (3 x 16 GiB;
     32768 x 65536 x 65536 when the scratch disk is short): (a) the eight calls the ranks of the 8-GPU run
     make (bof_dist.row_shard: 8192 C rows each, A and C pointers advanced, all of B), one after the
@@ -229,19 +229,37 @@ def test_cfg4_composition_65536_files(dev, tmp_path, how):
     import shutil
     import subprocess
     import sys
+    import tempfile
+    import warnings
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    free = shutil.disk_usage(str(tmp_path)).free
+    # the scratch directory: pytest's tmp_path, or -- when that is short of the 52 GiB the full size needs -- the first
+    # of $BOF_BENCH_DIR, $TMPDIR, /tmp, /var/tmp that has them.  Only when NONE has is the problem shrunk, and that is
+    # said where the driver's log shows it (a warning in pytest's summary); BOF_REQUIRE_FULL=1 fails instead.
+    need = 52 * 2**30
+    work, free = str(tmp_path), shutil.disk_usage(str(tmp_path)).free
+    made = None
+    if free <= need:
+        for cand in (os.environ.get("BOF_BENCH_DIR"), os.environ.get("TMPDIR"), "/tmp", "/var/tmp"):
+            try:
+                if cand and os.path.isdir(cand) and shutil.disk_usage(cand).free > need:
+                    made = tempfile.mkdtemp(prefix="bof_cfg4_", dir=cand)
+                    request.addfinalizer(lambda d=made: shutil.rmtree(d, ignore_errors=True))
+                    work, free = made, shutil.disk_usage(cand).free
+                    break
+            except OSError:
+                continue
     if free < 14 * 2**30:
         pytest.skip("needs at least 12 GiB of scratch disk")
-    n = 65536 if free > 52 * 2**30 else 32768
-    # which size ran is part of the result: printed (pytest -s / the captured log), recorded in
-    # gpurun_out/cfg4_composition_<how>.json when that directory exists, and with BOF_REQUIRE_FULL=1 a short
-    # scratch disk FAILS the test instead of shrinking it
+    n = 65536 if free > need else 32768
     if n != 65536 and os.environ.get("BOF_REQUIRE_FULL") == "1":
         pytest.fail(f"BOF_REQUIRE_FULL=1: the cfg4 composition needs 52 GiB of scratch disk for 3 x 16 GiB files, "
-                    f"{free / 2**30:.0f} GiB free under {tmp_path}")
-    print(f"[cfg4 composition / {how}] running {n} x 65536 x 65536" if n == 65536 else
-          f"[cfg4 composition / {how}] SHRUNK to {n}^3 ({free / 2**30:.0f} GiB of scratch disk free, 52 needed)")
+                    f"{free / 2**30:.0f} GiB free under {work} (and no more under $BOF_BENCH_DIR, $TMPDIR, /tmp, /var/tmp)")
+    msg = (f"[cfg4 composition / {how}] ran {n} x 65536 x 65536 (FULL SIZE) under {work}" if n == 65536 else
+           f"[cfg4 composition / {how}] SHRUNK to {n}^3: {free / 2**30:.0f} GiB of scratch disk free under {work}, 52 needed "
+           f"(set BOF_BENCH_DIR to a larger volume)")
+    warnings.warn(msg)
+    print(msg)
+    tmp_path = work
     torch.cuda.empty_cache()
     extra = ["--rank-calls", "8"] if how == "eight_rank_calls" else ["--devices", "0,0,0,0,0,0,0,0"]
     # (a) from the page cache (B is re-read by every call: 8 x 16 GiB would take a minute from the device)

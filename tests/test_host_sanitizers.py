@@ -93,6 +93,10 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
             ("asan", ["brief"], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_JITTER_US": "300", "BOF_VERIFY": "1"}),
             # the 8-GPU node's shape: C panels / row blocks over eight devices, eight "ranks" through the staging ring
             ("asan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8"}),
+            # ... and the same eight DISTINCT devices under ThreadSanitizer with BOF_VERIFY armed: per-repetition stream
+            # sets, the device-to-device broadcast of the shared panels (peer_bcast), consumer-side sums and spot checks
+            # on every compute stream -- an operand read by a launch without an event between it and its copy is a race
+            ("tsan", [], {"MOCK_HIP_ASYNC": "1", "MOCK_HIP_DEVICES": "8", "BOF_VERIFY": "1"}),
             # every hipMalloc / hipHostMalloc of a gemm call (both paths) and of the CSR calls fails once: an error code
             # each time, nothing leaked (LeakSanitizer), nothing hung, the next call fine
             ("asan", ["allocfail"], {"MOCK_HIP_ASYNC": "1", "ASAN_OPTIONS": "detect_leaks=1:handle_abort=1:fast_unwind_on_malloc=0"}),
