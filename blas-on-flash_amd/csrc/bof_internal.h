@@ -139,7 +139,7 @@ void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float 
 // full_dC: when g describes ONE DEVICE'S SLAB of a larger problem (size along the C panel dimension D
 // cut down), the stored width of an operand whose columns run along D is still the whole problem's
 // (its panels are shared by all devices); 0 = g is the whole problem.
-bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group, int64_t full_dC = 0);
+bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group, int64_t full_dC = 0, bool with_acc = false);
 
 // ---- fork/join of compute streams (c_api.hip) -----------------------------------
 struct StreamSet {

@@ -361,6 +361,13 @@ struct PanelHub {
   ShareSeg seg[2];               // share_world > 1: the shared operands' node-wide staging
   int share_world = 1, share_rank = 0;
   bool peer_bcast = false;       // bof_options.peer_bcast: shared panels device to device
+  // $BOF_PANEL_WRITES_AFTER_READS=1 (experiment, round 5): the writers hold C's file writes back until the call's last
+  // read request has completed.  On a disk whose mixed read + write rate is BELOW its pure rates (the scratch disk of
+  // some leases: reads 21 -> 13 GB/s with writes going at 3) a read phase at the full rate followed by a write phase
+  // at the full rate is shorter than the two mixed; only when every C panel has an HBM slot of its own (nothing
+  // computes into a slot whose write-back it would have to wait for).
+  bool writes_after_reads = false;
+  std::atomic<uint64_t> chunks_total{0}, chunks_done{0};
   double share_timeout_s = 120;
   std::mutex mu;
   std::condition_variable cv;
@@ -579,6 +586,7 @@ void PanelHub::reader_main(int home) {
       if (vlk.owns_lock()) vlk.unlock();
     }
     rring->release(ps);
+    chunks_done++;
     {
       // the copies above are enqueued before these decrements, so whoever brings a panel's count
       // to zero records `ready` behind every copy of the panel on that device
@@ -667,6 +675,10 @@ void PanelHub::writer_main(int home) {
   WriteReq rq;
   while (write_q.pop(rq)) {
     PanelRun &R = *runs[(size_t) rq.di];
+    if (writes_after_reads) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return io_error.load() || chunks_done.load() >= chunks_total.load(); });
+    }
     hipError_t e = hipEventSynchronize(R.res->wring.event(rq.wslot));
     if (e != hipSuccess) fail_io(-1000 - (int) e);
     evt("C chunk D2H complete, write begin", rq.panel, rq.wslot, rq.file_off >> 20);
@@ -742,10 +754,8 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
   // raw accumulator panels: only a chain of several launches on a C that is read (beta != 0) needs them -- one per C
   // panel of the ramp group, of a C slot's size
   need_acc = !ref_chain && c_read && Nk > 1;
-  auto fits = [&](const bof_panel_plan &p2) {
-    return p2.eligible && (!need_acc || p2.need_bytes + (uint64_t) p2.first_group * p2.slot_bytes[2] <= budget);
-  };
-  bof_panel_plan pl = plan_panels(g, budget, 1, full_dC);
+  auto fits = [&](const bof_panel_plan &p2) { return p2.eligible != 0; };      // (plan_panels counts the accumulator panels in)
+  bof_panel_plan pl = plan_panels(g, budget, 1, full_dC, need_acc);
   if (!fits(pl)) return 1;
   {
     // size of the ramp group (see the header): read time of one panel of the resident operand
@@ -764,7 +774,7 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
       want = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 8), NpC / 2));
     }
     for (int64_t G = std::min(want, NpC); G > 1; G--) {
-      const bof_panel_plan p2 = plan_panels(g, budget, G, full_dC);
+      const bof_panel_plan p2 = plan_panels(g, budget, G, full_dC, need_acc);
       if (fits(p2)) { pl = p2; break; }
     }
   }
@@ -1432,6 +1442,20 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     }
   }
   for (int x = 0; x < 2; x++) H.issued[x].assign(H.runs[0]->mat[x].panels.size(), 0);
+  {
+    uint64_t total = 0;
+    bool c_all_resident = true;
+    for (auto &R : H.runs) {
+      c_all_resident = c_all_resident && R->mat[2].natural;
+      for (const auto &xp : R->order) {
+        const Mat &M = R->mat[xp.first];
+        if (M.shared && R->di != 0) continue;          // read once for all devices
+        total += (uint64_t) M.n_chunks(xp.second, R->chunk);
+      }
+    }
+    H.chunks_total.store(total);
+    H.writes_after_reads = c_all_resident && env_long("BOF_PANEL_WRITES_AFTER_READS", 0) != 0;
+  }
   H.peer_bcast = H.runs.size() > 1 && (o.peer_bcast == 1 || (o.peer_bcast == 0 && env_long("BOF_PEER_BCAST", 0) > 0));
   guard.add([&H] {
     // a rank that gives up tells the peers so (they would wait for the timeout otherwise)

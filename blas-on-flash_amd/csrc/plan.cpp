@@ -62,7 +62,10 @@ void gemm_task_at(const GemmGeometry &g, int64_t l, int64_t i, int64_t j, float 
 // resident; the other one ("X") streams through a ring of 2*group slots when it is paneled along
 // D too, else it is resident as well; C gets a ring of 2*group+1 slots, deepened with spare
 // budget.  Slots are 2 MiB-aligned.
-bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group, int64_t full_dC) {
+// with_acc: the call also needs one raw accumulator panel (a C slot) per C panel of the first group (beta != 0 with the
+// default arithmetic, bof_options.gemm_chain): they are part of what must fit, and are set aside BEFORE spare budget
+// deepens the C ring.  need_bytes stays the panel slots alone; acc_bytes says what comes on top.
+bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group, int64_t full_dC, bool with_acc) {
   bof_panel_plan P{};
   P.streamed = -1;
   auto up = [](uint64_t v) { return (v + (2u << 20) - 1) / (2u << 20) * (2u << 20); };
@@ -94,8 +97,10 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
   // every panel slot is an HBM allocation of its own (flash_gemm_panels.cpp allocates them in
   // first-use order while the first panels are read), resident matrices hold one slot per panel
   auto need_of = [&](int x) { return (uint64_t) P.n_slots[x] * P.slot_bytes[x]; };
+  P.acc_bytes = g.nblk[1] > 1 ? (uint64_t) group * P.slot_bytes[2] : 0;
   uint64_t need = need_of(0) + need_of(1) + need_of(2);
   P.need_bytes = need;
+  if (with_acc) need += P.acc_bytes;
   if (need > budget) { P.why = 5; return P; }
   // spare budget: a deeper C ring lets compute run ahead of a slow write-back
   while (P.n_slots[2] < NpC && need + P.slot_bytes[2] <= budget && P.n_slots[2] < 2 * group + 4) {
@@ -104,7 +109,6 @@ bof_panel_plan plan_panels(const GemmGeometry &g, uint64_t budget, int64_t group
   }
   if (P.n_slots[2] == NpC) P.resident[2] = 1;
   P.need_bytes = need_of(0) + need_of(1) + need_of(2);
-  P.acc_bytes = g.nblk[1] > 1 ? (uint64_t) P.first_group * P.slot_bytes[2] : 0;
   P.eligible = 1;
   return P;
 }

@@ -145,7 +145,8 @@ def test_flash_gemm_result_does_not_depend_on_the_cut(dev, tmp_path, ord_, ta, t
             bofhip.flash_gemm(ord_, ta, tb, m, n, k, 0.5, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
                               bofhip.default_options(n_io_threads=3, pinned_slots=4, io_chunk_mib=1, verify=1, **kw))
             assert np.array_equal(F.read("c", np.float32, sc), ref), kw
-            if "hbm_budget" not in kw:       # (a budget of 14 tiles re-reads operands it had to evict)
+            if "hbm_budget" not in kw and not ("devices" in kw and kw["gemm_path"] == 1):
+                # (a budget of 14 tiles re-reads operands it had to evict; tile-cache slabs of several devices each read B)
                 assert bofhip.flash_last_stats()["bytes_read"] == 4 * (a.size + b.size + (c0.size if beta else 0)), kw
             c0.tofile(F.paths["c"])
             os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
