@@ -94,12 +94,25 @@ csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ v
           for (int u = 0; u < UNROLL; u++) vfma<VEC>(vv[u], bv[u], acc);
         }
       }
-      for (; tI < cnt; tI++) {
-        const int c = __builtin_amdgcn_readlane(mycol, tI);
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), tI));
+      // the last cnt % UNROLL entries of the chunk: ONE more batch with the absent slots switched off (wave-uniform
+      // tests), not one gather at a time -- at 100 non-zeros per row (cfg3: 64 + 36) the four single gathers of the
+      // second chunk were four exposed latencies out of sixteen per row
+      if (tI < cnt) {
+        const int rem = cnt - tI;
+        V bv[UNROLL];
+        float vv[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL - 1; u++) {
+          if (u < rem) {
+            const int c = __builtin_amdgcn_readlane(mycol, tI + u);
+            vv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), tI + u));
+            if (active) bv[u] = *reinterpret_cast<const V *>(B + (int64_t) c * ldb + j);
+          }
+        }
         if (active) {
-          const V b = *reinterpret_cast<const V *>(B + (int64_t) c * ldb + j);
-          vfma<VEC>(v, b, acc);
+#pragma unroll
+          for (int u = 0; u < UNROLL - 1; u++)
+            if (u < rem) vfma<VEC>(vv[u], bv[u], acc);
         }
       }
     }
@@ -235,7 +248,18 @@ csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
       sh[w][o + 128] = make_float2(v2, x2);
       sh[w][o + 192] = make_float2(v3, x3);
     }
-    for (; o < cnt; o += 64) sh[w][o] = make_float2(val[p0 + o], x[col[p0 + o]]);
+    // the last (up to three) chunks: their gathers in flight together too, absent ones switched off per lane -- at
+    // 10 non-zeros per row (cfg5: 640 entries per wave = two batches of four + two chunks) the two single chunks were
+    // two exposed gather latencies out of four
+    if (o < cnt) {
+      const bool h1 = o + 64 < cnt, h2 = o + 128 < cnt;
+      const int64_t c0 = col[p0 + o], c1 = h1 ? col[p0 + o + 64] : 0, c2 = h2 ? col[p0 + o + 128] : 0;
+      const float v0 = val[p0 + o], v1 = h1 ? val[p0 + o + 64] : 0.f, v2 = h2 ? val[p0 + o + 128] : 0.f;
+      const float x0 = x[c0], x1 = h1 ? x[c1] : 0.f, x2 = h2 ? x[c2] : 0.f;
+      sh[w][o] = make_float2(v0, x0);
+      if (h1) sh[w][o + 64] = make_float2(v1, x1);
+      if (h2) sh[w][o + 128] = make_float2(v2, x2);
+    }
   }
   __syncthreads();
   if (lane >= nrows) return;

@@ -382,6 +382,33 @@ inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUM
   fclose(f);
 }                          // times in a dump are relative to the last of these
 
+// ---- host-confirmed hand-overs (round 5) ----------------------------------------------------------------------
+// Every dependency between work that DIFFERENT host threads submit -- a reader's H2D copies and the kernels that
+// read them, a panel's last kernels and its write-back, a slot's old occupant and the copy that refills it -- is
+// confirmed ON THE HOST by the consuming side (hipEventSynchronize on an event that the producing thread itself
+// recorded right behind its own submission) before the dependent work is submitted; the device-side
+// hipStreamWaitEvent stays, as a second line.  Why: what the instrumented fuzz of round 5 finally SAW (1 in 936 000
+// cases, profiles/r5/fuzz_summary.md) is a kernel that summed an operand tile on one stream and got other words than a
+// kernel that summed it on another stream later -- one of them ran before an H2D copy that precedes it in stream /
+// event order had landed.  Every such order in the failing configuration crossed host threads (copies submitted by a
+// reader thread, the kernel behind them by a launcher thread, the event by whichever reader finished the group); all
+// wrong results of rounds 3-4 had cross-thread submission in common too.  The only ordering the pipelines still rely
+// on without a host check is the most basic one: operations one thread submits to one stream run in that order.
+// Cost: a reader waits ~0.6 ms for its 32 MiB copy before it takes the next request (the disk, not the readers,
+// bounds the pipelines).  $BOF_HOST_HANDOVER=0 restores the device-side-only hand-overs (A/B switch).
+inline bool host_handover() {
+  static const bool on = env_long("BOF_HOST_HANDOVER", 1) != 0;
+  return on;
+}
+// the consumer's side of a hand-over: host check (when on), then the device-side wait as before
+inline hipError_t wait_event_both(hipStream_t st, hipEvent_t ev) {
+  if (host_handover()) {
+    const hipError_t e = hipEventSynchronize(ev);
+    if (e != hipSuccess) return e;
+  }
+  return hipStreamWaitEvent(st, ev, 0);
+}
+
 // ---- persistent launcher threads ------------------------------------------------------------------------------
 // Kernel launches are only ever issued by the CALLING thread or by one of these long-lived threads, never by a
 // thread created for the call.  Why -- CORRELATED, NOT PROVEN (profiles/r4/fuzz_thread_bisect.md, sections 4-6): with a

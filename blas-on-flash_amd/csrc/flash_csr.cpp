@@ -263,6 +263,9 @@ struct CsrRun {
         cnt.h2d += c_bytes(b);
       }
       if (!rc && e == hipSuccess) e = hipEventRecord(c.ready, h2d);
+      // host-confirmed hand-over (flash_common.h): this thread saw its own copies of the block complete before the
+      // dispatcher (another thread, another stream) is shown the block
+      if (!rc && e == hipSuccess && host_handover()) e = hipEventSynchronize(c.ready);
       // the pinned buffers are reused only after this block retires (owner hand-over),
       // which is after its kernels, which wait for these copies
       if (rc) fail_io(rc);
@@ -833,7 +836,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
         const int fed = ex->shared_fed->get();      // the feeder has queued every copy and recorded the event
         if (fed) return fed;
       }
-      BOF_HIP_TRY(hipStreamWaitEvent(R.h2d, ex->shared_ready, 0));
+      BOF_HIP_TRY(wait_event_both(R.h2d, ex->shared_ready));      // (recorded by the feeder thread)
       if (!is_mm && trans == 'T' && !ext_y) BOF_HIP_TRY(hipMemsetAsync(d_y, 0, (size_t) ylen * 4, R.h2d));
       BOF_HIP_TRY(hipEventRecord(resident_ev, R.h2d));
       return BOF_OK;
@@ -937,6 +940,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     set_error("flash csr: bringing the resident operand (B / x) into HBM failed");
     fail = resident_rc;
   }
+  if (!fail && host_handover()) herr = hipEventSynchronize(resident_ev);       // (recorded by the upload thread)
   for (int i = 0; i < ss->n && !fail && herr == hipSuccess; i++) herr = hipStreamWaitEvent(ss->s[i], resident_ev, 0);
   for (int64_t b = 0; b < nb && !fail && herr == hipSuccess; b++) {
     CsrCtx &c = R.ctx[b % R.depth];

@@ -549,7 +549,7 @@ void PanelHub::reader_main(int home) {
       const int prev = M.natural ? -1 : rq.panel - M.n_slots;
       if (prev >= 0)  // WAR: the slot's previous occupant (its events were recorded before it retired)
         for (hipEvent_t w : M.panels[(size_t) prev].retire_ev)
-          if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, w, 0);
+          if (e == hipSuccess) e = wait_event_both(R.h2d, w);
       std::unique_lock<std::mutex> vlk(R.vf_mu, std::defer_lock);
       if (R.vf.on && !rc) {
         R.vf.on_host(M.panels[(size_t) rq.panel].ve[Panel::VE_HOST_IN], slot + delta, 1, (int64_t) (rq.bytes / 4), 0, rq.off / 4);
@@ -566,14 +566,18 @@ void PanelHub::reader_main(int home) {
           PN.poisoned = true;
           e = R.vf.poison(M.panel_ptr(rq.panel), PN.bytes, R.h2d);
           if (e == hipSuccess && M.kmajor_copy && !M.whole) e = R.vf.poison(M.tpanel_ptr(rq.panel), (size_t) PN.nr * (size_t) M.cols * 4, R.h2d);
+          // (the sum of the old panel and the poison were queued by the launcher thread, the copy below comes from
+          //  this one: host-confirmed so that the copy cannot overtake them)
+          if (e == hipSuccess && host_handover()) e = hipStreamSynchronize(R.h2d);
         }
       }
       if (bcast && d != home) {
         PanelRun &Hm = *runs[home];
-        if (e == hipSuccess) e = hipStreamWaitEvent(R.h2d, rring->event(ps, Hm.di), 0);     // the home copy of this chunk
+        if (e == hipSuccess) e = wait_event_both(R.h2d, rring->event(ps, Hm.di));     // the home copy of this chunk
         if (e == hipSuccess && !rc)
           e = hipMemcpyPeerAsync(M.panel_ptr(rq.panel) + rq.off, R.dev, Hm.mat[rq.mat].panel_ptr(rq.panel) + rq.off, Hm.dev,
                                  rq.bytes, R.h2d);
+        if (e == hipSuccess && rring->mark_busy(ps, R.h2d, R.di)) e = hipErrorUnknown;   // (an event behind the peer copy: confirmed below)
         cnt.p2p += rq.bytes;
         R.cnt.p2p += rq.bytes;
       } else {
@@ -584,42 +588,53 @@ void PanelHub::reader_main(int home) {
         R.cnt.h2d += rq.bytes;
       }
       if (vlk.owns_lock()) vlk.unlock();
+      // host-confirmed hand-over (flash_common.h): THIS thread saw its own copy of the chunk complete on this device
+      // before the chunk counts as delivered (the home copy of a broadcast chunk before its peers' copies start)
+      if (host_handover() && e == hipSuccess && !rc && bcast && pass == 0) e = hipEventSynchronize(rring->event(ps, R.di));
     }
+    if (host_handover() && e == hipSuccess && !rc)       // (all devices' copies are in flight; now each is confirmed)
+      for (size_t d = d0; d < d1 && e == hipSuccess; d++)
+        if (!(bcast && d == home)) e = hipEventSynchronize(rring->event(ps, runs[d]->di));
     rring->release(ps);
     chunks_done++;
+    // the chunk is delivered: whoever brings a panel's count to zero on a device finishes the panel there -- the
+    // kernels behind its last copy (k-major copy, BOF_VERIFY's sums), `ready`, and (host-confirmed hand-over) the
+    // wait for all of that -- OUTSIDE the hub's mutex, and only then shows the panel to the dispatcher
+    std::vector<size_t> finish;
     {
-      // the copies above are enqueued before these decrements, so whoever brings a panel's count
-      // to zero records `ready` behind every copy of the panel on that device
       std::lock_guard<std::mutex> lk(mu);
-      for (size_t d = d0; d < d1; d++) {
-        PanelRun &R = *runs[d];
-        Mat &M = R.mat[rq.mat];
-        Panel &P = M.panels[(size_t) rq.panel];
-        if (--P.remaining == 0) {
-          if (e == hipSuccess) e = hipSetDevice(R.dev);
-          // kernels behind the panel's last copy (the k-major copy; BOF_VERIFY's sums): launched by a PERSISTENT
-          // launcher thread, not by this reader, which was created for the call (flash_common.h, "persistent
-          // launcher threads"); this thread waits for the launches to be queued, then records `ready` behind them
-          if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
-          if (e == hipSuccess && M.kmajor_copy) {
-            e = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
-            if (e == hipSuccess)
-              e = launch_from_persistent(R.dev, [&] {
-                return transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
-                                     M.t_ld(rq.panel), R.h2d);
-              });
-            if (e == hipSuccess)
-              e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, M.t_ld(rq.panel), 0, M.cols, R.h2d);
-          }
-          if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
-          // a failed copy / record must be visible BEFORE the panel is: the dispatcher tests io_error right
-          // after it sees state 2, and a `ready` that was never recorded would make its wait a no-op
-          if (e != hipSuccess || rc) { int none = 0; io_error.compare_exchange_strong(none, rc ? rc : -1000 - (int) e); }
-          P.state = 2;
-          evt("panel H2D queued (ready recorded)", rq.mat, rq.panel, (uint64_t) R.di);
-          R.trace2("read + H2D queued:", rq.mat, rq.panel);
-        }
+      for (size_t d = d0; d < d1; d++)
+        if (--runs[d]->mat[rq.mat].panels[(size_t) rq.panel].remaining == 0) finish.push_back(d);
+    }
+    for (size_t d : finish) {
+      PanelRun &R = *runs[d];
+      Mat &M = R.mat[rq.mat];
+      Panel &P = M.panels[(size_t) rq.panel];
+      if (e == hipSuccess) e = hipSetDevice(R.dev);
+      // (launched by a PERSISTENT launcher thread, not by this reader, which was created for the call: flash_common.h,
+      //  "persistent launcher threads"; this thread waits for the launches to be queued, then records `ready` behind them)
+      if (e == hipSuccess) e = R.vf.on_device(P.ve[Panel::VE_DEV_IN], M.panel_ptr(rq.panel), 1, (int64_t) (P.bytes / 4), 0, 0, 0, R.h2d);
+      if (e == hipSuccess && M.kmajor_copy) {
+        e = R.vf.on_device(P.ve[Panel::VE_RECT_IN], M.panel_ptr(rq.panel), P.nr, M.cols, M.ld, 0, 0, R.h2d);
+        if (e == hipSuccess)
+          e = launch_from_persistent(R.dev, [&] {
+            return transpose_f32((const float *) M.panel_ptr(rq.panel), M.ld, P.nr, M.cols, (float *) M.tpanel_ptr(rq.panel),
+                                 M.t_ld(rq.panel), R.h2d);
+          });
+        if (e == hipSuccess)
+          e = R.vf.on_device(P.ve[Panel::VE_T_IN], M.tpanel_ptr(rq.panel), M.cols, P.nr, M.t_ld(rq.panel), 0, M.cols, R.h2d);
       }
+      if (e == hipSuccess) e = hipEventRecord(P.ready, R.h2d);
+      if (e == hipSuccess && host_handover() && (M.kmajor_copy || R.vf.on)) e = hipEventSynchronize(P.ready);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        // a failed copy / record must be visible BEFORE the panel is: the dispatcher tests io_error right
+        // after it sees state 2, and a `ready` that was never recorded would make its wait a no-op
+        if (e != hipSuccess || rc) { int none = 0; io_error.compare_exchange_strong(none, rc ? rc : -1000 - (int) e); }
+        P.state = 2;
+      }
+      evt("panel in HBM (ready recorded)", rq.mat, rq.panel, (uint64_t) R.di);
+      R.trace2("read + H2D done:", rq.mat, rq.panel);
     }
     if (e != hipSuccess) fail_io(-1000 - (int) e);
     cv.notify_all();
@@ -638,7 +653,7 @@ void PanelRun::flusher_main() {
     hipError_t e = hipSuccess;
     evt("C panel handed to the flusher", pc, di);
     for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
-      if (e == hipSuccess) e = hipStreamWaitEvent(d2h, w, 0);
+      if (e == hipSuccess) e = wait_event_both(d2h, w);      // (the dispatcher recorded them; this thread copies)
     if (e == hipSuccess) e = vf.on_device(P.ve[Panel::VE_C_DEV], C.panel_ptr(pc), 1, (int64_t) (P.bytes / 4), 0, 0, 0, d2h);
     const int nc = C.n_chunks(pc, chunk);
     for (int c = 0; c < nc && e == hipSuccess && !hub->io_error.load(); c++) {
@@ -1166,15 +1181,20 @@ void PanelRun::dispatch() {
           if (w) continue;
           w = 1;
           herr = hipStreamWaitEvent(st, mat[x].panels[(size_t) pp].ready, 0);
+          evt("stream waits for panel ready", x, (int) pp, (uint64_t) (((uint64_t) di << 8) | (uint64_t) sidx));
         }
       if (herr == hipSuccess && (reads_c || (writes_c && !c_read))) {
         char &w = waited[(size_t) 2 * (size_t) ss->n + (size_t) sidx][(size_t) L.pc];
         if (!w) {
           w = 1;
-          if (reads_c) herr = hipStreamWaitEvent(st, C.panels[(size_t) L.pc].ready, 0);
-          else if (cprev >= 0)
+          if (reads_c) {
+            herr = hipStreamWaitEvent(st, C.panels[(size_t) L.pc].ready, 0);
+            evt("stream waits for panel ready", 2, L.pc, (uint64_t) (((uint64_t) di << 8) | (uint64_t) sidx));
+          } else if (cprev >= 0) {
             for (hipEvent_t e : C.panels[(size_t) cprev].retire_ev)
-              if (herr == hipSuccess) herr = hipStreamWaitEvent(st, e, 0);
+              if (herr == hipSuccess) herr = wait_event_both(st, e);       // (the flusher recorded it behind its D2H copies)
+            evt("stream waits for C slot write-back", cprev, L.pc, (uint64_t) (((uint64_t) di << 8) | (uint64_t) sidx));
+          }
         }
       }
       if (herr != hipSuccess) break;

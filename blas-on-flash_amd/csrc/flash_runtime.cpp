@@ -425,7 +425,7 @@ struct GemmRun {
         const Tile &t = tiles[G.tiles[q]];
         DevSlot &s = slots[G.slots[q]];
         for (hipEvent_t w : G.waits[q])  // WAR: previous occupant's kernels / write-back (every chunk: cheap, order-free)
-          if (e == hipSuccess) e = hipStreamWaitEvent(h2d, w, 0);
+          if (e == hipSuccess) e = wait_event_both(h2d, w);      // (host-confirmed hand-over: flash_common.h)
         const size_t tw = (size_t) t.ncols * 4;
         std::unique_lock<std::mutex> vlk(vf_mu, std::defer_lock);
         if (vf.on && !rc) {
@@ -440,6 +440,8 @@ struct GemmRun {
             if (e == hipSuccess) e = verify_old_tile(G.prev_ve_in[q], s.ptr, G.prev_rows[q], G.prev_cols[q], h2d, G.tiles[q]);
             // ... and the slot is poisoned (NaN) before the first byte of the new tile: a read ahead of the fill shows
             if (e == hipSuccess) e = vf.poison(s.ptr, tile_bytes(t), h2d);
+            // (both were queued by the launcher thread, the copy below comes from this one: host-confirmed)
+            if (e == hipSuccess && host_handover()) e = hipStreamSynchronize(h2d);
           }
         }
         if (e == hipSuccess && !rc)
@@ -449,6 +451,8 @@ struct GemmRun {
         col += t.ncols;
       }
       if (e == hipSuccess && res->rring.mark_busy(ps, h2d)) e = hipErrorUnknown;   // or the slot would be refilled under the copy
+      // host-confirmed hand-over: this thread saw its own copies of the chunk complete before the chunk counts
+      if (host_handover() && e == hipSuccess && !rc) e = hipEventSynchronize(res->rring.event(ps));
       cnt.h2d += bytes;
       res->rring.release(ps);
       bool last = false;
@@ -959,7 +963,7 @@ static int flash_gemm_tilecache(char ord, char ta, char tb, int64_t m, int64_t n
       DevSlot &s = R.slots[tl.slot];
       if (x != 2 || (tk.l == 0 && tk.beta != 0.0f && !R.cin)) herr = hipStreamWaitEvent(st, s.ready, 0);
       for (hipEvent_t w : tl.launch_waits)
-        if (herr == hipSuccess) herr = hipStreamWaitEvent(st, w, 0);
+        if (herr == hipSuccess) herr = wait_event_both(st, w);
       tl.launch_waits.clear();
       if (tl.prev_ve_in != Verify::kNone && herr == hipSuccess) {   // slot taken without a fetch: its old tile, once more
         herr = R.verify_old_tile(tl.prev_ve_in, s.ptr, tl.prev_rows, tl.prev_cols, st, ids[x]);

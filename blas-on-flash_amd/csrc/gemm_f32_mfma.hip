@@ -1213,6 +1213,18 @@ sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float 
   }
 }
 
+// per-device pools of call-lifetime HIP events (flash_support.cpp)
+hipError_t pooled_event(hipEvent_t *e, bool timing);
+void pooled_event_return(hipEvent_t e);
+// the stream the ragged strips of a big launch run on beside its interior kernel: one per host thread and device
+static hipStream_t strip_stream() {
+  static thread_local hipStream_t s[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void) hipGetLastError(); return nullptr; }
+  if (!s[dev] && hipStreamCreateWithFlags(&s[dev], hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); s[dev] = nullptr; }
+  return s[dev];
+}
+
 // debug / test knobs of the kernel choice, read at every launch
 static int knob(const char *name, int dflt) {
   const char *e = getenv(name);
@@ -1259,6 +1271,14 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
   const int short_k = knob("BOF_GEMM_SHORT_K", 512);
   if (vec_ld && k_ok && K >= short_k && (int64_t) (Mi / 256) * (Ni / 256) >= 128 && lda < (1 << 22) && ldb < (1 << 22)) {
     const int tiles_m = Mi / 256, tiles_n = Ni / 256;
+    hipEvent_t fork_ev = nullptr;
+    if ((N > Ni || M > Mi) && (int64_t) tiles_m * tiles_n >= 1024 && knob("BOF_GEMM_STRIP_STREAM", 1) != 0) {
+      if (pooled_event(&fork_ev, false) != hipSuccess || hipEventRecord(fork_ev, st) != hipSuccess) {
+        (void) hipGetLastError();
+        if (fork_ev) pooled_event_return(fork_ev);
+        fork_ev = nullptr;
+      }
+    }
     if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
       hipLaunchKernelGGL(sgemm_tile256_dma2_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                          ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
@@ -1273,17 +1293,36 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
                          0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (N == Ni && M == Mi) return e;
+    // The strips touch other elements of C than the interior and only read A and B: on a big launch they run on a
+    // stream of their own BESIDE the interior kernel instead of behind it (forked from `st` in front of the interior,
+    // joined behind it) -- two launches of a 128-deep slab loop each, 0.9 ms of a 54 ms product at the paper's
+    // 31000-edge shape (profiles/r5/ragged_probe.txt: 146.7 TFLOP/s interior alone, 144.4 with the strips behind it).
+    // One such stream per host thread and device, kept for the life of the thread (BOF_GEMM_STRIP_STREAM=0: off).
+    hipStream_t ss = st;
+    hipEvent_t ev_join = nullptr;
+    if (fork_ev) {
+      ss = strip_stream();
+      if (!ss || hipStreamWaitEvent(ss, fork_ev, 0) != hipSuccess) { (void) hipGetLastError(); ss = st; }
+    }
     if (N > Ni) {  // right strip: rows [0, Mi), columns [Ni, N)
       const float *Bs = (BMODE == XMAJOR) ? B + (int64_t) Ni * ldb : B + Ni;
-      e = launch_guarded<AMODE, BMODE>(A, lda, Bs, ldb, C + Ni, ldc, Mi, N - Ni, K, alpha, beta, st,
+      e = launch_guarded<AMODE, BMODE>(A, lda, Bs, ldb, C + Ni, ldc, Mi, N - Ni, K, alpha, beta, ss,
                                        epi_shift(ep, 0, Ni));
-      if (e != hipSuccess) return e;
     }
-    if (M > Mi) {  // bottom strip: rows [Mi, M), all columns
+    if (e == hipSuccess && M > Mi) {  // bottom strip: rows [Mi, M), all columns
       const float *As = (AMODE == XMAJOR) ? A + (int64_t) Mi * lda : A + Mi;
       e = launch_guarded<AMODE, BMODE>(As, lda, B, ldb, C + (int64_t) Mi * ldc, ldc, M - Mi, N, K, alpha,
-                                       beta, st, epi_shift(ep, Mi, 0));
+                                       beta, ss, epi_shift(ep, Mi, 0));
     }
+    if (ss != st) {       // join: whatever comes behind this sgemm on `st` also waits for the strips
+      hipError_t j = pooled_event(&ev_join, false);
+      if (j == hipSuccess) j = hipEventRecord(ev_join, ss);
+      if (j == hipSuccess) j = hipStreamWaitEvent(st, ev_join, 0);
+      if (ev_join) pooled_event_return(ev_join);
+      if (e == hipSuccess) e = j;
+    }
+    if (fork_ev) pooled_event_return(fork_ev);
     return e;
   }
   const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;

@@ -55,6 +55,9 @@ namespace flash {
     o.use_odirect = sched.use_odirect ? 1 : 0;
     o.gemm_path = (int32_t) env_long("BOF_GEMM_PATH", 0);       // 0 choose, 1 tile cache, 2 panels
     o.io_chunk_mib = (int32_t) env_long("BOF_IO_CHUNK_MIB", 0);
+    // 0 (default): one k-ordered chain per output element over the whole K = drivers/in_mem_gemm.cpp's single call;
+    // 1: the reference's task arithmetic, one rounding per k-block (src/blas/gemm.cpp:122-127)
+    o.gemm_chain = (int32_t) env_long("BOF_GEMM_CHAIN", 0);
     o.n_devices = (int32_t) g_devices.size();
     for (size_t i = 0; i < g_devices.size(); i++) o.devices[i] = g_devices[i];
     return o;

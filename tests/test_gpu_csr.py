@@ -104,6 +104,26 @@ def test_csrmm_resident_blocks_and_panels(dev, golden):
                               "X", ptr(db), ptr(dc), opts, stream())
 
 
+@pytest.mark.parametrize("k", [64, 128, 200])
+def test_scsrmm_every_row_length(dev, k):
+    """Rows of 0 .. 139 non-zeros, one of each: every remainder of the kernel's batches of eight gathers (the last
+    1 .. 7 entries of a 64-entry chunk go out as ONE predicated batch), one and two chunks, and the chunk boundary
+    itself (64, 65, 128, 129); random values -- the fmaf chain per output element in storage order, bit for bit."""
+    rng = np.random.default_rng(100 + k)
+    m, n = 140, 3000
+    counts = np.arange(m)
+    ia = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ja = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts]).astype(np.int64)
+    val = rng.uniform(-1, 1, ja.size).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    ref = orc.scsrmm("R", m, k, n, 0.5, val, ja, ia, b, k, 2.0, c0.copy(), k)
+    dv, di, dj, db, dc = to_dev(val), to_dev(ia), to_dev(ja), to_dev(b), to_dev(c0)
+    bofhip.scsrmm("R", m, k, n, 0.5, ptr(dv), ptr(dj), ptr(di), ptr(db), k, 2.0, ptr(dc), k, stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+
+
 def test_golden_mkl_csrgemv(dev, golden):
     for t in meta_rows(golden, "csrgemv"):
         key, mat = t[0], t[4]

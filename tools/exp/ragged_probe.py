@@ -28,7 +28,7 @@ st = torch.cuda.current_stream().cuda_stream
 K = 4096
 big = 31040
 a = torch.empty(big * big, dtype=torch.float32, device=dev)      # large enough for every A / B / C below
-b = torch.empty(big * big, dtype=torch.float32, device=dev)
+b = torch.empty(32768 * 32768, dtype=torch.float32, device=dev)   # (the whole-K launches read a 32768 x 32768 B)
 c = torch.zeros(big * big, dtype=torch.float32, device=dev)
 bofhip.gen_dense(a.data_ptr(), 0, a.numel(), "u", 1, st)
 bofhip.gen_dense(b.data_ptr(), 0, b.numel(), "u", 2, st)
@@ -40,6 +40,7 @@ for label, ta, tb, m, n, lda, ldb, ldc in [
         ("interior 30976^2, tight, NN", "N", "N", 30976, 30976, K, 30976, 30976),
         ("interior 30976^2, ldb/ldc 31000, NN", "N", "N", 30976, 30976, K, 31000, 31000),
         ("whole 31000^2, NN", "N", "N", 31000, 31000, K, 31000, 31000),
+        ("C panel 4096+100 rows x 32768+100 (tail-merged panel of a ragged problem), TN", "T", "N", 4196, 30900, 4196, 30900, 30900),
         ("30720^2 (120 x 120 tiles), tight, TN", "T", "N", 30720, 30720, 30720, 30720, 30720),
         ("32768^2, tight, TN", "T", "N", 32768 - 2048, 32768 - 2048, 32768 - 2048, 32768 - 2048, 32768 - 2048)]:
     f = lambda: bofhip.sgemm("R", ta, tb, m, n, K, 1.0, a.data_ptr(), lda, b.data_ptr(), ldb, 0.0, c.data_ptr(), ldc, st)
