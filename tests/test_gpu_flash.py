@@ -297,6 +297,18 @@ def test_flash_gemm_io_uring_engine_subprocess(dev):
     assert r.returncode == 0, r.stdout[-2500:]
 
 
+def test_flash_gemm_device_side_handovers_subprocess(dev):
+    """BOF_HOST_HANDOVER=0 (read once per process): the hand-overs of rounds 1-4 -- device-side event waits only, no
+    host confirmation by the consuming thread -- stay a supported A/B configuration: the panel-ring, the 8-layout and the
+    reference-chain file tests again in a child process with it."""
+    import sys
+    env = dict(os.environ, BOF_HOST_HANDOVER="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                        "panels_ring_reuse or layouts_unaligned or reference_chain"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:]
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_flash_gemm_unaligned_foffset_small_dims(dev, tmp_path, path):
     """flash_ptr + a byte offset that is not sector aligned (12-byte headers), dimensions smaller
