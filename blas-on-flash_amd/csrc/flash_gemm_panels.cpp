@@ -9,20 +9,24 @@
 //   * reads and writes are a handful of large sequential requests per panel (io_chunk_mib,
 //     default 32 MiB) instead of thousands of row requests per tile; every request lands in a
 //     pinned staging slot and crosses PCIe as one linear SDMA copy;
-//   * no packing anywhere: a tile task is `pointer into a panel + leading dimension`, exactly
-//     what the level-2 tile DAG passes to the kernel (for a k-contiguous operand: into the
-//     panel's k-major copy, made once per panel on the H2D stream -- Mat::kmajor_copy);
+//   * no packing anywhere: a launch is `pointer into a panel + leading dimension` (for a
+//     k-contiguous operand: into the panel's k-major copy, made once per panel on the H2D stream --
+//     Mat::kmajor_copy);
 //   * C panels are written back as they complete, while the next panels compute.
 //
-// Schedule (same tasks, same k-order per accumulate chain as src/blas/gemm.cpp:83-129, so
-// the result is bit-identical to the tile path): the first `group` C panels are processed
-// together, l-major, the others one by one (l-major too).  The first group is the ramp: while the
-// resident operand streams in, panel l of it unlocks `group` x (tiles per C panel) tile tasks,
-// and `group` is chosen so that those take as long as the panel's read (65536^3 from O_DIRECT
-// files: a 1 GiB B panel takes 55 ms to read, the 16 tasks of one C panel 15 ms -- with one C
-// panel per group the first panel's time was all I/O: 4.9 s, with a ramp of 4 panels 4.4 s).
-// Later panels have everything resident but their own X panel, and finish -- and are written
-// back -- one at a time, which keeps the tail after the last kernel to one panel.
+// Schedule: a list of LAUNCHES (C panel, k-block range), round 5.  The first `group` C panels are the
+// ramp: while the resident operand streams in they run k-block by k-block, l-major -- one launch per
+// (panel, k-block) over the whole panel width -- so that panel l of the resident operand unlocks
+// `group` launches, and `group` is chosen so that those take as long as the panel's read (65536^3 from
+// O_DIRECT files: a 1 GiB B panel takes 55 ms to read, a panel's k-block launch 15 ms).  Every later C
+// panel has everything resident but its own X panel and runs as ONE launch over the whole K, and is
+// written back when it is done, which keeps the tail after the last kernel to one panel.  A chain
+// that runs as several launches hands its RAW fp32 accumulators from launch to launch and scales once
+// at the end (gemm_f32_mfma.hip, ChainEpi), so every cut of K gives the bits of a single launch over
+// the whole K: the C file does not depend on the tile size, the ramp group or the device list, and
+// equals what drivers/in_mem_gemm.cpp:63-70 computes (bof_options.gemm_chain = 1: the reference's task
+// arithmetic, one rounding per k-block, src/blas/gemm.cpp:122-127 -- always for flash::kmeans, whose
+// launches are the reference's tile tasks).
 // Let D be the dimension along which
 // C is paneled (m for row-major C, n for column-major).  The operand that does not contain D
 // ("Y": B for row-major) is needed whole by every group and stays resident; the other one
@@ -31,19 +35,23 @@
 // not contiguous in its file (ldc != stored width: writing whole panels would clobber what
 // lies between the rows), the call is handed to the tile cache of flash_runtime.cpp.
 //
-// HBM: one allocation per panel slot, made in first-use order by an allocator thread while the
-// first panels are already being read (a cold 65536^3 call spent 0.85 s in hipMalloc before its
-// first read otherwise); slots stay with the device's PanelResources between calls.
+// HBM: a resident operand is ONE allocation holding the matrix in file layout (Mat::whole: a launch
+// can then run over any range of its rows with one pointer); the streamed operand and C have one
+// allocation per ring slot.  All of it is made in first-use order by an allocator thread while the
+// first panels are already being read, and stays with the device's PanelResources between calls.
 //
-// Threads: n_io_threads readers (file -> pinned slot -> H2D), one dispatcher per device (tile
+// Threads: n_io_threads readers (file -> pinned slot -> H2D), one dispatcher per device (the
 // launches on its compute streams; the caller itself for the first device), one flusher per device
 // (HBM -> pinned, chunk by chunk) and writers (pinned -> file).  Everything is ordered by hipEvents
-// and one condition variable; nothing polls.
+// and one condition variable; nothing polls.  Hand-overs between threads are HOST-CONFIRMED
+// (flash_common.h): a reader sees its own copy complete before the chunk counts as delivered, the
+// flusher sees a group's kernels complete before it copies, a slot's old occupant is seen gone before
+// the copy that refills it is submitted; the device-side event waits stay as a second line.
 //
 // Several devices in ONE process (bof_options.devices / $BOF_DEVICES; the reference runs its
 // N_COMPUTE_THR workers behind flash::gemm inside one process, src/scheduler/scheduler.cpp:9-16):
 // the C panels are dealt to the devices in contiguous ranges (output row blocks), and
-// every device runs the schedule above on ITS slab -- same tiles, same k-order per chain, so the
+// every device runs the schedule above on ITS slab -- same k-order per output element, so the
 // C file is bit-identical to the single-device call.  A panel only one device needs (its C
 // panels, the A panels of its rows) is private to it; a panel every device needs (B for
 // row-major; A too when it is paneled along k) is SHARED: it is read from the file ONCE into a

@@ -245,9 +245,12 @@ int64_t bof_csr_blocks(const int64_t *ia, int64_t m, int64_t min_rows,
 /* ---- level 2: the tile DAG over HBM-resident matrices ----------------------- */
 /* flash::gemm semantics (src/blas/gemm.cpp:27-202) with a,b,c device pointers to
  * the whole matrices (file layout, leading dims as the caller passes them; 0 =
- * default).  Tasks run in the reference's order; every (i,j) accumulate chain
- * is serialised on one of opts->n_streams compute streams forked from / joined
- * into `stream`.  Asynchronous with respect to the host.
+ * default).  Default arithmetic (opts->gemm_chain 0 / 2): one k-ordered chain per output
+ * element over the whole K -- with everything resident that is ONE launch over the whole
+ * matrices, queued on `stream` (what drivers/in_mem_gemm.cpp:63-70 does with one call).
+ * gemm_chain = 1 (and alpha == 0): the reference's tasks in the reference's order, every
+ * (i,j) accumulate chain serialised on one of opts->n_streams compute streams forked from /
+ * joined into `stream`.  Asynchronous with respect to the host.
  * Scratch: when an operand is stored k-contiguous (A 'N', B 'T' in row-major terms), every
  * tile is reused by >= 4 tasks and a copy of that operand fits in a QUARTER of the free HBM,
  * the call first writes a k-major copy of it into library scratch (kept until

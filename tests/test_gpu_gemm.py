@@ -173,7 +173,17 @@ def test_gemm_resident_matches_flash_oracle(dev, ord_, ta, tb):
     got = dc.cpu().numpy()
     assert np.array_equal(got, ref), rel_err(got, ref)
     whole = orc.sgemm(ord_, ta, tb, m, n, k, alpha, a, sa[1], b, sb[1], beta, c0.copy(), sc[1])
-    assert rel_err(got, whole) < TOL   # in_mem_gemm oracle (gemm_run.sh comparison)
+    assert np.array_equal(got, whole)   # the default arithmetic IS the in-memory driver's single call (gemm_run.sh comparison)
+    # bof_options.gemm_chain = 1: the reference's tile DAG, task by task on the forked streams, one rounding per
+    # k-block -- bit-equal to the tile-by-tile restatement of flash::gemm, within rounding of the single chain
+    chained = orc.flash_gemm(ord_, ta, tb, m, n, k, alpha, beta, a, b, c0.copy(), 0, 0, 0, blk, chain=1)
+    dc1 = to_dev(c0)
+    bofhip.gemm_resident(ord_, ta, tb, m, n, k, alpha, beta, ptr(da), ptr(db), ptr(dc1), 0, 0, 0,
+                         bofhip.default_options(gemm_blk=blk, n_streams=3, gemm_chain=1), stream())
+    torch.cuda.synchronize()
+    got1 = dc1.cpu().numpy()
+    assert np.array_equal(got1, chained), rel_err(got1, chained)
+    assert rel_err(got1, whole) < TOL
 
 
 @pytest.mark.parametrize("ord_,ta,tb", list(__import__("itertools").product("RC", "NT", "NT")))
