@@ -2,6 +2,7 @@
 oracle (bit-exact: both are k-ordered fmaf chains) and the MKL golden vectors
 (1e-4 relative, BASELINE.json north_star)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -283,3 +284,50 @@ def test_big_kernels_vs_mkl_random(dev, golden_big, ord_, ta, tb):
                              bofhip.default_options(gemm_blk=blk), stream())
         torch.cuda.synchronize()
         check(c, f"bof_gemm_resident blk={blk}")
+
+
+@pytest.mark.parametrize("ta,tb,beta", [("T", "N", 0.0), ("N", "N", 1.5), ("N", "T", 0.0)])
+def test_sgemm_big_ragged_strips_on_the_side_stream(dev, ta, tb, beta):
+    """A launch whose 256-aligned interior has >= 1024 tiles runs its ragged strips (guarded 128 x 128 kernel) on a
+    stream of their own BESIDE the interior kernel, forked in front of it and joined behind it (gemm_f32_mfma.hip,
+    launch_modes).  8292 x 8244 x 512: interior 32 x 32 tiles, a 100-row bottom strip, a 52-column right strip; the
+    strips, the corner, the rows / columns next to them and a band of the interior against the oracle bit for bit;
+    then work queued on the SAME stream right behind the call (it must see the strips: the join), and the call
+    again with BOF_GEMM_STRIP_STREAM=0 (strips behind the interior, as until round 5) -- same bits."""
+    m, n, k = 8292, 8244, 512
+    rng = np.random.default_rng(77)
+    sa, sb, sc = stored_shapes("R", ta, tb, m, n, k)
+    a = rng.uniform(-1, 1, sa).astype(np.float32)
+    b = rng.uniform(-1, 1, sb).astype(np.float32)
+    c0 = rng.uniform(-1, 1, sc).astype(np.float32)
+    da, db = to_dev(a), to_dev(b)
+
+    def rows_of(r0, r1):          # the oracle on C rows [r0, r1)
+        asub = a[r0:r1] if ta == "N" else np.ascontiguousarray(a[:, r0:r1])
+        c = c0[r0:r1].copy()
+        orc.sgemm("R", ta, tb, r1 - r0, n, k, 0.5, asub, asub.shape[1], b, sb[1], beta, c, n)
+        return c
+
+    def cols_of(c0_, c1_):        # the oracle on C columns [c0_, c1_)
+        bsub = np.ascontiguousarray(b[:, c0_:c1_]) if tb == "N" else b[c0_:c1_]
+        c = np.ascontiguousarray(c0[:, c0_:c1_])
+        orc.sgemm("R", ta, tb, m, c1_ - c0_, k, 0.5, a, sa[1], bsub, bsub.shape[1], beta, c, c1_ - c0_)
+        return c
+    want_rows = {(0, 64): rows_of(0, 64), (8128, m): rows_of(8128, m)}
+    want_cols = {(8128, n): cols_of(8128, n)}
+    for knob in ("1", "0"):
+        os.environ["BOF_GEMM_STRIP_STREAM"] = knob
+        try:
+            dc = to_dev(c0)
+            tail = torch.zeros(1, dtype=torch.float32, device=dev)
+            bofhip.sgemm("R", ta, tb, m, n, k, 0.5, ptr(da), sa[1], ptr(db), sb[1], beta, ptr(dc), n, stream())
+            tail += dc[m - 1, n - 1]          # queued on the same stream right behind the call: sees the corner of the strips
+            torch.cuda.synchronize()
+            got = dc.cpu().numpy()
+        finally:
+            os.environ.pop("BOF_GEMM_STRIP_STREAM", None)
+        for (r0, r1), w in want_rows.items():
+            assert np.array_equal(got[r0:r1], w), (knob, r0, r1)
+        for (c0_, c1_), w in want_cols.items():
+            assert np.array_equal(got[:, c0_:c1_], w), (knob, c0_, c1_)
+        assert float(tail.item()) == float(got[m - 1, n - 1])
