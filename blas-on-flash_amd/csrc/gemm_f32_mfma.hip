@@ -1216,13 +1216,20 @@ sgemm_tile256_p1w3_kernel(const float *__restrict__ A, int64_t lda, const float 
 // per-device pools of call-lifetime HIP events (flash_support.cpp)
 hipError_t pooled_event(hipEvent_t *e, bool timing);
 void pooled_event_return(hipEvent_t e);
-// the stream the ragged strips of a big launch run on beside its interior kernel: one per host thread and device
+hipError_t pooled_stream(hipStream_t *s, bool copy_priority);
+void pooled_stream_return(hipStream_t s);
+// the stream the ragged strips of a big launch run on beside its interior kernel: one per host thread and device, taken
+// from the process's stream pool at the thread's first such launch and handed back when the thread ends
 static hipStream_t strip_stream() {
-  static thread_local hipStream_t s[64] = {};
+  struct Held {
+    hipStream_t s[64] = {};
+    ~Held() { for (hipStream_t x : s) pooled_stream_return(x); }
+  };
+  static thread_local Held held;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void) hipGetLastError(); return nullptr; }
-  if (!s[dev] && hipStreamCreateWithFlags(&s[dev], hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); s[dev] = nullptr; }
-  return s[dev];
+  if (!held.s[dev] && pooled_stream(&held.s[dev], false) != hipSuccess) { (void) hipGetLastError(); held.s[dev] = nullptr; }
+  return held.s[dev];
 }
 
 // debug / test knobs of the kernel choice, read at every launch

@@ -48,7 +48,8 @@ static bool g_truncate_a = false;    // the next gemm_case cuts its A file in ha
 static thread_local int g_last_rc = 0, g_prev_rc = 0;   // allocation-failure sweep (single-threaded; concurrent cases write their own)
 static bool g_any_error_ok = false;
 static bool g_accept_enomem = false; // stress mode: a drawn budget may legitimately be refused
-static struct { int io_threads = 3, pinned = 3, streams = 0, kmajor = 0, group = 0, chunk_mib = 1; } g_knobs;   // stress mode draws these
+static struct { int io_threads = 3, pinned = 3, streams = 0, kmajor = 0, group = 0, chunk_mib = 1, chain = 0; } g_knobs;   // stress mode draws these
+static bool g_stress = false;         // stress mode: the path a drawn case takes is not known beforehand, so no per-path counters are asserted
 static thread_local std::mt19937_64 g_rng(12345);
 static int ri(int lo, int hi) { return lo + (int) (g_rng() % (uint64_t) (hi - lo + 1)); }
 
@@ -144,6 +145,7 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   o.use_odirect = direct ? 1 : 0;
   o.hbm_budget = budget;
   o.peer_bcast = g_peer_bcast ? 1 : 2;
+  o.gemm_chain = g_knobs.chain;
   const uint64_t launches0 = mock_hip_kernel_launches();
   int rc;
   if (kmeans)
@@ -180,7 +182,7 @@ static void gemm_case(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
     CHECK(bof_flash_last_stats(&tot) == BOF_OK && tot.verify_checks >= 4);
     g_verify_checks += tot.verify_checks;
   }
-  if (g_peer_bcast && nd > 1 && t_prefix.empty() && path != 1) {
+  if (g_peer_bcast && nd > 1 && t_prefix.empty() && path != 1 && !g_stress) {
     // shared panels reach ONE device over PCIe and the others from that device's HBM: every byte read from the files
     // crosses the host-to-device link exactly once, the rest of the fan-out is device to device
     bof_flash_stats tot;
@@ -525,9 +527,12 @@ static int stress(double seconds) {
   const std::vector<std::vector<int>> lists = {{0, 1, 2, 3}, {0, 0, 0}, {2}, {0, 0, 1}, {1, 3}, {3, 3}};
   const time_t t_end = time(nullptr) + (time_t) seconds;
   int n = 0;
+  g_stress = true;
   while (time(nullptr) < t_end) {
     g_knobs.io_threads = ri(1, 4); g_knobs.pinned = ri(2, 4); g_knobs.streams = ri(1, 4);
     g_knobs.kmajor = ri(0, 3); g_knobs.group = ri(0, 3); g_knobs.chunk_mib = ri(1, 2);
+    g_knobs.chain = ri(0, 2) == 0 ? 1 : 0;      // a third with the reference's one-rounding-per-k-block arithmetic
+    g_peer_bcast = ri(0, 3) == 0;
     const char *grp[] = {"1", "3", "16"};
     setenv("BOF_TILE_GROUP", grp[ri(0, 2)], 1);
     const auto &devs = lists[(size_t) ri(0, (int) lists.size() - 1)];
@@ -558,6 +563,7 @@ static int stress(double seconds) {
     n++;
   }
   unsetenv("BOF_TILE_GROUP");
+  g_stress = false; g_peer_bcast = false; g_knobs.chain = 0;
   CHECK(bof_flash_release() == BOF_OK);
   return n;
 }
