@@ -1389,9 +1389,10 @@ int kmeans_upload(const KmeansHost &kh, KmeansVecs *kv) {
   if (e == hipSuccess) e = hipMemcpy(dv + kh.m + kh.n, kh.ones, (size_t) kh.n_ones * sizeof(float), hipMemcpyHostToDevice);
   // The caller's vectors are PAGEABLE host memory: a synchronous hipMemcpy may return once they are staged, with the
   // transfer still in flight on the null stream -- and the pipelines' compute streams are non-blocking, i.e. not
-  // ordered behind the null stream.  Wait for the device before anything is launched.  (Not what caused the wrong
-  // kmeans tiles of rounds 3-4 -- that was the launching thread, flash_common.h "persistent launcher threads" --
-  // but the same class of ordering hole; $BOF_KMEANS_UPLOAD_SYNC=0 restores the old behaviour.)
+  // ordered behind the null stream.  Wait for the device before anything is launched.  (Not what the wrong kmeans
+  // tiles of rounds 3-4 went away with -- they correlated with the launching thread and per-call event churn,
+  // flash_common.h "persistent launcher threads"; cause not proven -- but the same class of ordering hole;
+  // $BOF_KMEANS_UPLOAD_SYNC=0 restores the old behaviour.)
   if (e == hipSuccess && env_long("BOF_KMEANS_UPLOAD_SYNC", 1) != 0) e = hipDeviceSynchronize();
   if (e != hipSuccess) { (void) hipFree(dv); return hip_fail(e, "flash::kmeans: uploading the norm vectors"); }
   *kv = KmeansVecs{dv, dv + kh.m, dv + kh.m + kh.n};
