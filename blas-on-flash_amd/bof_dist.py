@@ -8,6 +8,8 @@ reduce of CSRGEMV 'T' (the reference's mutex-guarded vector add,
 include/tasks/csrgemv_task.h:169-176): each rank produces a full-length partial
 y_g = A_g^T x_g and one all-reduce(sum) combines them.
 """
+import math
+
 import numpy as np
 
 
@@ -289,7 +291,10 @@ def flash_csrmm_row_sharded(m, n, k, alpha, beta, fd_a, fd_ia, fd_ja, ord_b, fd_
     if ord_b != "R":
         raise ValueError("flash_csrmm_row_sharded: ord_b must be 'R'")
     world, rank = _world_rank(group)
-    r0, r1 = csr_row_shard(ia_host, world, rank, 128)
+    # the cuts between ranks fall on PAGES of the C file (r0 * k * 4 a multiple of 4096): each rank's call picks O_DIRECT
+    # or the page cache for C by the alignment of ITS row blocks, and a direct write must never meet a neighbour's
+    # buffered write in one page (csrc/flash_csr.cpp, c_blocks_aligned)
+    r0, r1 = csr_row_shard(ia_host, world, rank, max(128, 1024 // math.gcd(int(k), 1024)))
     if r1 > r0:
         bofhip.flash_csrmm("N", r1 - r0, n, k, alpha, beta, bofhip.FPtr(fd_a, 0), bofhip.FPtr(fd_ia, r0 * 8),
                            bofhip.FPtr(fd_ja, 0), "R", bofhip.FPtr(fd_b, 0), bofhip.FPtr(fd_c, r0 * k * 4), opts)

@@ -690,6 +690,24 @@ static int flash_csrcsc_impl(int64_t m, int64_t n, bof_fptr fia, bof_fptr fja, b
 }
 
 // What a multi-device call hands each device's pipeline (all null / absent in a single-device call).
+// Can every row block's piece(s) of the C file go through O_DIRECT?  The answer must be ONE per file per call, over
+// the blocks of every device: the blocks are cut by the nnz budget, so some are sector-aligned and some are not, and
+// a pipeline that wrote its aligned blocks with O_DIRECT beside one that wrote its unaligned blocks through the page
+// cache met it in a shared page -- the dirty page later went over the direct write (a lost update in the file; found
+// by tools/mock_stress.sh in round 5, regression: tests/native/host_pipeline.cpp "csrmix").  Callers that cut one C
+// file over PROCESSES keep the cuts page-aligned instead (bof_dist.csr_row_shard).
+static bool c_blocks_aligned(const bof_fptr &fc, char ord_b, int64_t k, int64_t c_ld, const int64_t *st, const int64_t *sz,
+                             int64_t nb) {
+  const uint64_t A = file_dio_align(fc.fd);
+  for (int64_t b = 0; b < nb; b++) {
+    const bool ok = ord_b == 'R' ? (fc.foffset + (uint64_t) st[b] * (uint64_t) k * 4) % A == 0 && ((uint64_t) sz[b] * (uint64_t) k * 4) % A == 0
+                                 : (fc.foffset + (uint64_t) st[b] * 4) % A == 0 && ((uint64_t) sz[b] * 4) % A == 0 &&
+                                       ((uint64_t) c_ld * 4) % A == 0;
+    if (!ok) return false;
+  }
+  return true;
+}
+
 struct CsrExtra {
   const int64_t *ia = nullptr;     // the offsets of this device's rows, already on the host
   char *shared_op = nullptr;       // B (csrmm) / x (csrgemv 'N') already on its way into THIS device's HBM ...
@@ -700,6 +718,8 @@ struct CsrExtra {
   float *partial_y = nullptr;      // csrgemv 'T': zeroed full-length vector in this device's HBM that takes
                                    // the partial sums and STAYS there (the caller reduces the partials)
   int64_t c_ld = 0;                // column-major C: rows of the whole matrix (0: this call's m)
+  int c_direct = -1;               // C file, decided by the caller over the row blocks of EVERY device of the call: 1 keep
+                                   // O_DIRECT, 0 through the buffered twin (-1: this pipeline decides on its own blocks)
   Counters *out = nullptr;         // counters are added here instead of being published
 };
 
@@ -770,15 +790,9 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   if (is_mm && fc.fd >= 0) {
     R.fd_c = fc.fd;
     if (file_is_direct(fc.fd)) {
-      const uint64_t A = file_dio_align(fc.fd);
-      bool aligned = true;
-      for (int64_t b = 0; b < nb && aligned; b++) {
-        if (ord_b == 'R')
-          aligned = (fc.foffset + (uint64_t) R.st[b] * k * 4) % A == 0 && ((uint64_t) R.sz[b] * k * 4) % A == 0;
-        else
-          aligned = (fc.foffset + (uint64_t) R.st[b] * 4) % A == 0 && ((uint64_t) R.sz[b] * 4) % A == 0 &&
-                    ((uint64_t) R.c_ld * 4) % A == 0;
-      }
+      // one descriptor mode per FILE per call (see c_blocks_aligned): with several devices the caller has decided
+      const bool aligned = ex && ex->c_direct >= 0 ? ex->c_direct == 1
+                                                   : c_blocks_aligned(fc, ord_b, k, R.c_ld, R.st.data(), R.sz.data(), nb);
       if (aligned) R.aio_c = R.use_aio;
       else R.fd_c = file_buffered_fd(fc.fd);
       if (R.fd_c < 0) { set_error("flash csrmm: cannot open a buffered descriptor of the C file"); return BOF_EIO; }
@@ -1241,6 +1255,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     if (feed_rc) feed_err = bof_last_error();
   });
 
+  // the C file's descriptor mode, over the row blocks of all devices (c_blocks_aligned)
+  const int c_direct = is_mm && fc.fd >= 0 && file_is_direct(fc.fd) ? (c_blocks_aligned(fc, ord_b, k, m, bst.data(), bsz.data(), nb) ? 1 : 0) : -1;
   // ---- one pipeline per device on its rows ------------------------------------------------------------
   auto run_shard = [&](Shard &S) {
     DeviceScope ds(S.dev);
@@ -1257,6 +1273,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     float *c_h = hc;
     if (is_mm) {
       ex.c_ld = m;
+      ex.c_direct = c_direct;
       const uint64_t c_off = ord_b == 'R' ? (uint64_t) S.row0 * (uint64_t) k : (uint64_t) S.row0;
       if (fc.fd >= 0) c_f.foffset += c_off * 4;
       if (c_h) c_h += c_off;

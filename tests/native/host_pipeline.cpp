@@ -748,6 +748,21 @@ int main(int argc, char **argv) {
   printf("host_pipeline ok: %d drawn cases, %llu kernel stand-in launches\n", n, (unsigned long long) mock_hip_kernel_launches());
     return 0;
   }
+  if (argc > 3 && !strcmp(argv[2], "csrmix")) {
+    // Row blocks cut by the nnz budget, some sector-aligned in the C file and some not, dealt to TWO devices, O_DIRECT:
+    // every device's pipeline must take the SAME descriptor mode for C.  (Round 5, found by tools/mock_stress.sh: one
+    // device wrote its aligned blocks with O_DIRECT while the other wrote its unaligned ones through the page cache;
+    // where the two met in one page the dirty page later went over the direct write -- a lost update in the file.)
+    g_rng.seed((uint64_t) atol(argv[3]) * 104729 + 7);
+    const int n = argc > 4 ? atoi(argv[4]) : 200;
+    for (int it = 0; it < n; it++) {
+      const std::vector<int> devs = it % 2 ? std::vector<int>{1, 3} : std::vector<int>{3, 3};
+      csr_case(768, ri(100, 300), ri(5, 9), 'C', 1.f, 1.f, devs, true);
+      csr_case(128 * ri(5, 9), ri(100, 300), 4 * ri(1, 3), 'R', 1.f, (float) ri(0, 1), devs, true);   // rows of 16-48 bytes
+    }
+    printf("host_pipeline ok: %d mixed-alignment csr cases\n", 2 * n);
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[2], "apifail")) {
     api_failure_sweep();
     if (g_verify_checks.load()) printf("BOF_VERIFY: %llu hand-over sums compared\n", (unsigned long long) g_verify_checks.load());

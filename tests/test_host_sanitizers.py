@@ -103,7 +103,13 @@ def test_level3_pipelines_on_mock_devices_under_sanitizers(tmp_path):
             # one call of a HIP API kind fails (copies, event records / waits / creations, stream creations, memsets),
             # position by position: an error code or -- where the library has a fallback -- a correct result, never a
             # wrong C behind BOF_OK
-            ("asan", ["apifail"], {"MOCK_HIP_ASYNC": "1", "BOF_STALL_TIMEOUT_S": "30", "HOST_PIPELINE_QUICK": "1"})]
+            ("asan", ["apifail"], {"MOCK_HIP_ASYNC": "1", "BOF_STALL_TIMEOUT_S": "30", "HOST_PIPELINE_QUICK": "1"}),
+            # csrmm on two devices whose row blocks are partly sector-aligned in an O_DIRECT C file and partly not: ONE
+            # descriptor mode for the file (round 5: a direct write of one device and a buffered write of the other in
+            # one page lost an update; three of these side by side reproduced it within minutes before the fix)
+            ("asan", ["csrmix", "1", "150"], {"MOCK_HIP_ASYNC": "1"}),
+            ("asan", ["csrmix", "2", "150"], {"MOCK_HIP_ASYNC": "1"}),
+            ("asan", ["csrmix", "3", "150"], {"MOCK_HIP_ASYNC": "1"})]
     runs = []
     for i, (k, extra, env_extra) in enumerate(plan):
         d = tmp_path / f"files_{i}"
