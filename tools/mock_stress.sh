@@ -32,5 +32,5 @@ rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
 grep -h "host_pipeline ok\|BOF_VERIFY:" "$out"/tsan_*.txt "$out"/asan_*.txt | tee "$out/summary.txt"
 grep -l "WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error\|CHECK failed\|want " "$out"/*.txt 2>/dev/null | tee -a "$out/summary.txt"
-rm -rf "$out"/tsan_[0-9]* "$out"/asan_[0-9]*/ 2>/dev/null
+[ $rc -eq 0 ] && rm -rf "$out"/tsan_[0-9]*/ "$out"/asan_[0-9]*/ 2>/dev/null   # (a failed process leaves its case files behind)
 exit $rc
