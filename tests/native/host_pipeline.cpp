@@ -760,6 +760,8 @@ int main(int argc, char **argv) {
       csr_case(768, ri(100, 300), ri(5, 9), 'C', 1.f, 1.f, devs, true);
       csr_case(128 * ri(5, 9), ri(100, 300), 4 * ri(1, 3), 'R', 1.f, (float) ri(0, 1), devs, true);   // rows of 16-48 bytes
     }
+    CHECK(bof_flash_release() == BOF_OK);
+    for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);
     printf("host_pipeline ok: %d mixed-alignment csr cases\n", 2 * n);
     return 0;
   }
