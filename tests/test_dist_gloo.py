@@ -40,6 +40,30 @@ def test_csr_row_shard_balances_nnz():
         assert a1 == b0
 
 
+def test_csrmm_rank_cuts_fall_on_pages_of_the_c_file(monkeypatch):
+    """Two processes must never share a page of an O_DIRECT C file (one may keep O_DIRECT for its row blocks while its
+    neighbour goes through the page cache: csrc/flash_csr.cpp, c_blocks_aligned): flash_csrmm_row_sharded cuts the
+    ranks' row ranges where r0 * k * 4 is a multiple of 4096, whatever k."""
+    import bofhip
+    rng = np.random.default_rng(1)
+    m = 50000
+    ia = np.concatenate([[0], np.cumsum(rng.integers(0, 20, m))]).astype(np.int64)
+    calls = []
+    monkeypatch.setattr(bofhip, "flash_csrmm", lambda *a: calls.append(a))
+    for k in (1, 3, 7, 8, 24, 100, 128, 130, 1000, 1024):
+        cuts = set()
+        for rank in range(3):
+            monkeypatch.setattr(bof_dist, "_world_rank", lambda group=None, r=rank: (3, r))
+            r0, r1 = bof_dist.flash_csrmm_row_sharded(m, 100, k, 1.0, 0.0, 3, 4, 5, "R", 6, 7, ia)
+            cuts.update((r0, r1))
+            if r1 > r0:
+                fc = calls[-1][-2]                    # the C file pointer handed to the call
+                assert fc.foffset == r0 * k * 4
+        assert 0 in cuts and m in cuts
+        for r in cuts - {0, m}:
+            assert (r * k * 4) % 4096 == 0, (k, r)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
