@@ -4,8 +4,8 @@
 # and under ASan + UBSan, with BOF_VERIFY=1 (producer- and consumer-side sums, spot checks, poison) inside every call.
 # No GPU: this is the stream-ordering / data-race / lifetime hunt the GPU fuzz cannot do (tests/test_host_sanitizers.py
 # runs the same binaries for a few seconds in the CPU suite).
-# Usage: tools/mock_stress.sh OUTDIR SECONDS [N_TSAN N_ASAN]
-out=$1; secs=$2; nt=${3:-2}; na=${4:-2}
+# Usage: tools/mock_stress.sh OUTDIR SECONDS [N_TSAN N_ASAN SEED_BASE]
+out=$1; secs=$2; nt=${3:-2}; na=${4:-2}; sb=${5:-0}
 root=$(cd "$(dirname "$0")/.." && pwd); csrc=$root/blas-on-flash_amd/csrc; T=$root/tests/native
 mkdir -p "$out"
 build() {  # build NAME FLAGS...
@@ -20,12 +20,12 @@ unset BOF_DEVICES
 pids=()
 for i in $(seq 1 "$nt"); do
   d="$out/tsan_$i"; mkdir -p "$d"
-  TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1" "$out/host_pipeline_tsan" "$d" stress $((100 + i)) "$secs" > "$out/tsan_$i.txt" 2>&1 &
+  TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1" "$out/host_pipeline_tsan" "$d" stress $((sb + 100 + i)) "$secs" > "$out/tsan_$i.txt" 2>&1 &
   pids+=($!)
 done
 for i in $(seq 1 "$na"); do
   d="$out/asan_$i"; mkdir -p "$d"
-  MOCK_HIP_JITTER_US=300 ASAN_OPTIONS="detect_leaks=1:handle_abort=1" UBSAN_OPTIONS="print_stacktrace=1" "$out/host_pipeline_asan" "$d" stress $((200 + i)) "$secs" > "$out/asan_$i.txt" 2>&1 &
+  MOCK_HIP_JITTER_US=300 ASAN_OPTIONS="detect_leaks=1:handle_abort=1" UBSAN_OPTIONS="print_stacktrace=1" "$out/host_pipeline_asan" "$d" stress $((sb + 200 + i)) "$secs" > "$out/asan_$i.txt" 2>&1 &
   pids+=($!)
 done
 rc=0
