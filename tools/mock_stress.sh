@@ -15,7 +15,7 @@ build() {  # build NAME FLAGS...
     -x c++ "$csrc"/c_api.hip -x none "$T"/mock_hip.cpp "$T"/host_pipeline.cpp -o "$out/host_pipeline_$name" -lpthread -ldl -lrt
 }
 build tsan -fsanitize=thread & build asan -fsanitize=address,undefined -fno-sanitize-recover=all & wait
-export MOCK_HIP_ASYNC=1 MOCK_HIP_DEVICES=4 BOF_VERIFY=1
+export MOCK_HIP_ASYNC=1 MOCK_HIP_DEVICES=4 BOF_VERIFY=1 LSAN_OPTIONS="suppressions=$T/lsan.supp:print_suppressions=0"
 unset BOF_DEVICES
 pids=()
 for i in $(seq 1 "$nt"); do
