@@ -165,8 +165,15 @@ def flash_gemm_row_sharded(m, n, k, alpha, beta, fd_a, fd_b, fd_c, lda=0, ldb=0,
                         bofhip.check(bofhip.lib().bof_mem_info(ctypes.byref(fr), ctypes.byref(tot)), "bof_mem_info")
                         budget = int(fr.value * 0.8)
                     pl = bofhip.flash_gemm_panel_plan("R", "N", "N", rows, n, k, tile, budget, lda, ldb, ldc, 0)
-                    # (beta != 0: the ramp group's chains also need their raw accumulator panels, bof_panel_plan.acc_bytes)
-                    can = bool(pl["eligible"]) and (beta == 0 or int(o.gemm_chain) == 1 or pl["need_bytes"] + pl["acc_bytes"] <= budget)
+                    # beta != 0: the ramp group's chains also need their raw accumulator panels (bof_panel_plan.acc_bytes).
+                    # The library sets them aside BEFORE spare budget deepens the C ring (plan_panels(..., with_acc),
+                    # plan.cpp), while the plan asked for here has already spent the spare budget on the ring and reports
+                    # need_bytes behind that -- so the test is made against the MINIMAL rings (2 * group + 1 C slots), as
+                    # PanelRun::plan does; need_bytes + acc_bytes could refuse a call the library would take.
+                    min_c = min(pl["n_panels"][2], 2 * pl["first_group"] + 1)
+                    need_min = (pl["n_slots"][0] * pl["slot_bytes"][0] + pl["n_slots"][1] * pl["slot_bytes"][1]
+                                + min_c * pl["slot_bytes"][2])
+                    can = bool(pl["eligible"]) and (beta == 0 or int(o.gemm_chain) == 1 or need_min + pl["acc_bytes"] <= budget)
             except Exception as e:      # noqa: BLE001 -- whatever it is, every rank must hear of it
                 can, pre_err = False, f"{type(e).__name__}: {e}"
         verdicts = [None] * world

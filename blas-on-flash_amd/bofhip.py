@@ -119,6 +119,7 @@ SYMBOLS = [
     ("bof_flash_gemm_simulate", C.c_int, [chr_, chr_, chr_, u64, u64, u64, f32, u64, u64, u64, i64, i64,
                                           C.c_int32, C.POINTER(FlashStats)]),
     ("bof_event_dump", u64, [C.c_char_p]),
+    ("bof_flash_last_c_file", C.c_int, [C.POINTER(C.c_uint64)]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_forget", C.c_int, [C.c_int]),
@@ -337,6 +338,14 @@ def flash_last_stats():
     s = FlashStats()
     check(lib().bof_flash_last_stats(C.byref(s)), "bof_flash_last_stats")
     return {f: getattr(s, f) for f, _ in s._fields_}
+
+
+def flash_last_c_file():
+    """How the last flash_csrmm call treated its C file: (mode, bytes of whole row blocks through the buffered twin);
+    mode 1 O_DIRECT, 2 O_DIRECT with widened reads / page-split writes, 0 buffered twin, -1 not an O_DIRECT file."""
+    tw = C.c_uint64(0)
+    mode = lib().bof_flash_last_c_file(C.byref(tw))
+    return mode, tw.value
 
 
 def flash_last_device_stats():

@@ -56,6 +56,7 @@ void hip_pools_release();
 
 class KernelTimer {
   std::vector<hipEvent_t> ev;   // begin / end pairs in launch order
+  std::vector<char> ended;      // pair i: end() recorded its second event (a pooled event carries an OLD record otherwise)
   std::mutex mu;                // several dispatch streams of one device share a timer
  public:
   bool on = false;
@@ -76,6 +77,7 @@ class KernelTimer {
     if (pair) *pair = ev.size() / 2;
     ev.push_back(a);
     ev.push_back(b);
+    ended.push_back(0);
     return hipSuccess;
   }
   // the end marker of pair `pair` (default: the most recent begin() -- a timer driven by ONE dispatcher thread)
@@ -84,14 +86,20 @@ class KernelTimer {
     std::lock_guard<std::mutex> lk(mu);
     if (ev.empty()) return hipSuccess;
     const size_t i = pair == (size_t) -1 ? ev.size() - 1 : 2 * pair + 1;
-    return i < ev.size() ? hipEventRecord(ev[i], st) : hipErrorInvalidValue;
+    if (i >= ev.size()) return hipErrorInvalidValue;
+    const hipError_t e = hipEventRecord(ev[i], st);
+    if (e == hipSuccess) ended[i / 2] = 1;
+    return e;
   }
   // after the streams have been synchronised: adds the pairs that completed to the counters, returns the events
   void collect(Counters &c) {
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i + 1 < ev.size(); i += 2) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
+      // a pair whose launch failed between begin() and end() is skipped: its pooled `end` event still holds the
+      // record of an earlier call, and the elapsed time against it would be garbage
+      if (!ended[i / 2]) {
+      } else if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
         c.klaunch++;
         c.kns += (uint64_t) ((double) ms * 1e6);
       } else {
@@ -101,6 +109,7 @@ class KernelTimer {
       pooled_event_return(ev[i + 1]);
     }
     ev.clear();
+    ended.clear();
   }
   ~KernelTimer() {
     for (hipEvent_t e : ev) pooled_event_return(e);

@@ -188,10 +188,24 @@ struct CsrRun {
   }
 
   // the C file is read and written by several threads at once: ONE descriptor mode for every
-  // request of the call (O_DIRECT only if every block's region is aligned, else the buffered
-  // twin), as in flash::gemm -- a direct and a buffered write must never meet in one page
+  // request of the call, as in flash::gemm -- a direct and a buffered write must never meet in one page:
+  //  * every block's region sector-aligned: O_DIRECT as it is;
+  //  * row-major C with unaligned blocks (k = 100: 400-byte rows): O_DIRECT is KEPT (c_widen) -- a block's whole
+  //    pages go out with O_DIRECT straight from the pinned buffer (the D2H copy lands at the block's file offset
+  //    modulo the page), the partial first / last page through the buffered twin, where the page two neighbouring
+  //    blocks share is merged by the page cache whichever device, thread or process writes it first
+  //    (file_write_split); a block's old contents (beta != 0) are read as the sector-aligned superset
+  //    (file_read_widened).  The reference: sector RMW with neighbour write ordering,
+  //    src/file_handles/flash_file_handle.cpp:558-716, src/scheduler/io_executor.cpp:28-156;
+  //  * column-major C with unaligned column pieces, $BOF_UNALIGNED_DIRECT=0, or a device whose O_DIRECT
+  //    granularity exceeds a page: the buffered twin for every request.
   int fd_c = -1;
   bool aio_c = false;
+  bool c_widen = false;
+  static constexpr uint64_t kPage = 4096;
+  uint64_t c_off(int64_t b) const { return fc.foffset + (uint64_t) st[b] * (uint64_t) k * 4; }     // row-major C
+  uint64_t c_wdelta(int64_t b) const { return c_widen ? c_off(b) % kPage : 0; }     // where the block sits in h_c for its write
+  std::atomic<uint64_t> cnt_buffered_c{0};   // bytes of C that went through the buffered twin although the caller's descriptor is O_DIRECT
   uint64_t fsize_ja = 0, fsize_a = 0;
   uint64_t sector = 512;  // the reference widens to SECTOR_LEN = 512; a 4Kn device reports more
   // sector-widened segment of a block (reference csrmm_task.h:156-172), clamped to the
@@ -247,19 +261,22 @@ struct CsrRun {
         cnt.h2d += l0 + l1;
       }
       if (!rc && e == hipSuccess && is_mm && beta != 0.f) {
+        uint64_t cdelta = 0;      // (widened read: where the block's first byte landed in h_c)
         // C block: 'R' contiguous rows, 'C' strided columns of the block (packed [k][r])
         if (host_c) {
           if (ord_b == 'R') memcpy(c.h_c, host_c + (size_t) st[b] * k, c_bytes(b));
           else
             for (int64_t j = 0; j < k; j++)
               memcpy(c.h_c + (size_t) j * sz[b] * 4, host_c + (size_t) j * c_ld + st[b], (size_t) sz[b] * 4);
-        } else if (ord_b == 'R')
+        } else if (ord_b == 'R' && c_widen)
+          rc = file_read_widened(fd_c, c_off(b), c_bytes(b), c.h_c, &cdelta, aio_c);
+        else if (ord_b == 'R')
           rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
         else
           rc = file_sread(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) c_ld * 4, (uint64_t) k,
                           (uint64_t) sz[b] * 4, c.h_c, aio_c);
         cnt.rd += c_bytes(b);
-        if (!rc) e = hipMemcpyAsync(c.d_c, c.h_c, c_bytes(b), hipMemcpyHostToDevice, h2d);
+        if (!rc) e = hipMemcpyAsync(c.d_c, c.h_c + cdelta, c_bytes(b), hipMemcpyHostToDevice, h2d);
         cnt.h2d += c_bytes(b);
       }
       if (!rc && e == hipSuccess) e = hipEventRecord(c.ready, h2d);
@@ -294,13 +311,16 @@ struct CsrRun {
             memcpy(host_c + (size_t) j * c_ld + st[b], c.h_c + (size_t) j * sz[b] * 4, (size_t) sz[b] * 4);
       } else if (is_mm && !io_error.load()) {
         int rc;
-        if (ord_b == 'R')
+        if (ord_b == 'R' && c_widen)
+          rc = file_write_split(fd_c, c_off(b), c_bytes(b), c.h_c + c_wdelta(b), aio_c);
+        else if (ord_b == 'R')
           rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * k * 4, 0, 1, c_bytes(b), c.h_c, aio_c);
         else
           rc = file_swrite(fd_c, fc.foffset + (uint64_t) st[b] * 4, (uint64_t) c_ld * 4, (uint64_t) k,
                            (uint64_t) sz[b] * 4, c.h_c, aio_c);
         if (rc) fail_io(rc);
         cnt.wr += c_bytes(b);
+        if (fd_c != fc.fd) cnt_buffered_c += c_bytes(b);
       }
       { std::lock_guard<std::mutex> lk(mu); c.owner = b + depth; c.state = 0; }
       cv.notify_all();
@@ -708,6 +728,21 @@ static bool c_blocks_aligned(const bof_fptr &fc, char ord_b, int64_t k, int64_t 
   return true;
 }
 
+// The C file's mode for one call (CsrRun::fd_c): 1 O_DIRECT as it is, 2 O_DIRECT with widened reads / page-split
+// writes (row-major C), 0 the buffered twin.
+static int c_file_mode(const bof_fptr &fc, char ord_b, int64_t k, int64_t c_ld, const int64_t *st, const int64_t *sz, int64_t nb,
+                       bool use_odirect) {
+  if (c_blocks_aligned(fc, ord_b, k, c_ld, st, sz, nb)) return 1;
+  if (ord_b == 'R' && use_odirect && file_dio_align(fc.fd) <= 4096 && env_long("BOF_UNALIGNED_DIRECT", 1) != 0) return 2;
+  return 0;
+}
+
+// What the last flash::csrmm call did with its C FILE (bof_flash_last_c_file: tests and drivers can see that an
+// unaligned C stayed on O_DIRECT): the mode (c_file_mode; -1 = C was not an O_DIRECT file) and the bytes of whole row
+// blocks that went through the buffered twin instead (mode 0 only; all pipelines of a multi-device call added up).
+static std::atomic<int> g_last_c_mode{-1};
+static std::atomic<uint64_t> g_last_c_twin_bytes{0};
+
 struct CsrExtra {
   const int64_t *ia = nullptr;     // the offsets of this device's rows, already on the host
   char *shared_op = nullptr;       // B (csrmm) / x (csrgemv 'N') already on its way into THIS device's HBM ...
@@ -718,8 +753,9 @@ struct CsrExtra {
   float *partial_y = nullptr;      // csrgemv 'T': zeroed full-length vector in this device's HBM that takes
                                    // the partial sums and STAYS there (the caller reduces the partials)
   int64_t c_ld = 0;                // column-major C: rows of the whole matrix (0: this call's m)
-  int c_direct = -1;               // C file, decided by the caller over the row blocks of EVERY device of the call: 1 keep
-                                   // O_DIRECT, 0 through the buffered twin (-1: this pipeline decides on its own blocks)
+  int c_direct = -1;               // C file, decided by the caller over the row blocks of EVERY device of the call
+                                   // (c_file_mode: 1 O_DIRECT, 2 O_DIRECT widened / page-split, 0 the buffered twin;
+                                   // -1: this pipeline decides on its own blocks)
   Counters *out = nullptr;         // counters are added here instead of being published
 };
 
@@ -791,9 +827,11 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     R.fd_c = fc.fd;
     if (file_is_direct(fc.fd)) {
       // one descriptor mode per FILE per call (see c_blocks_aligned): with several devices the caller has decided
-      const bool aligned = ex && ex->c_direct >= 0 ? ex->c_direct == 1
-                                                   : c_blocks_aligned(fc, ord_b, k, R.c_ld, R.st.data(), R.sz.data(), nb);
-      if (aligned) R.aio_c = R.use_aio;
+      const int mode = ex && ex->c_direct >= 0 ? ex->c_direct
+                                               : c_file_mode(fc, ord_b, k, R.c_ld, R.st.data(), R.sz.data(), nb, R.o.use_odirect != 0);
+      g_last_c_mode = mode;
+      if (mode == 1) R.aio_c = R.use_aio;
+      else if (mode == 2) { R.aio_c = R.use_aio; R.c_widen = true; }
       else R.fd_c = file_buffered_fd(fc.fd);
       if (R.fd_c < 0) { set_error("flash csrmm: cannot open a buffered descriptor of the C file"); return BOF_EIO; }
     }
@@ -925,7 +963,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       rc = dev_cache_alloc((void **) &c.d_c, max_c);
       if (!rc && ord_b == 'C') rc = dev_cache_alloc((void **) &c.d_c_rm, max_c);
       if (rc) return rc;
-      rc = pinned_alloc((void **) &c.h_c, max_c);
+      rc = pinned_alloc((void **) &c.h_c, max_c + 2 * CsrRun::kPage);      // slack: widened read / page-congruent placement
       if (rc) return rc;
     }
     BOF_HIP_TRY(pooled_event(&c.ready));
@@ -1002,7 +1040,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       herr = hipEventRecord(c.done, st);
       if (herr == hipSuccess) herr = hipStreamWaitEvent(R.d2h, c.done, 0);
       if (herr == hipSuccess)
-        herr = hipMemcpyAsync(c.h_c, c.d_c, R.c_bytes(b), hipMemcpyDeviceToHost, R.d2h);
+        herr = hipMemcpyAsync(c.h_c + R.c_wdelta(b), c.d_c, R.c_bytes(b), hipMemcpyDeviceToHost, R.d2h);
       if (herr == hipSuccess) herr = hipEventRecord(c.done, R.d2h);
       R.cnt.d2h += R.c_bytes(b);
     } else {
@@ -1042,6 +1080,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     set_error("flash csr: I/O pipeline failed: " + io_error_text(e));
     fail = BOF_EIO;
   }
+  if (is_mm) g_last_c_twin_bytes += R.cnt_buffered_c.load();
   if (ex && ex->out) {
     Counters &o = *ex->out;
     o.rd += R.cnt.rd.load(); o.wr += R.cnt.wr.load(); o.h2d += R.cnt.h2d.load(); o.d2h += R.cnt.d2h.load();
@@ -1131,6 +1170,7 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   if (rc) return rc;
   if (res) devs.resize(1);   // a matrix that already sits in one device's HBM (csrmm 'T') is used there
   DeviceCallLock call_lock(devs);
+  if (is_mm) { g_last_c_mode = -1; g_last_c_twin_bytes = 0; }      // (bof_flash_last_c_file: this call's C file)
   if (o.io_request_kib > 0) (void) bof_file_set_request_bytes((uint64_t) o.io_request_kib << 10);
   file_set_engine(o.io_engine);
   if (devs.size() == 1 || m == 0) {
@@ -1256,7 +1296,8 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
   });
 
   // the C file's descriptor mode, over the row blocks of all devices (c_blocks_aligned)
-  const int c_direct = is_mm && fc.fd >= 0 && file_is_direct(fc.fd) ? (c_blocks_aligned(fc, ord_b, k, m, bst.data(), bsz.data(), nb) ? 1 : 0) : -1;
+  const int c_direct = is_mm && fc.fd >= 0 && file_is_direct(fc.fd)
+                           ? c_file_mode(fc, ord_b, k, m, bst.data(), bsz.data(), nb, o.use_odirect != 0) : -1;
   // ---- one pipeline per device on its rows ------------------------------------------------------------
   auto run_shard = [&](Shard &S) {
     DeviceScope ds(S.dev);
@@ -1495,3 +1536,8 @@ int bof_flash_csrgemv(char trans_a, uint64_t m, uint64_t n, bof_fptr a, bof_fptr
 }
 
 }  // extern "C"
+
+extern "C" int bof_flash_last_c_file(uint64_t *twin_bytes) {
+  if (twin_bytes) *twin_bytes = bof::g_last_c_twin_bytes.load();
+  return bof::g_last_c_mode.load();
+}

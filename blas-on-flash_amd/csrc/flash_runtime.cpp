@@ -1127,8 +1127,15 @@ static int flash_gemm_impl(char ord, char ta, char tb, int64_t m, int64_t n, int
   if (o.io_request_kib > 0) (void) bof_file_set_request_bytes((uint64_t) o.io_request_kib << 10);
   file_set_engine(o.io_engine);
   const GemmGeometry g = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
-  if (g.nblk[0] * g.nblk[2] == 0) return BOF_OK;
-  if (g.nblk[1] == 0) { set_error("bof_flash_gemm: k == 0 is not supported on the file path"); return BOF_EINVAL; }
+  auto nothing_to_do = [&t_begin] {      // the call's statistics are those of a call that moved nothing
+    publish_stats(Counters(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    return BOF_OK;
+  };
+  if (g.nblk[0] * g.nblk[2] == 0) return nothing_to_do();
+  // k == 0: the reference's tiler has NUM_B[1] == 0 k-blocks, builds an empty task array, links nothing, hands the
+  // scheduler nothing and returns 0 -- the C file is never opened for I/O (src/blas/gemm.cpp:69-75 block counts,
+  // :83-129 the task loops, :176-200 add_task / flush).  Same here: no byte of C moves, not even by beta.
+  if (g.nblk[1] == 0) return nothing_to_do();
 
   // ---- large working budgets: whole row panels in file layout, big sequential requests ----
   // One process per GPU with a shared operand (share_world > 1): a rank that cannot do its part -- an error, or a

@@ -706,6 +706,44 @@ __device__ __forceinline__ void dma16(uint32_t voff, uint64_t sbase, uint32_t ld
 }
 #pragma clang diagnostic pop
 
+// ---- synchronisation of the four waves of a workgroup: s_barrier, or progress counters in LDS (SYNC = 1) -----------
+// With ONE wave per SIMD a wave that waits at s_barrier leaves its matrix pipe idle, and a barrier makes every slab as
+// slow as its slowest wave (sum over slabs of the max over waves).  SYNC = 1 replaces the rendezvous by two counters
+// in LDS that give every wave one k-group (~4 k cycles) of slack in both directions:
+//   landed:    += 1 by every wave once ITS DMA pieces of the next slab are in LDS (s_waitcnt vmcnt(0) at the start of
+//              k-group 2 -- the pieces were issued during group 0); a wave reads the next slab's first fragments (under
+//              the MFMAs of group 3) only after landed >= 4 * (slabs so far): RAW.
+//   read_done: += 1 by every wave once its last fragment reads of the current buffer have returned (start of group 3);
+//              a wave issues DMA pieces into the other buffer (group 0 of the next slab) only after
+//              read_done >= 4 * (slabs before this one): WAR.
+// A counter cannot be satisfied by a fast wave's NEXT increment standing in for a slow wave's missing one: to publish
+// `landed` of slab n + 2 a wave has passed group 3 of slab n, which needed `landed` of slab n + 1 from ALL four (and
+// likewise for read_done).  The value a check needs is fetched one slot ahead (a ds_read_b32 behind the fragment reads, covered by
+// the same s_waitcnt lgkmcnt(0) that opens the k-group); only a wave that is AHEAD of the others re-reads in a loop.
+__device__ __forceinline__ void lds_count_up(uint32_t addr, uint32_t one) {      // one lane adds 1
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(one) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_peek(uint32_t addr) {                  // issue only; the next lgkmcnt(0) covers it
+  uint32_t r;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lds_wait_count(uint32_t addr, uint32_t peeked, uint32_t target) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(peeked) :: "memory");      // (pins the use behind the peek's return; already 0 here)
+  uint32_t v = __builtin_amdgcn_readfirstlane(peeked);
+  while (v < target) {       // (a wave ahead of the others: spin on the counter)
+    uint32_t r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory");
+    v = __builtin_amdgcn_readfirstlane(r);
+  }
+}
+struct SlabSync {
+  uint32_t landed_addr, read_addr;   // LDS byte addresses of the two counters
+  uint32_t one;                      // 1 in a VGPR
+  uint32_t slab;                     // index of the slab being multiplied (uniform)
+  uint32_t peek_land, peek_read;     // counter values fetched one slot ahead
+};
+
 // One 32-deep slab out of LDS buffer BUF.  Slots 0-3 issue the 16 DMA pieces of the next slab
 // (origins a_next / b_next, 4-k-row stride a_step4 / b_step4 bytes) into the other buffer; 4 per
 // slot is the measured optimum (all in slot 0: 141.9, 8 per slot: 144.5, 4: 146.1-146.7, 2: 145.0,
@@ -714,17 +752,31 @@ __device__ __forceinline__ void dma16(uint32_t voff, uint64_t sbase, uint32_t ld
 // group 3 were fetched during group 2) and the DMA pieces have had 8 slots to land, so the
 // fragments of the next slab's group 0 are read under the MFMAs of group 3 and a slab starts
 // with its operands in registers.  On entry a[0] / b[0] hold group 0 of this slab.
-template <int BUF>
+// ABL (tools/exp/dma2_ablate.hip, timing only -- results are wrong by construction): 1 no barrier, 2 no vmcnt wait,
+// 4 no DMA pieces, 8 no fragment reads.
+template <int BUF, int ABL = 0, int SYNC = 0>
 __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const uint32_t (&b_base)[2][4],
                                           uint64_t a_next, uint64_t b_next, uint64_t a_step4, uint64_t b_step4,
                                           unsigned a_goff, unsigned b_goff, uint32_t a_dst, uint32_t b_dst,
-                                          f32x4 (&a)[2][4], f32x4 (&b)[2][4], f32x16 (&acc)[4][4]) {
+                                          f32x4 (&a)[2][4], f32x4 (&b)[2][4], f32x16 (&acc)[4][4], SlabSync &sy) {
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     lgkm_fence(a[q & 1], b[q & 1]);
-    if (q == 3) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
-      __syncthreads();
+    if (SYNC == 0) {
+      if (q == 3) {
+        if (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        if (!(ABL & 1)) __syncthreads();
+      }
+    } else {
+      if (q == 0) lds_wait_count(sy.read_addr, sy.peek_read, 4u * sy.slab);          // WAR: the other buffer is free
+      if (q == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // my pieces of the next slab are in LDS
+        lds_count_up(sy.landed_addr, sy.one);
+      }
+      if (q == 3) {
+        lds_count_up(sy.read_addr, sy.one);                                           // my reads of this buffer are done
+        lds_wait_count(sy.landed_addr, sy.peek_land, 4u * (sy.slab + 1u));            // RAW: everybody's pieces are in
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -734,7 +786,7 @@ __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const 
         for (int nt = 0; nt < 4; nt++)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
                                                              acc[mt][nt], 0, 0, 0);
-      if (c < 3) {
+      if (c < 3 && !(ABL & 8)) {
 #pragma unroll
         for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
           if (q == 0) { a[1][x] = rd_frag<1>(a_base[BUF][x]); b[1][x] = rd_frag<1>(b_base[BUF][x]); }
@@ -743,8 +795,12 @@ __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const 
           if (q == 3) { a[0][x] = rd_frag<0>(a_base[BUF ^ 1][x]); b[0][x] = rd_frag<0>(b_base[BUF ^ 1][x]); }
         }
       }
+      if (SYNC == 1 && c == 2) {        // behind this slot's fragment reads: what the next k-group's check will look at
+        if (q == 2) sy.peek_land = lds_peek(sy.landed_addr);
+        if (q == 3) sy.peek_read = lds_peek(sy.read_addr);
+      }
       const int s = 4 * q + c;
-      if (s < 4) {  // pieces 2s, 2s+1 of A and of B; piece p = k-rows 4p..4p+3 (one per wave)
+      if (s < 4 && !(ABL & 4)) {  // pieces 2s, 2s+1 of A and of B; piece p = k-rows 4p..4p+3 (one per wave)
         dma16(a_goff, a_next + (uint64_t) (2 * s) * a_step4, a_dst + (2 * s) * 4096);
         dma16(b_goff, b_next + (uint64_t) (2 * s) * b_step4, b_dst + (2 * s) * 4096);
         dma16(a_goff, a_next + (uint64_t) (2 * s + 1) * a_step4, a_dst + (2 * s + 1) * 4096);
@@ -753,15 +809,16 @@ __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  sy.slab++;
 }
 
-template <class EP = NoEpi>
+template <class EP = NoEpi, int ABL = 0, int SYNC = 0>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                           int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
                           float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
   constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;   // floats
-  __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF];
+  __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF + (SYNC ? 4 : 0)];
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -800,6 +857,13 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
   const uint64_t a_slab = a_step4 * 8, b_slab = b_step4 * 8;                     // 32 k-rows
 
   f32x16 acc[4][4];
+  SlabSync sy{};
+  if (SYNC) {
+    sy.landed_addr = lds0 + 4u * (unsigned) (2 * LDS_BUF);
+    sy.read_addr = sy.landed_addr + 4u;
+    sy.one = 1u;
+    if (t == 0) { lds[2 * LDS_BUF] = 0.f; lds[2 * LDS_BUF + 1] = 0.f; }      // (bit pattern 0; in place before the barrier below)
+  }
 
   const int nkt = K / BK;
 #pragma unroll
@@ -822,10 +886,10 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
   // again (valid memory, never used), which keeps the accumulators in one register assignment.
   uint64_t a_next = a_org + a_slab, b_next = b_org + b_slab;
   for (int kt = 0; kt < nkt; kt += 2) {
-    slab_dma2<0>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc);
+    slab_dma2<0, ABL, SYNC>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
     const bool more = kt + 2 < nkt;
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
-    slab_dma2<1>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc);
+    slab_dma2<1, ABL, SYNC>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead fragment reads of the last slab
@@ -1299,8 +1363,10 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
       hipLaunchKernelGGL((sgemm_tile256_1w2_kernel<AMODE, BMODE, true, EP>), dim3(tiles_m * tiles_n), dim3(256),
                          0, st, A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (N == Ni && M == Mi) return e;
+    if (e != hipSuccess || (N == Ni && M == Mi)) {
+      if (fork_ev) pooled_event_return(fork_ev);     // (a failed interior launch must not keep the pool's event: ADVICE r5)
+      return e;
+    }
     // The strips touch other elements of C than the interior and only read A and B: on a big launch they run on a
     // stream of their own BESIDE the interior kernel instead of behind it (forked from `st` in front of the interior,
     // joined behind it) -- two launches of a 128-deep slab loop each, 0.9 ms of a 54 ms product at the paper's
@@ -1367,10 +1433,14 @@ static hipError_t sgemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, c
   // MKL's behaviour is pinned by tests/golden/mkl_golden_special.npz.
   // An accumulate chain (ChainEpi): the quick return belongs to the FINAL launch, which then also ignores the partial
   // sums (they may hold the 0 * NaN the rule exists to keep out); a raw launch just accumulates.
+  // The FINAL launch of a chain over zero k-slabs (K == 0, alpha != 0) still owes the chain's partial sums their
+  // alpha: only alpha == 0 is a quick return there (what spot_check_kernel recomputes) -- the kernels run
+  // zero slabs from acc_in and apply the store rule with the caller's alpha.
   bool quick = alpha == 0.f || K == 0;
   if constexpr (EP::chain) {
     if (ep.raw_out) quick = false;
     else if (alpha == 0.f) ep.acc_in = nullptr;
+    else if (ep.acc_in) quick = false;
   }
   if (quick) {
     K = 0;

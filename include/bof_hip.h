@@ -429,6 +429,14 @@ int64_t bof_share_selftest(const char *share_name, int rank, int world, int64_t 
  * stall watchdog fires, when a BOF_VERIFY check fails, and after every level-3 call when
  * $BOF_EVENT_DUMP names a file.  Returns the number of events recorded so far. */
 uint64_t bof_event_dump(const char *path);
+/* How the last bof_flash_csrmm call treated its C FILE (additive to ABI v5).  Returns the mode: 1 = every row block's
+ * region was sector-aligned, O_DIRECT as it is; 2 = unaligned row blocks of a row-major C (k = 100: 400-byte rows) kept
+ * on O_DIRECT -- whole pages with O_DIRECT, the partial first / last page of a block through the page cache, where the
+ * page two neighbouring blocks share is merged (the reference: sector read-modify-write with neighbour ordering,
+ * src/file_handles/flash_file_handle.cpp:558-716, src/scheduler/io_executor.cpp:28-156); 0 = the buffered twin for every
+ * request (column-major C with unaligned column pieces, $BOF_UNALIGNED_DIRECT=0); -1 = C was not an O_DIRECT file.
+ * *twin_bytes (may be NULL): bytes of whole row blocks written through the buffered twin (0 unless the mode is 0). */
+int bof_flash_last_c_file(uint64_t *twin_bytes);
 
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
  * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided

@@ -378,6 +378,7 @@ static Csr random_csr(int64_t m, int64_t n) {
   if (c.val.empty()) { c.val.push_back(0); c.ja.push_back(0); }   // files are never empty; nnz stays 0
   return c;
 }
+static long g_c_kept_direct = 0, g_c_widened = 0;      // csrmm calls whose O_DIRECT C file stayed direct / took the widened mode
 static void csr_case(int64_t m, int64_t n, int64_t k, char ord_b, float alpha, float beta, const std::vector<int> &devs, bool direct) {
   const Csr a = random_csr(m, n);
   TmpFile fv("val.bin", a.val, 0, direct), fj("ja.bin", a.ja, 0, direct), fi("ia.bin", a.ia, 0, direct);
@@ -406,6 +407,14 @@ static void csr_case(int64_t m, int64_t n, int64_t k, char ord_b, float alpha, f
     if (g_any_error_ok && rc != BOF_OK) return;
     if (rc) fprintf(stderr, "csrmm %ldx%ldx%ld %c devs %zu: rc %d (%s)\n", (long) m, (long) n, (long) k, ord_b, devs.size(), rc, bof_last_error());
     CHECK(rc == BOF_OK);
+    {
+      // a row-major C on an O_DIRECT descriptor STAYS on O_DIRECT whatever the alignment of its row blocks (round 6:
+      // widened reads / page-split writes, bof_flash_last_c_file mode 2); no row block goes through the buffered twin
+      uint64_t twin = ~0ull;
+      const int mode = bof_flash_last_c_file(&twin);
+      if (ord_b == 'R' && direct && mode >= 0) { CHECK(mode == 1 || mode == 2); CHECK(twin == 0); g_c_kept_direct++; }
+      if (mode == 2) g_c_widened++;
+    }
     const std::vector<float> got = fc.read<float>(C.size());
     for (size_t i = 0; i < got.size(); i++)
       if (got[i] != want[i]) {
@@ -762,7 +771,8 @@ int main(int argc, char **argv) {
     }
     CHECK(bof_flash_release() == BOF_OK);
     for (int d = 0; d < 4; d++) CHECK(mock_hip_bytes_in_use(d) == 0);
-    printf("host_pipeline ok: %d mixed-alignment csr cases\n", 2 * n);
+    printf("host_pipeline ok: %d mixed-alignment csr cases (%ld row-major C files kept on O_DIRECT, %ld of them with widened reads / "
+           "page-split writes)\n", 2 * n, g_c_kept_direct, g_c_widened);
     return 0;
   }
   if (argc > 2 && !strcmp(argv[2], "apifail")) {

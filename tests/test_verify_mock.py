@@ -78,3 +78,46 @@ def test_damaged_word_is_caught_and_named(tmp_path, mock_lib, path, inject, need
     assert out["rc"] == 1, "a damaged word / a dropped launch went unnoticed"
     assert "BOF_VERIFY mismatch" in out["err"] and needle in out["err"], out["err"]
     assert "[bof events]" in err            # the event ring came with it
+
+
+K_ZERO_CHILD = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "blas-on-flash_amd"))
+from test_dist_gloo import _use_mock_library
+_use_mock_library(SO)
+import bofhip
+m, n, blk = 300, 280, 128
+rng = np.random.default_rng(4)
+c0 = rng.integers(-3, 4, (m, n)).astype(np.float32)
+c0[2, 3] = np.nan
+for name, x in (("A", np.zeros(8, np.float32)), ("B", np.zeros(8, np.float32)), ("C", c0)): x.tofile(os.path.join(DIR, name))
+fds = [os.open(os.path.join(DIR, x), os.O_RDWR) for x in "ABC"]
+out = {"rc": []}
+for path in (0, 1, 2):
+    for beta in (0.0, 2.0):
+        try:
+            bofhip.flash_gemm("R", "N", "N", m, n, 0, 1.5, beta, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
+                              bofhip.FPtr(fds[2], 0), 0, 0, 0, bofhip.default_options(gemm_blk=blk, gemm_path=path, use_odirect=0))
+            st = bofhip.flash_last_stats()
+            out["rc"].append([0, st["bytes_written"], st["bytes_read"], st["tasks"]])
+        except bofhip.BofError as e:
+            out["rc"].append([1, str(e)])
+got = np.fromfile(os.path.join(DIR, "C"), np.uint32)
+out["untouched"] = bool(np.array_equal(got, c0.view(np.uint32).ravel()))
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_k_zero_on_files_returns_ok_and_leaves_c_alone(tmp_path, mock_lib):
+    """flash::gemm with k == 0: the reference's tiler has zero k-blocks, creates no task and returns 0 -- C is not
+    touched, not even by beta (src/blas/gemm.cpp:69-75, 83-129, 176-200); both paths and the chooser."""
+    import json
+    code = f"ROOT={ROOT!r}\nSO={mock_lib!r}\nDIR={str(tmp_path)!r}\n" + K_ZERO_CHILD
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MOCK_HIP_DEVICES="1"))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(line[-1][7:])
+    assert out["rc"] == [[0, 0, 0, 0]] * 6, out
+    assert out["untouched"]
