@@ -44,7 +44,7 @@ def _best_of(fn, reps):
     return best
 
 
-def cpu_baseline(with_csr=True):
+def cpu_baseline(with_csr=True, full_step=False):
     """The reference's CPU arithmetic timed on this box's host cores (path B):
     tools/cpu_baseline.py in a CHILD process that never touches the GPU (its OpenMP runtime and thread
     pinning stay out of this process) -- Intel MKL's cblas_sgemm / mkl_scsrmm / mkl_cspblas_scsrgemv
@@ -52,9 +52,10 @@ def cpu_baseline(with_csr=True):
     MKL-linked CPU ops; one thread per physical core, pinned; best of 3 and the spread; bounded
     samples (sizes in `sample`).  kind "port": the routine the reference calls, not its binary."""
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py")] + ([] if with_csr else ["--no-csr"])
+    cmd = ([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py")] + ([] if with_csr else ["--no-csr"])
+           + (["--full-step"] if full_step else []))
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode == 0 and line:
             return json.loads(line[-1])
@@ -678,6 +679,7 @@ def roofline_e2e(leg, ceil, flops, kernel_s, mode):
     out = {"seconds": leg["seconds"], "gflops": leg["gflops"], "bound": bound, "t_bound_s": round(t_bound, 4),
            "frac": round(t_bound / leg["seconds"], 3), "terms_s": {k: round(v, 4) for k, v in terms.items()},
            "run_disk_GBps": round((st["bytes_read"] + st["bytes_written"]) / leg["seconds"] / 1e9, 2)}
+    out["frac_raw"] = out["frac"]        # against the probes as they are; > 1 names a mis-probed ceiling
     if t_bound > leg["seconds"]:
         # the call moved its bytes faster than the probe of that stage did: the stage CAN do what it just did, so its
         # ceiling is raised to the call's own rate (and says so) -- the probe moves, never the run
@@ -1315,11 +1317,18 @@ def run_single(args, bofhip, torch, dev, st):
     achieved = flops_per_launch / max(avg_launch_ms, 1e-9) / 1e9          # TFLOP/s
     traffic, traffic_src = pmc_traffic()
     nk = max(n // blk, 1)
+    # the launch mix of the row-panel schedule, recovered from the call's own counters: launches = G nk + (np - G);
+    # the ramp group's k-block launches are <ChainEpi> instantiations, the whole-K launches <NoEpi> (beta == 0)
+    lps = launches / max(args.steps, 1)
+    g_ramp = min(nk, max(0, round((lps - nk) / (nk - 1)))) if nk > 1 else 0
+    kernel_mix = {"sgemm_tile256_dma2_kernel<ChainEpi> (ramp group, one k-block per launch)": int(g_ramp * nk),
+                  "sgemm_tile256_dma2_kernel<NoEpi> (one launch over the whole K)": int(round(lps - g_ramp * nk))}
     mean_step = {q: _mean(p[q] for p in per) for q in ("bytes_read", "bytes_written", "bytes_h2d", "bytes_d2h")}
     bound, t_bound, terms = e2e_bound(mean_step, ceil if "error" not in ceil else {}, args.steps, ksec / args.steps)
     secs = sorted(p["seconds"] for p in per)
     med_step = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
     probe_note = None
+    e2e_frac_raw = round(t_bound / (dt / args.steps), 3)          # against the probes as they are (may exceed 1: a bad probe)
     if t_bound > dt / args.steps and bound.startswith("disk"):
         # the steps moved bytes faster than every probe: the device CAN do what it just did -- the ceiling is raised to
         # the rate the steps themselves showed (flagged), never the other way round
@@ -1346,7 +1355,8 @@ def run_single(args, bofhip, torch, dev, st):
                    "ms_per_step_median": round(med_step * 1e3, 2),
                    "mean_over_median": round(dt / args.steps / med_step, 3),
                    "C_verified": h["verified"], "parallelism": "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel<NoEpi>",
+        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel (both instantiations; launches per step in kernel_mix)",
+                     "kernel_mix": kernel_mix,
                      "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(avg_launch_ms, 4),
                      "launches": launches, "timed_with": "HIP events around every tile launch on its compute stream, "
@@ -1354,10 +1364,10 @@ def run_single(args, bofhip, torch, dev, st):
                      "flops_per_launch": flops_per_launch,
                      "launches_per_step": round(launches / args.steps, 1),
                      "algorithmic_bytes_per_launch": _alg_bytes_per_launch(n, blk, launches / args.steps),
-                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic": traffic, "traffic_source": f"static: {traffic_src} (PMC passes of this command, committed; not this run)",
                      "kernel_s_per_step": round(ksec / args.steps, 4),
                      "e2e_bound": bound, "e2e_t_bound_s": round(t_bound, 4),
-                     "e2e_frac": round(t_bound / (dt / args.steps), 3), "e2e_terms_s": terms,
+                     "e2e_frac": round(t_bound / (dt / args.steps), 3), "e2e_frac_raw": e2e_frac_raw, "e2e_terms_s": terms,
                      **({"e2e_probe_note": probe_note} if probe_note else {}),
                      "e2e_probe": {k: ceil.get(k) for k in ("disk_read_GBps", "disk_write_GBps",
                                                             "disk_read_GBps_while_writing",
@@ -1365,7 +1375,7 @@ def run_single(args, bofhip, torch, dev, st):
                                                             "pcie_d2h_GBps") if k in ceil}},
     }
     if not args.no_cpu:
-        cb = cpu_baseline(with_csr=not args.no_extras and not args.size)
+        cb = cpu_baseline(with_csr=not args.no_extras and not args.size, full_step=not args.size and not args.no_cpu_full_step)
         detail["cpu_baseline"] = cb
         line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit", "GFLOP/s"), "cores": cb.get("cores"),
                                 "kind": cb.get("kind", "port"),
@@ -1375,6 +1385,10 @@ def run_single(args, bofhip, torch, dev, st):
             if isinstance(cb.get(q), dict):
                 line["cpu_baseline"][q + "_gflops"] = cb[q].get("value")
                 line["cpu_baseline"][q + "_cores"] = cb[q].get("cores")
+        # the workload itself beside the sample: one in-memory 32768^3 cblas_sgemm (drivers/in_mem_gemm.cpp:63-70)
+        for q in ("full_step_s", "full_step_gflops", "full_step_skipped"):
+            if cb.get(q) is not None:
+                line["cpu_baseline"][q] = cb[q]
         if cb.get("error"):
             line["cpu_baseline"]["error"] = str(cb["error"])[:120]
     if not args.no_extras and not args.size:
@@ -1780,6 +1794,8 @@ def main():
                          "per-kernel average is compared with; 0 = the library's default of two, whose "
                          "launches overlap pairwise)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-full-step", action="store_true",
+                    help="cpu_baseline: only the 16384^3 sample, not the one in-memory 32768^3 sgemm (about a minute on 128 cores)")
     ap.add_argument("--resident-only", action="store_true",
                     help="only the HBM-resident tile DAG of configs[1] (no file I/O, no D2H: what tools/profile_bench.sh puts "
                          "under rocprofv3 --kernel-trace to corroborate the kernel's launch time); prints its record")

@@ -754,7 +754,13 @@ struct SlabSync {
 // with its operands in registers.  On entry a[0] / b[0] hold group 0 of this slab.
 // ABL (tools/exp/dma2_ablate.hip, timing only -- results are wrong by construction): 1 no barrier, 2 no vmcnt wait,
 // 4 no DMA pieces, 8 no fragment reads.
-template <int BUF, int ABL = 0, int SYNC = 0>
+// IL = 1: the side work of a slot (fragment reads of the next k-group, DMA pieces of the next slab) is spread over the
+// gaps between the slot's 16 MFMAs, at most one piece per gap, instead of standing in ONE gap behind them.  A wave
+// issues an instruction every ~4 cycles and an MFMA keeps the pipe busy for 64: the ~35 instructions of slot 0's
+// 8 reads + 4 DMA pieces (v_readlane, s_mov m0, s_nop, global_load_lds, two scalar adds each) took longer than the
+// gap they stood in -- the ablation (tools/exp/dma2_ablate, profiles/r6/kernel_ablation.jsonl) prices the DMA pieces
+// at 1.9 % and the fragment reads at 0.8 % of the whole-K launch, which is what a drained pipe per slot costs.
+template <int BUF, int ABL = 0, int SYNC = 0, int IL = 0>
 __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const uint32_t (&b_base)[2][4],
                                           uint64_t a_next, uint64_t b_next, uint64_t a_step4, uint64_t b_step4,
                                           unsigned a_goff, unsigned b_goff, uint32_t a_dst, uint32_t b_dst,
@@ -780,39 +786,70 @@ __device__ __forceinline__ void slab_dma2(const uint32_t (&a_base)[2][4], const 
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
+      const int s = 4 * q + c;
+      // fragment of sub-tile x of the NEXT k-group (A if !second, B if second): the buffer and k-group follow from q
+      auto read_piece = [&](int x, bool second) {
+        if (ABL & 8) return;
+        if (!second) {
+          if (q == 0) a[1][x] = rd_frag<1>(a_base[BUF][x]);
+          if (q == 1) a[0][x] = rd_frag<2>(a_base[BUF][x]);
+          if (q == 2) a[1][x] = rd_frag<3>(a_base[BUF][x]);
+          if (q == 3) a[0][x] = rd_frag<0>(a_base[BUF ^ 1][x]);
+        } else {
+          if (q == 0) b[1][x] = rd_frag<1>(b_base[BUF][x]);
+          if (q == 1) b[0][x] = rd_frag<2>(b_base[BUF][x]);
+          if (q == 2) b[1][x] = rd_frag<3>(b_base[BUF][x]);
+          if (q == 3) b[0][x] = rd_frag<0>(b_base[BUF ^ 1][x]);
+        }
+      };
+      // DMA piece p (0..3) of slot s: pieces 2s, 2s+1 of A and of B; piece = k-rows 4p..4p+3 (one per wave)
+      auto dma_piece = [&](int p) {
+        if (ABL & 4) return;
+        const int pc = 2 * s + (p >> 1);
+        if (!(p & 1)) dma16(a_goff, a_next + (uint64_t) pc * a_step4, a_dst + pc * 4096);
+        else dma16(b_goff, b_next + (uint64_t) pc * b_step4, b_dst + pc * 4096);
+      };
+      if (IL == 0) {
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+        for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
-                                                             acc[mt][nt], 0, 0, 0);
-      if (c < 3 && !(ABL & 8)) {
+          for (int nt = 0; nt < 4; nt++)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mt][c], b[q & 1][nt][c],
+                                                               acc[mt][nt], 0, 0, 0);
+        if (c < 3) {
 #pragma unroll
-        for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) {
-          if (q == 0) { a[1][x] = rd_frag<1>(a_base[BUF][x]); b[1][x] = rd_frag<1>(b_base[BUF][x]); }
-          if (q == 1) { a[0][x] = rd_frag<2>(a_base[BUF][x]); b[0][x] = rd_frag<2>(b_base[BUF][x]); }
-          if (q == 2) { a[1][x] = rd_frag<3>(a_base[BUF][x]); b[1][x] = rd_frag<3>(b_base[BUF][x]); }
-          if (q == 3) { a[0][x] = rd_frag<0>(a_base[BUF ^ 1][x]); b[0][x] = rd_frag<0>(b_base[BUF ^ 1][x]); }
+          for (int x = (c == 0 ? 0 : c + 1); x <= c + 1; x++) { read_piece(x, false); read_piece(x, true); }
+        }
+        if (SYNC == 1 && c == 2) {        // behind this slot's fragment reads: what the next k-group's check will look at
+          if (q == 2) sy.peek_land = lds_peek(sy.landed_addr);
+          if (q == 3) sy.peek_read = lds_peek(sy.read_addr);
+        }
+        if (s < 4) { dma_piece(0); dma_piece(1); dma_piece(2); dma_piece(3); }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        const int x0 = c == 0 ? 0 : c + 1;        // first sub-tile whose next-group fragments this slot fetches (c < 3)
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          acc[j >> 2][j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][j >> 2][c], b[q & 1][j & 3][c],
+                                                                     acc[j >> 2][j & 3], 0, 0, 0);
+          // gap behind MFMA j: reads in the even gaps 0, 2 (, 4, 6 in slot 0 of a group), DMA pieces in gaps 1, 5, 9, 13,
+          // the counter peek in gap 8
+          if (c < 3 && (j == 0 || j == 2)) read_piece(x0, j == 2);
+          if (c == 0 && (j == 4 || j == 6)) read_piece(1, j == 6);
+          if (s < 4 && (j & 3) == 1) dma_piece(j >> 2);
+          if (SYNC == 1 && c == 2 && j == 8) {
+            if (q == 2) sy.peek_land = lds_peek(sy.landed_addr);
+            if (q == 3) sy.peek_read = lds_peek(sy.read_addr);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (SYNC == 1 && c == 2) {        // behind this slot's fragment reads: what the next k-group's check will look at
-        if (q == 2) sy.peek_land = lds_peek(sy.landed_addr);
-        if (q == 3) sy.peek_read = lds_peek(sy.read_addr);
-      }
-      const int s = 4 * q + c;
-      if (s < 4 && !(ABL & 4)) {  // pieces 2s, 2s+1 of A and of B; piece p = k-rows 4p..4p+3 (one per wave)
-        dma16(a_goff, a_next + (uint64_t) (2 * s) * a_step4, a_dst + (2 * s) * 4096);
-        dma16(b_goff, b_next + (uint64_t) (2 * s) * b_step4, b_dst + (2 * s) * 4096);
-        dma16(a_goff, a_next + (uint64_t) (2 * s + 1) * a_step4, a_dst + (2 * s + 1) * 4096);
-        dma16(b_goff, b_next + (uint64_t) (2 * s + 1) * b_step4, b_dst + (2 * s + 1) * 4096);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   sy.slab++;
 }
 
-template <class EP = NoEpi, int ABL = 0, int SYNC = 0>
+template <class EP = NoEpi, int ABL = 0, int SYNC = 0, int IL = 0>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                           int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
@@ -886,10 +923,10 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
   // again (valid memory, never used), which keeps the accumulators in one register assignment.
   uint64_t a_next = a_org + a_slab, b_next = b_org + b_slab;
   for (int kt = 0; kt < nkt; kt += 2) {
-    slab_dma2<0, ABL, SYNC>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
+    slab_dma2<0, ABL, SYNC, IL>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
     const bool more = kt + 2 < nkt;
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
-    slab_dma2<1, ABL, SYNC>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
+    slab_dma2<1, ABL, SYNC, IL>(a_base, b_base, a_next, b_next, a_step4, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead fragment reads of the last slab
@@ -1350,9 +1387,17 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
         fork_ev = nullptr;
       }
     }
-    if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0)
-      hipLaunchKernelGGL(sgemm_tile256_dma2_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
-                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
+    if (AMODE == KMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0) {
+      // round 6 default: the four waves synchronise through progress counters in LDS and the slot's side work is spread
+      // over the MFMA gaps (SYNC = 1, IL = 1: 0.975 of peak on a whole-K panel launch against 0.956 with s_barrier, bit
+      // for bit the same C -- profiles/r6/kernel/); BOF_GEMM_DMA2_SYNC=0 launches the s_barrier kernel (A/B)
+      if (knob("BOF_GEMM_DMA2_SYNC", 1) != 0)
+        hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<EP, 0, 1, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
+                           ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
+      else
+        hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<EP, 0, 0, 0>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
+                           ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
+    }
     else if (K % (2 * BK) == 0)
       hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE, EP>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
                          A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);

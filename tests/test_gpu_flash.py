@@ -115,10 +115,10 @@ def test_flash_gemm_reference_chain(dev, tmp_path, ord_, ta, tb, path):
         F.close()
 
 
-@pytest.mark.parametrize("kw", [dict(gemm_path=1, devices=[0, 0]), dict(gemm_path=1, devices=[0, 0, 0], hbm_budget=3 * 20 * 128 * 128 * 4),
+@pytest.mark.parametrize("kw", [dict(gemm_path=1, devices=[0, 0]), dict(gemm_path=1, devices=[0, 0, 0], hbm_budget=3 * 40 * 128 * 128 * 4),
                                 dict(gemm_path=2, devices=[0, 0, 0]), dict(gemm_path=2, devices=[0, 0], peer_bcast=1),
                                 dict(gemm_path=2, panel_group=1, panel_streams=1), dict(gemm_path=2, panel_group=3, panel_streams=2),
-                                dict(gemm_path=1, hbm_budget=14 * 128 * 128 * 4), dict(gemm_path=0)],
+                                dict(gemm_path=1, hbm_budget=40 * 128 * 128 * 4), dict(gemm_path=0)],
                          ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()).replace(" ", ""))
 @pytest.mark.parametrize("ord_,ta,tb,beta", [("R", "N", "N", 2.0), ("R", "T", "N", 0.0), ("C", "N", "T", 2.0), ("C", "T", "T", 0.0)])
 def test_flash_gemm_reference_chain_every_path(dev, tmp_path, ord_, ta, tb, beta, kw):

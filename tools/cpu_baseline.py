@@ -129,6 +129,41 @@ def main():
     out["sgemm_4096_gflops_worst_of_3"] = round(2.0 * 4096 ** 3 / t4hi / 1e9, 1)
     out["sample"] = (f"sgemm 16384^3 fp32 (1/8 of a step), best of 3 after warm-up: {t16:.2f} s (worst {t16hi:.2f}); "
                      f"4096^3 (BASELINE configs[0], one tile task): {t4 * 1e3:.0f} ms (worst {t4hi * 1e3:.0f})")
+    if "--full-step" in sys.argv:
+        # the WORKLOAD itself, not a sample of it: one in-memory 32768^3 cblas_sgemm, what
+        # drivers/in_mem_gemm.cpp:63-70 times for BASELINE configs[1]'s matrices -- one call, no warm-up beyond the
+        # sample above; only when the sample predicts <= 150 s and the box has the 12 GiB + slack
+        try:
+            avail = 0
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable"):
+                    avail = int(ln.split()[1]) * 1024
+            n2 = 2 * n_big
+            if 8 * t16 > 150:
+                out["full_step_skipped"] = f"predicted {8 * t16:.0f} s"
+            elif avail < (40 << 30):
+                out["full_step_skipped"] = f"{avail >> 30} GiB of memory available"
+            else:
+                a2 = np.empty((n2, n2), np.float32)
+                b2 = np.empty((n2, n2), np.float32)
+                for i in (0, 1):
+                    for j in (0, 1):
+                        a2[i * n_big:(i + 1) * n_big, j * n_big:(j + 1) * n_big] = a
+                        b2[i * n_big:(i + 1) * n_big, j * n_big:(j + 1) * n_big] = b
+                c2 = np.zeros((n2, n2), np.float32)        # (pages touched before the clock starts)
+                t0 = time.perf_counter()
+                if mkl is not None:
+                    mkl.cblas_sgemm(101, 111, 111, n2, n2, n2, 1.0, p(a2), n2, p(b2), n2, 0.0, p(c2), n2)
+                else:
+                    import torch
+                    torch.mm(torch.from_numpy(a2), torch.from_numpy(b2), out=torch.from_numpy(c2))
+                tf = time.perf_counter() - t0
+                out["full_step_s"] = round(tf, 2)
+                out["full_step_gflops"] = round(2.0 * n2 ** 3 / tf / 1e9, 1)
+                out["full_step_what"] = "ONE in-memory 32768^3 sgemm = BASELINE configs[1]'s matrices (drivers/in_mem_gemm.cpp:63-70), one call"
+                del a2, b2, c2
+        except Exception as e:
+            out["full_step_skipped"] = f"{type(e).__name__}: {str(e)[:120]}"
     del a, b, c
     flags = []
     if out["value"] < SURVEY_8CORE["sgemm_gflops"]:

@@ -35,7 +35,7 @@ __global__ void diff_count(const float *a, const float *b, size_t n, unsigned lo
   if (bad) atomicAdd(out, bad);
 }
 
-template <int ABL, int SYNC>
+template <int ABL, int SYNC, int IL = 0>
 static double run(const char *name, const float *A, const float *B, float *C, int M, int N, int K, int reps) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -43,7 +43,7 @@ static double run(const char *name, const float *A, const float *B, float *C, in
   double best = 1e30, sum = 0;
   for (int r = 0; r < reps + 1; r++) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<NoEpi, ABL, SYNC>), dim3(tm * tn), dim3(256), 0, 0, A, (int64_t) M, B, (int64_t) N, C,
+    hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<NoEpi, ABL, SYNC, IL>), dim3(tm * tn), dim3(256), 0, 0, A, (int64_t) M, B, (int64_t) N, C,
                        (int64_t) N, M, N, K, 1.0f, 0.0f, tm, tn, NoEpi{});
     CK(hipGetLastError());
     CK(hipEventRecord(e1));
@@ -83,6 +83,17 @@ int main(int argc, char **argv) {
     unsigned long long hb = 0;
     CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
     printf("{\"check\":\"counters vs barrier, K=%d\",\"words_that_differ\":%llu}\n", K, hb);
+    for (int pass = 0; pass < 2; pass++) {      // the candidates with their side work spread over the MFMA gaps (IL = 1)
+      float *Cx = pass ? C2 : C2;
+      if (pass == 0) run<0, 0, 1>("barrier, side work interleaved", A, B, Cx, M, N, K, reps);
+      else run<0, 1, 1>("LDS counters, side work interleaved", A, B, Cx, M, N, K, reps);
+      CK(hipMemset(bad, 0, 8));
+      diff_count<<<2048, 256>>>(C, C2, (size_t) M * N, bad);
+      CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
+      printf("{\"check\":\"%s vs barrier, K=%d\",\"words_that_differ\":%llu}\n", pass ? "counters + interleave" : "barrier + interleave", K, hb);
+    }
+    run<4, 0, 1>("ablate: interleaved, no DMA pieces", A, B, C2, M, N, K, reps);
+    run<8, 0, 1>("ablate: interleaved, no fragment reads", A, B, C2, M, N, K, reps);
     run<1, 0>("ablate: no barrier", A, B, C2, M, N, K, reps);
     run<2, 0>("ablate: no vmcnt wait", A, B, C2, M, N, K, reps);
     run<3, 0>("ablate: no barrier, no vmcnt wait", A, B, C2, M, N, K, reps);
