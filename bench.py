@@ -1496,6 +1496,13 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
     import numpy as np
     import torch.distributed as dist
     import bof_dist
+    # Full size (the driver's SCALE runs): every rank owns 8192 C rows of a 65536-wide problem -- the flops of one
+    # configs[1] step per rank (70.4 TFLOP: weak scaling), configs[3] itself at N = 8.  Disk need at N = 8 on ONE
+    # volume: A 16 + B 16 + C 16 GiB + 2 GiB slack = 50 GiB (checked below before anything is written); with
+    # $BOF_BENCH_DIRS over D volumes 4 * (users * 8192 * 131072 + 65536^2) bytes each (B replicated per volume).
+    # Wall time against the driver's 1800 s: files created at the disk's write rate (48 GiB: 4-6 s on the pool's
+    # disks, by all ranks in parallel), every step disk-bound at ~2.1-2.8 s, verification one
+    # read of C (16 GiB: ~1 s) -- warm-up 5 + 20 steps stay under 2 minutes; the CSR extras add ~1 minute.
     k = n = args.size or 65536
     m_local = (args.size or 65536) // 8
     m = m_local * world
@@ -1616,6 +1623,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
         if not good:
             break
     per_rank_s, agg_steps = [], []
+    my_secs = []            # this rank's own seconds per timed step (gathered: `rank_mean_s` in the line)
     dt = float("nan")
     if good:
         if rank == 0 or local_slabs:
@@ -1624,7 +1632,9 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            t_step = time.perf_counter()
             good, smax, smin, err = phase(step)        # ends in an all-reduce = the barrier between steps
+            my_secs.append(last.get("seconds", time.perf_counter() - t_step) if isinstance(last, dict) else time.perf_counter() - t_step)
             per_rank_s.append((smin, smax))
             agg_steps.append(dict(last))
             if not good:
@@ -1634,6 +1644,11 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # every rank's mean seconds per step, in rank order (what an uneven disk share or a slow rank looks like)
+    rank_means = torch.zeros(world, dtype=torch.float64, device=red_dev)
+    rank_means[rank] = sum(my_secs) / max(len(my_secs), 1)
+    dist.all_reduce(rank_means)
+    rank_means = [round(float(v), 3) for v in rank_means.tolist()]
     keys = ("bytes_read", "bytes_written", "bytes_peer", "bytes_h2d", "bytes_d2h", "kernel_launches", "kernel_seconds", "tasks")
     agg = torch.tensor([sum(float(s.get(q, 0)) for s in agg_steps) for q in keys], dtype=torch.float64, device=red_dev)
     dist.all_reduce(agg)
@@ -1700,6 +1715,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
                    "file_dirs": (f"{D} directories ($BOF_BENCH_DIRS): per-rank A / C slab files, a replica of B in each"
                                  if local_slabs else "one shared A / B / C file set"),
                    "rank_s_min": round(min(a for a, _ in per_rank_s), 3), "rank_s_max": round(max(b for _, b in per_rank_s), 3),
+                   "rank_mean_s": rank_means,
                    "read_amplification": round(agg["bytes_read"] / args.steps / (4.0 * (m * k + k * n)), 3),
                    "write_amplification": round(agg["bytes_written"] / args.steps / (4.0 * m * n), 3),
                    "B_GiB_from_peers_per_step": round(agg["bytes_peer"] / args.steps / 2**30, 2),
@@ -1707,12 +1723,13 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
                    "aggregate_write_GBps": round(agg["bytes_written"] / dt / 1e9, 2),
                    "C_verified": bool(match), "create_files_s": round(create_s, 1)},
         "ranks_seen": args.ranks_seen,
-        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel<NoEpi>", "achieved": round(achieved, 2),
+        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel (<ChainEpi> ramp launches + <NoEpi> whole-K launches)",
+                     "achieved": round(achieved, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(launches),
                      "timed_with": "HIP events around every tile launch on its compute stream, all ranks",
                      "algorithmic_bytes_per_launch": int(4 * blk * blk * (3 + (nk - 1) / nk)),
-                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic": traffic, "traffic_source": f"static: {traffic_src} (N = 1 PMC passes, committed; not this run)",
                      "kernel_s_per_step_per_rank": round(ksec / args.steps / world, 4)},
     }
     if verr:

@@ -185,7 +185,11 @@ struct ChunkReq { int di, mat, panel, c; uint64_t off, bytes; };   // di < 0: a 
 // One kernel launch of the schedule: C panel pc, its tiles [q0, q1) along C's other dimension, the k-blocks [l0, l1).
 // flash::gemm: a whole C panel per launch -- one k-block at a time while the resident operand streams in (the ramp
 // group), the whole K afterwards; flash::kmeans: one tile task per launch, as the reference has them.
-struct Launch { int pc; int64_t q0, q1, l0, l1; };
+// d0 .. d1: the launch's part of its C panel along the panel dimension (stored rows of the panel); d1 == 0: all of it.
+// A C panel that runs as ONE launch over the whole K is cut into row slices (PanelRun::slices): slice s is copied out
+// and written while slice s + 1 is still being multiplied, so what follows the last kernel of a call is the write-back
+// of a quarter panel instead of a whole one -- the tail that a fast disk or the page cache exposes.
+struct Launch { int pc; int64_t q0, q1, l0, l1; int64_t d0 = 0, d1 = 0; };
 struct WriteReq { int di, wslot; uint64_t file_off, bytes, delta; int panel; bool last; };
 
 // Per device (and per repetition of one ordinal in the device list): the HBM panel slots and the
@@ -327,6 +331,10 @@ struct PanelRun {
   std::vector<int64_t> gb;                        // first C panel of each group, then NpC
   int n_groups = 0;
   std::vector<std::vector<hipEvent_t>> group_ev;  // per group: one event per compute stream
+  // row slices of the C panels that run as one launch over the whole K: per C panel the slices' last rows and the
+  // events recorded behind their launches (empty: the panel is not sliced, the flusher waits for group_ev)
+  std::vector<std::vector<int64_t>> slice_end;
+  std::vector<std::vector<hipEvent_t>> slice_ev;
   std::vector<int> group_of;                      // C panel -> group
   KmeansVecs kv{nullptr, nullptr, nullptr};
   bool has_kv = false;
@@ -660,13 +668,28 @@ void PanelRun::flusher_main() {
     Panel &P = C.panels[(size_t) pc];
     hipError_t e = hipSuccess;
     evt("C panel handed to the flusher", pc, di);
-    for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
-      if (e == hipSuccess) e = wait_event_both(d2h, w);      // (the dispatcher recorded them; this thread copies)
+    // a panel multiplied in row slices leaves slice by slice: a chunk waits for the slices that cover its rows only
+    const std::vector<int64_t> &send = slice_end[(size_t) pc];
+    size_t slices_waited = 0;
+    auto wait_slices_through = [&](uint64_t last_byte) {       // every slice that holds a byte <= last_byte of the panel
+      const int64_t last_row = (int64_t) (last_byte / ((uint64_t) C.ld * 4));
+      while (e == hipSuccess && slices_waited < send.size() && (slices_waited == 0 || send[slices_waited - 1] <= last_row)) {
+        e = wait_event_both(d2h, slice_ev[(size_t) pc][slices_waited]);      // (the dispatcher recorded it; this thread copies)
+        slices_waited++;
+      }
+    };
+    if (send.empty() || vf.on) {
+      for (hipEvent_t w : group_ev[(size_t) group_of[(size_t) pc]])
+        if (e == hipSuccess) e = wait_event_both(d2h, w);      // (the dispatcher recorded them; this thread copies)
+      slices_waited = send.size();
+    }
     if (e == hipSuccess) e = vf.on_device(P.ve[Panel::VE_C_DEV], C.panel_ptr(pc), 1, (int64_t) (P.bytes / 4), 0, 0, 0, d2h);
     const int nc = C.n_chunks(pc, chunk);
     for (int c = 0; c < nc && e == hipSuccess && !hub->io_error.load(); c++) {
       uint64_t off, len;
       C.chunk_span(pc, c, chunk, &off, &len);
+      wait_slices_through(off + len - 1);
+      if (e != hipSuccess) break;
       // a widened C panel lands in the pinned slot at its file offset modulo the page (file_write_split)
       const uint64_t delta = C.widen ? (C.file_off(pc) + off) % Mat::kPage : 0;
       const int ws = res->wring.acquire();
@@ -837,6 +860,8 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
 
   // ---- launch list in execution order, panels in first-use order ------------------------------
   group_of.assign((size_t) NpC, 0);
+  slice_end.assign((size_t) NpC, std::vector<int64_t>());
+  slice_ev.assign((size_t) NpC, std::vector<hipEvent_t>());
   std::vector<std::vector<char>> seen(3);
   for (int x = 0; x < 3; x++) seen[x].assign(mat[x].panels.size(), 0);
   gb.push_back(0);
@@ -867,12 +892,40 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     } else if (gx == 0 || ref_chain) {
       // the ramp group (the resident operand is still streaming in): k-block by k-block, l-major, so that panel l of
       // it unlocks work on every C panel of the group; the reference's chain keeps that cut for all groups
-      for (int64_t l = 0; l < Nk; l++)
-        for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, l + 1);
+      // Order inside the group: by anti-diagonals (C panel + k-block), so that the first-use order of the panels --
+      // which is the order they are READ in -- alternates between the two operands: A0 B0 | B1 A1 | B2 A2 | ...  The
+      // launches a read enables grow with every panel of EITHER operand from the start (n panels of each in: n^2
+      // launches), where the l-major order (every A panel of the group first) kept the GPU at one launch per A panel
+      // until the group's last A panel was in -- 0.3 s of a 65536^3 call.  A chain's launches stay
+      // in k order on their stream.  $BOF_PANEL_RAMP_ORDER=0: l-major as until round 5.
+      if (env_long("BOF_PANEL_RAMP_ORDER", 1) != 0) {
+        for (int64_t d = 0; d < Nk + (G1 - G0) - 1; d++)
+          for (int64_t pc = G0; pc < G1; pc++) {
+            const int64_t l = d - (pc - G0);
+            if (l >= 0 && l < Nk) add_launch(pc, 0, Nq, l, l + 1);
+          }
+      } else {
+        for (int64_t l = 0; l < Nk; l++)
+          for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, l + 1);
+      }
     } else {
       // behind the ramp everything a C panel needs but its own streamed panel is resident: ONE launch over the
       // whole K -- no C round trip between the k-blocks, an eighth of the launch boundaries
-      for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, 0, Nk);
+      // ... in row slices of the panel, so that its write-back starts before its last kernel has ended
+      // (bof_options: none; $BOF_PANEL_SLICES, default 4; slices are multiples of 256 rows: whole tile rows)
+      for (int64_t pc = G0; pc < G1; pc++) {
+        const int64_t nr = mat[2].panels[(size_t) pc].nr;
+        const int64_t want = std::max<int64_t>(1, env_long("BOF_PANEL_SLICES", 4));
+        const int64_t unit = std::max<int64_t>(1, env_long("BOF_PANEL_SLICE_ROWS", 256));      // (tests: small panels)
+        const int64_t rows = std::max<int64_t>(unit, (nr / want + unit - 1) / unit * unit);
+        if (want <= 1 || rows >= nr) { add_launch(pc, 0, Nq, 0, Nk); continue; }
+        for (int64_t d0 = 0; d0 < nr; d0 += rows) {
+          add_launch(pc, 0, Nq, 0, Nk);
+          launches.back().d0 = d0;
+          launches.back().d1 = std::min(nr, d0 + rows);
+          slice_end[(size_t) pc].push_back(launches.back().d1);
+        }
+      }
     }
     group_end.push_back(launches.size());
   }
@@ -1001,6 +1054,13 @@ int PanelRun::prepare() {
       const int rc0 = res->take_event(&e);
       if (rc0) return rc0;
       v.push_back(e);
+    }
+  for (size_t pc = 0; pc < slice_end.size(); pc++)
+    for (size_t s = 0; s < slice_end[pc].size(); s++) {
+      hipEvent_t e;
+      const int rc0 = res->take_event(&e);
+      if (rc0) return rc0;
+      slice_ev[pc].push_back(e);
     }
   const int rc = res->wring.init(std::max(2, o.pinned_slots), chunk + 2 * Mat::kPage);   // slack: widened / page-congruent placement
   if (rc) return rc;
@@ -1145,7 +1205,7 @@ void PanelRun::dispatch() {
     for (int q = 0; q < ss->n; q++) waited[(size_t) x * (size_t) ss->n + (size_t) q].assign(mat[x].panels.size(), 0);
   // first stored row / column of a launch's part of matrix x along logical dimension d (0 m, 1 k, 2 n)
   auto start_of = [&](const Launch &L, int d) -> int64_t {
-    return d == dC ? (int64_t) L.pc * g.blk[dC] : (d == 1 ? L.l0 * g.blk[1] : L.q0 * g.blk[qdim]);
+    return d == dC ? (int64_t) L.pc * g.blk[dC] + L.d0 : (d == 1 ? L.l0 * g.blk[1] : L.q0 * g.blk[qdim]);
   };
   auto range_of = [&](const Launch &L, int x, int64_t *p0, int64_t *p1) {
     const int rd = mat[x].rdim;
@@ -1229,10 +1289,10 @@ void PanelRun::dispatch() {
         }
       }
       int64_t ext[3];
-      ext[dC] = C.panels[(size_t) L.pc].nr;
+      ext[dC] = L.d1 > 0 ? L.d1 - L.d0 : C.panels[(size_t) L.pc].nr;
       ext[1] = last ? g.size[1] - L.l0 * g.blk[1] : (L.l1 - L.l0) * g.blk[1];
       ext[qdim] = L.q1 == Nq ? g.size[qdim] - L.q0 * g.blk[qdim] : (L.q1 - L.q0) * g.blk[qdim];
-      float *pcp = (float *) C.panel_ptr(L.pc) + L.q0 * C.blk_c;
+      float *pcp = (float *) C.panel_ptr(L.pc) + L.d0 * C.ld + L.q0 * C.blk_c;
       // what the launch is, in the terms of its kernel entry point
       const bool chain_step = !ref_chain && !(first && last);   // one k-range of a chain that carries raw sums
       float *accp = chain_step && need_acc ? (float *) res->acc[(size_t) (L.pc - gb[0])] + L.q0 * C.blk_c : pcp;
@@ -1247,11 +1307,11 @@ void PanelRun::dispatch() {
         sa.u1 = kv.c_l2sq + row_base + ti * g.blk[0]; sa.v1 = kv.ones;
         sa.u2 = kv.ones; sa.v2 = kv.p_l2sq + col_base + tj * g.blk[2];
       }
-      sa.seed = ((uint64_t) L.pc << 40) ^ ((uint64_t) L.l0 << 20) ^ (uint64_t) L.q0 ^ ((uint64_t) di << 56);
+      sa.seed = ((uint64_t) L.pc << 40) ^ ((uint64_t) L.l0 << 20) ^ (uint64_t) L.q0 ^ ((uint64_t) di << 56) ^ ((uint64_t) L.d0 << 8);
       evt("launch", L.pc, (int) (L.l0 * 1024 + L.l1), (uint64_t) (((uint64_t) di << 24) | ((uint64_t) sidx << 16) | (uint64_t) L.q0));
       Verify::Spot spot;
       // the rectangle of C (or of the raw accumulator panel) the launch stores into; the same one it starts from
-      const int64_t c_rows = C.panels[(size_t) L.pc].nr, c_cols = ext[qdim];
+      const int64_t c_rows = ext[dC], c_cols = ext[qdim];
       if (vf.on) {
         // CONSUMER-side sums, on the compute stream in front of the launch: every operand panel it reads (and the
         // panel's k-major copy), the C panel its beta applies to, the raw sums it continues -- against what the
@@ -1272,7 +1332,9 @@ void PanelRun::dispatch() {
               herr = vf.on_device(e2, M.tpanel_ptr((int) pp), M.cols, P.nr, M.t_ld((int) pp), 0, M.cols, st);
             }
           }
-        if (herr == hipSuccess && reads_c && C.panels[(size_t) L.pc].ve[Panel::VE_DEV_IN] != Verify::kNone) {
+        // (a panel multiplied in row slices is whole only in front of its FIRST slice: later ones find the rows the
+        //  earlier slices stored)
+        if (herr == hipSuccess && reads_c && L.d0 == 0 && C.panels[(size_t) L.pc].ve[Panel::VE_DEV_IN] != Verify::kNone) {
           const size_t e1 = vf.entry();
           vf.expect(C.panels[(size_t) L.pc].ve[Panel::VE_DEV_IN], e1, "C panel: HBM after H2D vs on the COMPUTE stream in front of the launch that reads it (panel, device)",
                     L.pc, di);
@@ -1319,8 +1381,13 @@ void PanelRun::dispatch() {
           herr = vf.on_device(e1, sa.c, c_rows, c_cols, C.ld, 0, 0, st);
         }
       }
+      if (herr == hipSuccess && L.d1 > 0) {       // a row slice: its own event, what the flusher waits for chunk by chunk
+        size_t si = 0;
+        while (slice_end[(size_t) L.pc][si] != L.d1) si++;
+        herr = hipEventRecord(slice_ev[(size_t) L.pc][si], st);
+      }
       if (herr != hipSuccess) break;
-      const uint64_t n_tasks = (uint64_t) ((L.q1 - L.q0) * (L.l1 - L.l0));     // in the reference's tile tasks
+      const uint64_t n_tasks = L.d0 > 0 ? 0 : (uint64_t) ((L.q1 - L.q0) * (L.l1 - L.l0));     // in the reference's tile tasks
       cnt.tasks += n_tasks;
       H.cnt.tasks += n_tasks;
     }
