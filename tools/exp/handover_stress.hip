@@ -23,6 +23,7 @@
 //   --launcher 0|1                that kernel and the ready record come from a THIRD thread (the tile cache's launcher)
 //   --host-confirm 0|1            the reader waits for its copy on the host before it hands over (BOF_HOST_HANDOVER)
 //   --readers R  --streams S  --words W  --seconds T
+//   --pipelines P                 P independent pipelines in this process (more HIP streams than hardware queues)
 //   --no-wait 1                   self-test of the checker: the dispatcher skips the wait for `ready`
 // Build: hipcc --offload-arch=gfx950 -O2 -pthread tools/exp/handover_stress.hip -o tools/exp/handover_stress
 #include <hip/hip_runtime.h>
@@ -112,6 +113,7 @@ struct EventPool {       // flash_common.h's pool in miniature: a returned event
 struct Cfg {
   std::string events = "fixed", copy = "1d";
   int wgs = 8, prior_read = 1, h2d_check = 1, launcher = 0, host_confirm = 0, readers = 2, streams = 2;
+  int pipelines = 1;      // pipelines side by side in this process (a device list that repeats its ordinal)
   int no_wait = 0;        // self-test: the dispatcher does NOT wait for `ready` -- the checker must then see stale words
   uint32_t words = 65536;
   double seconds = 20;
@@ -119,29 +121,20 @@ struct Cfg {
 
 struct Handed { uint64_t gen; hipEvent_t ready; };
 
-int main(int argc, char **argv) {
-  Cfg c;
-  for (int i = 1; i + 1 < argc; i += 2) {
-    std::string k = argv[i], v = argv[i + 1];
-    if (k == "--events") c.events = v;
-    else if (k == "--copy") c.copy = v;
-    else if (k == "--wgs") c.wgs = atoi(v.c_str());
-    else if (k == "--prior-read") c.prior_read = atoi(v.c_str());
-    else if (k == "--h2d-check") c.h2d_check = atoi(v.c_str());
-    else if (k == "--launcher") c.launcher = atoi(v.c_str());
-    else if (k == "--host-confirm") c.host_confirm = atoi(v.c_str());
-    else if (k == "--readers") c.readers = atoi(v.c_str());
-    else if (k == "--streams") c.streams = atoi(v.c_str());
-    else if (k == "--words") c.words = (uint32_t) atol(v.c_str());
-    else if (k == "--seconds") c.seconds = atof(v.c_str());
-    else if (k == "--no-wait") c.no_wait = atoi(v.c_str());
-    else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
-  }
+static EventPool g_pool;
+
+struct Result { unsigned long long handovers = 0, a[8] = {0}, b[8] = {0}; double dt = 0; int slots = 0; };
+
+// ONE pipeline: its own h2d stream, compute streams, HBM slots, events, reader / launcher / dispatcher threads.
+// --pipelines P runs P of them side by side in this process -- what a device list that repeats an ordinal ([0,0,0]: the
+// configuration of the one sighting) does: 3 x (copy streams + compute streams) on ONE device, i.e. more HIP streams
+// than the runtime has hardware queues (GPU_MAX_HW_QUEUES, 4 by default), so streams of different pipelines SHARE a
+// hardware queue and whatever per-queue state the runtime keeps about pending copies and cache invalidates.
+static void run_pipeline(const Cfg &c, const std::vector<uint32_t *> &pin, int P, Result *res) {
   const size_t bytes = (size_t) c.words * 4;
   // prior-read 1: 4 slots, each still (partly) in the L2s that read it when it is refilled; 0: enough slots that
   // 2 x (L2 + Infinity Cache = 32 + 256 MiB) of other slots pass through in between
   const int K = c.prior_read ? 4 : (int) std::max<size_t>(8, (size_t) (640ull << 20) / bytes);
-  const int P = 61;                       // patterns (prime, > any slot's reuse distance in patterns: gen % P differs from (gen - K) % P)
   CK(hipSetDevice(0));
   hipStream_t h2d;
   int least, greatest;
@@ -149,11 +142,7 @@ int main(int argc, char **argv) {
   CK(hipStreamCreateWithPriority(&h2d, hipStreamNonBlocking, greatest));
   std::vector<hipStream_t> comp((size_t) c.streams);
   for (auto &s : comp) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  std::vector<uint32_t *> pin((size_t) P), slot((size_t) K);
-  for (int p = 0; p < P; p++) {
-    CK(hipHostMalloc((void **) &pin[(size_t) p], bytes, hipHostMallocPortable));
-    for (uint32_t i = 0; i < c.words; i++) pin[(size_t) p][i] = word_of((uint32_t) p, i);
-  }
+  std::vector<uint32_t *> slot((size_t) K);
   for (int s = 0; s < K; s++) {
     CK(hipMalloc((void **) &slot[(size_t) s], bytes));
     CK(hipMemset(slot[(size_t) s], 0xFF, bytes));
@@ -170,7 +159,7 @@ int main(int argc, char **argv) {
     CK(hipEventCreateWithFlags(&ready_fixed[(size_t) s], hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&used[(size_t) s], hipEventDisableTiming));
   }
-  EventPool pool;
+  EventPool &pool = g_pool;      // ONE pool per device, shared by the pipelines, as in the library
   // slot s is free for generation g once the dispatcher has SUBMITTED the consumer of generation g - K and recorded
   // used[s] behind it (the device-side WAR wait does the rest)
   std::vector<std::atomic<int64_t>> consumed((size_t) K);
@@ -266,16 +255,60 @@ int main(int argc, char **argv) {
   to_dispatcher.close();
   td.join();
   CK(hipDeviceSynchronize());
-  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  unsigned long long a[8], b[8];
-  CK(hipMemcpy(a, cnt_h2d, 64, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(b, cnt_comp, 64, hipMemcpyDeviceToHost));
+  res->dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  CK(hipMemcpy(res->a, cnt_h2d, 64, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(res->b, cnt_comp, 64, hipMemcpyDeviceToHost));
+  res->handovers = done_gens.load();
+  res->slots = K;
+}
+
+int main(int argc, char **argv) {
+  Cfg c;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    std::string k = argv[i], v = argv[i + 1];
+    if (k == "--events") c.events = v;
+    else if (k == "--copy") c.copy = v;
+    else if (k == "--wgs") c.wgs = atoi(v.c_str());
+    else if (k == "--prior-read") c.prior_read = atoi(v.c_str());
+    else if (k == "--h2d-check") c.h2d_check = atoi(v.c_str());
+    else if (k == "--launcher") c.launcher = atoi(v.c_str());
+    else if (k == "--host-confirm") c.host_confirm = atoi(v.c_str());
+    else if (k == "--readers") c.readers = atoi(v.c_str());
+    else if (k == "--streams") c.streams = atoi(v.c_str());
+    else if (k == "--words") c.words = (uint32_t) atol(v.c_str());
+    else if (k == "--seconds") c.seconds = atof(v.c_str());
+    else if (k == "--no-wait") c.no_wait = atoi(v.c_str());
+    else if (k == "--pipelines") c.pipelines = atoi(v.c_str());
+    else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+  }
+  const size_t bytes = (size_t) c.words * 4;
+  const int P = 61;                       // patterns (prime: gen % P differs from (gen - K) % P for the K used)
+  CK(hipSetDevice(0));
+  std::vector<uint32_t *> pin((size_t) P);
+  for (int p = 0; p < P; p++) {
+    CK(hipHostMalloc((void **) &pin[(size_t) p], bytes, hipHostMallocPortable));
+    for (uint32_t i = 0; i < c.words; i++) pin[(size_t) p][i] = word_of((uint32_t) p, i);
+  }
+  std::vector<Result> results((size_t) c.pipelines);
+  std::vector<std::thread> pipes;
+  for (int q = 0; q < c.pipelines; q++) pipes.emplace_back(run_pipeline, std::cref(c), std::cref(pin), P, &results[(size_t) q]);
+  for (auto &t : pipes) t.join();
+  unsigned long long a[8] = {0}, b[8] = {0}, total = 0;
+  double dt = 0;
+  for (const Result &r : results) {
+    total += r.handovers;
+    dt = r.dt > dt ? r.dt : dt;
+    a[0] += r.a[0]; a[1] += r.a[1]; b[0] += r.b[0]; b[1] += r.b[1];
+    if (r.a[1] && !a[2]) for (int i = 2; i < 6; i++) a[i] = r.a[i];
+    if (r.b[1] && !b[2]) for (int i = 2; i < 6; i++) b[i] = r.b[i];
+  }
+  const int K = results[0].slots;
   printf("{\"events\":\"%s\",\"copy\":\"%s\",\"wgs\":%d,\"prior_read\":%d,\"h2d_check\":%d,\"launcher\":%d,\"host_confirm\":%d,"
-         "\"no_wait\":%d,\"readers\":%d,\"streams\":%d,\"slot_KiB\":%zu,\"slots\":%d,\"seconds\":%.1f,\"handovers\":%llu,\"per_s\":%.0f,"
+         "\"no_wait\":%d,\"pipelines\":%d,\"readers\":%d,\"streams\":%d,\"slot_KiB\":%zu,\"slots\":%d,\"seconds\":%.1f,\"handovers\":%llu,\"per_s\":%.0f,"
          "\"h2d_stream_check\":{\"wrong_words\":%llu,\"launches_wrong\":%llu,\"first\":[%llu,%llu,%llu,%llu]},"
          "\"compute_stream_check\":{\"wrong_words\":%llu,\"launches_wrong\":%llu,\"first\":[%llu,%llu,%llu,%llu]}}\n",
-         c.events.c_str(), c.copy.c_str(), c.wgs, c.prior_read, c.h2d_check, c.launcher, c.host_confirm, c.no_wait, c.readers, c.streams,
-         bytes >> 10, K, dt, (unsigned long long) done_gens.load(), done_gens.load() / dt, a[0], a[1], a[2], a[3], a[4], a[5],
+         c.events.c_str(), c.copy.c_str(), c.wgs, c.prior_read, c.h2d_check, c.launcher, c.host_confirm, c.no_wait, c.pipelines, c.readers, c.streams,
+         bytes >> 10, K, dt, total, total / dt, a[0], a[1], a[2], a[3], a[4], a[5],
          b[0], b[1], b[2], b[3], b[4], b[5]);
   fflush(stdout);
   return (a[0] || b[0]) ? 1 : 0;

@@ -30,3 +30,8 @@ run cold_slots_pooled     --events pooled --prior-read 0 --launcher 1
 run no_h2d_check          --events fixed --h2d-check 0
 run big_slots             --events fixed --words 1048576
 run small_slots           --events pooled --words 4096 --readers 3 --streams 3
+# round-6 addition: several pipelines in ONE process (a device list that repeats its ordinal: more HIP streams than
+# hardware queues) -- the ingredient of the one sighting that the single-pipeline variants above lack
+run pipelines3_pooled_2d  --events pooled --copy 2d --launcher 1 --pipelines 3 --streams 3
+run pipelines3_fixed      --events fixed --pipelines 3 --streams 4
+run pipelines6_small      --events pooled --launcher 1 --pipelines 6 --streams 2 --words 16384
