@@ -892,13 +892,14 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     } else if (gx == 0 || ref_chain) {
       // the ramp group (the resident operand is still streaming in): k-block by k-block, l-major, so that panel l of
       // it unlocks work on every C panel of the group; the reference's chain keeps that cut for all groups
-      // Order inside the group: by anti-diagonals (C panel + k-block), so that the first-use order of the panels --
-      // which is the order they are READ in -- alternates between the two operands: A0 B0 | B1 A1 | B2 A2 | ...  The
-      // launches a read enables grow with every panel of EITHER operand from the start (n panels of each in: n^2
-      // launches), where the l-major order (every A panel of the group first) kept the GPU at one launch per A panel
-      // until the group's last A panel was in -- 0.3 s of a 65536^3 call.  A chain's launches stay
-      // in k order on their stream.  $BOF_PANEL_RAMP_ORDER=0: l-major as until round 5.
-      if (env_long("BOF_PANEL_RAMP_ORDER", 1) != 0) {
+      // Order inside the group: l-major (every C panel of the group takes k-block l, then l + 1): the panels' first-use
+      // order -- the order they are READ in -- is then A0 B0 A1 .. A(G-1) B1 B2 ...  $BOF_PANEL_RAMP_ORDER=1 orders the
+      // launches by anti-diagonals (C panel + k-block) instead, so that the reads alternate between the operands from
+      // the start (A0 B0 | B1 A1 | B2 A2 ...) and n panels of each enable n^2 launches early (VERDICT r5 item 4's
+      // wavefront).  Measured in round 6 (profiles/r6/sched_ab.md): 65536^3 from O_DIRECT files 4.21-4.24 s against
+      // 4.10-4.15 s l-major -- the launches of one diagonal stand behind its first one, which waits for the newest B
+      // panel, and the dispatcher issues in list order -- so l-major stays the default.
+      if (env_long("BOF_PANEL_RAMP_ORDER", 0) != 0) {
         for (int64_t d = 0; d < Nk + (G1 - G0) - 1; d++)
           for (int64_t pc = G0; pc < G1; pc++) {
             const int64_t l = d - (pc - G0);
