@@ -1180,7 +1180,7 @@ def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, ste
         bofhip.flash_gemm("R", "N", "N", n, n, n, 1.0, 0.0, bofhip.FPtr(fds[0], 0), bofhip.FPtr(fds[1], 0),
                           bofhip.FPtr(fds[2], 0), 0, 0, 0, opts)
         return bofhip.flash_last_stats()
-    probes, slow_events, median_events = [], None, None
+    probes, slow_events, median_events, launch_mix = [], None, None, None
     try:
         warm = []
         for _ in range(warmup):
@@ -1202,6 +1202,7 @@ def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, ste
                 L.bof_event_dump(dumps[-1].encode())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        launch_mix = bofhip.flash_last_launch_mix()
         ok = verify()
         if direct and probe:
             probes.append(disk_probe(bofhip, (pa, pb), pc, io_threads, label="after the timed steps"))
@@ -1234,7 +1235,7 @@ def headline_flash_gemm(bofhip, torch, dev, st, workdir, n, blk, io_threads, ste
     return {"dt": dt, "per_step": per, "warmup_steps": warm, "verified": bool(ok) and ok_warm is not False,
             "verified_after_warmup": ok_warm, "odirect": direct, "create_files_s": round(create_s, 1),
             "file_system": _fs_of(workdir), "disk_probes": probes, "slowest_step_events": slow_events,
-            "median_step_events": median_events}
+            "median_step_events": median_events, "launch_mix_last_step": launch_mix}
 
 
 def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
@@ -1255,18 +1256,35 @@ def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
     return bound, terms[bound], {k: round(v, 4) for k, v in terms.items()}
 
 
-def _alg_bytes_per_launch(n, blk, launches_per_step):
+def row_panel_disk_bound(n, blk, ceil):
+    """A tighter lower bound for any schedule that emits C by row panels (contiguous file extents, what the row-panel
+    pipeline writes): no byte of C exists before ALL of B and one A panel have been read -- that much at the read-alone
+    rate -- and only the rest (the other A panels, all of C) can move at the disk's best rate, reads and writes mixed.
+    Returned beside the schedule-agnostic `disk_total` bound, never instead of it."""
+    if not ceil.get("disk_read_GBps"):
+        return None
+    first = 4.0 * (n * n + blk * n)
+    rest = 4.0 * (n * n - blk * n) + 4.0 * n * n
+    best = max(ceil["disk_read_GBps"], ceil["disk_write_GBps"],
+               ceil.get("disk_read_GBps_while_writing", 0) + ceil.get("disk_write_GBps_while_reading", 0))
+    return first / (ceil["disk_read_GBps"] * 1e9) + rest / (best * 1e9)
+
+
+def _alg_bytes_per_launch(n, blk, mix, launches_per_step):
     """GEMM bytes = 4 (M K + K N + M N (1 + [C is read])) per launch, averaged over the launches of one
-    step of the row-panel schedule: G C panels of the ramp group run one k-block per launch (the raw sums of the
-    k-blocks before it are read back: [C is read] = 1 for all but the first), the others ONE launch over the whole K.
-    G is recovered from the launch count: launches = G Nk + (Np - G)."""
+    step of the row-panel schedule as the library counted them (bof_flash_last_launch_mix): the G C panels of the ramp
+    group run one k-block per launch (the raw sums of the k-blocks before it are read back: [C is read] = 1 for all
+    but the first), every other C panel ONE launch over the whole K -- the last one in row slices, each of which
+    reads its rows of A, all of B and writes its rows of C."""
     nk = npan = max(n // blk, 1)
-    if nk <= 1:
+    if nk <= 1 or not mix:
         return int(4 * 3 * n * n)
-    g = min(npan, max(0, round((launches_per_step - npan) / (nk - 1))))
+    g = max(0, round((mix.get("chain_k_ranges") or 0) / nk))
+    slices = mix.get("whole_k_row_slices") or 0
     ramp = g * (4.0 * (blk * n + blk * n * nk + blk * n * (2 * nk - 1)))        # A panel once; B panel l per launch; C write + read-back
-    whole = (npan - g) * 4.0 * (blk * n + n * n + blk * n)
-    return int((ramp + whole) / max(launches_per_step, 1))
+    whole = (mix.get("whole_k_panels") or 0) * 4.0 * (blk * n + n * n + blk * n)
+    sliced = (4.0 * (blk * n + slices * n * n + blk * n)) if slices else 0.0     # the last panel: B once per slice
+    return int((ramp + whole + sliced) / max(launches_per_step, 1))
 
 
 def _mean(xs):
@@ -1317,16 +1335,17 @@ def run_single(args, bofhip, torch, dev, st):
     achieved = flops_per_launch / max(avg_launch_ms, 1e-9) / 1e9          # TFLOP/s
     traffic, traffic_src = pmc_traffic()
     nk = max(n // blk, 1)
-    # the launch mix of the row-panel schedule, recovered from the call's own counters: launches = G nk + (np - G);
+    # the launch mix of the row-panel schedule as the library counted it in the last timed step (bof_flash_last_launch_mix):
     # the ramp group's k-block launches are <ChainEpi> instantiations, the whole-K launches <NoEpi> (beta == 0)
-    lps = launches / max(args.steps, 1)
-    g_ramp = min(nk, max(0, round((lps - nk) / (nk - 1)))) if nk > 1 else 0
-    kernel_mix = {"sgemm_tile256_dma2_kernel<ChainEpi> (ramp group, one k-block per launch)": int(g_ramp * nk),
-                  "sgemm_tile256_dma2_kernel<NoEpi> (one launch over the whole K)": int(round(lps - g_ramp * nk))}
+    mix = h.get("launch_mix_last_step") or {}
+    kernel_mix = {"sgemm_tile256_dma2_kernel<ChainEpi> (ramp group, one k-block per launch)": mix.get("chain_k_ranges"),
+                  "sgemm_tile256_dma2_kernel<NoEpi> (one launch over the whole K, a whole C panel)": mix.get("whole_k_panels"),
+                  "sgemm_tile256_dma2_kernel<NoEpi> (one launch over the whole K, a row slice of the last C panel)": mix.get("whole_k_row_slices")}
     mean_step = {q: _mean(p[q] for p in per) for q in ("bytes_read", "bytes_written", "bytes_h2d", "bytes_d2h")}
     bound, t_bound, terms = e2e_bound(mean_step, ceil if "error" not in ceil else {}, args.steps, ksec / args.steps)
     secs = sorted(p["seconds"] for p in per)
     med_step = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
+    rp_bound = row_panel_disk_bound(n, blk, ceil) if "error" not in ceil else None
     probe_note = None
     e2e_frac_raw = round(t_bound / (dt / args.steps), 3)          # against the probes as they are (may exceed 1: a bad probe)
     if t_bound > dt / args.steps and bound.startswith("disk"):
@@ -1347,7 +1366,7 @@ def run_single(args, bofhip, torch, dev, st):
                    "what_is_timed": "bof_flash_gemm on O_DIRECT files, page cache dropped, C write-back included "
                                     "(reference: drivers/gemm.cpp:57-62)",
                    "odirect": h["odirect"], "file_system": h["file_system"], "io_threads": args.io_threads,
-                   "compute_streams": args.streams or "library default (2)",
+                   "compute_streams": args.streams or "library default (1)",
                    "tile_tasks_per_step": int(_mean(p["tasks"] for p in per)),
                    "GiB_read_per_step": round(mean_step["bytes_read"] / 2**30, 3),
                    "GiB_written_per_step": round(mean_step["bytes_written"] / 2**30, 3),
@@ -1363,11 +1382,14 @@ def run_single(args, bofhip, torch, dev, st):
                                                          "inside the timed steps (bof_options.kernel_timing)",
                      "flops_per_launch": flops_per_launch,
                      "launches_per_step": round(launches / args.steps, 1),
-                     "algorithmic_bytes_per_launch": _alg_bytes_per_launch(n, blk, launches / args.steps),
+                     "algorithmic_bytes_per_launch": _alg_bytes_per_launch(n, blk, mix, launches / args.steps),
                      "traffic": traffic, "traffic_source": f"static: {traffic_src} (PMC passes of this command, committed; not this run)",
                      "kernel_s_per_step": round(ksec / args.steps, 4),
                      "e2e_bound": bound, "e2e_t_bound_s": round(t_bound, 4),
                      "e2e_frac": round(t_bound / (dt / args.steps), 3), "e2e_frac_raw": e2e_frac_raw, "e2e_terms_s": terms,
+                     **({"e2e_row_panel_bound_s": round(rp_bound, 4),
+                         "e2e_frac_of_row_panel_bound": round(min(rp_bound / (dt / args.steps), 1.0), 3),
+                         "e2e_frac_median_step_of_row_panel_bound": round(min(rp_bound / med_step, 1.0), 3)} if rp_bound else {}),
                      **({"e2e_probe_note": probe_note} if probe_note else {}),
                      "e2e_probe": {k: ceil.get(k) for k in ("disk_read_GBps", "disk_write_GBps",
                                                             "disk_read_GBps_while_writing",
@@ -1805,11 +1827,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=0, help="override problem edge (debug; skips the extras)")
     ap.add_argument("--blk", type=int, default=4096)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="compute streams of the row-panel pipeline (1: tile launches are serialised, so the "
-                         "event-timed avg_launch_ms is one kernel alone on the chip -- the figure rocprofv3's "
-                         "per-kernel average is compared with; 0 = the library's default of two, whose "
-                         "launches overlap pairwise)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="compute streams of the row-panel pipeline: 0 = the library's default (ONE since round 6: panel "
+                         "launches are serialised, so the event-timed avg_launch_ms is one kernel alone on the chip -- the "
+                         "figure rocprofv3's per-kernel average is compared with); 2+ = launches overlap pairwise")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-full-step", action="store_true",
                     help="cpu_baseline: only the 16384^3 sample, not the one in-memory 32768^3 sgemm (about a minute on 128 cores)")

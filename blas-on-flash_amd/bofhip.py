@@ -120,6 +120,7 @@ SYMBOLS = [
                                           C.c_int32, C.POINTER(FlashStats)]),
     ("bof_event_dump", u64, [C.c_char_p]),
     ("bof_flash_last_c_file", C.c_int, [C.POINTER(C.c_uint64)]),
+    ("bof_flash_last_launch_mix", C.c_int, [C.POINTER(C.c_uint64)]),
     ("bof_file_sread", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_swrite", C.c_int, [C.c_int, u64, u64, u64, u64, P, C.c_int]),
     ("bof_file_forget", C.c_int, [C.c_int]),
@@ -338,6 +339,13 @@ def flash_last_stats():
     s = FlashStats()
     check(lib().bof_flash_last_stats(C.byref(s)), "bof_flash_last_stats")
     return {f: getattr(s, f) for f, _ in s._fields_}
+
+
+def flash_last_launch_mix():
+    """Compute launches of the last row-panel flash_gemm by kind: chain k-ranges / whole-K panels / whole-K row slices."""
+    out = (C.c_uint64 * 3)()
+    check(lib().bof_flash_last_launch_mix(out), "bof_flash_last_launch_mix")
+    return {"chain_k_ranges": out[0], "whole_k_panels": out[1], "whole_k_row_slices": out[2]}
 
 
 def flash_last_c_file():

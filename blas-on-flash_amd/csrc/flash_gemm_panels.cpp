@@ -98,6 +98,11 @@
 namespace bof {
 namespace {
 
+// compute launches of the last bof_flash_gemm that took the row-panel path, by kind (bof_flash_last_launch_mix):
+// [0] one k-range of a chain (<ChainEpi>: the ramp group), [1] whole-K launches of a whole C panel, [2] whole-K launches
+// of a row slice of a C panel; all devices of the call added up
+std::atomic<uint64_t> g_mix[3];
+
 struct Panel {
   int64_t r0 = 0, nr = 0;       // stored rows [r0, r0 + nr)
   uint64_t bytes = 0;           // extent: (nr-1)*ld + cols elements
@@ -912,11 +917,16 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     } else {
       // behind the ramp everything a C panel needs but its own streamed panel is resident: ONE launch over the
       // whole K -- no C round trip between the k-blocks, an eighth of the launch boundaries
-      // ... in row slices of the panel, so that its write-back starts before its last kernel has ended
-      // (bof_options: none; $BOF_PANEL_SLICES, default 4; slices are multiples of 256 rows: whole tile rows)
+      // ... the LAST C panel of the slab in row slices, so that its write-back starts before its last kernel has
+      // ended: what follows the last kernel of the call is then the write-back of a quarter panel.  Only the last:
+      // a launch boundary costs ~0.3 ms (the spread of the workgroups' finishing times in a launch's last round), and
+      // four slices of every panel took back the round-6 kernel's gain on the whole-K launches (rocprofv3: 4 x 15.10 ms
+      // against 57.3 ms for the panel in one launch).  $BOF_PANEL_SLICES (default 4; 1 = off), $BOF_PANEL_SLICES_ALL=1
+      // (every whole-K panel: tests), $BOF_PANEL_SLICE_ROWS (rounding unit of a slice, default 256: whole tile rows)
+      const bool slice_all = env_long("BOF_PANEL_SLICES_ALL", 0) != 0;
       for (int64_t pc = G0; pc < G1; pc++) {
         const int64_t nr = mat[2].panels[(size_t) pc].nr;
-        const int64_t want = std::max<int64_t>(1, env_long("BOF_PANEL_SLICES", 4));
+        const int64_t want = (slice_all || pc == NpC - 1) ? std::max<int64_t>(1, env_long("BOF_PANEL_SLICES", 4)) : 1;
         const int64_t unit = std::max<int64_t>(1, env_long("BOF_PANEL_SLICE_ROWS", 256));      // (tests: small panels)
         const int64_t rows = std::max<int64_t>(unit, (nr / want + unit - 1) / unit * unit);
         if (want <= 1 || rows >= nr) { add_launch(pc, 0, Nq, 0, Nk); continue; }
@@ -1045,8 +1055,13 @@ int PanelRun::prepare() {
   // interleave whole-chip kernels of different chains and starve the copy queues: measured on
   // cfg2 files (page cache) 0.70 s with 4 streams, 0.58 s with 2, 0.59 s with 1
   // (profiles/r2/e2e_sweep_*.txt).  bof_options.panel_streams / BOF_PANEL_STREAMS override.
+  // Round 6: flash::gemm's panel launches go to ONE compute stream by default -- a panel launch is 512-2048
+  // workgroups, i.e. 2-8 rounds of the whole chip, and the same-lease A/B of the headline (profiles/r6/ab_headline:
+  // 0.831 s median with two streams, 0.824-0.868 s with one) shows no difference; with one stream the per-launch
+  // kernel timing is one kernel alone on the chip, and bench.py measures the library's default instead of a special
+  // configuration.  flash::kmeans keeps two (its tile tasks are 256 workgroups each).
   const long senv = o.panel_streams > 0 ? o.panel_streams : env_long("BOF_PANEL_STREAMS", 0);
-  ss = stream_set(senv > 0 ? (int) std::min<long>(senv, 16) : std::min(o.n_streams, 2));
+  ss = stream_set(senv > 0 ? (int) std::min<long>(senv, 16) : (kmeans ? std::min(o.n_streams, 2) : 1));
   if (!ss) { set_error("bof_flash_gemm: stream creation failed"); return BOF_EHIP; }
   group_ev.assign((size_t) n_groups, std::vector<hipEvent_t>());
   for (auto &v : group_ev)
@@ -1382,6 +1397,7 @@ void PanelRun::dispatch() {
           herr = vf.on_device(e1, sa.c, c_rows, c_cols, C.ld, 0, 0, st);
         }
       }
+      g_mix[chain_step ? 0 : (L.d1 > 0 ? 2 : 1)]++;
       if (herr == hipSuccess && L.d1 > 0) {       // a row slice: its own event, what the flusher waits for chunk by chunk
         size_t si = 0;
         while (slice_end[(size_t) L.pc][si] != L.d1) si++;
@@ -1474,6 +1490,7 @@ int flash_gemm_panels(char ord, char ta, char tb, int64_t m, int64_t n, int64_t 
   H.t_begin = std::chrono::steady_clock::now();
   evt_mark_call_begin();
   evt("bof_flash_gemm (panels) begin", (int) m, (int) n, (uint64_t) k);
+  for (auto &x : g_mix) x = 0;
   const GemmGeometry gfull = gemm_geometry(ord, ta, tb, m, n, k, lda, ldb, ldc, o.gemm_blk);
   if (gfull.nblk[0] * gfull.nblk[2] == 0 || gfull.nblk[1] == 0) return 1;
   int caller_dev = 0;
@@ -1741,4 +1758,10 @@ extern "C" int64_t bof_share_selftest(const char *share_name, int rank, int worl
   if (rc) ring.fail_all();
   ring.unmap();
   return rc ? rc : verified;
+}
+
+extern "C" int bof_flash_last_launch_mix(uint64_t out[3]) {
+  if (!out) return BOF_EINVAL;
+  for (int i = 0; i < 3; i++) out[i] = bof::g_mix[i].load();
+  return BOF_OK;
 }

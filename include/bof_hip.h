@@ -104,7 +104,7 @@ typedef struct {
   int32_t io_engine;      /* 1 kernel AIO, 2 io_uring      ($BOF_IO_ENGINE=uring)           */
   int32_t io_request_kib; /* O_DIRECT request size         ($BOF_IO_REQUEST_KIB, 4096)      */
   int32_t panel_group;    /* C panels of the ramp group    ($BOF_PANEL_GROUP, computed)     */
-  int32_t panel_streams;  /* compute streams, panel path   ($BOF_PANEL_STREAMS, min(n_streams, 2)) */
+  int32_t panel_streams;  /* compute streams, panel path   ($BOF_PANEL_STREAMS; 1, flash::kmeans min(n_streams, 2)) */
   int32_t panel_writers;  /* writer threads, panel path    ($BOF_PANEL_WRITERS, n_io_threads / 2)  */
   int32_t panel_kmajor;   /* k-major panel copies: 1 off, 2 on, 3 on even for tiles reused
                              fewer than 4 times            ($BOF_PANEL_KMAJOR + 1, 2)       */
@@ -437,6 +437,12 @@ uint64_t bof_event_dump(const char *path);
  * request (column-major C with unaligned column pieces, $BOF_UNALIGNED_DIRECT=0); -1 = C was not an O_DIRECT file.
  * *twin_bytes (may be NULL): bytes of whole row blocks written through the buffered twin (0 unless the mode is 0). */
 int bof_flash_last_c_file(uint64_t *twin_bytes);
+/* The compute launches of the last bof_flash_gemm call that took the row-panel path, by kind (additive to ABI v5; all
+ * devices of the call added up): out[0] = one k-range of a chain (the ramp group's k-block launches, the <ChainEpi>
+ * instantiation of the tile kernel), out[1] = one launch over the whole K for a whole C panel, out[2] = one launch over
+ * the whole K for a row slice of a C panel (the last panel of a slab leaves in slices).  bench.py names the kernels
+ * behind roofline.achieved from this instead of assuming a schedule. */
+int bof_flash_last_launch_mix(uint64_t out[3]);
 
 /* File handle primitives (FlashFileHandle::read/write/sread/swrite,
  * src/file_handles/flash_file_handle.cpp:247-716) exposed for tests: strided

@@ -547,6 +547,7 @@ static int stress(double seconds) {
     const char *slices[] = {"1", "2", "3", "4"}, *srows[] = {"32", "64", "256"};      // row slices of the whole-K panel launches
     setenv("BOF_PANEL_SLICES", slices[ri(0, 3)], 1);
     setenv("BOF_PANEL_SLICE_ROWS", srows[ri(0, 2)], 1);
+    setenv("BOF_PANEL_SLICES_ALL", ri(0, 1) ? "1" : "0", 1);
     const auto &devs = lists[(size_t) ri(0, (int) lists.size() - 1)];
     const int64_t m = ri(100, 420), nn = ri(100, 420), k = ri(40, 420);
     const bool kmeans = ri(0, 3) == 0;
@@ -577,6 +578,7 @@ static int stress(double seconds) {
   unsetenv("BOF_TILE_GROUP");
   unsetenv("BOF_PANEL_SLICES");
   unsetenv("BOF_PANEL_SLICE_ROWS");
+  unsetenv("BOF_PANEL_SLICES_ALL");
   g_stress = false; g_peer_bcast = false; g_knobs.chain = 0;
   CHECK(bof_flash_release() == BOF_OK);
   return n;

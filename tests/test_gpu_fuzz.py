@@ -24,7 +24,7 @@ import orc  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-ENV_KNOBS = ("BOF_TILE_GROUP", "BOF_UNALIGNED_DIRECT", "BOF_MMAP_WRITES", "BOF_PANEL_SLICES", "BOF_PANEL_SLICE_ROWS")
+ENV_KNOBS = ("BOF_TILE_GROUP", "BOF_UNALIGNED_DIRECT", "BOF_MMAP_WRITES", "BOF_PANEL_SLICES", "BOF_PANEL_SLICE_ROWS", "BOF_PANEL_SLICES_ALL")
 LAST = {}      # the parameters of the case being run (printed when it fails)
 VERIFY_SUMS = [0]   # BOF_VERIFY: hand-over sums compared so far
 FORCE_KIND = ""   # --kind: only gemm / kmeans / csr cases
@@ -104,7 +104,8 @@ def common_opts(rng, kw):
            "BOF_MMAP_WRITES": pick(rng, ["", "0", "1"]),
            # row slices of the whole-K panel launches (round 6): off, the default, 2-3 slices of small panels
            "BOF_PANEL_SLICES": pick(rng, ["", "1", "2", "3"]),
-           "BOF_PANEL_SLICE_ROWS": pick(rng, ["", "32", "64"])}
+           "BOF_PANEL_SLICE_ROWS": pick(rng, ["", "32", "64"]),
+           "BOF_PANEL_SLICES_ALL": pick(rng, ["", "1"])}
     return env
 
 

@@ -49,7 +49,7 @@ def mock_lib(tmp_path_factory):
 
 def run_child(tmp_path, so, path, beta, budget, devs, inject, verify=1, extra_env=None):
     import json
-    d = tmp_path / f"p{path}_i{inject}_{len(devs)}_{budget}_{verify}"
+    d = tmp_path / f"p{path}_i{inject}_{len(devs)}_{budget}_{verify}_{len(extra_env or {})}"
     d.mkdir()
     code = (f"ROOT={ROOT!r}\nSO={so!r}\nDIR={str(d)!r}\nPATH={path}\nBETA={beta}\nBUDGET={budget}\nDEVS={devs!r}\nVERIFY={verify}\n" + CHILD)
     env = dict(os.environ, MOCK_HIP_DEVICES="4", MOCK_HIP_ASYNC="1", MOCK_HIP_JITTER_US="100", BOF_VERIFY_INJECT=str(inject))
@@ -127,13 +127,15 @@ def test_k_zero_on_files_returns_ok_and_leaves_c_alone(tmp_path, mock_lib):
 @pytest.mark.parametrize("devs", [[0], [0, 1, 2]])
 @pytest.mark.parametrize("beta", [0.0, 2.0])
 @pytest.mark.parametrize("verify", [2, 1])
-def test_whole_k_panels_in_row_slices(tmp_path, mock_lib, devs, beta, verify):
-    """Round 6: a C panel that runs as one launch over the whole K is multiplied in row slices, each copied out and
-    written while the next is still being multiplied ($BOF_PANEL_SLICES, here 3 slices of multiples of 32 rows on
-    128-row panels).  Asynchronous, jittered mock streams: a chunk that left before its slice's launch had run would
+@pytest.mark.parametrize("every_panel", ["1", "0"])
+def test_whole_k_panels_in_row_slices(tmp_path, mock_lib, devs, beta, verify, every_panel):
+    """Round 6: the LAST C panel of a slab ($BOF_PANEL_SLICES_ALL=1: every C panel that runs as one launch over the
+    whole K) is multiplied in row slices, each copied out and written while the next is still being multiplied
+    ($BOF_PANEL_SLICES, here 3 slices of multiples of 32 rows on 128-row panels).  Asynchronous, jittered mock streams: a chunk that left before its slice's launch had run would
     carry the old C.  With the hand-over checks off (the flusher then waits slice by slice) and on."""
     out, err = run_child(tmp_path, mock_lib, 2, beta, 0, devs, 0, verify=verify,
-                         extra_env={"BOF_PANEL_SLICES": "3", "BOF_PANEL_SLICE_ROWS": "32", "BOF_PANEL_GROUP": "1"})
+                         extra_env={"BOF_PANEL_SLICES": "3", "BOF_PANEL_SLICE_ROWS": "32", "BOF_PANEL_GROUP": "1",
+                                    "BOF_PANEL_SLICES_ALL": every_panel})
     assert out["rc"] == 0, out.get("err", "") + err[-2000:]
     assert out["exact"]
     assert out["stats"]["tasks"] == 5 * 4 * 3          # 640 x 600 x 500 in 128-tiles (merged tails): a slice is not a task
