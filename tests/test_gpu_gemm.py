@@ -331,3 +331,98 @@ def test_sgemm_big_ragged_strips_on_the_side_stream(dev, ta, tb, beta):
         for (c0_, c1_), w in want_cols.items():
             assert np.array_equal(got[:, c0_:c1_], w), (knob, c0_, c1_)
         assert float(tail.item()) == float(got[m - 1, n - 1])
+
+
+# ---- round 6: the LDS-DMA tile kernel with progress counters instead of s_barrier (sgemm_tile256_dma2_kernel<EP, 0, 1, 1>) ----
+def _both_syncs(monkeypatch, run):
+    """run() with the round-6 default kernel and with the s_barrier kernel of rounds 2-5 ($BOF_GEMM_DMA2_SYNC=0, read at
+    every launch): the two C must be bit-identical."""
+    out = []
+    for sync in ("1", "0"):
+        monkeypatch.setenv("BOF_GEMM_DMA2_SYNC", sync)
+        out.append(run())
+    monkeypatch.delenv("BOF_GEMM_DMA2_SYNC")
+    return out
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 512), (4096, 2048, 576), (2304, 4096, 1024), (2048, 4352, 4160),
+                                   (2100, 4200, 640), (4096, 4096, 64 * 37), (8192, 2048, 128 * 5)])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (0.5, 2.0)])
+def test_dma2_counter_kernel_equals_barrier_kernel(dev, monkeypatch, m, n, k, alpha, beta):
+    """'T','N' operands (k-major x k-major: the LDS-DMA kernel) on shapes with >= 128 interior tiles and K % 64 == 0,
+    incl. ragged edges (strips on the guarded kernel) and slab counts that are odd multiples of the slab pair: the
+    kernel whose four waves synchronise through LDS counters must store exactly what the barrier kernel stores, and
+    both the k-ordered fmaf chain of the oracle (checked on sampled rows in float64-free form: torch fp32 matmul is NOT
+    the reference here, the oracle's chain is -- so a 96-row band goes through orc.sgemm)."""
+    g = torch.Generator(device="cpu").manual_seed(m * 7 + n * 3 + k)
+    a = torch.rand(k, m, generator=g) * 2 - 1          # 'T': stored [k][m]
+    b = torch.rand(k, n, generator=g) * 2 - 1          # 'N': stored [k][n]
+    c0 = torch.rand(m, n, generator=g) * 2 - 1
+    da, db = a.cuda(), b.cuda()
+
+    def run():
+        dc = c0.cuda()
+        bofhip.sgemm("R", "T", "N", m, n, k, alpha, da.data_ptr(), m, db.data_ptr(), n, beta, dc.data_ptr(), n, stream())
+        torch.cuda.synchronize()
+        return dc.cpu()
+    new, old = _both_syncs(monkeypatch, run)
+    assert torch.equal(new.view(torch.int32), old.view(torch.int32))
+    rows = 96
+    band = orc.sgemm("R", "T", "N", rows, n, k, alpha, np.ascontiguousarray(a.numpy()[:, :rows]), rows, b.numpy(), n, beta,
+                     c0.numpy()[:rows].copy(), n)
+    assert np.array_equal(new.numpy()[:rows], band)
+
+
+def test_dma2_counter_kernel_kmeans_epilogue(dev, monkeypatch):
+    """The Rank1x2 instantiation (flash::kmeans' task: the product + two rank-1 terms in the tile store,
+    include/tasks/kmeans_task.h:53-82) of the counter kernel against the barrier kernel, K = 512."""
+    m, n, k = 2048, 4096, 512
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = (torch.rand(k, m, generator=g) * 2 - 1).cuda()
+    b = (torch.rand(k, n, generator=g) * 2 - 1).cuda()
+    u = torch.rand(m, generator=g).cuda()
+    v = torch.rand(n, generator=g).cuda()
+    ones = torch.ones(max(m, n)).cuda()
+
+    def run():
+        dc = torch.zeros(m, n).cuda()
+        bofhip.skmeans_task("R", "T", "N", m, n, k, -2.0, a.data_ptr(), m, b.data_ptr(), n, 0.0, dc.data_ptr(), n,
+                            u.data_ptr(), v.data_ptr(), ones.data_ptr(), stream())
+        torch.cuda.synchronize()
+        return dc.cpu()
+    new, old = _both_syncs(monkeypatch, run)
+    assert torch.equal(new.view(torch.int32), old.view(torch.int32))
+    assert torch.isfinite(new).all() and float(new.abs().max()) > 1.0
+
+
+@pytest.mark.parametrize("beta", [0.0, 2.0])
+def test_dma2_counter_kernel_in_the_panel_pipeline(dev, tmp_path, monkeypatch, beta):
+    """The <ChainEpi> instantiation where the product uses it: flash::gemm on files through the row panels with
+    2048-tiles (ramp launches 2048 x 4096 x 2048 = 128 tiles each, raw sums handed from k-block to k-block, the last
+    panel in row slices): the C file with the counter kernel == the C file with the barrier kernel == one bof_sgemm
+    over the whole matrices (the default arithmetic does not depend on the cut)."""
+    from test_gpu_flash import Files
+    n = 4096
+    rng = np.random.default_rng(41)
+    a = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c0)
+    bofhip.sgemm("R", "N", "N", n, n, n, 0.5, ptr(da), n, ptr(db), n, beta, ptr(dc), n, stream())
+    torch.cuda.synchronize()
+    whole = dc.cpu().numpy()
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        def run():
+            c0.tofile(F.paths["c"])
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+            bofhip.flash_gemm("R", "N", "N", n, n, n, 0.5, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              bofhip.default_options(gemm_blk=2048, gemm_path=2, panel_group=1, io_chunk_mib=4, panel_kmajor=3))
+            mix = bofhip.flash_last_launch_mix()
+            assert mix["chain_k_ranges"] == 2 and mix["whole_k_row_slices"] >= 2, mix
+            return F.read("c", np.float32, (n, n))
+        new, old = _both_syncs(monkeypatch, run)
+        assert np.array_equal(new.view(np.uint32), old.view(np.uint32))
+        assert np.array_equal(new.view(np.uint32), whole.view(np.uint32))
+    finally:
+        F.close()
