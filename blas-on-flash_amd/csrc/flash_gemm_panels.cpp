@@ -911,8 +911,12 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
             if (l >= 0 && l < Nk) add_launch(pc, 0, Nq, l, l + 1);
           }
       } else {
-        for (int64_t l = 0; l < Nk; l++)
-          for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, l + 1);
+        // $BOF_PANEL_RAMP_K k-blocks per launch of the ramp group (default 1; the reference's chain: always 1).  A
+        // launch over R k-blocks waits for R panels of the streaming operand and halves (R = 2) the raw-sum round
+        // trips and launch boundaries of the group.
+        const int64_t R = ref_chain ? 1 : std::max<int64_t>(1, env_long("BOF_PANEL_RAMP_K", 1));
+        for (int64_t l = 0; l < Nk; l += R)
+          for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, std::min(Nk, l + R));
       }
     } else {
       // behind the ramp everything a C panel needs but its own streamed panel is resident: ONE launch over the

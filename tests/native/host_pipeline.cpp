@@ -548,6 +548,7 @@ static int stress(double seconds) {
     setenv("BOF_PANEL_SLICES", slices[ri(0, 3)], 1);
     setenv("BOF_PANEL_SLICE_ROWS", srows[ri(0, 2)], 1);
     setenv("BOF_PANEL_SLICES_ALL", ri(0, 1) ? "1" : "0", 1);
+    setenv("BOF_PANEL_RAMP_K", ri(0, 2) == 0 ? "2" : "1", 1);
     const auto &devs = lists[(size_t) ri(0, (int) lists.size() - 1)];
     const int64_t m = ri(100, 420), nn = ri(100, 420), k = ri(40, 420);
     const bool kmeans = ri(0, 3) == 0;
@@ -579,6 +580,7 @@ static int stress(double seconds) {
   unsetenv("BOF_PANEL_SLICES");
   unsetenv("BOF_PANEL_SLICE_ROWS");
   unsetenv("BOF_PANEL_SLICES_ALL");
+  unsetenv("BOF_PANEL_RAMP_K");
   g_stress = false; g_peer_bcast = false; g_knobs.chain = 0;
   CHECK(bof_flash_release() == BOF_OK);
   return n;

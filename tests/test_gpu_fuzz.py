@@ -24,7 +24,7 @@ import orc  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-ENV_KNOBS = ("BOF_TILE_GROUP", "BOF_UNALIGNED_DIRECT", "BOF_MMAP_WRITES", "BOF_PANEL_SLICES", "BOF_PANEL_SLICE_ROWS", "BOF_PANEL_SLICES_ALL")
+ENV_KNOBS = ("BOF_TILE_GROUP", "BOF_UNALIGNED_DIRECT", "BOF_MMAP_WRITES", "BOF_PANEL_SLICES", "BOF_PANEL_SLICE_ROWS", "BOF_PANEL_SLICES_ALL", "BOF_PANEL_RAMP_K")
 LAST = {}      # the parameters of the case being run (printed when it fails)
 VERIFY_SUMS = [0]   # BOF_VERIFY: hand-over sums compared so far
 FORCE_KIND = ""   # --kind: only gemm / kmeans / csr cases
@@ -105,7 +105,8 @@ def common_opts(rng, kw):
            # row slices of the whole-K panel launches (round 6): off, the default, 2-3 slices of small panels
            "BOF_PANEL_SLICES": pick(rng, ["", "1", "2", "3"]),
            "BOF_PANEL_SLICE_ROWS": pick(rng, ["", "32", "64"]),
-           "BOF_PANEL_SLICES_ALL": pick(rng, ["", "1"])}
+           "BOF_PANEL_SLICES_ALL": pick(rng, ["", "1"]),
+           "BOF_PANEL_RAMP_K": pick(rng, ["", "", "2", "3"])}
     return env
 
 
