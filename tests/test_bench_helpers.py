@@ -10,16 +10,33 @@ import bench  # noqa: E402
 
 def test_algorithmic_bytes_per_launch_of_cfg2():
     n, blk = 32768, 4096
-    # G = 4 ramp panels x 8 k-blocks + 4 whole-K launches
-    per = bench._alg_bytes_per_launch(n, blk, 36.0)
+    # the launch mix as the library counts it (bof_flash_last_launch_mix): G = 4 ramp panels x 8 k-blocks, 3 whole-K
+    # panels, the last panel in 4 row slices
+    mix = {"chain_k_ranges": 32, "whole_k_panels": 3, "whole_k_row_slices": 4}
+    per = bench._alg_bytes_per_launch(n, blk, mix, 39.0)
     ramp_first = 4 * (blk * n + blk * n + blk * n)                # A panel, B panel l, C written
     whole = 4 * (blk * n + n * n + blk * n)
     # every launch moves at least its operands once; the average sits between the ramp launch and the whole-K one
     assert ramp_first < per < whole
     # one k-block, one launch: the whole product's SURVEY 8(d) bytes
-    assert bench._alg_bytes_per_launch(4096, 4096, 1.0) == 4 * 3 * 4096 * 4096
+    assert bench._alg_bytes_per_launch(4096, 4096, {}, 1.0) == 4 * 3 * 4096 * 4096
     # all panels in the ramp (G = 8): 64 launches
-    assert bench._alg_bytes_per_launch(n, blk, 64.0) < per
+    assert bench._alg_bytes_per_launch(n, blk, {"chain_k_ranges": 64, "whole_k_panels": 0, "whole_k_row_slices": 0}, 64.0) < per
+    # slices re-read B: the sliced panel's bytes exceed a whole panel's
+    unsliced = bench._alg_bytes_per_launch(n, blk, {"chain_k_ranges": 32, "whole_k_panels": 4, "whole_k_row_slices": 0}, 36.0)
+    assert per * 39 > unsliced * 36
+
+
+def test_row_panel_disk_bound_is_tighter_than_the_agnostic_one():
+    n, blk = 32768, 4096
+    ceil = {"disk_read_GBps": 18.0, "disk_write_GBps": 14.0, "disk_read_GBps_while_writing": 12.0,
+            "disk_write_GBps_while_reading": 8.0}
+    rp = bench.row_panel_disk_bound(n, blk, ceil)
+    agnostic = (8 * n * n + 4 * n * n) / (20.0e9)
+    first = 4.0 * (n * n + blk * n)
+    assert rp > agnostic                                   # B + one A panel cannot overlap with any write
+    assert abs(rp - (first / 18e9 + (12.0 * n * n - first) / 20e9)) < 1e-9
+    assert bench.row_panel_disk_bound(n, blk, {}) is None
 
 
 def test_merge_ceilings_keeps_the_best_probe():
@@ -40,6 +57,7 @@ def test_a_leg_that_beats_its_bound_raises_the_ceiling_and_says_so():
     leg = {"seconds": 0.5, "gflops": 1.0, "stats": {"bytes_read": 8e9, "bytes_written": 0, "bytes_h2d": 8e9, "bytes_d2h": 0}}
     r = bench.roofline_e2e(leg, ceil, 2e9, 0.001, "odirect")
     assert r["bound"] == "disk_read" and r["frac"] == 1.0 and "probe_raised" in r and r["t_bound_s"] == 0.5
+    assert r["frac_raw"] == 1.6          # the unclamped fraction names the mis-probed ceiling
     leg["seconds"] = 1.0
     r = bench.roofline_e2e(leg, ceil, 2e9, 0.001, "odirect")
-    assert r["frac"] == 0.8 and "probe_raised" not in r
+    assert r["frac"] == 0.8 and "probe_raised" not in r and r["frac_raw"] == 0.8
