@@ -937,7 +937,19 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   // its sequential rate only with several large requests queued, so as many blocks are in flight
   // as there are staging slots, each read by its own thread, and retired (C written back) by a
   // small pool instead of one thread
-  R.depth = (int) std::min<int64_t>(std::max(2, R.o.pinned_slots), nb);
+  // Row-block contexts in flight.  csrmm: TWICE the reader threads (round 6) -- a context is busy from its block's
+  // first read to the end of its C write-back, and with as many contexts as readers a reader waits for a context about
+  // a quarter of the time: cfg3 from files, three interleaved rounds on one lease (profiles/r6/cfg3_sweep.txt): 8
+  // readers x 16 contexts 0.99-1.03 s O_DIRECT / 0.236-0.248 s page cache, every call; x 8 contexts 1.00-1.18 /
+  // 0.25-0.31; x 12 and 6 x 12 in between.  Bounded by 3 GiB of pinned staging (the pinned-block cache keeps 4 GiB;
+  // 24 contexts of cfg3's 171 MB went past it and paid for re-pinning: 0.33 s from the page cache).
+  int64_t want_depth = std::max(2, R.o.pinned_slots);
+  if (is_mm) {
+    const int64_t per_ctx = (int64_t) (max_idx + max_val + max_c) + (max_rows + 1) * 8;
+    const int64_t cap = std::max<int64_t>(want_depth, (int64_t) (3ull << 30) / std::max<int64_t>(per_ctx, 1));
+    want_depth = std::min<int64_t>(std::max<int64_t>(want_depth, 2 * (int64_t) std::max(1, R.o.n_io_threads)), cap);
+  }
+  R.depth = (int) std::min<int64_t>(want_depth, nb);
   R.ctx.resize((size_t) R.depth);
   for (int i = 0; i < R.depth; i++) {
     CsrCtx &c = R.ctx[i];

@@ -911,10 +911,12 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
             if (l >= 0 && l < Nk) add_launch(pc, 0, Nq, l, l + 1);
           }
       } else {
-        // $BOF_PANEL_RAMP_K k-blocks per launch of the ramp group (default 1; the reference's chain: always 1).  A
-        // launch over R k-blocks waits for R panels of the streaming operand and halves (R = 2) the raw-sum round
-        // trips and launch boundaries of the group.
-        const int64_t R = ref_chain ? 1 : std::max<int64_t>(1, env_long("BOF_PANEL_RAMP_K", 1));
+        // $BOF_PANEL_RAMP_K k-blocks per launch of the ramp group (default 2 since round 6; the reference's chain:
+        // always 1).  A launch over two k-blocks waits for two panels of the streaming operand and halves the raw-sum
+        // round trips and launch boundaries of the group: inside the cfg2 steps the tile kernel runs at 0.957 of peak
+        // against 0.951 with one k-block per launch, the steps themselves (disk-bound) and cfg2 from the page cache
+        // (0.515-0.53 s either way) do not move (profiles/r6/sched/README.md).
+        const int64_t R = ref_chain ? 1 : std::max<int64_t>(1, env_long("BOF_PANEL_RAMP_K", 2));
         for (int64_t l = 0; l < Nk; l += R)
           for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, std::min(Nk, l + R));
       }

@@ -61,3 +61,21 @@ def test_a_leg_that_beats_its_bound_raises_the_ceiling_and_says_so():
     leg["seconds"] = 1.0
     r = bench.roofline_e2e(leg, ceil, 2e9, 0.001, "odirect")
     assert r["frac"] == 0.8 and "probe_raised" not in r and r["frac_raw"] == 0.8
+
+
+def test_step_timeline_phases_from_an_event_ring():
+    """tools/r6/step_timeline.py on a synthetic ring: 4 chunk reads (two before the first write begins), 2 chunk writes."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "r6"))
+    import step_timeline as T
+    ev = ["0.000  t1   bof_flash_gemm (panels) begin      8 8 8",
+          "1.000  t2   panel chunk read begin             0 0 0", "11.000  t2   panel chunk read end               0 0 0",
+          "11.500  t2   panel chunk read begin             0 0 1", "21.000  t2   panel chunk read end               0 0 1",
+          "21.500  t3   panel in HBM (ready recorded)      0 0 0", "21.600  t1   launch                             0 1 0",
+          "22.000  t2   panel chunk read begin             1 0 0", "32.000  t2   panel chunk read end               1 0 0",
+          "30.000  t4   C chunk D2H complete, write begin  0 0 0", "45.000  t4   C chunk write end                  0 0 0",
+          "33.000  t2   panel chunk read begin             1 0 1", "43.000  t2   panel chunk read end               1 0 1",
+          "46.000  t4   C chunk D2H complete, write begin  0 1 32", "60.000  t4   C chunk write end                  0 1 32"]
+    txt = T.summarize(T.parse(ev), 0.060, win=20.0, chunk=1 << 20)
+    assert "4 chunk reads, 2 chunk writes, 1 launches" in txt
+    assert "phase 1, reads alone (0-30 ms)" in txt and "phase 3, writes alone (43-60 ms)" in txt
+    assert "A0@22" in txt and "0:1@22" in txt

@@ -402,6 +402,7 @@ def test_dma2_counter_kernel_in_the_panel_pipeline(dev, tmp_path, monkeypatch, b
     panel in row slices): the C file with the counter kernel == the C file with the barrier kernel == one bof_sgemm
     over the whole matrices (the default arithmetic does not depend on the cut)."""
     from test_gpu_flash import Files
+    monkeypatch.setenv("BOF_PANEL_RAMP_K", "1")          # one k-block per ramp launch: the chain hands raw sums on
     n = 4096
     rng = np.random.default_rng(41)
     a = rng.uniform(-1, 1, (n, n)).astype(np.float32)
