@@ -935,6 +935,182 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
 }
 
 // ---------------------------------------------------------------------------------------
+// Variant 5 (round 6): 'N','N' -- A x-major (row-major [m][k], the reference's own layout), B k-major -- through LDS-DMA
+// as well, with NO k-major copy of A.  LDS-DMA writes 16 bytes per lane to CONSECUTIVE LDS addresses, so it cannot
+// produce the padded / permuted x-major image the register-staged kernels read with ds_read_b128; but every lane may
+// FETCH any 16-byte chunk.  A slab of A is 256 rows x 128 bytes (32 k); one DMA piece is 8 rows = 64 lanes x 16 B, and
+// lane (r, p) fetches chunk p ^ r of row r: the image is [row][chunk ^ (row & 7)] (an XOR swizzle of the 16-byte chunks
+// inside each row).  Lane (i, h) of a wave needs, per group of four k (one chunk), the floats k = 4g + h and 4g + 2 + h of
+// row i: ONE ds_read2_b32 (offset0:0 offset1:2) at  row * 128 + ((g ^ (i & 7)) << 4) + 4 h -- the two dwords of all 64
+// lanes fall on 32 different banks four times each, the minimum for 128 dwords.  The chunk address is the per-lane base
+// XOR (g << 4): one v_xor per sub-tile and group (32 VALU instructions per slab, in the MFMA gaps).  The slab loop runs
+// in EIGHT groups of four k (fragments double-buffered in half the registers of the k-major loop); MFMA step c of
+// group g consumes k = 4g + 2c + h, i.e. the same k-ordered chain as every other kernel: bit-identical results.
+// Synchronisation and side-work placement as in slab_dma2<SYNC = 1, IL = 1>; the DMA pieces go out during groups 1-2,
+// `landed` is published at group 5, checked at group 7; `read_done` published at group 7, checked at group 1.
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_rd2_b32(uint32_t addr) {
+  f32x2 r;
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lgkm_fence2(f32x2 (&a)[4], f32x2 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+               :: "memory");
+}
+// B fragment (k-major image [k][256]) of group G: k-rows 4G + h and 4G + 2 + h (the base holds h and the sub-tile)
+template <int G>
+__device__ __forceinline__ f32x2 rd_frag4_k(uint32_t base) { return lds_rd2st64<G * 16, G * 16 + 8>(base); }
+
+template <int BUF>
+__device__ __forceinline__ void slab_dmax(const uint32_t (&a_base)[2][4], const uint32_t (&b_base)[2][4],
+                                          uint64_t a_next, uint64_t b_next, uint64_t a_step32, uint64_t b_step4,
+                                          unsigned a_goff, unsigned b_goff, uint32_t a_dst, uint32_t b_dst,
+                                          f32x2 (&a)[2][4], f32x2 (&b)[2][4], f32x16 (&acc)[4][4], SlabSync &sy) {
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    lgkm_fence2(a[g & 1], b[g & 1]);
+    if (g == 1) lds_wait_count(sy.read_addr, sy.peek_read, 4u * sy.slab);            // WAR: the other buffer is free
+    if (g == 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // my pieces of the next slab are in LDS
+      lds_count_up(sy.landed_addr, sy.one);
+    }
+    if (g == 7) {
+      lds_count_up(sy.read_addr, sy.one);                                             // my reads of this buffer are done
+      lds_wait_count(sy.landed_addr, sy.peek_land, 4u * (sy.slab + 1u));              // RAW: everybody's pieces are in
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        acc[j >> 2][j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][j >> 2][c], b[g & 1][j & 3][c],
+                                                                   acc[j >> 2][j & 3], 0, 0, 0);
+        // gaps behind the MFMAs of step 0: the fragments of the NEXT group (A in gaps 0, 4, 8, 12, B in 2, 6, 10, 14);
+        // of step 1: nothing but the DMA pieces (groups 1-2) and the counter peeks
+        if (c == 0 && (j & 1) == 0) {
+          const int x = j >> 2;
+          const bool second = (j & 2) != 0;
+          if (!second) {
+            if (g == 0) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (1u << 4));
+            if (g == 1) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (2u << 4));
+            if (g == 2) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (3u << 4));
+            if (g == 3) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (4u << 4));
+            if (g == 4) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (5u << 4));
+            if (g == 5) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (6u << 4));
+            if (g == 6) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (7u << 4));
+            if (g == 7) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF ^ 1][x]);
+          } else {
+            if (g == 0) b[1][x] = rd_frag4_k<1>(b_base[BUF][x]);
+            if (g == 1) b[0][x] = rd_frag4_k<2>(b_base[BUF][x]);
+            if (g == 2) b[1][x] = rd_frag4_k<3>(b_base[BUF][x]);
+            if (g == 3) b[0][x] = rd_frag4_k<4>(b_base[BUF][x]);
+            if (g == 4) b[1][x] = rd_frag4_k<5>(b_base[BUF][x]);
+            if (g == 5) b[0][x] = rd_frag4_k<6>(b_base[BUF][x]);
+            if (g == 6) b[1][x] = rd_frag4_k<7>(b_base[BUF][x]);
+            if (g == 7) b[0][x] = rd_frag4_k<0>(b_base[BUF ^ 1][x]);
+          }
+        }
+        if ((g == 1 || g == 2) && (j & 3) == 1) {       // 16 DMA pieces over the four steps of groups 1-2, one per fourth gap
+          const int s = 2 * (g - 1) + c, pc = 2 * s + (j >> 3);
+          if (!((j >> 2) & 1)) dma16(a_goff, a_next + (uint64_t) pc * a_step32, a_dst + pc * 4096);
+          else dma16(b_goff, b_next + (uint64_t) pc * b_step4, b_dst + pc * 4096);
+        }
+        if (c == 1 && j == 8) {
+          if (g == 6) sy.peek_land = lds_peek(sy.landed_addr);
+          if (g == 0) sy.peek_read = lds_peek(sy.read_addr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  sy.slab++;
+}
+
+template <class EP = NoEpi>
+__global__ void __launch_bounds__(256, 1)
+sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                          int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
+                          float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
+  constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;   // floats
+  __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF + 4];
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = bid / per_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (bid % per_group) % gsz;
+  const int tn = (bid % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) lds;
+  uint32_t a_base[2][4], b_base[2][4];
+#pragma unroll
+  for (int bf = 0; bf < 2; bf++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      // A image: [row][chunk ^ (row & 7)], 128 bytes a row; group 0's chunk of this lane's row, its float h
+      a_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF) + (unsigned) (wm * 128 + x * 32 + i) * 128u + (unsigned) (i & 7) * 16u + 4u * (unsigned) h;
+      b_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF + LDS_A + h * 256 + wn * 128 + x * 32 + i);
+    }
+  // DMA: A piece = 8 rows (lane = row r8, position p: fetches chunk p ^ r8), wave w takes rows 8w.. of every 32;
+  //      B piece = 4 k-rows (one per wave), as in the k-major kernel
+  const int r8 = lane >> 3, pp = lane & 7;
+  const unsigned a_goff = 4u * (unsigned) ((8 * wave + r8) * (int) lda + ((pp ^ r8) << 2));
+  const unsigned b_goff = 4u * (unsigned) ((t >> 6) * (int) ldb + 4 * (t & 63));
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t a_dst0 = lds0 + 4u * (unsigned) (wv * 256), b_dst0 = a_dst0 + 4u * LDS_A;
+  const uint32_t a_dst1 = a_dst0 + 4u * LDS_BUF, b_dst1 = b_dst0 + 4u * LDS_BUF;
+  const uint64_t a_org = reinterpret_cast<uint64_t>(A + (int64_t) m0 * lda), b_org = reinterpret_cast<uint64_t>(B + n0);
+  const uint64_t a_step32 = (uint64_t) lda * 128, b_step4 = (uint64_t) ldb * 16;   // 32 rows of A / 4 k-rows of B, bytes
+  const uint64_t a_slab = 128, b_slab = b_step4 * 8;                               // 32 k: 128 bytes along A's rows
+
+  f32x16 acc[4][4];
+  SlabSync sy{};
+  sy.landed_addr = lds0 + 4u * (unsigned) (2 * LDS_BUF);
+  sy.read_addr = sy.landed_addr + 4u;
+  sy.one = 1u;
+  if (t == 0) { lds[2 * LDS_BUF] = 0.f; lds[2 * LDS_BUF + 1] = 0.f; }
+
+  const int nkt = K / BK;
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    dma16(a_goff, a_org + (uint64_t) p * a_step32, a_dst0 + p * 4096);
+    dma16(b_goff, b_org + (uint64_t) p * b_step4, b_dst0 + p * 4096);
+  }
+  init_wave_tile_128(acc, ep, m0, n0, wm, wn, h, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x2 fa[2][4], fb[2][4];
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    fa[0][x] = lds_rd2_b32<0, 2>(a_base[0][x]);
+    fb[0][x] = rd_frag4_k<0>(b_base[0][x]);
+    fa[1][x] = fa[0][x]; fb[1][x] = fb[0][x];
+  }
+  uint64_t a_next = a_org + a_slab, b_next = b_org + b_slab;
+  for (int kt = 0; kt < nkt; kt += 2) {
+    slab_dmax<0>(a_base, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
+    const bool more = kt + 2 < nkt;
+    a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
+    slab_dmax<1>(a_base, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
+    a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  store_wave_tile_128(C, ldc, m0, n0, wm, wn, h, i, acc, alpha, beta, ep);
+}
+
+// ---------------------------------------------------------------------------------------
 // Variant 4 for the layouts with an x-major operand (register staging: LDS-DMA cannot produce
 // the permuted x-major image): the same hand-scheduled loop as sgemm_tile256_dma2_kernel --
 // explicit LDS reads/writes with immediate offsets, global loads in the "SGPR base + VGPR
@@ -1398,6 +1574,10 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
         hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<EP, 0, 0, 0>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                            ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     }
+    else if (AMODE == XMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 0) != 0)
+      // 'N','N' with A straight from its row-major rows through swizzled LDS-DMA (variant 5; $BOF_GEMM_DMAX)
+      hipLaunchKernelGGL(sgemm_tile256_dmax_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb, C, ldc,
+                         Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else if (K % (2 * BK) == 0)
       hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE, EP>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
                          A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
