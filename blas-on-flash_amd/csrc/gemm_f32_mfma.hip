@@ -941,18 +941,37 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
 // FETCH any 16-byte chunk.  A slab of A is 256 rows x 128 bytes (32 k); one DMA piece is 8 rows = 64 lanes x 16 B, and
 // lane (r, p) fetches chunk p ^ r of row r: the image is [row][chunk ^ (row & 7)] (an XOR swizzle of the 16-byte chunks
 // inside each row).  Lane (i, h) of a wave needs, per group of four k (one chunk), the floats k = 4g + h and 4g + 2 + h of
-// row i: ONE ds_read2_b32 (offset0:0 offset1:2) at  row * 128 + ((g ^ (i & 7)) << 4) + 4 h -- the two dwords of all 64
-// lanes fall on 32 different banks four times each, the minimum for 128 dwords.  The chunk address is the per-lane base
-// XOR (g << 4): one v_xor per sub-tile and group (32 VALU instructions per slab, in the MFMA gaps).  The slab loop runs
-// in EIGHT groups of four k (fragments double-buffered in half the registers of the k-major loop); MFMA step c of
-// group g consumes k = 4g + 2c + h, i.e. the same k-ordered chain as every other kernel: bit-identical results.
-// Synchronisation and side-work placement as in slab_dma2<SYNC = 1, IL = 1>; the DMA pieces go out during groups 1-2,
-// `landed` is published at group 5, checked at group 7; `read_done` published at group 7, checked at group 1.
-template <int O0, int O1>
-__device__ __forceinline__ f32x2 lds_rd2_b32(uint32_t addr) {
-  f32x2 r;
-  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+// its row: two ds_read_b32 at  row * 128 + ((g ^ (i & 7)) << 4) + 4 h  (+ 8).  The XOR with g cannot be an immediate, so
+// it is folded ONCE into eight base registers per buffer (sub-tile 0's chunk of group g); the sub-tile (32 rows =
+// 4096 bytes) is the instructions' 16-bit immediate.  The slab loop therefore has no VALU instruction, like the
+// k-major kernel's -- measured on the way here: the same loop with one v_xor per read (56 per slab) runs at 0.934 of
+// peak, with a ds_read_b128 + two v_cndmask per fragment (120 VALU per slab) at 0.877, without VALU at 0.968: every
+// VALU instruction between the MFMAs of a one-wave-per-SIMD loop costs ~10 cycles of the matrix pipe
+// (profiles/r6/kernel/dmax_variants.txt).  The loop runs in EIGHT groups of four k (fragments double-buffered in half
+// the registers of the k-major loop); MFMA step c of group g consumes k = 4g + 2c + h -- the same k-ordered chain as
+// every other kernel: bit-identical results.  Synchronisation and side-work placement as in slab_dma2<SYNC = 1, IL = 1>:
+// the DMA pieces go out during groups 1-2, `landed` is published at group 5 and checked at group 7, `read_done`
+// published at group 7 and checked at group 1.  4096 x 32768 x 32768: 152.2 TFLOP/s = 0.968 ('T','N' through the
+// k-major kernel on the same box: 0.966; the register-staged 'N','N' kernel: 0.930).
+template <int O>
+__device__ __forceinline__ float lds_rd32(uint32_t addr) {
+  float r;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(O) : "memory");
   return r;
+}
+// the lane's two floats of sub-tile X's chunk, off the group's base register
+template <int X>
+__device__ __forceinline__ f32x2 rd_frag4_x(uint32_t base_g) {
+  f32x2 v;
+  v[0] = lds_rd32<X * 4096>(base_g);
+  v[1] = lds_rd32<X * 4096 + 8>(base_g);
+  return v;
+}
+__device__ __forceinline__ f32x2 rd_frag4_xs(uint32_t base_g, int x) {
+  if (x == 0) return rd_frag4_x<0>(base_g);
+  if (x == 1) return rd_frag4_x<1>(base_g);
+  if (x == 2) return rd_frag4_x<2>(base_g);
+  return rd_frag4_x<3>(base_g);
 }
 __device__ __forceinline__ void lgkm_fence2(f32x2 (&a)[4], f32x2 (&b)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
@@ -964,7 +983,7 @@ template <int G>
 __device__ __forceinline__ f32x2 rd_frag4_k(uint32_t base) { return lds_rd2st64<G * 16, G * 16 + 8>(base); }
 
 template <int BUF>
-__device__ __forceinline__ void slab_dmax(const uint32_t (&a_base)[2][4], const uint32_t (&b_base)[2][4],
+__device__ __forceinline__ void slab_dmax(const uint32_t (&a_gb)[2][8], const uint32_t (&b_base)[2][4],
                                           uint64_t a_next, uint64_t b_next, uint64_t a_step32, uint64_t b_step4,
                                           unsigned a_goff, unsigned b_goff, uint32_t a_dst, uint32_t b_dst,
                                           f32x2 (&a)[2][4], f32x2 (&b)[2][4], f32x16 (&acc)[4][4], SlabSync &sy) {
@@ -987,19 +1006,12 @@ __device__ __forceinline__ void slab_dmax(const uint32_t (&a_base)[2][4], const 
         acc[j >> 2][j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][j >> 2][c], b[g & 1][j & 3][c],
                                                                    acc[j >> 2][j & 3], 0, 0, 0);
         // gaps behind the MFMAs of step 0: the fragments of the NEXT group (A in gaps 0, 4, 8, 12, B in 2, 6, 10, 14);
-        // of step 1: nothing but the DMA pieces (groups 1-2) and the counter peeks
+        // of step 1: the DMA pieces (groups 1-2) and the counter peeks
         if (c == 0 && (j & 1) == 0) {
           const int x = j >> 2;
-          const bool second = (j & 2) != 0;
-          if (!second) {
-            if (g == 0) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (1u << 4));
-            if (g == 1) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (2u << 4));
-            if (g == 2) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (3u << 4));
-            if (g == 3) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (4u << 4));
-            if (g == 4) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (5u << 4));
-            if (g == 5) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (6u << 4));
-            if (g == 6) a[1][x] = lds_rd2_b32<0, 2>(a_base[BUF][x] ^ (7u << 4));
-            if (g == 7) a[0][x] = lds_rd2_b32<0, 2>(a_base[BUF ^ 1][x]);
+          if (!(j & 2)) {
+            if (g < 7) a[(g + 1) & 1][x] = rd_frag4_xs(a_gb[BUF][g + 1], x);
+            else a[0][x] = rd_frag4_xs(a_gb[BUF ^ 1][0], x);
           } else {
             if (g == 0) b[1][x] = rd_frag4_k<1>(b_base[BUF][x]);
             if (g == 1) b[0][x] = rd_frag4_k<2>(b_base[BUF][x]);
@@ -1053,15 +1065,18 @@ sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float 
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) lds;
-  uint32_t a_base[2][4], b_base[2][4];
+  // A image: [row][chunk ^ (row & 7)], 128 bytes a row.  a_gb[buffer][g]: chunk g of this lane's row in sub-tile 0, its
+  // float h -- row * 128 + ((g ^ (i & 7)) << 4) + 4 h; sub-tile x is + x * 4096 (an immediate of the reads)
+  uint32_t a_gb[2][8], b_base[2][4];
 #pragma unroll
-  for (int bf = 0; bf < 2; bf++)
+  for (int bf = 0; bf < 2; bf++) {
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
-      // A image: [row][chunk ^ (row & 7)], 128 bytes a row; group 0's chunk of this lane's row, its float h
-      a_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF) + (unsigned) (wm * 128 + x * 32 + i) * 128u + (unsigned) (i & 7) * 16u + 4u * (unsigned) h;
+    for (int g = 0; g < 8; g++)
+      a_gb[bf][g] = lds0 + 4u * (unsigned) (bf * LDS_BUF) + (unsigned) (wm * 128 + i) * 128u + (unsigned) ((g ^ (i & 7)) << 4) + 4u * (unsigned) h;
+#pragma unroll
+    for (int x = 0; x < 4; x++)
       b_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF + LDS_A + h * 256 + wn * 128 + x * 32 + i);
-    }
+  }
   // DMA: A piece = 8 rows (lane = row r8, position p: fetches chunk p ^ r8), wave w takes rows 8w.. of every 32;
   //      B piece = 4 k-rows (one per wave), as in the k-major kernel
   const int r8 = lane >> 3, pp = lane & 7;
@@ -1093,16 +1108,16 @@ sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float 
   f32x2 fa[2][4], fb[2][4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    fa[0][x] = lds_rd2_b32<0, 2>(a_base[0][x]);
+    fa[0][x] = rd_frag4_xs(a_gb[0][0], x);
     fb[0][x] = rd_frag4_k<0>(b_base[0][x]);
     fa[1][x] = fa[0][x]; fb[1][x] = fb[0][x];
   }
   uint64_t a_next = a_org + a_slab, b_next = b_org + b_slab;
   for (int kt = 0; kt < nkt; kt += 2) {
-    slab_dmax<0>(a_base, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
+    slab_dmax<0>(a_gb, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
     const bool more = kt + 2 < nkt;
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
-    slab_dmax<1>(a_base, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
+    slab_dmax<1>(a_gb, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1574,8 +1589,9 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
         hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<EP, 0, 0, 0>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                            ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     }
-    else if (AMODE == XMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 0) != 0)
-      // 'N','N' with A straight from its row-major rows through swizzled LDS-DMA (variant 5; $BOF_GEMM_DMAX)
+    else if (AMODE == XMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 1) != 0)
+      // 'N','N': A straight from its row-major rows through XOR-swizzled LDS-DMA (variant 5, round 6; $BOF_GEMM_DMAX=0
+      // restores the register-staged kernel)
       hipLaunchKernelGGL(sgemm_tile256_dmax_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb, C, ldc,
                          Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else if (K % (2 * BK) == 0)

@@ -422,8 +422,69 @@ def test_dma2_counter_kernel_in_the_panel_pipeline(dev, tmp_path, monkeypatch, b
             mix = bofhip.flash_last_launch_mix()
             assert mix["chain_k_ranges"] == 2 and mix["whole_k_row_slices"] >= 2, mix
             return F.read("c", np.float32, (n, n))
+        # default: A's row-major panels straight through the x-major DMA kernel (dmax), no k-major copy of A
+        dmax = run()
+        # $BOF_GEMM_DMAX=0: k-major copies of A's panels + the k-major DMA kernel, with counters and with s_barrier
+        monkeypatch.setenv("BOF_GEMM_DMAX", "0")
         new, old = _both_syncs(monkeypatch, run)
+        monkeypatch.delenv("BOF_GEMM_DMAX")
         assert np.array_equal(new.view(np.uint32), old.view(np.uint32))
         assert np.array_equal(new.view(np.uint32), whole.view(np.uint32))
+        assert np.array_equal(dmax.view(np.uint32), whole.view(np.uint32))
     finally:
         F.close()
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 512), (4096, 2048, 576), (2304, 4096, 1024), (2048, 4352, 4160),
+                                   (2100, 4200, 640), (4096, 4096, 64 * 37), (8192, 2048, 128 * 5)])
+@pytest.mark.parametrize("alpha,beta,pad", [(1.0, 0.0, 0), (0.5, 2.0, 4)])
+def test_dmax_kernel_equals_register_staged_kernel(dev, monkeypatch, m, n, k, alpha, beta, pad):
+    """'N','N' (the reference's own layout: A row-major = x-major, B k-major) through sgemm_tile256_dmax_kernel -- A's
+    rows by XOR-swizzled LDS-DMA, no k-major copy -- against the register-staged kernel of rounds 1-5
+    ($BOF_GEMM_DMAX=0) bit for bit, padded leading dimensions and ragged edges included, and a 96-row band against the
+    oracle's k-ordered fmaf chain."""
+    g = torch.Generator(device="cpu").manual_seed(m * 5 + n * 11 + k)
+    lda, ldb = k + pad, n + 2 * pad
+    a = torch.rand(m, lda, generator=g) * 2 - 1
+    b = torch.rand(k, ldb, generator=g) * 2 - 1
+    c0 = torch.rand(m, n, generator=g) * 2 - 1
+    da, db = a.cuda(), b.cuda()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BOF_GEMM_DMAX", flag)
+        dc = c0.cuda()
+        bofhip.sgemm("R", "N", "N", m, n, k, alpha, da.data_ptr(), lda, db.data_ptr(), ldb, beta, dc.data_ptr(), n, stream())
+        torch.cuda.synchronize()
+        outs.append(dc.cpu())
+    monkeypatch.delenv("BOF_GEMM_DMAX")
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    rows = 96
+    band = orc.sgemm("R", "N", "N", rows, n, k, alpha, a.numpy()[:rows].copy(), lda, b.numpy(), ldb, beta, c0.numpy()[:rows].copy(), n)
+    assert np.array_equal(outs[0].numpy()[:rows], band)
+
+
+def test_dmax_kernel_column_major_and_kmeans_epilogue(dev, monkeypatch):
+    """Column-major 'N','N' runs as the row-major product of the swapped operands (again x-major x k-major: dmax), and
+    the Rank1x2 instantiation (flash::kmeans' task) of the same kernel: both against $BOF_GEMM_DMAX=0."""
+    m, n, k = 4096, 2048, 512
+    g = torch.Generator(device="cpu").manual_seed(9)
+    a = (torch.rand(k, m, generator=g) * 2 - 1).cuda()        # column-major m x k: stored [k][m]
+    b = (torch.rand(n, k, generator=g) * 2 - 1).cuda()        # column-major k x n: stored [n][k]
+    u = torch.rand(m, generator=g).cuda()
+    v = torch.rand(n, generator=g).cuda()
+    ones = torch.ones(max(m, n)).cuda()
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BOF_GEMM_DMAX", flag)
+        c1 = torch.zeros(n, m).cuda()                         # column-major m x n: stored [n][m]
+        bofhip.sgemm("C", "N", "N", m, n, k, 1.0, a.data_ptr(), m, b.data_ptr(), k, 0.0, c1.data_ptr(), m, stream())
+        c2 = torch.zeros(n, m).cuda()
+        bofhip.skmeans_task("C", "N", "N", m, n, k, -2.0, a.data_ptr(), m, b.data_ptr(), k, 0.0, c2.data_ptr(), m,
+                            u.data_ptr(), v.data_ptr(), ones.data_ptr(), stream())
+        torch.cuda.synchronize()
+        res[flag] = (c1.cpu(), c2.cpu())
+    monkeypatch.delenv("BOF_GEMM_DMAX")
+    assert torch.equal(res["1"][0].view(torch.int32), res["0"][0].view(torch.int32))
+    assert torch.equal(res["1"][1].view(torch.int32), res["0"][1].view(torch.int32))
+    ref = (b.cpu().double() @ a.cpu().double()).float()      # [n][m] = (A B)^T
+    assert (res["1"][0] - ref).abs().max() / ref.abs().max() < 1e-5

@@ -20,7 +20,7 @@ def run(m, n, k, alpha, beta, lda_pad=0, ldb_pad=0):
     b = (torch.rand(k, ldb, generator=g) * 2 - 1).to(dev)
     c0 = (torch.rand(m, n, generator=g) * 2 - 1).to(dev)
     outs = []
-    for flag in ("1", "0"):
+    for flag in (os.environ.get("DMAX_VARIANT", "1"), "0"):
         os.environ["BOF_GEMM_DMAX"] = flag
         c = c0.clone()
         bofhip.sgemm("R", "N", "N", m, n, k, alpha, a.data_ptr(), lda, b.data_ptr(), ldb, beta, c.data_ptr(), n, st)
@@ -60,7 +60,7 @@ for (m, n, k) in [(4096, 4096, 4096), (4096, 32768, 4096), (4096, 32768, 32768)]
     c = torch.zeros(m * n, dtype=torch.float32, device=dev)
     bofhip.gen_dense(a.data_ptr(), 0, a.numel(), "u", 1, st)
     bofhip.gen_dense(b.data_ptr(), 0, b.numel(), "u", 2, st)
-    for name, flag, ta in (("NN dmax", "1", "N"), ("NN 1w3", "0", "N"), ("TN dma2", "0", "T")):
+    for name, flag, ta in (("NN dmax (b128 + pick)", "1", "N"), ("NN dmax (read2_b32 + xor)", "2", "N"), ("NN dmax (2 x b32, per-group bases)", "3", "N"), ("NN 1w3", "0", "N"), ("TN dma2", "0", "T")):
         os.environ["BOF_GEMM_DMAX"] = flag
         lda = k if ta == "N" else m
         f = lambda: bofhip.sgemm("R", ta, "N", m, n, k, 1.0, a.data_ptr(), lda, b.data_ptr(), n, 0.0, c.data_ptr(), n, st)
