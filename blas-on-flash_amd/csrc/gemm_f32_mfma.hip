@@ -982,11 +982,26 @@ __device__ __forceinline__ void lgkm_fence2(f32x2 (&a)[4], f32x2 (&b)[4]) {
 template <int G>
 __device__ __forceinline__ f32x2 rd_frag4_k(uint32_t base) { return lds_rd2st64<G * 16, G * 16 + 8>(base); }
 
-template <int BUF>
-__device__ __forceinline__ void slab_dmax(const uint32_t (&a_gb)[2][8], const uint32_t (&b_base)[2][4],
-                                          uint64_t a_next, uint64_t b_next, uint64_t a_step32, uint64_t b_step4,
+// AX / BX: the operand is x-major (swizzled image, per-group bases *_gb) or k-major ([k][256] image, per-sub-tile bases
+// *_kb); *_step: bytes between two DMA pieces of the operand (32 rows x-major, 4 k-rows k-major)
+template <int BUF, bool AX, bool BX>
+__device__ __forceinline__ void slab_dmax(const uint32_t (&a_gb)[2][8], const uint32_t (&b_gb)[2][8],
+                                          const uint32_t (&a_kb)[2][4], const uint32_t (&b_kb)[2][4],
+                                          uint64_t a_next, uint64_t b_next, uint64_t a_step, uint64_t b_step,
                                           unsigned a_goff, unsigned b_goff, uint32_t a_dst, uint32_t b_dst,
                                           f32x2 (&a)[2][4], f32x2 (&b)[2][4], f32x16 (&acc)[4][4], SlabSync &sy) {
+  // operand fragment of the NEXT group (g + 1; the other buffer's group 0 behind group 7)
+  auto next_frag = [&](bool x_major, const uint32_t (&gb)[2][8], const uint32_t (&kb)[2][4], int g, int x) -> f32x2 {
+    if (x_major) return g < 7 ? rd_frag4_xs(gb[BUF][g + 1], x) : rd_frag4_xs(gb[BUF ^ 1][0], x);
+    if (g == 0) return rd_frag4_k<1>(kb[BUF][x]);
+    if (g == 1) return rd_frag4_k<2>(kb[BUF][x]);
+    if (g == 2) return rd_frag4_k<3>(kb[BUF][x]);
+    if (g == 3) return rd_frag4_k<4>(kb[BUF][x]);
+    if (g == 4) return rd_frag4_k<5>(kb[BUF][x]);
+    if (g == 5) return rd_frag4_k<6>(kb[BUF][x]);
+    if (g == 6) return rd_frag4_k<7>(kb[BUF][x]);
+    return rd_frag4_k<0>(kb[BUF ^ 1][x]);
+  };
 #pragma unroll
   for (int g = 0; g < 8; g++) {
     lgkm_fence2(a[g & 1], b[g & 1]);
@@ -1009,24 +1024,13 @@ __device__ __forceinline__ void slab_dmax(const uint32_t (&a_gb)[2][8], const ui
         // of step 1: the DMA pieces (groups 1-2) and the counter peeks
         if (c == 0 && (j & 1) == 0) {
           const int x = j >> 2;
-          if (!(j & 2)) {
-            if (g < 7) a[(g + 1) & 1][x] = rd_frag4_xs(a_gb[BUF][g + 1], x);
-            else a[0][x] = rd_frag4_xs(a_gb[BUF ^ 1][0], x);
-          } else {
-            if (g == 0) b[1][x] = rd_frag4_k<1>(b_base[BUF][x]);
-            if (g == 1) b[0][x] = rd_frag4_k<2>(b_base[BUF][x]);
-            if (g == 2) b[1][x] = rd_frag4_k<3>(b_base[BUF][x]);
-            if (g == 3) b[0][x] = rd_frag4_k<4>(b_base[BUF][x]);
-            if (g == 4) b[1][x] = rd_frag4_k<5>(b_base[BUF][x]);
-            if (g == 5) b[0][x] = rd_frag4_k<6>(b_base[BUF][x]);
-            if (g == 6) b[1][x] = rd_frag4_k<7>(b_base[BUF][x]);
-            if (g == 7) b[0][x] = rd_frag4_k<0>(b_base[BUF ^ 1][x]);
-          }
+          if (!(j & 2)) a[(g + 1) & 1][x] = next_frag(AX, a_gb, a_kb, g, x);
+          else b[(g + 1) & 1][x] = next_frag(BX, b_gb, b_kb, g, x);
         }
         if ((g == 1 || g == 2) && (j & 3) == 1) {       // 16 DMA pieces over the four steps of groups 1-2, one per fourth gap
           const int s = 2 * (g - 1) + c, pc = 2 * s + (j >> 3);
-          if (!((j >> 2) & 1)) dma16(a_goff, a_next + (uint64_t) pc * a_step32, a_dst + pc * 4096);
-          else dma16(b_goff, b_next + (uint64_t) pc * b_step4, b_dst + pc * 4096);
+          if (!((j >> 2) & 1)) dma16(a_goff, a_next + (uint64_t) pc * a_step, a_dst + pc * 4096);
+          else dma16(b_goff, b_next + (uint64_t) pc * b_step, b_dst + pc * 4096);
         }
         if (c == 1 && j == 8) {
           if (g == 6) sy.peek_land = lds_peek(sy.landed_addr);
@@ -1039,11 +1043,12 @@ __device__ __forceinline__ void slab_dmax(const uint32_t (&a_gb)[2][8], const ui
   sy.slab++;
 }
 
-template <class EP = NoEpi>
+template <int AMODE, int BMODE, class EP = NoEpi>
 __global__ void __launch_bounds__(256, 1)
 sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
                           int64_t ldb, float *__restrict__ C, int64_t ldc, int M, int N, int K,
                           float alpha, float beta, int tiles_m, int tiles_n, EP ep) {
+  constexpr bool AX = AMODE == XMAJOR, BX = BMODE == XMAJOR;      // at least one of them (launch_modes)
   constexpr int LDS_A = BK * 256, LDS_BUF = 2 * BK * 256;   // floats
   __shared__ __attribute__((aligned(1024))) float lds[2 * LDS_BUF + 4];
   const int nwg = tiles_m * tiles_n;
@@ -1065,29 +1070,36 @@ sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float 
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) float *) lds;
-  // A image: [row][chunk ^ (row & 7)], 128 bytes a row.  a_gb[buffer][g]: chunk g of this lane's row in sub-tile 0, its
-  // float h -- row * 128 + ((g ^ (i & 7)) << 4) + 4 h; sub-tile x is + x * 4096 (an immediate of the reads)
-  uint32_t a_gb[2][8], b_base[2][4];
+  // x-major image: [row][chunk ^ (row & 7)], 128 bytes a row.  *_gb[buffer][g]: chunk g of this lane's row in sub-tile
+  // 0, its float h -- row * 128 + ((g ^ (i & 7)) << 4) + 4 h; sub-tile x is + x * 4096 (an immediate of the reads).
+  // k-major image: [k][256]; *_kb[buffer][x]: k-row h, this lane's column of sub-tile x.
+  uint32_t a_gb[2][8], b_gb[2][8], a_kb[2][4], b_kb[2][4];
 #pragma unroll
   for (int bf = 0; bf < 2; bf++) {
 #pragma unroll
-    for (int g = 0; g < 8; g++)
-      a_gb[bf][g] = lds0 + 4u * (unsigned) (bf * LDS_BUF) + (unsigned) (wm * 128 + i) * 128u + (unsigned) ((g ^ (i & 7)) << 4) + 4u * (unsigned) h;
+    for (int g = 0; g < 8; g++) {
+      a_gb[bf][g] = AX ? lds0 + 4u * (unsigned) (bf * LDS_BUF) + (unsigned) (wm * 128 + i) * 128u + (unsigned) ((g ^ (i & 7)) << 4) + 4u * (unsigned) h : 0u;
+      b_gb[bf][g] = BX ? lds0 + 4u * (unsigned) (bf * LDS_BUF + LDS_A) + (unsigned) (wn * 128 + i) * 128u + (unsigned) ((g ^ (i & 7)) << 4) + 4u * (unsigned) h : 0u;
+    }
 #pragma unroll
-    for (int x = 0; x < 4; x++)
-      b_base[bf][x] = lds0 + 4u * (unsigned) (bf * LDS_BUF + LDS_A + h * 256 + wn * 128 + x * 32 + i);
+    for (int x = 0; x < 4; x++) {
+      a_kb[bf][x] = AX ? 0u : lds0 + 4u * (unsigned) (bf * LDS_BUF + h * 256 + wm * 128 + x * 32 + i);
+      b_kb[bf][x] = BX ? 0u : lds0 + 4u * (unsigned) (bf * LDS_BUF + LDS_A + h * 256 + wn * 128 + x * 32 + i);
+    }
   }
-  // DMA: A piece = 8 rows (lane = row r8, position p: fetches chunk p ^ r8), wave w takes rows 8w.. of every 32;
-  //      B piece = 4 k-rows (one per wave), as in the k-major kernel
+  // DMA.  x-major operand: a piece = 8 rows (lane = row r8, position p: fetches chunk p ^ r8), wave w takes rows 8w.. of
+  // every 32; k-major operand: a piece = 4 k-rows (one per wave), as in the k-major kernel
   const int r8 = lane >> 3, pp = lane & 7;
-  const unsigned a_goff = 4u * (unsigned) ((8 * wave + r8) * (int) lda + ((pp ^ r8) << 2));
-  const unsigned b_goff = 4u * (unsigned) ((t >> 6) * (int) ldb + 4 * (t & 63));
+  const unsigned a_goff = AX ? 4u * (unsigned) ((8 * wave + r8) * (int) lda + ((pp ^ r8) << 2)) : 4u * (unsigned) ((t >> 6) * (int) lda + 4 * (t & 63));
+  const unsigned b_goff = BX ? 4u * (unsigned) ((8 * wave + r8) * (int) ldb + ((pp ^ r8) << 2)) : 4u * (unsigned) ((t >> 6) * (int) ldb + 4 * (t & 63));
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const uint32_t a_dst0 = lds0 + 4u * (unsigned) (wv * 256), b_dst0 = a_dst0 + 4u * LDS_A;
   const uint32_t a_dst1 = a_dst0 + 4u * LDS_BUF, b_dst1 = b_dst0 + 4u * LDS_BUF;
-  const uint64_t a_org = reinterpret_cast<uint64_t>(A + (int64_t) m0 * lda), b_org = reinterpret_cast<uint64_t>(B + n0);
-  const uint64_t a_step32 = (uint64_t) lda * 128, b_step4 = (uint64_t) ldb * 16;   // 32 rows of A / 4 k-rows of B, bytes
-  const uint64_t a_slab = 128, b_slab = b_step4 * 8;                               // 32 k: 128 bytes along A's rows
+  const uint64_t a_org = reinterpret_cast<uint64_t>(AX ? A + (int64_t) m0 * lda : A + m0);
+  const uint64_t b_org = reinterpret_cast<uint64_t>(BX ? B + (int64_t) n0 * ldb : B + n0);
+  // bytes between two pieces (32 rows x-major / 4 k-rows k-major) and between two slabs (32 k)
+  const uint64_t a_step = AX ? (uint64_t) lda * 128 : (uint64_t) lda * 16, b_step = BX ? (uint64_t) ldb * 128 : (uint64_t) ldb * 16;
+  const uint64_t a_slab = AX ? 128 : (uint64_t) lda * 128, b_slab = BX ? 128 : (uint64_t) ldb * 128;
 
   f32x16 acc[4][4];
   SlabSync sy{};
@@ -1099,8 +1111,8 @@ sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float 
   const int nkt = K / BK;
 #pragma unroll
   for (int p = 0; p < 8; p++) {
-    dma16(a_goff, a_org + (uint64_t) p * a_step32, a_dst0 + p * 4096);
-    dma16(b_goff, b_org + (uint64_t) p * b_step4, b_dst0 + p * 4096);
+    dma16(a_goff, a_org + (uint64_t) p * a_step, a_dst0 + p * 4096);
+    dma16(b_goff, b_org + (uint64_t) p * b_step, b_dst0 + p * 4096);
   }
   init_wave_tile_128(acc, ep, m0, n0, wm, wn, h, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1108,16 +1120,16 @@ sgemm_tile256_dmax_kernel(const float *__restrict__ A, int64_t lda, const float 
   f32x2 fa[2][4], fb[2][4];
 #pragma unroll
   for (int x = 0; x < 4; x++) {
-    fa[0][x] = rd_frag4_xs(a_gb[0][0], x);
-    fb[0][x] = rd_frag4_k<0>(b_base[0][x]);
+    fa[0][x] = AX ? rd_frag4_xs(a_gb[0][0], x) : rd_frag4_k<0>(a_kb[0][x]);
+    fb[0][x] = BX ? rd_frag4_xs(b_gb[0][0], x) : rd_frag4_k<0>(b_kb[0][x]);
     fa[1][x] = fa[0][x]; fb[1][x] = fb[0][x];
   }
   uint64_t a_next = a_org + a_slab, b_next = b_org + b_slab;
   for (int kt = 0; kt < nkt; kt += 2) {
-    slab_dmax<0>(a_gb, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
+    slab_dmax<0, AX, BX>(a_gb, b_gb, a_kb, b_kb, a_next, b_next, a_step, b_step, a_goff, b_goff, a_dst1, b_dst1, fa, fb, acc, sy);
     const bool more = kt + 2 < nkt;
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
-    slab_dmax<1>(a_gb, b_base, a_next, b_next, a_step32, b_step4, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
+    slab_dmax<1, AX, BX>(a_gb, b_gb, a_kb, b_kb, a_next, b_next, a_step, b_step, a_goff, b_goff, a_dst0, b_dst0, fa, fb, acc, sy);
     a_next += more ? a_slab : 0; b_next += more ? b_slab : 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1589,11 +1601,12 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
         hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<EP, 0, 0, 0>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                            ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     }
-    else if (AMODE == XMAJOR && BMODE == KMAJOR && K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 1) != 0)
-      // 'N','N': A straight from its row-major rows through XOR-swizzled LDS-DMA (variant 5, round 6; $BOF_GEMM_DMAX=0
-      // restores the register-staged kernel)
-      hipLaunchKernelGGL(sgemm_tile256_dmax_kernel<EP>, dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B, ldb, C, ldc,
-                         Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
+    else if (K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 1) != 0 &&
+             (knob("BOF_GEMM_DMAX", 1) >= 2 || (AMODE == XMAJOR && BMODE == KMAJOR)))
+      // an x-major operand straight from its rows through XOR-swizzled LDS-DMA (variant 5, round 6).  Default: 'N','N'
+      // (x-major A, k-major B); $BOF_GEMM_DMAX=2: every layout with an x-major operand; =0: the register-staged kernel
+      hipLaunchKernelGGL((sgemm_tile256_dmax_kernel<AMODE, BMODE, EP>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
+                         ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else if (K % (2 * BK) == 0)
       hipLaunchKernelGGL((sgemm_tile256_1w3_kernel<AMODE, BMODE, EP>), dim3(tiles_m * tiles_n), dim3(256), 0, st,
                          A, lda, B, ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
