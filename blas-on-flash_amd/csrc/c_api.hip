@@ -321,12 +321,14 @@ static int gemm_resident_impl(char ord, char ta, char tb, int64_t m, int64_t n, 
   {
     const bool pre = !getenv("BOF_GEMM_PRETRANSPOSE") || atoi(getenv("BOF_GEMM_PRETRANSPOSE")) != 0;
     const bool dma = !getenv("BOF_GEMM_VARIANT") || atoi(getenv("BOF_GEMM_VARIANT")) >= 3;
-    // Round 6: the operand that is the row-major core's A (a for 'R', b for 'C': sgemm swaps them) needs no copy any
-    // more -- sgemm_tile256_dmax_kernel takes an x-major A straight through swizzled LDS-DMA; only the core's B does
-    // ($BOF_GEMM_DMAX=0: the register-staged kernel is back, and with it both copies)
+    // Round 6: no copy at all when the x-major kernel can take the operand as it is (sgemm_tile256_dmax_kernel: any
+    // layout, straight through swizzled LDS-DMA; needs 16-byte aligned rows); $BOF_GEMM_DMAX=0: the register-staged
+    // kernels are back, and with them the copies
     const bool dmax = !getenv("BOF_GEMM_DMAX") || atoi(getenv("BOF_GEMM_DMAX")) != 0;
-    const int core_b = ord == 'C' ? 0 : 1;
-    const bool xm[2] = {g.cdim[0] == 1 && (!dmax || core_b == 0), g.cdim[1] == 1 && (!dmax || core_b == 1)};  // k is the stored column dimension
+    const int64_t ld_of[2] = {g.ld[0], g.ld[1]};
+    const void *base_of[2] = {a, b};
+    auto direct_ok = [&](int x) { return dmax && ld_of[x] % 4 == 0 && (reinterpret_cast<uintptr_t>(base_of[x]) & 15) == 0; };
+    const bool xm[2] = {g.cdim[0] == 1 && !direct_ok(0), g.cdim[1] == 1 && !direct_ok(1)};  // k is the stored column dimension, and a copy is needed
     const int64_t reuse[2] = {g.nblk[2], g.nblk[0]};
     size_t need = 0;
     bool worth = pre && dma && k > 0 && k % 32 == 0 && m >= 2048 && n >= 2048 && (xm[0] || xm[1]);

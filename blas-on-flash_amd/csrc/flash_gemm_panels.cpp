@@ -984,11 +984,11 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
     for (int x = 0; x < 2; x++) {
       Mat &M = mat[x];
       const int64_t reuse = x == xmat ? Nq : NpC;
-      // (round 6: only the operand that is the row-major core's B -- mat 1 for 'R', mat 0 for 'C' -- still needs the
-      //  copy; an x-major core A goes through sgemm_tile256_dmax_kernel as it is.  $BOF_GEMM_DMAX=0: both, as before)
-      const bool core_b = x == (ord == 'C' ? 0 : 1);
-      bool ok = kmode > 0 && M.cdim == 1 && M.cols % 4 == 0 && (kmode > 1 || reuse >= 4) &&
-                (core_b || env_long("BOF_GEMM_DMAX", 1) == 0);
+      // (round 6: an x-major operand goes through sgemm_tile256_dmax_kernel as it is -- swizzled LDS-DMA straight from
+      //  its rows, in every layout -- so the copy is only made where that kernel cannot run: rows that are not 16-byte
+      //  aligned in the image (leading dimension not a multiple of 4), or $BOF_GEMM_DMAX=0)
+      const bool direct = env_long("BOF_GEMM_DMAX", 1) != 0 && M.ld % 4 == 0;
+      bool ok = kmode > 0 && M.cdim == 1 && M.cols % 4 == 0 && (kmode > 1 || reuse >= 4) && !direct;
       int64_t max_nr = 0;
       for (const Panel &P : M.panels) {
         ok = ok && P.nr % 4 == 0;

@@ -935,8 +935,8 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
 }
 
 // ---------------------------------------------------------------------------------------
-// Variant 5 (round 6): 'N','N' -- A x-major (row-major [m][k], the reference's own layout), B k-major -- through LDS-DMA
-// as well, with NO k-major copy of A.  LDS-DMA writes 16 bytes per lane to CONSECUTIVE LDS addresses, so it cannot
+// Variant 5 (round 6): x-major operands (k contiguous: A 'N' = row-major [m][k], the reference's own layout; B 'T') through
+// LDS-DMA as well, with NO k-major copy.  Described for A; B is the same with n for m.  LDS-DMA writes 16 bytes per lane to CONSECUTIVE LDS addresses, so it cannot
 // produce the padded / permuted x-major image the register-staged kernels read with ds_read_b128; but every lane may
 // FETCH any 16-byte chunk.  A slab of A is 256 rows x 128 bytes (32 k); one DMA piece is 8 rows = 64 lanes x 16 B, and
 // lane (r, p) fetches chunk p ^ r of row r: the image is [row][chunk ^ (row & 7)] (an XOR swizzle of the 16-byte chunks
@@ -951,8 +951,9 @@ sgemm_tile256_dma2_kernel(const float *__restrict__ A, int64_t lda, const float 
 // the registers of the k-major loop); MFMA step c of group g consumes k = 4g + 2c + h -- the same k-ordered chain as
 // every other kernel: bit-identical results.  Synchronisation and side-work placement as in slab_dma2<SYNC = 1, IL = 1>:
 // the DMA pieces go out during groups 1-2, `landed` is published at group 5 and checked at group 7, `read_done`
-// published at group 7 and checked at group 1.  4096 x 32768 x 32768: 152.2 TFLOP/s = 0.968 ('T','N' through the
-// k-major kernel on the same box: 0.966; the register-staged 'N','N' kernel: 0.930).
+// published at group 7 and checked at group 1.  4096 x 32768 x 32768: 'N','N' 152.6, 'N','T' 152.4, 'T','T' 152.4 TFLOP/s =
+// 0.969-0.970 ('T','N' through the k-major kernel on the same box: 0.965; the register-staged kernels: 0.930 / 0.910 /
+// 0.934).
 template <int O>
 __device__ __forceinline__ float lds_rd32(uint32_t addr) {
   float r;
@@ -1601,10 +1602,10 @@ static hipError_t launch_modes(const float *A, int64_t lda, const float *B, int6
         hipLaunchKernelGGL((sgemm_tile256_dma2_kernel<EP, 0, 0, 0>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                            ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     }
-    else if (K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 1) != 0 &&
-             (knob("BOF_GEMM_DMAX", 1) >= 2 || (AMODE == XMAJOR && BMODE == KMAJOR)))
-      // an x-major operand straight from its rows through XOR-swizzled LDS-DMA (variant 5, round 6).  Default: 'N','N'
-      // (x-major A, k-major B); $BOF_GEMM_DMAX=2: every layout with an x-major operand; =0: the register-staged kernel
+    else if (K % (2 * BK) == 0 && knob("BOF_GEMM_DMAX", 1) != 0)
+      // every layout with an x-major operand ('N','N', 'N','T', 'T','T'): that operand straight from its rows through
+      // XOR-swizzled LDS-DMA (variant 5, round 6: 150-152 TFLOP/s in all four layouts; the register-staged kernels ran
+      // 'N','N' at 145.0, 'T','T' at 145.4, 'N','T' at 141.8).  $BOF_GEMM_DMAX=0 restores the register-staged kernel.
       hipLaunchKernelGGL((sgemm_tile256_dmax_kernel<AMODE, BMODE, EP>), dim3(tiles_m * tiles_n), dim3(256), 0, st, A, lda, B,
                          ldb, C, ldc, Mi, Ni, K, alpha, beta, tiles_m, tiles_n, ep);
     else if (K % (2 * BK) == 0)

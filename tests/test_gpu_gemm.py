@@ -438,28 +438,33 @@ def test_dma2_counter_kernel_in_the_panel_pipeline(dev, tmp_path, monkeypatch, b
 @pytest.mark.parametrize("m,n,k", [(2048, 4096, 512), (4096, 2048, 576), (2304, 4096, 1024), (2048, 4352, 4160),
                                    (2100, 4200, 640), (4096, 4096, 64 * 37), (8192, 2048, 128 * 5)])
 @pytest.mark.parametrize("alpha,beta,pad", [(1.0, 0.0, 0), (0.5, 2.0, 4)])
-def test_dmax_kernel_equals_register_staged_kernel(dev, monkeypatch, m, n, k, alpha, beta, pad):
-    """'N','N' (the reference's own layout: A row-major = x-major, B k-major) through sgemm_tile256_dmax_kernel -- A's
-    rows by XOR-swizzled LDS-DMA, no k-major copy -- against the register-staged kernel of rounds 1-5
-    ($BOF_GEMM_DMAX=0) bit for bit, padded leading dimensions and ragged edges included, and a 96-row band against the
-    oracle's k-ordered fmaf chain."""
-    g = torch.Generator(device="cpu").manual_seed(m * 5 + n * 11 + k)
-    lda, ldb = k + pad, n + 2 * pad
-    a = torch.rand(m, lda, generator=g) * 2 - 1
-    b = torch.rand(k, ldb, generator=g) * 2 - 1
+@pytest.mark.parametrize("ta,tb", [("N", "N"), ("N", "T"), ("T", "T")])
+def test_dmax_kernel_equals_register_staged_kernel(dev, monkeypatch, ta, tb, m, n, k, alpha, beta, pad):
+    """Every layout with an x-major operand ('N','N' = the reference's own: A row-major; 'N','T'; 'T','T') through
+    sgemm_tile256_dmax_kernel -- the x-major operand's rows by XOR-swizzled LDS-DMA, no k-major copy -- against the
+    register-staged kernels of rounds 1-5 ($BOF_GEMM_DMAX=0) bit for bit, padded leading dimensions and ragged edges
+    included, and a 96-row band against the oracle's k-ordered fmaf chain."""
+    g = torch.Generator(device="cpu").manual_seed(m * 5 + n * 11 + k + ord(ta) + 3 * ord(tb))
+    sa = (m, k) if ta == "N" else (k, m)
+    sb = (k, n) if tb == "N" else (n, k)
+    lda, ldb = sa[1] + pad, sb[1] + 2 * pad
+    a = torch.rand(sa[0], lda, generator=g) * 2 - 1
+    b = torch.rand(sb[0], ldb, generator=g) * 2 - 1
     c0 = torch.rand(m, n, generator=g) * 2 - 1
     da, db = a.cuda(), b.cuda()
     outs = []
     for flag in ("1", "0"):
         monkeypatch.setenv("BOF_GEMM_DMAX", flag)
         dc = c0.cuda()
-        bofhip.sgemm("R", "N", "N", m, n, k, alpha, da.data_ptr(), lda, db.data_ptr(), ldb, beta, dc.data_ptr(), n, stream())
+        bofhip.sgemm("R", ta, tb, m, n, k, alpha, da.data_ptr(), lda, db.data_ptr(), ldb, beta, dc.data_ptr(), n, stream())
         torch.cuda.synchronize()
         outs.append(dc.cpu())
     monkeypatch.delenv("BOF_GEMM_DMAX")
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     rows = 96
-    band = orc.sgemm("R", "N", "N", rows, n, k, alpha, a.numpy()[:rows].copy(), lda, b.numpy(), ldb, beta, c0.numpy()[:rows].copy(), n)
+    a_band = a.numpy()[:rows].copy() if ta == "N" else np.ascontiguousarray(a.numpy()[:, :rows])
+    band = orc.sgemm("R", ta, tb, rows, n, k, alpha, a_band, lda if ta == "N" else rows, b.numpy(), ldb, beta,
+                     c0.numpy()[:rows].copy(), n)
     assert np.array_equal(outs[0].numpy()[:rows], band)
 
 
