@@ -1338,9 +1338,12 @@ def run_single(args, bofhip, torch, dev, st):
     # the launch mix of the row-panel schedule as the library counted it in the last timed step (bof_flash_last_launch_mix):
     # the ramp group's k-block launches are <ChainEpi> instantiations, the whole-K launches <NoEpi> (beta == 0)
     mix = h.get("launch_mix_last_step") or {}
-    kernel_mix = {"sgemm_tile256_dma2_kernel<ChainEpi> (ramp group, one k-block per launch)": mix.get("chain_k_ranges"),
-                  "sgemm_tile256_dma2_kernel<NoEpi> (one launch over the whole K, a whole C panel)": mix.get("whole_k_panels"),
-                  "sgemm_tile256_dma2_kernel<NoEpi> (one launch over the whole K, a row slice of the last C panel)": mix.get("whole_k_row_slices")}
+    # row-major 'N','N': A's panels are x-major -> sgemm_tile256_dmax_kernel<XMAJOR, KMAJOR, EP> (round 6: swizzled LDS-DMA
+    # straight from A's rows); with $BOF_GEMM_DMAX=0 k-major copies + sgemm_tile256_dma2_kernel<EP>, as until round 5
+    kname = "sgemm_tile256_dma2_kernel" if os.environ.get("BOF_GEMM_DMAX", "1") == "0" else "sgemm_tile256_dmax_kernel"
+    kernel_mix = {f"{kname}<ChainEpi> (ramp group, $BOF_PANEL_RAMP_K k-blocks per launch)": mix.get("chain_k_ranges"),
+                  f"{kname}<NoEpi> (one launch over the whole K, a whole C panel)": mix.get("whole_k_panels"),
+                  f"{kname}<NoEpi> (one launch over the whole K, a row slice of the last C panel)": mix.get("whole_k_row_slices")}
     mean_step = {q: _mean(p[q] for p in per) for q in ("bytes_read", "bytes_written", "bytes_h2d", "bytes_d2h")}
     bound, t_bound, terms = e2e_bound(mean_step, ceil if "error" not in ceil else {}, args.steps, ksec / args.steps)
     secs = sorted(p["seconds"] for p in per)
@@ -1374,7 +1377,7 @@ def run_single(args, bofhip, torch, dev, st):
                    "ms_per_step_median": round(med_step * 1e3, 2),
                    "mean_over_median": round(dt / args.steps / med_step, 3),
                    "C_verified": h["verified"], "parallelism": "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel (both instantiations; launches per step in kernel_mix)",
+        "roofline": {"bound": "mfma", "kernel": f"{kname} (<ChainEpi> and <NoEpi> instantiations; launches per step in kernel_mix)",
                      "kernel_mix": kernel_mix,
                      "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(avg_launch_ms, 4),
@@ -1745,7 +1748,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
                    "aggregate_write_GBps": round(agg["bytes_written"] / dt / 1e9, 2),
                    "C_verified": bool(match), "create_files_s": round(create_s, 1)},
         "ranks_seen": args.ranks_seen,
-        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dma2_kernel (<ChainEpi> ramp launches + <NoEpi> whole-K launches)",
+        "roofline": {"bound": "mfma", "kernel": "sgemm_tile256_dmax_kernel (<ChainEpi> ramp launches + <NoEpi> whole-K launches)",
                      "achieved": round(achieved, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                      "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(launches),

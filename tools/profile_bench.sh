@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/resident" -o res -
 cd "$root"
 f=$(find "$out/resident" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/resident_kernel_stats.csv"
 rm -rf "$out/resident"
-python3 tools/pmc_summary.py sgemm_tile256_dma2_kernel "$out/bench_gemm_pmc.json" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq"
+python3 tools/pmc_summary.py sgemm_tile256_dma "$out/bench_gemm_pmc.json" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq"
 f=$(find "$out/stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/bench_gemm_kernel_stats.csv" && python3 tools/kstats.py "$f" sgemm transpose
 # keep only the summaries (the raw traces are tens of MB)
 rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq"
