@@ -1562,6 +1562,7 @@ def run_sharded(args, bofhip, torch, dev, st, rank, world, red_dev, one_gpu):
         try:
             made = []
             for bdir in (dirs or [base]):
+                os.makedirs(bdir, exist_ok=True)        # ($BOF_BENCH_DIRS may name directories that do not exist yet)
                 d = tempfile.mkdtemp(prefix="bof_bench_sharded_", dir=bdir)
                 made.append(d)
                 users = len([g for g in range(world) if g % D == len(made) - 1]) if local_slabs else world
