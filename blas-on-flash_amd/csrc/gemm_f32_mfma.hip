@@ -1724,12 +1724,45 @@ hipError_t expand_tile_local(const float *src, float *dst, int64_t len, int64_t 
   return hipGetLastError();
 }
 
+// K % 64 != 0 on a product that is big enough for the 256 x 256 LDS-DMA kernels (round 6): those kernels take K in
+// pairs of 32-deep slabs, and the whole launch used to fall to the register-staged kernel with a guarded last slab
+// (0.89-0.90 of peak).  A chain cut at ANY k equals one launch bit for bit (ChainEpi), so the product runs as TWO launches
+// of one chain: K - K % 64 through the DMA kernel with its raw sums stored, the last < 64 k through the guarded
+// 128 x 128 kernel, which starts from those sums and applies the caller's alpha / beta.  `raw`: where the first launch
+// may put its raw sums (laid out like C, leading dimension ld_raw) -- C itself when nothing of C is needed any more
+// (beta == 0), the chain's own accumulator otherwise; nullptr: no such place, one launch.  $BOF_GEMM_KSPLIT=0: off.
+static hipError_t sgemm_rm_ksplit(bool ta, bool tb, int M, int N, int K, float alpha, const float *A, int64_t lda, const float *B,
+                                  int64_t ldb, float beta, float *C, int64_t ldc, hipStream_t st, ChainEpi ep, float *raw,
+                                  int64_t ld_raw) {
+  const int r = K % (2 * BK), K1 = K - r;
+  const bool vec_ld = (lda % 4 == 0) && (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  const bool big = vec_ld && (int64_t) (M / 256) * (N / 256) >= 128 && K1 >= std::max(knob("BOF_GEMM_SHORT_K", 512), 16 * 2 * BK) &&
+                   lda < (1 << 22) && ldb < (1 << 22);
+  if (r == 0 || !big || !raw || alpha == 0.f || knob("BOF_GEMM_KSPLIT", 1) == 0)
+    return sgemm_rm(ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st, ep);
+  const ChainEpi head{ep.acc_in, ep.ld_acc, nullptr, 0, 1};
+  hipError_t e = sgemm_rm(ta, tb, M, N, K1, alpha, A, lda, B, ldb, beta, raw, ld_raw, st, head);
+  if (e != hipSuccess) return e;
+  // the operands' k origin moves on by K1: along the row of an x-major image ('N' A, 'T' B), down the rows of a k-major one
+  const float *A2 = ta ? A + (int64_t) K1 * lda : A + K1;
+  const float *B2 = tb ? B + K1 : B + (int64_t) K1 * ldb;
+  const ChainEpi tail{raw, ld_raw, ep.c_in, ep.ld_cin, ep.raw_out};
+  return sgemm_rm(ta, tb, M, N, r, alpha, A2, lda, B2, ldb, beta, C, ldc, st, tail);
+}
+
 // cblas_sgemm argument meaning.  Column-major: C^T = op(B)^T * op(A)^T.
 hipError_t sgemm(char ord, char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha,
                  const float *a, int64_t lda, const float *b, int64_t ldb, float beta, float *c,
                  int64_t ldc, hipStream_t st) {
   drop_stale_error();
   if (m == 0 || n == 0) return hipSuccess;
+  if (k % (2 * BK) != 0 && beta == 0.f && k > 0) {       // (C is free to carry the chain's raw sums between the two launches)
+    const ChainEpi whole{nullptr, 0, nullptr, 0, 0};
+    if (ord == 'C')
+      return sgemm_rm_ksplit(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta, c, ldc, st, whole, c, ldc);
+    return sgemm_rm_ksplit(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c, ldc, st, whole, c, ldc);
+  }
   if (ord == 'C')
     return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta,
                     c, ldc, st, NoEpi{});
@@ -1745,9 +1778,14 @@ hipError_t sgemm_chain(char ord, char ta, char tb, int64_t m, int64_t n, int64_t
   drop_stale_error();
   if (m == 0 || n == 0) return hipSuccess;
   const ChainEpi ep{ch.acc_in, ch.ld_acc, ch.c_in, ch.ld_cin, ch.raw_out ? 1 : 0};
+  // where a ragged K's first launch may leave its raw sums (sgemm_rm_ksplit): the launch's own output when that is raw
+  // anyway; the chain's accumulator (rewritten in place: its old contents are consumed by this very launch); C when
+  // nothing of it is read (beta == 0 and no separate c_in)
+  float *raw = ch.raw_out ? c : (ch.acc_in ? const_cast<float *>(ch.acc_in) : ((beta == 0.f && !ch.c_in) ? c : nullptr));
+  const int64_t ld_raw = ch.raw_out ? ldc : (ch.acc_in ? ch.ld_acc : ldc);
   if (ord == 'C')
-    return sgemm_rm(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta, c, ldc, st, ep);
-  return sgemm_rm(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c, ldc, st, ep);
+    return sgemm_rm_ksplit(tb == 'T', ta == 'T', (int) n, (int) m, (int) k, alpha, b, ldb, a, lda, beta, c, ldc, st, ep, raw, ld_raw);
+  return sgemm_rm_ksplit(ta == 'T', tb == 'T', (int) m, (int) n, (int) k, alpha, a, lda, b, ldb, beta, c, ldc, st, ep, raw, ld_raw);
 }
 
 // KMeansTask::execute on one tile (reference include/tasks/kmeans_task.h:53-82):

@@ -493,3 +493,64 @@ def test_dmax_kernel_column_major_and_kmeans_epilogue(dev, monkeypatch):
     assert torch.equal(res["1"][1].view(torch.int32), res["0"][1].view(torch.int32))
     ref = (b.cpu().double() @ a.cpu().double()).float()      # [n][m] = (A B)^T
     assert (res["1"][0] - ref).abs().max() / ref.abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("ord_,ta,tb", [("R", "N", "N"), ("R", "T", "N"), ("R", "N", "T"), ("C", "N", "N"), ("C", "T", "T")])
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 1024 + 4), (4096, 2048, 2048 + 37), (2304, 4352, 1600 + 32), (2100, 4200, 1100)])
+def test_ragged_k_runs_as_two_launches_of_one_chain(dev, monkeypatch, ord_, ta, tb, m, n, k):
+    """K % 64 != 0 on a product big enough for the LDS-DMA kernels (round 6, sgemm_rm_ksplit): K - K % 64 through the
+    DMA kernel with its raw sums stored in C, the last < 64 k through the guarded kernel starting from them -- one
+    chain, so the result equals the single launch of the register-staged kernel ($BOF_GEMM_KSPLIT=0) bit for bit,
+    and a 64-row band equals the oracle's k-ordered chain."""
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    sa, sb, sc = stored_shapes(ord_, ta, tb, m, n, k)
+    a = torch.rand(*sa, generator=g) * 2 - 1
+    b = torch.rand(*sb, generator=g) * 2 - 1
+    da, db = a.cuda(), b.cuda()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BOF_GEMM_KSPLIT", flag)
+        dc = torch.full(sc, float("nan")).cuda()            # beta == 0: whatever C held must not matter
+        bofhip.sgemm(ord_, ta, tb, m, n, k, 0.75, da.data_ptr(), sa[1], db.data_ptr(), sb[1], 0.0, dc.data_ptr(), sc[1], stream())
+        torch.cuda.synchronize()
+        outs.append(dc.cpu())
+    monkeypatch.delenv("BOF_GEMM_KSPLIT")
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    ref = orc.sgemm(ord_, ta, tb, m, n, k, 0.75, a.numpy(), sa[1], b.numpy(), sb[1], 0.0, np.zeros(sc, np.float32), sc[1]) \
+        if m * n * k < 2.5e10 else None
+    if ref is not None:
+        assert np.array_equal(outs[0].numpy(), ref)
+
+
+@pytest.mark.parametrize("beta", [0.0, 2.0])
+def test_ragged_k_in_the_panel_pipeline(dev, tmp_path, monkeypatch, beta):
+    """flash::gemm on files with K = 4100 and 2048-tiles: the k tiles are 2048 + 2052 (merged tail), so the second ramp
+    launch and the whole-K launches have K % 64 = 4 -- each runs as two launches of its chain.  Against one bof_sgemm over
+    the whole matrices and against the unsplit run."""
+    from test_gpu_flash import Files
+    monkeypatch.setenv("BOF_PANEL_RAMP_K", "1")
+    m, n, k = 4096, 4096, 4100
+    rng = np.random.default_rng(43)
+    a = rng.uniform(-1, 1, (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    F = Files(tmp_path, a=a, b=b, c=c0)
+    try:
+        res = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("BOF_GEMM_KSPLIT", flag)
+            c0.tofile(F.paths["c"])
+            os.posix_fadvise(F.fds["c"], 0, 0, os.POSIX_FADV_DONTNEED)
+            bofhip.flash_gemm("R", "N", "N", m, n, k, 0.5, beta, F.fptr("a"), F.fptr("b"), F.fptr("c"), 0, 0, 0,
+                              bofhip.default_options(gemm_blk=2048, gemm_path=2, panel_group=1, io_chunk_mib=4, verify=1))
+            res.append(F.read("c", np.float32, (m, n)))
+        monkeypatch.delenv("BOF_GEMM_KSPLIT")
+        assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+        da, db, dc = to_dev(a), to_dev(b), to_dev(c0)
+        monkeypatch.setenv("BOF_GEMM_KSPLIT", "0")
+        bofhip.sgemm("R", "N", "N", m, n, k, 0.5, ptr(da), k, ptr(db), n, beta, ptr(dc), n, stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(res[0].view(np.uint32), dc.cpu().numpy().view(np.uint32))
+    finally:
+        F.close()
