@@ -949,7 +949,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     const int64_t cap = std::max<int64_t>(want_depth, (int64_t) (3ull << 30) / std::max<int64_t>(per_ctx, 1));
     want_depth = std::min<int64_t>(std::max<int64_t>(want_depth, 2 * (int64_t) std::max(1, R.o.n_io_threads)), cap);
   }
-  if (const long forced = env_long("BOF_CSR_CONTEXTS", 0)) want_depth = std::max<long>(2, forced);      // (experiments)
+  if (const long forced = env_long("BOF_CSR_CONTEXTS", 0))      // (experiments: N contexts; negative: the rule of rounds 1-5)
+    want_depth = forced < 0 ? std::max(2, R.o.pinned_slots) : std::max<long>(2, forced);
   R.depth = (int) std::min<int64_t>(want_depth, nb);
   R.ctx.resize((size_t) R.depth);
   for (int i = 0; i < R.depth; i++) {

@@ -287,7 +287,18 @@ def csr_case(rng, tmp):
             files += [fb, fc]
             bofhip.flash_csrmm("T" if kind == "csrmm_T" else "N", m, n, k, alpha, beta, fv.fptr(), fi.fptr(), fj.fptr(), ord_b,
                                fb.fptr(), fc.fptr(), opts)
-            fc.check_against(ref)
+            try:
+                fc.check_against(ref)
+            except AssertionError:
+                if os.environ.get("BOF_FUZZ_DUMP"):      # everything needed to look at the failure offline
+                    raw = open(fc.path, "rb").read()
+                    got = np.frombuffer(raw[fc.head:fc.head + fc.payload.nbytes], np.float32).reshape(fc.payload.shape)
+                    cfile = bofhip.flash_last_c_file()
+                    np.savez_compressed(os.path.join(os.environ["BOF_FUZZ_DUMP"], f"fuzz_csr_fail_{os.getpid()}_{int(time.time())}.npz"),
+                                        got=got, ref=ref, c0=c0, ia=ia, ja=ja, val=val, b=b,
+                                        desc=np.array(repr(dict(desc, c_file_mode=cfile[0], c_twin_bytes=cfile[1],
+                                                                stats=bofhip.flash_last_stats()))))
+                raise
             fb.check_against(b)
         elif kind == "csrcsc":
             vt, it, jt = orc.csrcsc(m, n, val, ia, ja)
