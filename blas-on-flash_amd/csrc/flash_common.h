@@ -404,9 +404,19 @@ inline void evt_dump_env(const char *why) {                 // to $BOF_EVENT_DUM
 // wrong results of rounds 3-4 had cross-thread submission in common too.  The only ordering the pipelines still rely
 // on without a host check is the most basic one: operations one thread submits to one stream run in that order.
 // Cost: a reader waits ~0.6 ms for its 32 MiB copy before it takes the next request (the disk, not the readers,
-// bounds the pipelines).  $BOF_HOST_HANDOVER=0 restores the device-side-only hand-overs (A/B switch).
+// bounds the pipelines).
+// ROUND 6: OFF by default again ($BOF_HOST_HANDOVER=1 turns it on).  The events this was built against are not a
+// hand-over problem: (1) the stand-alone stress of exactly this pattern (tools/exp/handover_stress.hip) ran 58 million
+// hand-overs over every ingredient named above without a wrong word; (2) the round's final fuzz caught three wrong
+// csrmm results whose dumps show ONE launch in which the workgroups of one XCD did their neighbours' rows (rows of
+// blockIdx w - 1 updated twice, rows of w not at all, for every w = x mod 8), and tools/exp/wg_id_stress.hip -- no
+// library, two trivial kernels, eight processes on the GPU -- reproduced that: one launch in ~7 million in which 93
+// workgroups of one XCD (blockIdx = 3 mod 8) did not write their rows.  A sum kernel or a tile kernel some of whose
+// workgroups run under a wrong ID explains every unexplained event of rounds 3-5 (a tile's two sums differ by a few
+// thousand words; a k-block missing from one tile column), and no ordering on the host can prevent it.  It has only
+// ever been seen with several processes sharing the GPU (profiles/r6/incident_csrmm/README.md).
 inline bool host_handover() {
-  static const bool on = env_long("BOF_HOST_HANDOVER", 1) != 0;
+  static const bool on = env_long("BOF_HOST_HANDOVER", 0) != 0;
   return on;
 }
 // the consumer's side of a hand-over: host check (when on), then the device-side wait as before

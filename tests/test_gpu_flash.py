@@ -329,12 +329,14 @@ def test_flash_gemm_io_uring_engine_subprocess(dev):
     assert r.returncode == 0, r.stdout[-2500:]
 
 
-def test_flash_gemm_device_side_handovers_subprocess(dev):
-    """BOF_HOST_HANDOVER=0 (read once per process): the hand-overs of rounds 1-4 -- device-side event waits only, no
-    host confirmation by the consuming thread -- stay a supported A/B configuration: the panel-ring, the 8-layout and the
-    reference-chain file tests again in a child process with it."""
+def test_flash_gemm_host_confirmed_handovers_subprocess(dev):
+    """BOF_HOST_HANDOVER=1 (read once per process): the host-confirmed hand-overs of round 5 (the consuming thread
+    waits on the host for the producer's event before it submits dependent work; off by default again since round 6,
+    whose stand-alone stresses showed the events it was built against to be workgroups running under a wrong ID, not
+    hand-overs) stay a supported A/B configuration: the panel-ring, the 8-layout and the reference-chain file tests
+    again in a child process with it."""
     import sys
-    env = dict(os.environ, BOF_HOST_HANDOVER="0")
+    env = dict(os.environ, BOF_HOST_HANDOVER="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
                         "panels_ring_reuse or layouts_unaligned or reference_chain"], env=env, capture_output=True,
                        text=True, timeout=900)
