@@ -83,9 +83,14 @@ inline hipError_t tile_sgemm(char ord, char ta, char tb, int64_t M, int64_t N, i
   return sgemm_rank1x2(ord, ta, tb, M, N, K, alpha, a, lda, b, ldb, beta, c, ldc, kv->c_l2sq + row0, kv->ones,
                        kv->ones, kv->p_l2sq + col0, st);
 }
+// `seen` (optional, BOF_VERIFY): a launch receipt -- every workgroup adds 1 to seen[blockIdx.x] (row-major kernels: one
+// entry per 4 rows); csr_receipt_check compares the first n entries with 1, adds the number of misses to *flag and
+// zeroes them again.  What it catches: workgroups that ran under a neighbour's ID (profiles/r6/incident_csrmm).
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
-                  float *c, int64_t ldc, hipStream_t st);
+                  float *c, int64_t ldc, hipStream_t st, unsigned *seen = nullptr);
+int64_t scsrmm_receipt_entries(char ord_b, int64_t m);      // how many entries of `seen` a launch over m rows marks
+hipError_t csr_receipt_check(unsigned *seen, int64_t n, unsigned *flag, hipStream_t st);
 hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t cols, float *out,
                          int64_t ld_out, hipStream_t st);
 size_t csrcsc_workspace_bytes(int64_t n, int64_t nnz);

@@ -56,9 +56,10 @@ __global__ void __launch_bounds__(64 * CSR_WAVES)
 csrmm_rowmajor_kernel(int64_t m, int n, float alpha, const float *__restrict__ val,
                       const int64_t *__restrict__ col, const int64_t *__restrict__ ptr,
                       const float *__restrict__ B, int64_t ldb, float beta,
-                      float *__restrict__ C, int64_t ldc) {
+                      float *__restrict__ C, int64_t ldc, unsigned *__restrict__ seen) {
   typedef typename vecf<VEC>::type V;
   const int lane = threadIdx.x & 63;
+  if (seen && threadIdx.x == 0) atomicAdd(&seen[blockIdx.x], 1u);      // launch receipt (BOF_VERIFY)
   const int64_t row = (int64_t) blockIdx.x * CSR_WAVES + (threadIdx.x >> 6);
   if (row >= m) return;
   const int64_t base = ptr[0];
@@ -183,9 +184,24 @@ hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t c
   return hipGetLastError();
 }
 
+// launch receipts (bof_internal.h): entries a launch marks, and the checker
+int64_t scsrmm_receipt_entries(char ord_b, int64_t m) { return ord_b == 'R' ? (m + CSR_WAVES - 1) / CSR_WAVES : 0; }
+__global__ void __launch_bounds__(256) csr_receipt_check_kernel(unsigned *seen, int64_t n, unsigned *flag) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (seen[i] != 1u) atomicAdd(flag, 1u);
+  seen[i] = 0u;
+}
+hipError_t csr_receipt_check(unsigned *seen, int64_t n, unsigned *flag, hipStream_t st) {
+  drop_stale_error();
+  if (!seen || n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(csr_receipt_check_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, seen, n, flag);
+  return hipGetLastError();
+}
+
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val,
                   const int64_t *col, const int64_t *ptr, const float *b, int64_t ldb, float beta,
-                  float *c, int64_t ldc, hipStream_t st) {
+                  float *c, int64_t ldc, hipStream_t st, unsigned *seen) {
   drop_stale_error();
   (void) k;
   if (m == 0 || n == 0) return hipSuccess;
@@ -199,13 +215,13 @@ hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, cons
     dim3 grid((unsigned) ((m + CSR_WAVES - 1) / CSR_WAVES)), block(64 * CSR_WAVES);
     if (al16 && n > 128)
       hipLaunchKernelGGL((csrmm_rowmajor_kernel<4, 8>), grid, block, 0, st, m, (int) n, alpha, val,
-                         col, ptr, b, ldb, beta, c, ldc);
+                         col, ptr, b, ldb, beta, c, ldc, seen);
     else if (al8 && n > 64)
       hipLaunchKernelGGL((csrmm_rowmajor_kernel<2, 8>), grid, block, 0, st, m, (int) n, alpha, val,
-                         col, ptr, b, ldb, beta, c, ldc);
+                         col, ptr, b, ldb, beta, c, ldc, seen);
     else
       hipLaunchKernelGGL((csrmm_rowmajor_kernel<1, 8>), grid, block, 0, st, m, (int) n, alpha, val,
-                         col, ptr, b, ldb, beta, c, ldc);
+                         col, ptr, b, ldb, beta, c, ldc, seen);
   } else {
     dim3 grid((unsigned) ((m + 255) / 256), (unsigned) n), block(256);
     hipLaunchKernelGGL(csrmm_strided_kernel, grid, block, 0, st, m, (int) n, alpha, val, col, ptr,

@@ -1001,6 +1001,36 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   KernelTimer ktimer;
   ktimer.on = R.o.kernel_timing > 0;
   int fail = 0;
+  // bof_options.verify / $BOF_VERIFY: a LAUNCH RECEIPT per csrmm launch (round 6, profiles/r6/incident_csrmm: in one
+  // launch in ~10^7, with several processes on the GPU, the workgroups of one XCD ran under their predecessors' IDs --
+  // one set of rows updated twice, another not at all).  Every workgroup counts itself in seen[blockIdx.x], a checker
+  // behind the launch on the same stream compares every entry with 1 and clears it; one region of `seen` per compute
+  // stream.  A miss fails the call with BOF_EVERIFY when it has drained.
+  unsigned *d_seen = nullptr, *d_flag = nullptr;
+  int64_t seen_stride = 0;
+  uint64_t receipts = 0;
+  if (is_mm && verify_wanted(R.o)) {
+    int64_t rmax = 0;
+    for (int64_t b = 0; b < nb; b++) rmax = std::max(rmax, R.sz[b]);
+    seen_stride = scsrmm_receipt_entries('R', rmax);
+    const size_t words = (size_t) seen_stride * (size_t) ss->n + 1;
+    herr = hipMalloc((void **) &d_seen, words * sizeof(unsigned));
+    if (herr == hipSuccess) herr = hipMemset(d_seen, 0, words * sizeof(unsigned));
+    if (herr == hipSuccess) d_flag = d_seen + words - 1;
+  }
+  // one csrmm launch + its receipt check ($BOF_VERIFY_INJECT=4, self-test: the first launch of the call runs twice)
+  auto csrmm_launch = [&](int64_t b, int64_t r, int64_t w, const float *val, const int64_t *col, const int64_t *bia,
+                          const float *bp, float *cp, hipStream_t st) -> hipError_t {
+    unsigned *seen = d_flag ? d_seen + (size_t) seen_stride * (size_t) (b % ss->n) : nullptr;
+    hipError_t e = scsrmm('R', r, w, n, alpha, val, col, bia, bp, k, beta, cp, k, st, seen);
+    if (e == hipSuccess && seen && receipts == 0 && env_long("BOF_VERIFY_INJECT", 0) == 4)
+      e = scsrmm('R', r, w, n, alpha, val, col, bia, bp, k, beta, cp, k, st, seen);
+    if (e == hipSuccess && seen) {
+      e = csr_receipt_check(seen, scsrmm_receipt_entries('R', r), d_flag, st);
+      receipts++;
+    }
+    return e;
+  };
   resident_thread.join();
   if (resident_rc) {
     set_error("flash csr: bringing the resident operand (B / x) into HBM failed");
@@ -1039,12 +1069,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
         herr = transpose_f32((const float *) c.d_c, r, k, r, (float *) c.d_c_rm, k, st);
       for (int64_t j0 = 0; j0 < k && herr == hipSuccess; j0 += R.o.csrmm_cblk) {
         const int64_t w = std::min(k - j0, R.o.csrmm_cblk);
-        if (ord_b == 'R')
-          herr = scsrmm('R', r, w, n, alpha, val, col, bia, (const float *) d_b + j0, k, beta,
-                        (float *) c.d_c + j0, k, st);
-        else  // 'C': same row-major kernel on the transposed block (d_b is row-major here)
-          herr = scsrmm('R', r, w, n, alpha, val, col, bia, (const float *) d_b + j0, k, beta,
-                        (float *) c.d_c_rm + j0, k, st);
+        // ('C': same row-major kernel on the transposed block; d_b is row-major here)
+        herr = csrmm_launch(b, r, w, val, col, bia, (const float *) d_b + j0, (float *) (ord_b == 'R' ? c.d_c : c.d_c_rm) + j0, st);
       }
       if (ord_b == 'C' && herr == hipSuccess)  // [r][k] -> packed column-major block [k][r]
         herr = transpose_f32((const float *) c.d_c_rm, k, r, k, (float *) c.d_c, r, st);
@@ -1083,6 +1109,18 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   (void) hipDeviceSynchronize();
   ktimer.collect(R.cnt);
   BOF_TRACE_T("csr: drained (C written)");
+  if (d_seen) {
+    unsigned missed = 0;
+    if (herr == hipSuccess && !fail) herr = hipMemcpy(&missed, d_flag, sizeof(missed), hipMemcpyDeviceToHost);
+    (void) hipFree(d_seen);
+    R.cnt.vchecks += receipts;
+    if (herr == hipSuccess && !fail && missed) {
+      evt("verify mismatch", (int) missed, 0, receipts);
+      set_error("flash csrmm: BOF_VERIFY: " + std::to_string(missed) + " workgroup receipts of the call's " + std::to_string(receipts) +
+                " csrmm launches are not 1 (a workgroup ran twice or not at all: profiles/r6/incident_csrmm) -- the C file is not to be trusted");
+      fail = BOF_EVERIFY;
+    }
+  }
   if (!is_mm && !ext_y && !fail && herr == hipSuccess && !R.host_y) {
     if (device_to_pageable(hc, d_y, (uint64_t) ylen * 4, R.o.n_io_threads)) herr = hipErrorUnknown;
     R.cnt.d2h += (uint64_t) ylen * 4;
@@ -1100,6 +1138,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     o.rd += R.cnt.rd.load(); o.wr += R.cnt.wr.load(); o.h2d += R.cnt.h2d.load(); o.d2h += R.cnt.d2h.load();
     o.tasks += R.cnt.tasks.load();
     o.klaunch += R.cnt.klaunch.load(); o.kns += R.cnt.kns.load();
+    o.vchecks += R.cnt.vchecks.load();
   } else {
     publish_stats(R.cnt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   }
@@ -1411,10 +1450,12 @@ static int flash_csr_impl(bool is_mm, char trans, int64_t m, int64_t n, int64_t 
     total.rd += S.cnt.rd.load(); total.wr += S.cnt.wr.load(); total.h2d += S.cnt.h2d.load(); total.d2h += S.cnt.d2h.load();
     total.tasks += S.cnt.tasks.load();
     total.klaunch += S.cnt.klaunch.load(); total.kns += S.cnt.kns.load();
+    total.vchecks += S.cnt.vchecks.load();
     bof_flash_stats ps{};
     ps.bytes_read = S.cnt.rd; ps.bytes_written = S.cnt.wr; ps.bytes_h2d = S.cnt.h2d; ps.bytes_d2h = S.cnt.d2h;
     ps.tasks = S.cnt.tasks; ps.seconds = S.seconds;
     ps.kernel_launches = S.cnt.klaunch; ps.kernel_seconds = (double) S.cnt.kns.load() * 1e-9;
+    ps.verify_checks = S.cnt.vchecks;
     per.push_back(ps);
   }
   publish_stats(total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());

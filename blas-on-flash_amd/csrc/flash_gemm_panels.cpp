@@ -194,7 +194,7 @@ struct ChunkReq { int di, mat, panel, c; uint64_t off, bytes; };   // di < 0: a 
 // A C panel that runs as ONE launch over the whole K is cut into row slices (PanelRun::slices): slice s is copied out
 // and written while slice s + 1 is still being multiplied, so what follows the last kernel of a call is the write-back
 // of a quarter panel instead of a whole one -- the tail that a fast disk or the page cache exposes.
-struct Launch { int pc; int64_t q0, q1, l0, l1; int64_t d0 = 0, d1 = 0; };
+struct Launch { int pc; int64_t q0, q1, l0, l1; int64_t d0 = 0, d1 = 0; bool fin = false; };      // fin: PanelRun::slice_end
 struct WriteReq { int di, wslot; uint64_t file_off, bytes, delta; int panel; bool last; };
 
 // Per device (and per repetition of one ordinal in the device list): the HBM panel slots and the
@@ -337,7 +337,9 @@ struct PanelRun {
   int n_groups = 0;
   std::vector<std::vector<hipEvent_t>> group_ev;  // per group: one event per compute stream
   // row slices of the C panels that run as one launch over the whole K: per C panel the slices' last rows and the
-  // events recorded behind their launches (empty: the panel is not sliced, the flusher waits for group_ev)
+  // events recorded behind their launches (empty: the panel is not sliced, the flusher waits for group_ev).  A panel
+  // of the ramp group is entered as ONE "slice" of all its rows whose event stands behind the last launch of its chain
+  // (Launch::fin), so that it leaves when IT is complete and not when the whole group is ($BOF_PANEL_RAMP_FLUSH).
   std::vector<std::vector<int64_t>> slice_end;
   std::vector<std::vector<hipEvent_t>> slice_ev;
   std::vector<int> group_of;                      // C panel -> group
@@ -920,6 +922,18 @@ int PanelRun::plan(const std::vector<int> &all_devs, int reps_of_dev, int64_t fu
         for (int64_t l = 0; l < Nk; l += R)
           for (int64_t pc = G0; pc < G1; pc++) add_launch(pc, 0, Nq, l, std::min(Nk, l + R));
       }
+      // The group's C panels complete one after the other in its last k-range (l-major: panel G0 first, a launch
+      // apart each): every panel's last launch carries an event of its own and the flusher takes the panel when THAT
+      // has run, instead of waiting for the group's last kernel -- cfg2 from O_DIRECT files: the first C panel starts
+      // its write-back three launches (44 ms) earlier, while A's later panels are still being read
+      // ($BOF_PANEL_RAMP_FLUSH=0: the round-5 behaviour, every panel of the group waits for group_ev).
+      if (G1 - G0 > 1 && env_long("BOF_PANEL_RAMP_FLUSH", 1) != 0)
+        for (size_t t2 = group_end.empty() ? 0 : group_end.back(); t2 < launches.size(); t2++) {
+          Launch &L2 = launches[t2];
+          if (L2.l1 != Nk || L2.q0 != 0 || L2.q1 != Nq) continue;
+          L2.fin = true;
+          slice_end[(size_t) L2.pc].assign(1, mat[2].panels[(size_t) L2.pc].nr);
+        }
     } else {
       // behind the ramp everything a C panel needs but its own streamed panel is resident: ONE launch over the
       // whole K -- no C round trip between the k-blocks, an eighth of the launch boundaries
@@ -1412,6 +1426,8 @@ void PanelRun::dispatch() {
         size_t si = 0;
         while (slice_end[(size_t) L.pc][si] != L.d1) si++;
         herr = hipEventRecord(slice_ev[(size_t) L.pc][si], st);
+      } else if (herr == hipSuccess && L.fin) {   // the last launch of a ramp panel's chain: the panel may leave
+        herr = hipEventRecord(slice_ev[(size_t) L.pc][0], st);
       }
       if (herr != hipSuccess) break;
       const uint64_t n_tasks = L.d0 > 0 ? 0 : (uint64_t) ((L.q1 - L.q0) * (L.l1 - L.l0));     // in the reference's tile tasks

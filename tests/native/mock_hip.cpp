@@ -709,12 +709,33 @@ hipError_t transpose_f32(const float *in, int64_t ld_in, int64_t rows, int64_t c
   return hipSuccess;
 }
 // mkl_scsrmm's naming: A is m x k, B k x n, C m x n
+// launch receipts (bof_internal.h): the mock "workgroup" is 4 rows, as in the product's row-major kernels
+int64_t scsrmm_receipt_entries(char ord_b, int64_t m) { return ord_b == 'R' ? (m + 3) / 4 : 0; }
+hipError_t csr_receipt_check(unsigned *seen, int64_t n, unsigned *flag, hipStream_t st) {
+  MockStream *ms = kernel_stream(st, "csr_receipt_check");
+  if (!seen || n <= 0) return hipSuccess;
+  const int dev = ms->dev;
+  ms->enqueue([=] {
+    need_device_mem(seen, (size_t) n * 4, dev, "csr_receipt_check");
+    need_device_mem(flag, 4, dev, "csr_receipt_check");
+    for (int64_t i = 0; i < n; i++) {
+      if (seen[i] != 1u) __atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED);
+      seen[i] = 0u;
+    }
+  });
+  return hipSuccess;
+}
 hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, const float *val, const int64_t *col,
-                  const int64_t *ptr, const float *b, int64_t ldb, float beta, float *c, int64_t ldc, hipStream_t st) {
+                  const int64_t *ptr, const float *b, int64_t ldb, float beta, float *c, int64_t ldc, hipStream_t st,
+                  unsigned *seen) {
   MockStream *ms = kernel_stream(st, "scsrmm");
   if (m <= 0 || n <= 0) return hipSuccess;
   const int dev = ms->dev;
   ms->enqueue([=] {
+    if (seen && ord_b == 'R') {
+      need_device_mem(seen, (size_t) ((m + 3) / 4) * 4, dev, "scsrmm receipts");
+      for (int64_t i = 0; i < (m + 3) / 4; i++) seen[i]++;
+    }
     need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrmm");
     const int64_t base = ptr[0], nnz = ptr[m] - base;
     need_device_mem(val, (size_t) nnz * 4, dev, "scsrmm");

@@ -67,3 +67,57 @@ def test_verify_names_a_damaged_word(dev, tmp_path, path, inject, needle, capfd)
     assert "rc=-6" in err or "-6" in err          # BOF_EVERIFY
     assert not exact                              # the damage was real: C differs from the oracle's
     assert "[bof events]" in capfd.readouterr().err
+
+
+def run_csrmm(tmp_path, ord_b, k, beta, inject=0, devices=None, n_streams=0):
+    """flash::csrmm on files with the launch receipts of round 6 on (bof_options.verify): every workgroup of every
+    csrmm launch must have run exactly once (profiles/r6/incident_csrmm)."""
+    m, n = 2500, 1500
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    b = orc.dense_fill(n, k, "s")
+    c0 = np.random.default_rng(k).integers(0, 5, (m, k)).astype(np.float32)
+    if ord_b == "C":
+        b, c0 = np.ascontiguousarray(b.T), np.ascontiguousarray(c0.T)
+    want = orc.flash_csrmm(ord_b, m, n, k, 0.5, beta, val, ia, ja, b, c0.copy(), 300, 5000, 1024)
+    arrs = dict(val=val, ia=ia, ja=ja, b=b, c=c0)
+    paths = {nm: str(tmp_path / nm) for nm in arrs}
+    for nm, x in arrs.items():
+        x.tofile(paths[nm])
+    fds = {nm: os.open(p, os.O_RDWR) for nm, p in paths.items()}
+    os.environ["BOF_VERIFY_INJECT"] = str(inject)
+    err = None
+    try:
+        kw = dict(max_nnzs=5000, csrmm_rblk=300, n_io_threads=2, use_odirect=0, verify=1)
+        if devices:
+            kw["devices"] = devices
+        if n_streams:
+            kw["n_streams"] = n_streams
+        bofhip.flash_csrmm("N", m, n, k, 0.5, beta, *(bofhip.FPtr(fds[x], 0) for x in ("val", "ia", "ja")), ord_b,
+                           bofhip.FPtr(fds["b"], 0), bofhip.FPtr(fds["c"], 0), bofhip.default_options(**kw))
+    except bofhip.BofError as e:
+        err = str(e)
+    finally:
+        os.environ.pop("BOF_VERIFY_INJECT", None)
+        for fd in fds.values():
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+    got = np.fromfile(paths["c"], np.float32).reshape(c0.shape)
+    return err, bofhip.flash_last_stats(), bool(np.array_equal(got, want))
+
+
+@pytest.mark.parametrize("ord_b,k,devices,n_streams", [("R", 128, None, 0), ("R", 200, [0, 0], 3), ("R", 37, None, 1),
+                                                       ("C", 72, None, 0)])
+@pytest.mark.parametrize("beta", [0.0, 2.0])
+def test_csrmm_launch_receipts_clean(dev, tmp_path, ord_b, k, devices, n_streams, beta):
+    err, st, exact = run_csrmm(tmp_path, ord_b, k, beta, devices=devices, n_streams=n_streams)
+    assert err is None, err
+    assert exact
+    assert st["verify_checks"] >= 9, st              # one receipt per csrmm launch: >= one per row block
+
+
+def test_csrmm_launch_receipts_catch_a_launch_that_ran_twice(dev, tmp_path):
+    """$BOF_VERIFY_INJECT=4: the call's first csrmm launch is submitted twice -- what the workgroups of one XCD did in
+    the incident's dumps, for a whole launch; beta != 0, so the second pass also damages C."""
+    err, st, exact = run_csrmm(tmp_path, "R", 128, 2.0, inject=4)
+    assert err is not None and "workgroup receipts" in err and ("-6" in err), err
+    assert not exact

@@ -139,3 +139,55 @@ def test_whole_k_panels_in_row_slices(tmp_path, mock_lib, devs, beta, verify, ev
     assert out["rc"] == 0, out.get("err", "") + err[-2000:]
     assert out["exact"]
     assert out["stats"]["tasks"] == 5 * 4 * 3          # 640 x 600 x 500 in 128-tiles (merged tails): a slice is not a task
+
+
+CSRMM_CHILD = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "blas-on-flash_amd"))
+from test_dist_gloo import _use_mock_library
+_use_mock_library(SO)
+import bofhip
+m, n, k = 700, 400, 24
+rng = np.random.default_rng(5)
+dense = (rng.random((m, n)) < 0.02) * rng.integers(1, 4, (m, n))
+ia = np.concatenate([[0], np.cumsum((dense != 0).sum(1))]).astype(np.int64)
+ja = np.nonzero(dense)[1].astype(np.int64); val = dense[dense != 0].astype(np.float32)
+b = rng.integers(-3, 4, (n, k)).astype(np.float32); c0 = rng.integers(-3, 4, (m, k)).astype(np.float32)
+arrs = dict(val=val, ia=ia, ja=ja, b=b, c=c0)
+for nm, x in arrs.items(): x.tofile(os.path.join(DIR, nm))
+fds = {nm: os.open(os.path.join(DIR, nm), os.O_RDWR) for nm in arrs}
+out = {}
+try:
+    bofhip.flash_csrmm("N", m, n, k, 1.0, 2.0, *(bofhip.FPtr(fds[x], 0) for x in ("val", "ia", "ja")), "R",
+                       bofhip.FPtr(fds["b"], 0), bofhip.FPtr(fds["c"], 0),
+                       bofhip.default_options(max_nnzs=600, csrmm_rblk=90, n_io_threads=2, use_odirect=0, verify=1, devices=DEVS))
+    out["rc"] = 0
+except bofhip.BofError as e:
+    out["rc"] = 1; out["err"] = str(e)
+out["stats"] = bofhip.flash_last_stats()
+got = np.fromfile(os.path.join(DIR, "c"), np.float32).reshape(m, k)
+out["exact"] = bool(np.array_equal(got, (dense.astype(np.float64) @ b + 2.0 * c0).astype(np.float32)))
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("devs,inject", [([0], 0), ([0, 1, 2], 0), ([0], 4)])
+def test_csrmm_launch_receipts(tmp_path, mock_lib, devs, inject):
+    """Round 6 (profiles/r6/incident_csrmm): under bof_options.verify every csrmm launch carries a receipt -- each
+    workgroup counts itself, a checker behind the launch compares with 1.  $BOF_VERIFY_INJECT=4 submits the call's first
+    launch twice (what the workgroups of one XCD did in the incident): BOF_EVERIFY, and with beta != 0 a wrong C."""
+    import json
+    code = f"ROOT={ROOT!r}\nSO={mock_lib!r}\nDIR={str(tmp_path)!r}\nDEVS={devs!r}\n" + CSRMM_CHILD
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MOCK_HIP_DEVICES="4", MOCK_HIP_ASYNC="1", MOCK_HIP_JITTER_US="100",
+                                BOF_VERIFY_INJECT=str(inject)))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(line[-1][7:])
+    if inject == 0:
+        assert out["rc"] == 0 and out["exact"], out
+        assert out["stats"]["verify_checks"] >= 8, out["stats"]
+    else:
+        assert out["rc"] == 1 and "workgroup receipts" in out["err"], out
+        assert not out["exact"]
