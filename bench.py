@@ -450,6 +450,41 @@ def _drop_cache(paths):
             os.close(fd)
 
 
+def mixed_window_rates(read_stamps, write_stamps, chunk_bytes, own):
+    """Rates of the two directions of a mixed pass OVER THE WINDOW IN WHICH BOTH WERE ACTIVE: `*_stamps` = the pass's
+    start time followed by the completion time of every chunk.  Until the second session of round 6 each direction's
+    bytes were divided by its OWN duration -- the reads (8 GiB) end long before the writes (8 GiB), so the writes'
+    figure averaged over a stretch in which they had the disk to themselves (a lease of read 21 / write 16.5 GB/s
+    reported 15.4 + 9.0 "mixed" where the window holds 15.4 + 3.7: this disk moves no more when the directions mix
+    than when it only reads).  The old figures stay in the probe as `mixed_pass_own_duration_GBps`."""
+    t0 = max(read_stamps[0], write_stamps[0])
+    t1 = min(max(read_stamps), max(write_stamps))
+    out = {"mixed_pass_own_duration_GBps": [round(own["r"], 2), round(own["w"], 2)]}
+    if t1 - t0 < 0.05:                     # the passes did not overlap long enough to say anything
+        return out
+    nr = sum(1 for t in read_stamps[1:] if t0 < t <= t1)
+    nw = sum(1 for t in write_stamps[1:] if t0 < t <= t1)
+    out.update({"disk_read_GBps_while_writing": round(nr * chunk_bytes / (t1 - t0) / 1e9, 2),
+                "disk_write_GBps_while_reading": round(nw * chunk_bytes / (t1 - t0) / 1e9, 2),
+                "mixed_window_s": round(t1 - t0, 3)})
+    return out
+
+
+def disk_time_bound(rd_bytes, wr_bytes, ceil):
+    """Lower bound on the time the scratch disk needs for rd_bytes of reads and wr_bytes of writes, from its three
+    probed operating points: reads alone (r), writes alone (w), both directions at once (rm + wm, over the window in
+    which both were active).  The disk is time-shared between them; mixing pays only if rm / r + wm / w > 1 -- then the
+    bound mixes for as long as both directions have bytes and finishes the rest alone; otherwise (the disks of this
+    pool: 0.91-0.96) reads and writes simply add up.  Returns (seconds, "reads + writes" | "mixed, then the rest")."""
+    r, w = ceil["disk_read_GBps"] * 1e9, ceil["disk_write_GBps"] * 1e9
+    rm, wm = ceil.get("disk_read_GBps_while_writing", 0) * 1e9, ceil.get("disk_write_GBps_while_reading", 0) * 1e9
+    serial = rd_bytes / r + wr_bytes / w
+    if rm <= 0 or wm <= 0 or rm / r + wm / w <= 1.0:
+        return serial, "reads + writes"
+    tau = min(rd_bytes / rm, wr_bytes / wm)
+    return tau + (rd_bytes - rm * tau) / r + (wr_bytes - wm * tau) / w, "mixed, then the rest"
+
+
 def disk_probe(bofhip, read_paths, write_path, io_threads=8, passes=3, label=""):
     """The scratch disk's O_DIRECT rates measured ON THE WORKLOAD'S OWN FILES with the pipeline's own request
     shape -- bof_file_sread / bof_file_swrite, 32 MiB per call cut into the library's 4 MiB requests, kernel AIO,
@@ -480,12 +515,16 @@ def disk_probe(bofhip, read_paths, write_path, io_threads=8, passes=3, label="")
     rchunks = [(fd, off) for fd, sz in zip(rfds, sizes) for off in range(0, sz, slot)]
     wchunks = [(wfd, off) for _ in range(2) for off in range(0, sizes[-1], slot)]
 
-    def run(chunks, nthr, fn, base=0):
+    def run(chunks, nthr, fn, base=0, stamps=None):
         def work(i):
             for fd, off in chunks[i::nthr]:
                 fn(fd, off, hbuf[base + i])
+                if stamps is not None:
+                    stamps.append(time.perf_counter())       # (list.append is atomic under the GIL)
         th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
         t0 = time.perf_counter()
+        if stamps is not None:
+            stamps.append(t0)
         for x in th:
             x.start()
         for x in th:
@@ -507,13 +546,13 @@ def disk_probe(bofhip, read_paths, write_path, io_threads=8, passes=3, label="")
         for _ in range(passes):
             writes.append(run(wchunks, io_threads, wr))
         _drop_cache(read_paths)
-        both = {}
-        ta = threading.Thread(target=lambda: both.__setitem__("r", run(rchunks, io_threads, rd)))
-        tb = threading.Thread(target=lambda: both.__setitem__("w", run(wchunks, io_threads, wr, io_threads)))
+        both, rs, ws = {}, [], []
+        ta = threading.Thread(target=lambda: both.__setitem__("r", run(rchunks, io_threads, rd, 0, rs)))
+        tb = threading.Thread(target=lambda: both.__setitem__("w", run(wchunks, io_threads, wr, io_threads, ws)))
         ta.start(); tb.start(); ta.join(); tb.join()
         out.update({"disk_read_GBps": round(max(reads), 2), "disk_write_GBps": round(max(writes), 2),
-                    "read_passes_GBps": [round(x, 2) for x in reads], "write_passes_GBps": [round(x, 2) for x in writes],
-                    "disk_read_GBps_while_writing": round(both["r"], 2), "disk_write_GBps_while_reading": round(both["w"], 2)})
+                    "read_passes_GBps": [round(x, 2) for x in reads], "write_passes_GBps": [round(x, 2) for x in writes]})
+        out.update(mixed_window_rates(rs, ws, slot, both))
     finally:
         for h in hbuf:
             L.bof_host_free(h)
@@ -534,8 +573,9 @@ def merge_ceilings(ceil, *probes):
         mixed_new = pr.get("disk_read_GBps_while_writing", 0) + pr.get("disk_write_GBps_while_reading", 0)
         mixed_old = out.get("disk_read_GBps_while_writing", 0) + out.get("disk_write_GBps_while_reading", 0)
         if mixed_new > mixed_old:
-            out["disk_read_GBps_while_writing"] = pr["disk_read_GBps_while_writing"]
-            out["disk_write_GBps_while_reading"] = pr["disk_write_GBps_while_reading"]
+            for q in ("disk_read_GBps_while_writing", "disk_write_GBps_while_reading", "mixed_window_s", "mixed_pass_own_duration_GBps"):
+                if q in pr:
+                    out[q] = pr[q]
     return out
 
 
@@ -560,9 +600,11 @@ def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
         hbuf.append(p.value)
     nchunks = size // slot
 
-    def run(nthr, fn):
+    def run(nthr, fn, stamps=None):
         th = [threading.Thread(target=fn, args=(i, nthr)) for i in range(nthr)]
         t0 = time.perf_counter()
+        if stamps is not None:
+            stamps.append(t0)
         for x in th:
             x.start()
         for x in th:
@@ -571,13 +613,17 @@ def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
     try:
         fd, direct = _open(path, True)
         if direct:
-            def rd(i, nthr, fd_=fd, base=0):
+            def rd(i, nthr, fd_=fd, base=0, stamps=None):
                 for cidx in range(i, nchunks, nthr):
                     L.bof_file_sread(fd_, cidx * slot, 0, 1, slot, hbuf[base + i], 1)
+                    if stamps is not None:
+                        stamps.append(time.perf_counter())
 
-            def wr(i, nthr, fd_=fd, base=0):
+            def wr(i, nthr, fd_=fd, base=0, stamps=None):
                 for cidx in range(i, nchunks, nthr):
                     L.bof_file_swrite(fd_, cidx * slot, 0, 1, slot, hbuf[base + i], 1)
+                    if stamps is not None:
+                        stamps.append(time.perf_counter())
             # a ceiling must not be lower than what a pipeline can get: best over two queue depths
             # (all read passes before the first write pass: right behind 4 GiB of writes the device reads slower than
             # the pipelines, whose inputs were written long before, ever see -- round 4's probes read 14 GB/s where
@@ -596,13 +642,12 @@ def io_ceilings(bofhip, torch, dev, st, workdir, io_threads=8, gib=4.0):
             _write_device_tensor(bofhip, t, path2, True, bofhip.default_options(n_io_threads=io_threads), st)
             fd2, _ = _open(path2, True)
             os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
-            both = {}
-            ta = threading.Thread(target=lambda: both.__setitem__("r", run(io_threads, rd)))
+            both, rs, ws = {}, [], []
+            ta = threading.Thread(target=lambda: both.__setitem__("r", run(io_threads, lambda i, n: rd(i, n, fd, 0, rs), rs)))
             tb = threading.Thread(target=lambda: both.__setitem__(
-                "w", run(io_threads, lambda i, n: wr(i, n, fd2, io_threads))))
+                "w", run(io_threads, lambda i, n: wr(i, n, fd2, io_threads, ws), ws)))
             ta.start(); tb.start(); ta.join(); tb.join()
-            out["disk_read_GBps_while_writing"] = round(both["r"], 2)
-            out["disk_write_GBps_while_reading"] = round(both["w"], 2)
+            out.update(mixed_window_rates(rs, ws, slot, both))      # (over the window in which both directions ran)
             L.bof_file_forget(fd2)
             os.close(fd2)
             os.remove(path2)
@@ -669,9 +714,7 @@ def roofline_e2e(leg, ceil, flops, kernel_s, mode):
     if mode == "odirect" and ceil.get("disk_read_GBps"):
         terms["disk_read"] = st["bytes_read"] / (ceil["disk_read_GBps"] * 1e9)
         terms["disk_write"] = st["bytes_written"] / (ceil["disk_write_GBps"] * 1e9)
-        total = max(ceil["disk_read_GBps"], ceil["disk_write_GBps"],
-                    ceil.get("disk_read_GBps_while_writing", 0) + ceil.get("disk_write_GBps_while_reading", 0))
-        terms["disk_total"] = (st["bytes_read"] + st["bytes_written"]) / (total * 1e9)
+        terms["disk_total"] = disk_time_bound(st["bytes_read"], st["bytes_written"], ceil)[0]
     elif mode == "buffered" and ceil.get("page_cache_read_GBps"):
         terms["page_cache_read"] = st["bytes_read"] / (ceil["page_cache_read_GBps"] * 1e9)
     bound = max(terms, key=terms.get)
@@ -1249,9 +1292,7 @@ def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
     if ceil.get("disk_read_GBps"):
         terms["disk_read"] = st["bytes_read"] / (ceil["disk_read_GBps"] * 1e9)
         terms["disk_write"] = st["bytes_written"] / (ceil["disk_write_GBps"] * 1e9)
-        total = max(ceil["disk_read_GBps"], ceil["disk_write_GBps"],
-                    ceil.get("disk_read_GBps_while_writing", 0) + ceil.get("disk_write_GBps_while_reading", 0))
-        terms["disk_total"] = (st["bytes_read"] + st["bytes_written"]) / (total * 1e9)
+        terms["disk_total"] = disk_time_bound(st["bytes_read"], st["bytes_written"], ceil)[0]
     bound = max(terms, key=terms.get)
     return bound, terms[bound], {k: round(v, 4) for k, v in terms.items()}
 
@@ -1259,15 +1300,13 @@ def e2e_bound(per_step, ceil, n_steps, kernel_s_per_step):
 def row_panel_disk_bound(n, blk, ceil):
     """A tighter lower bound for any schedule that emits C by row panels (contiguous file extents, what the row-panel
     pipeline writes): no byte of C exists before ALL of B and one A panel have been read -- that much at the read-alone
-    rate -- and only the rest (the other A panels, all of C) can move at the disk's best rate, reads and writes mixed.
-    Returned beside the schedule-agnostic `disk_total` bound, never instead of it."""
+    rate -- and only the rest (the other A panels, all of C) can mix reads and writes (disk_time_bound: which pays only
+    where the disk moves more in total when the directions mix).  Returned beside the schedule-agnostic `disk_total`
+    bound, never instead of it; equal to it on a disk that gains nothing from mixing."""
     if not ceil.get("disk_read_GBps"):
         return None
     first = 4.0 * (n * n + blk * n)
-    rest = 4.0 * (n * n - blk * n) + 4.0 * n * n
-    best = max(ceil["disk_read_GBps"], ceil["disk_write_GBps"],
-               ceil.get("disk_read_GBps_while_writing", 0) + ceil.get("disk_write_GBps_while_reading", 0))
-    return first / (ceil["disk_read_GBps"] * 1e9) + rest / (best * 1e9)
+    return first / (ceil["disk_read_GBps"] * 1e9) + disk_time_bound(4.0 * (n * n - blk * n), 4.0 * n * n, ceil)[0]
 
 
 def _alg_bytes_per_launch(n, blk, mix, launches_per_step):
@@ -1349,6 +1388,12 @@ def run_single(args, bofhip, torch, dev, st):
     secs = sorted(p["seconds"] for p in per)
     med_step = secs[len(secs) // 2] if len(secs) % 2 else 0.5 * (secs[len(secs) // 2 - 1] + secs[len(secs) // 2])
     rp_bound = row_panel_disk_bound(n, blk, ceil) if "error" not in ceil else None
+    disk_model = disk_time_bound(mean_step["bytes_read"], mean_step["bytes_written"], ceil)[1] if ceil.get("disk_read_GBps") else None
+    # the fraction as rounds 4-6 defined it until the probe was corrected (mixed_window_rates): every byte at the sum of
+    # the mixed pass's own-duration rates -- kept so that the rounds stay comparable, not a bound the disk can reach
+    own = ceil.get("mixed_pass_own_duration_GBps")
+    legacy_frac = (round((mean_step["bytes_read"] + mean_step["bytes_written"]) / (max(sum(own), ceil.get("disk_read_GBps", 0)) * 1e9)
+                         / (dt / args.steps), 3) if own else None)
     probe_note = None
     e2e_frac_raw = round(t_bound / (dt / args.steps), 3)          # against the probes as they are (may exceed 1: a bad probe)
     if t_bound > dt / args.steps and bound.startswith("disk"):
@@ -1394,9 +1439,13 @@ def run_single(args, bofhip, torch, dev, st):
                          "e2e_frac_of_row_panel_bound": round(min(rp_bound / (dt / args.steps), 1.0), 3),
                          "e2e_frac_median_step_of_row_panel_bound": round(min(rp_bound / med_step, 1.0), 3)} if rp_bound else {}),
                      **({"e2e_probe_note": probe_note} if probe_note else {}),
+                     **({"e2e_disk_model": disk_model} if disk_model else {}),
+                     **({"e2e_frac_r5_definition": legacy_frac} if legacy_frac else {}),
+                     "e2e_frac_median_step": round(min(t_bound / med_step, 1.0), 3),
                      "e2e_probe": {k: ceil.get(k) for k in ("disk_read_GBps", "disk_write_GBps",
                                                             "disk_read_GBps_while_writing",
-                                                            "disk_write_GBps_while_reading", "pcie_h2d_GBps",
+                                                            "disk_write_GBps_while_reading", "mixed_window_s",
+                                                            "mixed_pass_own_duration_GBps", "pcie_h2d_GBps",
                                                             "pcie_d2h_GBps") if k in ceil}},
     }
     if not args.no_cpu:

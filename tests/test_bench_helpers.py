@@ -27,15 +27,49 @@ def test_algorithmic_bytes_per_launch_of_cfg2():
     assert per * 39 > unsliced * 36
 
 
+def test_disk_time_bound_mixes_only_where_mixing_pays():
+    R, W = 8 * 2**30, 4 * 2**30
+    # this pool's disks: 15.4 / 21 + 3.7 / 16.5 = 0.96 <= 1 -> reads and writes add up
+    t, model = bench.disk_time_bound(R, W, {"disk_read_GBps": 21.0, "disk_write_GBps": 16.5,
+                                            "disk_read_GBps_while_writing": 15.4, "disk_write_GBps_while_reading": 3.7})
+    assert model == "reads + writes" and abs(t - (R / 21e9 + W / 16.5e9)) < 1e-12
+    # no mixed probe at all: the same
+    assert bench.disk_time_bound(R, W, {"disk_read_GBps": 21.0, "disk_write_GBps": 16.5})[1] == "reads + writes"
+    # a disk that gains from mixing (12 / 18 + 8 / 14 = 1.24): mixed while both have bytes, the rest alone
+    ceil = {"disk_read_GBps": 18.0, "disk_write_GBps": 14.0, "disk_read_GBps_while_writing": 12.0,
+            "disk_write_GBps_while_reading": 8.0}
+    t, model = bench.disk_time_bound(R, W, ceil)
+    tau = min(R / 12e9, W / 8e9)
+    assert model == "mixed, then the rest"
+    assert abs(t - (tau + (R - 12e9 * tau) / 18e9 + (W - 8e9 * tau) / 14e9)) < 1e-12
+    assert max(R / 18e9, W / 14e9) < t < R / 18e9 + W / 14e9
+
+
+def test_mixed_window_rates_count_only_the_common_window():
+    # reads: 10 chunks, one every 0.1 s from t = 0; writes: 20 chunks, one every 0.2 s: the reads end at 1.0, the writes at
+    # 4.0 -- over their own durations 10 and 5 chunks per second, inside the common window (0 .. 1.0) 10 and 5
+    rs = [0.0] + [0.1 * (i + 1) for i in range(10)]
+    ws = [0.0] + [0.2 * (i + 1) for i in range(5)] + [1.0 + 0.2 * (i + 1) for i in range(15)]      # faster once alone
+    out = bench.mixed_window_rates(rs, ws, 10**9, {"r": 10.0, "w": 20 / 4.0})
+    assert out["mixed_window_s"] == 1.0
+    assert out["disk_read_GBps_while_writing"] == 10.0 and out["disk_write_GBps_while_reading"] == 5.0
+    assert out["mixed_pass_own_duration_GBps"] == [10.0, 5.0]
+    # passes that barely overlap say nothing about mixing
+    assert "disk_read_GBps_while_writing" not in bench.mixed_window_rates([0.0, 0.01], [0.0, 5.0], 10**9, {"r": 1.0, "w": 1.0})
+
+
 def test_row_panel_disk_bound_is_tighter_than_the_agnostic_one():
     n, blk = 32768, 4096
     ceil = {"disk_read_GBps": 18.0, "disk_write_GBps": 14.0, "disk_read_GBps_while_writing": 12.0,
             "disk_write_GBps_while_reading": 8.0}
     rp = bench.row_panel_disk_bound(n, blk, ceil)
-    agnostic = (8 * n * n + 4 * n * n) / (20.0e9)
+    agnostic = bench.disk_time_bound(8.0 * n * n, 4.0 * n * n, ceil)[0]
     first = 4.0 * (n * n + blk * n)
     assert rp > agnostic                                   # B + one A panel cannot overlap with any write
-    assert abs(rp - (first / 18e9 + (12.0 * n * n - first) / 20e9)) < 1e-9
+    assert abs(rp - (first / 18e9 + bench.disk_time_bound(4.0 * (n * n - blk * n), 4.0 * n * n, ceil)[0])) < 1e-9
+    # a disk that gains nothing from mixing: both bounds are reads + writes
+    flat = {"disk_read_GBps": 21.0, "disk_write_GBps": 16.5, "disk_read_GBps_while_writing": 15.4, "disk_write_GBps_while_reading": 3.7}
+    assert abs(bench.row_panel_disk_bound(n, blk, flat) - bench.disk_time_bound(8.0 * n * n, 4.0 * n * n, flat)[0]) < 1e-9
     assert bench.row_panel_disk_bound(n, blk, {}) is None
 
 
