@@ -1015,7 +1015,11 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     seen_stride = scsrmm_receipt_entries('R', rmax);
     const size_t words = (size_t) seen_stride * (size_t) ss->n + 1;
     herr = hipMalloc((void **) &d_seen, words * sizeof(unsigned));
-    if (herr == hipSuccess) herr = hipMemset(d_seen, 0, words * sizeof(unsigned));
+    // (cleared ON A COMPUTE STREAM and waited for: hipMemset of device memory returns before the fill has run and the
+    //  null stream does not order the non-blocking compute streams behind it -- under load the first launches counted
+    //  into words the fill then cleared: 8-process fuzz of the second session, profiles/r6/session2/fuzz_csr_receipts)
+    if (herr == hipSuccess) herr = hipMemsetAsync(d_seen, 0, words * sizeof(unsigned), ss->s[0]);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ss->s[0]);
     if (herr == hipSuccess) d_flag = d_seen + words - 1;
   }
   // one csrmm launch + its receipt check ($BOF_VERIFY_INJECT=4, self-test: the first launch of the call runs twice)
