@@ -113,8 +113,10 @@ enum { SCR_B_RM = 0, SCR_C_RM0 = 1, SCR_CSRCSC = 17, SCR_TR_VAL = 18, SCR_TR_COL
        SCR_GEMM_A = 21, SCR_GEMM_B = 22, SCR_KM_ONES = 23, SCR_COUNT = 24 };
 int scratch_get(int which, size_t bytes, void **ptr);
 void scratch_release_all();
+// (`seen`: a launch receipt as for scsrmm -- one entry per workgroup of 256 rows, both kernels)
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
-                    const int64_t *col, const float *x, float *y, hipStream_t st);
+                    const int64_t *col, const float *x, float *y, hipStream_t st, unsigned *seen = nullptr);
+int64_t scsrgemv_receipt_entries(int64_t m);
 // dst = sum of n_src vectors (fixed order; sources may be peer-device memory, dst may alias one of them)
 hipError_t sum_partials(float *dst, const float *const *srcs, int n_src, int64_t len, hipStream_t st);
 hipError_t gen_dense(float *d, int64_t first, int64_t count, char mode, uint64_t seed,

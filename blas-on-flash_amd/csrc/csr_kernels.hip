@@ -241,8 +241,9 @@ constexpr int GEMV_CAP = 1024;  // LDS entries per wave (8 KB): 64 rows x 16 nnz
 __global__ void __launch_bounds__(256)
 csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__restrict__ ptr,
                  const int64_t *__restrict__ col, const float *__restrict__ x,
-                 float *__restrict__ y) {
+                 float *__restrict__ y, unsigned *__restrict__ seen) {
   __shared__ float2 sh[4][GEMV_CAP];
+  if (seen && threadIdx.x == 0) atomicAdd(&seen[blockIdx.x], 1u);      // launch receipt (BOF_VERIFY)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t r0 = ((int64_t) blockIdx.x * 4 + w) * 64;
   const int nrows = (int) max((int64_t) 0, min((int64_t) 64, m - r0));
@@ -299,7 +300,8 @@ csrgemv_n_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
 __global__ void __launch_bounds__(256)
 csrgemv_t_kernel(int64_t m, const float *__restrict__ val, const int64_t *__restrict__ ptr,
                  const int64_t *__restrict__ col, const float *__restrict__ x,
-                 float *__restrict__ y) {
+                 float *__restrict__ y, unsigned *__restrict__ seen) {
+  if (seen && threadIdx.x == 0) atomicAdd(&seen[blockIdx.x], 1u);      // launch receipt (BOF_VERIFY)
   const int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (row >= m) return;
   const int64_t base = ptr[0];
@@ -308,16 +310,17 @@ csrgemv_t_kernel(int64_t m, const float *__restrict__ val, const int64_t *__rest
     atomicAdd(y + col[p], val[p] * xv);
 }
 
+int64_t scsrgemv_receipt_entries(int64_t m) { return (m + 255) / 256; }       // (both kernels: a workgroup = 256 rows)
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr,
-                    const int64_t *col, const float *x, float *y, hipStream_t st) {
+                    const int64_t *col, const float *x, float *y, hipStream_t st, unsigned *seen) {
   drop_stale_error();
   (void) n;
   if (m == 0) return hipSuccess;
   dim3 grid((unsigned) ((m + 255) / 256)), block(256);
   if (trans == 'N')  // same grid: a block = 4 waves x 64 rows
-    hipLaunchKernelGGL(csrgemv_n_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+    hipLaunchKernelGGL(csrgemv_n_kernel, grid, block, 0, st, m, val, ptr, col, x, y, seen);
   else
-    hipLaunchKernelGGL(csrgemv_t_kernel, grid, block, 0, st, m, val, ptr, col, x, y);
+    hipLaunchKernelGGL(csrgemv_t_kernel, grid, block, 0, st, m, val, ptr, col, x, y, seen);
   return hipGetLastError();
 }
 

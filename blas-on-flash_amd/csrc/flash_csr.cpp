@@ -1001,7 +1001,7 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   KernelTimer ktimer;
   ktimer.on = R.o.kernel_timing > 0;
   int fail = 0;
-  // bof_options.verify / $BOF_VERIFY: a LAUNCH RECEIPT per csrmm launch (round 6, profiles/r6/incident_csrmm: in one
+  // bof_options.verify / $BOF_VERIFY: a LAUNCH RECEIPT per csrmm / csrgemv launch (round 6, profiles/r6/incident_csrmm: in one
   // launch in ~10^7, with several processes on the GPU, the workgroups of one XCD ran under their predecessors' IDs --
   // one set of rows updated twice, another not at all).  Every workgroup counts itself in seen[blockIdx.x], a checker
   // behind the launch on the same stream compares every entry with 1 and clears it; one region of `seen` per compute
@@ -1009,10 +1009,10 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
   unsigned *d_seen = nullptr, *d_flag = nullptr;
   int64_t seen_stride = 0;
   uint64_t receipts = 0;
-  if (is_mm && verify_wanted(R.o)) {
+  if (verify_wanted(R.o)) {
     int64_t rmax = 0;
     for (int64_t b = 0; b < nb; b++) rmax = std::max(rmax, R.sz[b]);
-    seen_stride = scsrmm_receipt_entries('R', rmax);
+    seen_stride = is_mm ? scsrmm_receipt_entries('R', rmax) : scsrgemv_receipt_entries(rmax);
     const size_t words = (size_t) seen_stride * (size_t) ss->n + 1;
     herr = hipMalloc((void **) &d_seen, words * sizeof(unsigned));
     // (cleared ON A COMPUTE STREAM and waited for: hipMemset of device memory returns before the fill has run and the
@@ -1088,10 +1088,20 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
       if (herr == hipSuccess) herr = hipEventRecord(c.done, R.d2h);
       R.cnt.d2h += R.c_bytes(b);
     } else {
+      unsigned *seen = d_flag ? d_seen + (size_t) seen_stride * (size_t) (b % ss->n) : nullptr;
       if (trans == 'N')
-        herr = scsrgemv('N', r, n, val, bia, col, (const float *) d_x, (float *) d_y + s, st);
+        herr = scsrgemv('N', r, n, val, bia, col, (const float *) d_x, (float *) d_y + s, st, seen);
       else
-        herr = scsrgemv('T', r, n, val, bia, col, (const float *) d_x + s, (float *) d_y, st);
+        herr = scsrgemv('T', r, n, val, bia, col, (const float *) d_x + s, (float *) d_y, st, seen);
+      // ($BOF_VERIFY_INJECT=4, self-test: the call's first launch runs twice -- 'T' adds its products twice, 'N' stores
+      //  the same y again: the receipt is what tells)
+      if (herr == hipSuccess && seen && receipts == 0 && env_long("BOF_VERIFY_INJECT", 0) == 4)
+        herr = scsrgemv(trans == 'N' ? 'N' : 'T', r, n, val, bia, col, (const float *) d_x + (trans == 'N' ? 0 : s),
+                        (float *) d_y + (trans == 'N' ? s : 0), st, seen);
+      if (herr == hipSuccess && seen) {
+        herr = csr_receipt_check(seen, scsrgemv_receipt_entries(r), d_flag, st);
+        receipts++;
+      }
       if (herr == hipSuccess) herr = ktimer.end(st);
       if (herr == hipSuccess) herr = hipEventRecord(c.done, st);
       if (herr == hipSuccess && c.h_y) {      // 'N': this block's slice of y leaves now (the retire thread copies it out)
@@ -1120,8 +1130,8 @@ static int flash_csr_device(bool is_mm, char trans, int64_t m, int64_t n, int64_
     R.cnt.vchecks += receipts;
     if (herr == hipSuccess && !fail && missed) {
       evt("verify mismatch", (int) missed, 0, receipts);
-      set_error("flash csrmm: BOF_VERIFY: " + std::to_string(missed) + " workgroup receipts of the call's " + std::to_string(receipts) +
-                " csrmm launches are not 1 (a workgroup ran twice or not at all: profiles/r6/incident_csrmm) -- the C file is not to be trusted");
+      set_error(std::string(is_mm ? "flash csrmm" : "flash csrgemv") + ": BOF_VERIFY: " + std::to_string(missed) + " workgroup receipts of the call's " + std::to_string(receipts) +
+                (is_mm ? " csrmm" : " csrgemv") + " launches are not 1 (a workgroup ran twice or not at all: profiles/r6/incident_csrmm) -- the result is not to be trusted");
       fail = BOF_EVERIFY;
     }
   }

@@ -43,7 +43,8 @@ hipError_t scsrmm(char, int64_t, int64_t, int64_t, float, const float *, const i
 int64_t scsrmm_receipt_entries(char, int64_t) { return 0; }
 hipError_t csr_receipt_check(unsigned *, int64_t, unsigned *, hipStream_t) { return hipErrorUnknown; }
 hipError_t scsrgemv(char, int64_t, int64_t, const float *, const int64_t *, const int64_t *, const float *,
-                    float *, hipStream_t) { return hipErrorUnknown; }
+                    float *, hipStream_t, unsigned *) { return hipErrorUnknown; }
+int64_t scsrgemv_receipt_entries(int64_t) { return 0; }
 hipError_t transpose_f32(const float *, int64_t, int64_t, int64_t, float *, int64_t, hipStream_t) {
   return hipErrorUnknown;
 }

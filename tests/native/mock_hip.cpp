@@ -753,12 +753,17 @@ hipError_t scsrmm(char ord_b, int64_t m, int64_t n, int64_t k, float alpha, cons
   });
   return hipSuccess;
 }
+int64_t scsrgemv_receipt_entries(int64_t m) { return (m + 255) / 256; }
 hipError_t scsrgemv(char trans, int64_t m, int64_t n, const float *val, const int64_t *ptr, const int64_t *col, const float *x,
-                    float *y, hipStream_t st) {
+                    float *y, hipStream_t st, unsigned *seen) {
   MockStream *ms = kernel_stream(st, "scsrgemv");
   if (m <= 0) return hipSuccess;
   const int dev = ms->dev;
   ms->enqueue([=] {
+    if (seen) {
+      need_device_mem(seen, (size_t) ((m + 255) / 256) * 4, dev, "scsrgemv receipts");
+      for (int64_t i = 0; i < (m + 255) / 256; i++) seen[i]++;
+    }
     need_device_mem(ptr, (size_t) (m + 1) * 8, dev, "scsrgemv");
     const int64_t base = ptr[0], nnz = ptr[m] - base;
     need_device_mem(val, (size_t) nnz * 4, dev, "scsrgemv");

@@ -121,3 +121,54 @@ def test_csrmm_launch_receipts_catch_a_launch_that_ran_twice(dev, tmp_path):
     err, st, exact = run_csrmm(tmp_path, "R", 128, 2.0, inject=4)
     assert err is not None and "workgroup receipts" in err and ("-6" in err), err
     assert not exact
+
+
+def run_csrgemv(tmp_path, trans, inject=0, devices=None):
+    """flash::csrgemv on files with the launch receipts on: y against the oracle's fmaf chain ('N') / exact integer
+    sums ('T')."""
+    m, n = 5000, 3000
+    val, ja, ia = orc.sparse_create(m, n, 0.01)
+    x = (np.arange(n if trans == "N" else m) % 10).astype(np.float32)
+    y = np.full(m if trans == "N" else n, 3.0, np.float32)
+    dense = np.zeros((m, n), np.float64)
+    for i in range(m):
+        dense[i, ja[ia[i]:ia[i + 1]]] = val[ia[i]:ia[i + 1]]
+    want = (dense @ x if trans == "N" else dense.T @ x).astype(np.float32)       # integer data: exact in any order
+    arrs = dict(val=val, ia=ia, ja=ja)
+    paths = {nm: str(tmp_path / nm) for nm in arrs}
+    for nm, a in arrs.items():
+        a.tofile(paths[nm])
+    fds = {nm: os.open(p, os.O_RDWR) for nm, p in paths.items()}
+    os.environ["BOF_VERIFY_INJECT"] = str(inject)
+    err = None
+    try:
+        kw = dict(max_nnzs=5000, csrmm_rblk=700, n_io_threads=2, use_odirect=0, verify=1)
+        if devices:
+            kw["devices"] = devices
+        bofhip.flash_csrgemv(trans, m, n, *(bofhip.FPtr(fds[q], 0) for q in ("val", "ia", "ja")), x.ctypes.data, y.ctypes.data,
+                             bofhip.default_options(**kw))
+    except bofhip.BofError as e:
+        err = str(e)
+    finally:
+        os.environ.pop("BOF_VERIFY_INJECT", None)
+        for fd in fds.values():
+            bofhip.lib().bof_file_forget(fd)
+            os.close(fd)
+    return err, bofhip.flash_last_stats(), bool(np.array_equal(y, want))
+
+
+@pytest.mark.parametrize("trans", ["N", "T"])
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_csrgemv_launch_receipts_clean(dev, tmp_path, trans, devices):
+    err, st, exact = run_csrgemv(tmp_path, trans, devices=devices)
+    assert err is None, err
+    assert exact
+    assert st["verify_checks"] >= 8, st              # one receipt per csrgemv launch = per row block
+
+
+@pytest.mark.parametrize("trans", ["N", "T"])
+def test_csrgemv_launch_receipts_catch_a_launch_that_ran_twice(dev, tmp_path, trans):
+    """$BOF_VERIFY_INJECT=4: the call's first launch is submitted twice.  'T' adds that block's products twice (a wrong
+    y); 'N' stores the same values again -- only the receipt can tell."""
+    err, st, exact = run_csrgemv(tmp_path, trans, inject=4)
+    assert err is not None and "flash csrgemv" in err and "workgroup receipts" in err and "-6" in err, err

@@ -191,3 +191,53 @@ def test_csrmm_launch_receipts(tmp_path, mock_lib, devs, inject):
     else:
         assert out["rc"] == 1 and "workgroup receipts" in out["err"], out
         assert not out["exact"]
+
+
+CSRGEMV_CHILD = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "blas-on-flash_amd"))
+from test_dist_gloo import _use_mock_library
+_use_mock_library(SO)
+import bofhip
+m, n = 900, 500
+rng = np.random.default_rng(6)
+dense = (rng.random((m, n)) < 0.02) * rng.integers(1, 4, (m, n))
+ia = np.concatenate([[0], np.cumsum((dense != 0).sum(1))]).astype(np.int64)
+ja = np.nonzero(dense)[1].astype(np.int64); val = dense[dense != 0].astype(np.float32)
+arrs = dict(val=val, ia=ia, ja=ja)
+for nm, a in arrs.items(): a.tofile(os.path.join(DIR, nm))
+fds = {nm: os.open(os.path.join(DIR, nm), os.O_RDWR) for nm in arrs}
+out = {}
+for trans in ("N", "T"):
+    x = rng.integers(-3, 4, n if trans == "N" else m).astype(np.float32)
+    y = np.zeros(m if trans == "N" else n, np.float32)
+    try:
+        bofhip.flash_csrgemv(trans, m, n, *(bofhip.FPtr(fds[q], 0) for q in ("val", "ia", "ja")), x.ctypes.data, y.ctypes.data,
+                             bofhip.default_options(max_nnzs=700, csrmm_rblk=90, n_io_threads=2, use_odirect=0, verify=1, devices=DEVS))
+        out[trans] = {"rc": 0}
+    except bofhip.BofError as e:
+        out[trans] = {"rc": 1, "err": str(e)}
+    out[trans]["checks"] = bofhip.flash_last_stats()["verify_checks"]
+    out[trans]["exact"] = bool(np.array_equal(y, ((dense if trans == "N" else dense.T).astype(np.float64) @ x).astype(np.float32)))
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("devs,inject", [([0], 0), ([0, 1, 2], 0), ([0], 4)])
+def test_csrgemv_launch_receipts(tmp_path, mock_lib, devs, inject):
+    """The csrgemv twin of test_csrmm_launch_receipts: one receipt per row-block launch of either kernel."""
+    import json
+    code = f"ROOT={ROOT!r}\nSO={mock_lib!r}\nDIR={str(tmp_path)!r}\nDEVS={devs!r}\n" + CSRGEMV_CHILD
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MOCK_HIP_DEVICES="4", MOCK_HIP_ASYNC="1", MOCK_HIP_JITTER_US="100",
+                                BOF_VERIFY_INJECT=str(inject)))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(line[-1][7:])
+    for trans in ("N", "T"):
+        o = out[trans]
+        if inject == 0:
+            assert o["rc"] == 0 and o["exact"] and o["checks"] >= 5, out
+        else:
+            assert o["rc"] == 1 and "flash csrgemv" in o["err"] and "workgroup receipts" in o["err"], out
