@@ -129,9 +129,9 @@ typedef struct {
                              bof_flash_stats.kernel_seconds / kernel_launches.  0 = off           */
   int32_t verify;         /* hand-over checksums of the level-3 pipelines ($BOF_VERIFY): 0 = the
                              environment variable, else off; 1 = on; 2 = off whatever the
-                             environment says.  See "Instrumentation" below.  flash::csrmm: a
-                             receipt per csrmm launch (every workgroup counts itself, a checker
-                             behind the launch compares with 1; BOF_EVERIFY on a miss)              */
+                             environment says.  See "Instrumentation" below.  flash::csrmm /
+                             flash::csrgemv: a receipt per launch (every workgroup counts itself, a
+                             checker behind the launch compares with 1; BOF_EVERIFY on a miss)      */
   int32_t peer_bcast;     /* in-process device list: an operand every device needs is copied over
                              PCIe to ONE device only and passed on device to device
                              (hipMemcpyPeerAsync over xGMI); 0 = $BOF_PEER_BCAST, else off; 1 on;
