@@ -241,3 +241,19 @@ def test_csrgemv_launch_receipts(tmp_path, mock_lib, devs, inject):
             assert o["rc"] == 0 and o["exact"] and o["checks"] >= 5, out
         else:
             assert o["rc"] == 1 and "flash csrgemv" in o["err"] and "workgroup receipts" in o["err"], out
+
+
+@pytest.mark.parametrize("devs", [[0], [0, 1]])
+@pytest.mark.parametrize("beta", [0.0, 2.0])
+@pytest.mark.parametrize("flush", ["1", "0"])
+def test_ramp_group_panels_leave_one_by_one(tmp_path, mock_lib, devs, beta, flush):
+    """Round 6, second session: every C panel of the ramp group carries an event behind the LAST launch of its chain
+    and leaves when that has run ($BOF_PANEL_RAMP_FLUSH=1, the default; 0 = the whole group behind its last kernel).
+    Hand-over checks off (with them on the flusher waits for the group), asynchronous jittered mock streams, a ramp
+    group of 3 of the 5 C panels, one k-block per launch: a panel that left before its last k-block had been added
+    would carry a partial sum into the file."""
+    out, err = run_child(tmp_path, mock_lib, 2, beta, 0, devs, 0, verify=2,
+                         extra_env={"BOF_PANEL_GROUP": "3", "BOF_PANEL_RAMP_K": "1", "BOF_PANEL_RAMP_FLUSH": flush,
+                                    "MOCK_HIP_JITTER_US": "400"})
+    assert out["rc"] == 0, out.get("err", "") + err[-2000:]
+    assert out["exact"]
