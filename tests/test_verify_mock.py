@@ -36,7 +36,7 @@ except bofhip.BofError as e:
 out["stats"] = bofhip.flash_last_stats()
 got = np.fromfile(os.path.join(DIR, "C"), np.float32).reshape(m, n)
 out["exact"] = bool(np.array_equal(got, (a.astype(np.float64) @ b.astype(np.float64) + BETA * c0).astype(np.float32)))
-print("RESULT " + json.dumps(out))
+print("RESULT " + json.dumps(out), flush=True)
 '''
 
 
@@ -106,7 +106,7 @@ for path in (0, 1, 2):
             out["rc"].append([1, str(e)])
 got = np.fromfile(os.path.join(DIR, "C"), np.uint32)
 out["untouched"] = bool(np.array_equal(got, c0.view(np.uint32).ravel()))
-print("RESULT " + json.dumps(out))
+print("RESULT " + json.dumps(out), flush=True)
 '''
 
 
@@ -168,7 +168,7 @@ except bofhip.BofError as e:
 out["stats"] = bofhip.flash_last_stats()
 got = np.fromfile(os.path.join(DIR, "c"), np.float32).reshape(m, k)
 out["exact"] = bool(np.array_equal(got, (dense.astype(np.float64) @ b + 2.0 * c0).astype(np.float32)))
-print("RESULT " + json.dumps(out))
+print("RESULT " + json.dumps(out), flush=True)
 '''
 
 
@@ -181,9 +181,11 @@ def test_csrmm_launch_receipts(tmp_path, mock_lib, devs, inject):
     code = f"ROOT={ROOT!r}\nSO={mock_lib!r}\nDIR={str(tmp_path)!r}\nDEVS={devs!r}\n" + CSRMM_CHILD
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, MOCK_HIP_DEVICES="4", MOCK_HIP_ASYNC="1", MOCK_HIP_JITTER_US="100",
-                                BOF_VERIFY_INJECT=str(inject)))
+                                BOF_VERIFY_INJECT=str(inject), BOF_CRASH_TRACE="1"))
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
-    assert line, r.stdout[-2000:] + r.stderr[-3000:]
+    # (RESULT is flushed as soon as it is known: a crash while the mock runtime's worker threads are torn down at exit
+    #  does not cost the verdict; one before it shows its exit code and, with BOF_CRASH_TRACE, its native stack)
+    assert line, f"child exit code {r.returncode}\n" + r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads(line[-1][7:])
     if inject == 0:
         assert out["rc"] == 0 and out["exact"], out
@@ -220,7 +222,7 @@ for trans in ("N", "T"):
         out[trans] = {"rc": 1, "err": str(e)}
     out[trans]["checks"] = bofhip.flash_last_stats()["verify_checks"]
     out[trans]["exact"] = bool(np.array_equal(y, ((dense if trans == "N" else dense.T).astype(np.float64) @ x).astype(np.float32)))
-print("RESULT " + json.dumps(out))
+print("RESULT " + json.dumps(out), flush=True)
 '''
 
 
@@ -231,9 +233,11 @@ def test_csrgemv_launch_receipts(tmp_path, mock_lib, devs, inject):
     code = f"ROOT={ROOT!r}\nSO={mock_lib!r}\nDIR={str(tmp_path)!r}\nDEVS={devs!r}\n" + CSRGEMV_CHILD
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, MOCK_HIP_DEVICES="4", MOCK_HIP_ASYNC="1", MOCK_HIP_JITTER_US="100",
-                                BOF_VERIFY_INJECT=str(inject)))
+                                BOF_VERIFY_INJECT=str(inject), BOF_CRASH_TRACE="1"))
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
-    assert line, r.stdout[-2000:] + r.stderr[-3000:]
+    # (RESULT is flushed as soon as it is known: a crash while the mock runtime's worker threads are torn down at exit
+    #  does not cost the verdict; one before it shows its exit code and, with BOF_CRASH_TRACE, its native stack)
+    assert line, f"child exit code {r.returncode}\n" + r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads(line[-1][7:])
     for trans in ("N", "T"):
         o = out[trans]
@@ -243,9 +247,7 @@ def test_csrgemv_launch_receipts(tmp_path, mock_lib, devs, inject):
             assert o["rc"] == 1 and "flash csrgemv" in o["err"] and "workgroup receipts" in o["err"], out
 
 
-@pytest.mark.parametrize("devs", [[0], [0, 1]])
-@pytest.mark.parametrize("beta", [0.0, 2.0])
-@pytest.mark.parametrize("flush", ["1", "0"])
+@pytest.mark.parametrize("devs,beta,flush", [([0], 0.0, "1"), ([0, 1], 2.0, "1"), ([0], 2.0, "0")])
 def test_ramp_group_panels_leave_one_by_one(tmp_path, mock_lib, devs, beta, flush):
     """Round 6, second session: every C panel of the ramp group carries an event behind the LAST launch of its chain
     and leaves when that has run ($BOF_PANEL_RAMP_FLUSH=1, the default; 0 = the whole group behind its last kernel).
